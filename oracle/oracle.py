@@ -1,0 +1,191 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY -- may be imported by tests/, __graft_entry__.smoke()
+and the cpu_baseline leg of bench.py, never by the product package.
+PARITY UNPINNED: see the header of ldu_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PRECOND = {"none": 0, "diagonal": 1, "AINV": 2, "DIC": 2, "DILU": 2,  # RapidCFD aliases
+           "DIC_upstream": 3, "DILU_upstream": 4}
+
+
+class Perf(C.Structure):
+    _fields_ = [("initialResidual", C.c_double), ("finalResidual", C.c_double),
+                ("normFactor", C.c_double), ("nIterations", C.c_int32),
+                ("converged", C.c_int32), ("singular", C.c_int32)]
+
+
+class Controls(C.Structure):
+    _fields_ = [("tolerance", C.c_double), ("relTol", C.c_double),
+                ("maxIter", C.c_int32), ("minIter", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith("_oracle.c")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_sys_create.restype = C.c_void_p
+        L.orc_sys_size.restype = C.c_int64
+        for name in ("orc_gSumProd", "orc_gSumMag", "orc_gSum", "orc_norm_factor"):
+            getattr(L, name).restype = C.c_double
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class System:
+    """D sub-domains solved in lock-step (D=1: an ordinary serial case)."""
+
+    def __init__(self, cases: Sequence):
+        L = lib()
+        self.cases = list(cases)
+        self.h = C.c_void_p(L.orc_sys_create(len(self.cases)))
+        for d, cs in enumerate(self.cases):
+            lo, up = _i(cs.lower_addr), _i(cs.upper_addr)
+            L.orc_sys_set_domain(self.h, d, C.c_int32(cs.n_cells), C.c_int32(cs.n_faces),
+                                 _p(lo, C.c_int32), _p(up, C.c_int32), _p(_d(cs.diag), C.c_double),
+                                 _p(_d(cs.lower), C.c_double) if cs.lower is not None else None,
+                                 _p(_d(cs.upper), C.c_double))
+        for d, cs in enumerate(self.cases):
+            for itf in cs.interfaces:
+                fc = _i(itf.face_cells)
+                L.orc_sys_add_interface(self.h, d, C.c_int32(itf.nbr_domain), C.c_int32(itf.nbr_patch),
+                                        C.c_int32(fc.shape[0]), _p(fc, C.c_int32),
+                                        _p(_d(itf.bou_coeffs), C.c_double), _p(_d(itf.int_coeffs), C.c_double))
+        self.n = int(L.orc_sys_size(self.h))
+
+    def __del__(self):
+        try:
+            lib().orc_sys_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_accurate(self, on: bool):
+        lib().orc_sys_set_accurate(self.h, int(on))
+
+    # --- operators ------------------------------------------------------
+    def _unary(self, fn, psi):
+        x = _d(psi)
+        y = np.empty(self.n)
+        getattr(lib(), fn)(self.h, _p(x, C.c_double), _p(y, C.c_double))
+        return y
+
+    def amul(self, psi):
+        return self._unary("orc_amul", psi)
+
+    def tmul(self, psi):
+        return self._unary("orc_tmul", psi)
+
+    def amul_faceloop(self, psi):
+        return self._unary("orc_amul_faceloop", psi)
+
+    def H(self, psi):
+        return self._unary("orc_H", psi)
+
+    def sumA(self):
+        y = np.empty(self.n)
+        lib().orc_sumA(self.h, _p(y, C.c_double))
+        return y
+
+    def H1(self):
+        y = np.empty(self.n)
+        lib().orc_H1(self.h, _p(y, C.c_double))
+        return y
+
+    def faceH(self, psi, d=0):
+        x = _d(psi)
+        y = np.empty(self.cases[d].n_faces)
+        lib().orc_faceH(self.h, d, _p(x, C.c_double), _p(y, C.c_double))
+        return y
+
+    def residual(self, psi, source):
+        x, b = _d(psi), _d(source)
+        y = np.empty(self.n)
+        lib().orc_residual(self.h, _p(x, C.c_double), _p(b, C.c_double), _p(y, C.c_double))
+        return y
+
+    def norm_factor(self, psi, source, Apsi):
+        x, b, a = _d(psi), _d(source), _d(Apsi)
+        tmp = np.empty(self.n)
+        return float(lib().orc_norm_factor(self.h, _p(x, C.c_double), _p(b, C.c_double),
+                                           _p(a, C.c_double), _p(tmp, C.c_double)))
+
+    def precondition(self, kind, r, transpose=False):
+        x = _d(r)
+        y = np.empty(self.n)
+        lib().orc_precondition(self.h, PRECOND[kind], int(transpose), _p(x, C.c_double), _p(y, C.c_double))
+        return y
+
+    def jacobi_smooth(self, psi, source, n_sweeps, omega=0.9):
+        x = _d(psi).copy()
+        b = _d(source)
+        lib().orc_jacobi_smooth(self.h, C.c_double(omega), _p(x, C.c_double), _p(b, C.c_double), n_sweeps)
+        return x
+
+    def gauss_seidel_upstream(self, psi, source, n_sweeps):
+        x = _d(psi).copy()
+        b = _d(source)
+        lib().orc_gauss_seidel_upstream(self.h, _p(x, C.c_double), _p(b, C.c_double), n_sweeps)
+        return x
+
+    # --- solvers --------------------------------------------------------
+    def _solve(self, fn, psi, source, extra, tolerance, relTol, maxIter, minIter, hist_len):
+        x = _d(psi).copy()
+        b = _d(source)
+        ctl = Controls(tolerance, relTol, maxIter, minIter)
+        perf = Perf()
+        hist = np.full(hist_len, np.nan)
+        getattr(lib(), fn)(self.h, _p(x, C.c_double), _p(b, C.c_double), C.byref(ctl), *extra,
+                           C.byref(perf), _p(hist, C.c_double), hist_len)
+        out = {k: getattr(perf, k) for k, _ in Perf._fields_}
+        out["history"] = hist[: min(hist_len, max(perf.nIterations, 0) + 1)].copy()
+        return x, out
+
+    def pcg(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):
+        return self._solve("orc_pcg_solve", psi, source, (C.c_int(PRECOND[precond]),),
+                           tolerance, relTol, maxIter, minIter, maxIter + 2)
+
+    def pbicg(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):
+        return self._solve("orc_pbicg_solve", psi, source, (C.c_int(PRECOND[precond]),),
+                           tolerance, relTol, maxIter, minIter, maxIter + 2)
+
+    def pbicgstab(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000,
+                  minIter=0, replicate_quirk=True):
+        return self._solve("orc_pbicgstab_solve", psi, source,
+                           (C.c_int(PRECOND[precond]), C.c_int(int(replicate_quirk))),
+                           tolerance, relTol, maxIter, minIter, maxIter + 2)
+
+    def smooth_solve(self, psi, source, n_sweeps=1, omega=0.9, tolerance=1e-6, relTol=0.0,
+                     maxIter=1000, minIter=0):
+        return self._solve("orc_smooth_solve", psi, source, (C.c_double(omega), C.c_int(n_sweeps)),
+                           tolerance, relTol, maxIter, minIter, maxIter + 2)

@@ -1,0 +1,214 @@
+"""Synthetic hex-box lduMatrix inputs (SURVEY.md section 8d "synthetic inputs").
+
+The reference ships no meshes or tutorials, so tests and bench.py build their
+inputs here: a structured ``nx x ny x nz`` box with cells numbered
+lexicographically (``c = i + nx*(j + ny*k)``) and internal faces in OpenFOAM's
+upper-triangular order (for every cell ascending: its +x, +y, +z neighbours),
+so that ``lowerAddr`` is sorted and ``lowerAddr[f] < upperAddr[f]`` exactly as
+``fvMeshLduAddressing`` hands them to ``lduMatrix``
+(src/finiteVolume/fvMesh/fvMeshLduAddressing.H:91-121).
+
+Coefficients follow OpenFOAM's sign convention: ``fvm::laplacian`` gives
+``upper = +gamma*|Sf|*deltaCoeffs`` and ``diag = -sum(offdiag)``
+(gaussLaplacianScheme.C:63-64 + lduMatrix::negSumDiag), plus the fixedValue
+``internalCoeffs = -2h`` on the x-min patch, which is what
+``fvMatrix::addBoundaryDiag`` (fvMatrix.C:208-226) folds into the diagonal
+before the solver is called.
+
+All random numbers come from a splitmix64 counter hash so that every consumer
+(numpy here, C in the oracle, tests on any box) sees identical bits.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+_U64 = np.uint64
+
+
+def splitmix_uniform(seed: int, n: int, start: int = 0) -> np.ndarray:
+    """``n`` doubles in [0,1): u[i] = splitmix64(seed + (start+i)*0x9E37..15) >> 11 * 2^-53."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(start, start + n, dtype=np.uint64) + _U64(1)) * _U64(0x9E3779B97F4A7C15)
+        z = z + _U64(seed & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
+        z = z ^ (z >> _U64(31))
+    return (z >> _U64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+@dataclass
+class Interface:
+    """One processor patch of a sub-domain (processorLduInterface + coeffs)."""
+    nbr_domain: int
+    nbr_patch: int
+    face_cells: np.ndarray  # int32 [Pf]
+    bou_coeffs: np.ndarray  # float64 [Pf]  interfaceBouCoeffs
+    int_coeffs: np.ndarray  # float64 [Pf]  interfaceIntCoeffs
+
+
+@dataclass
+class LduCase:
+    """Host-side LDU matrix + addressing in the caller's (OpenFOAM) order."""
+    n_cells: int
+    lower_addr: np.ndarray  # int32 [F] owner
+    upper_addr: np.ndarray  # int32 [F] neighbour
+    diag: np.ndarray
+    upper: np.ndarray
+    lower: Optional[np.ndarray]  # None => symmetric
+    source: np.ndarray
+    dims: tuple = ()
+    interfaces: List[Interface] = field(default_factory=list)
+    global_cells: Optional[np.ndarray] = None  # for decomposed cases: global cell id of each local cell
+
+    @property
+    def n_faces(self) -> int:
+        return int(self.lower_addr.shape[0])
+
+    @property
+    def symmetric(self) -> bool:
+        return self.lower is None
+
+
+def box_addressing(nx: int, ny: int, nz: int):
+    """(lowerAddr, upperAddr, direction) of the internal faces in OpenFOAM order."""
+    n = nx * ny * nz
+    c = np.arange(n, dtype=np.int64)
+    i = c % nx
+    j = (c // nx) % ny
+    k = c // (nx * ny)
+    nbr = np.full((n, 3), -1, dtype=np.int64)
+    nbr[i < nx - 1, 0] = c[i < nx - 1] + 1
+    nbr[j < ny - 1, 1] = c[j < ny - 1] + nx
+    nbr[k < nz - 1, 2] = c[k < nz - 1] + nx * ny
+    valid = nbr >= 0
+    own = np.broadcast_to(c[:, None], (n, 3))[valid]
+    nei = nbr[valid]
+    direction = np.broadcast_to(np.arange(3)[None, :], (n, 3))[valid]
+    return own.astype(np.int32), nei.astype(np.int32), direction.astype(np.int8)
+
+
+def box_case(nx: int, ny: int, nz: int, *, symmetric: bool = True, vary: float = 0.1,
+             seed: int = 12345, rhs_seed: int = 777, dirichlet_all: bool = False) -> LduCase:
+    """Pressure-like (symmetric) or momentum-like (asymmetric) matrix on a hex box."""
+    n = nx * ny * nz
+    lo, up, direction = box_addressing(nx, ny, nz)
+    nf = lo.shape[0]
+    h = 1.0 / nx
+    u = splitmix_uniform(seed, nf)
+    c = np.arange(n, dtype=np.int64)
+    i = c % nx
+    j = (c // nx) % ny
+    k = c // (nx * ny)
+    if symmetric:
+        upper = h * (1.0 + vary * u)
+        lower = None
+        lo_c = upper
+    else:
+        # -nu*laplacian + upwind convection (flux 0.3 h^2 in +x) + ddt; positive diagonal
+        nu_h = h * (1.0 + vary * u)
+        phi = np.where(direction == 0, 0.3 * h * h, 0.0)
+        upper = -nu_h
+        lower = -nu_h - phi
+        lo_c = lower
+    # negSumDiag (lduMatrixOperations.C:62-83): diag[l] -= lower ; diag[u] -= upper
+    diag = np.zeros(n)
+    np.subtract.at(diag, lo, lo_c)
+    np.subtract.at(diag, up, upper)
+    sign = -1.0 if symmetric else 1.0
+    bnd = (i == 0)
+    if dirichlet_all:
+        nb = ((i == 0).astype(np.int64) + (i == nx - 1) + (j == 0) + (j == ny - 1)
+              + (k == 0) + (k == nz - 1))
+        diag += sign * 2.0 * h * nb
+    else:
+        diag[bnd] += sign * 2.0 * h
+    if not symmetric:
+        diag += h ** 3 / 1e-3  # V/deltaT
+    source = (2.0 * splitmix_uniform(rhs_seed, n) - 1.0) * h ** 3
+    return LduCase(n, lo, up, diag, upper, lower, source, dims=(nx, ny, nz))
+
+
+def decompose_box(case: LduCase, parts) -> List[LduCase]:
+    """Split a box case into px*py*pz sub-domains with processor interfaces.
+
+    Mirrors what ``decomposePar`` produces for the solver: every cut face
+    becomes a face of a processor patch whose ``boundaryCoeffs`` hold minus
+    the off-diagonal coefficient seen from this side and whose
+    ``internalCoeffs`` hold minus the one seen from the other side, so that
+    ``Apsi[faceCells] -= bouCoeffs*psiNbr`` (coupledFvPatchField.C:236-257)
+    reproduces the undecomposed product.  Local cells and faces keep their
+    relative global order (what decomposePar does), so local addressing is
+    again upper-triangular and owner-sorted.
+    """
+    nx, ny, nz = case.dims
+    px, py, pz = parts
+    n = case.n_cells
+    c = np.arange(n, dtype=np.int64)
+    i = c % nx
+    j = (c // nx) % ny
+    k = c // (nx * ny)
+
+    def chunk(idx, nd, p):
+        b = (np.arange(p + 1) * nd) // p
+        return np.searchsorted(b, idx, side="right") - 1
+
+    dom = chunk(i, nx, px) + px * (chunk(j, ny, py) + py * chunk(k, nz, pz))
+    nd = px * py * pz
+    lo = case.lower_addr.astype(np.int64)
+    up = case.upper_addr.astype(np.int64)
+    lower_c = case.upper if case.lower is None else case.lower
+    local_id = np.empty(n, dtype=np.int64)
+    cells_of = []
+    for d in range(nd):
+        ids = np.nonzero(dom == d)[0]
+        cells_of.append(ids)
+        local_id[ids] = np.arange(ids.shape[0])
+    dl, du = dom[lo], dom[up]
+    out: List[LduCase] = []
+    # cut faces grouped per ordered domain pair
+    cut = np.nonzero(dl != du)[0]
+    pair_faces = {}
+    for d in range(nd):
+        pair_faces[d] = {}
+    for a, b in sorted(set(zip(dl[cut].tolist(), du[cut].tolist()))):
+        f = cut[(dl[cut] == a) & (du[cut] == b)]
+        pair_faces[a].setdefault(b, []).append(("own", f))
+        pair_faces[b].setdefault(a, []).append(("nei", f))
+    patch_index = {d: {nb: idx for idx, nb in enumerate(sorted(pair_faces[d]))} for d in range(nd)}
+    for d in range(nd):
+        ids = cells_of[d]
+        fint = np.nonzero((dl == d) & (du == d))[0]
+        sub = LduCase(
+            n_cells=int(ids.shape[0]),
+            lower_addr=local_id[lo[fint]].astype(np.int32),
+            upper_addr=local_id[up[fint]].astype(np.int32),
+            diag=case.diag[ids].copy(),
+            upper=case.upper[fint].copy(),
+            lower=None if case.lower is None else case.lower[fint].copy(),
+            source=case.source[ids].copy(),
+            dims=(),
+            global_cells=ids.astype(np.int64),
+        )
+        for nb in sorted(pair_faces[d]):
+            fcs, bou, inte = [], [], []
+            # faces ordered by global face id on both sides so the two patches match 1:1
+            entries = sorted(pair_faces[d][nb], key=lambda t: int(t[1][0]) if len(t[1]) else 0)
+            allf = np.concatenate([e[1] for e in entries])
+            side = np.concatenate([np.full(len(e[1]), e[0] == "own") for e in entries])
+            order = np.argsort(allf, kind="stable")
+            allf, side = allf[order], side[order]
+            for f, is_own in zip(allf.tolist(), side.tolist()):
+                if is_own:   # this domain holds the owner: row lo[f], coefficient upper[f]
+                    fcs.append(local_id[lo[f]]); bou.append(-case.upper[f]); inte.append(-lower_c[f])
+                else:        # this domain holds the neighbour: row up[f], coefficient lower[f]
+                    fcs.append(local_id[up[f]]); bou.append(-lower_c[f]); inte.append(-case.upper[f])
+            sub.interfaces.append(Interface(
+                nbr_domain=nb, nbr_patch=patch_index[nb][d],
+                face_cells=np.asarray(fcs, dtype=np.int32),
+                bou_coeffs=np.asarray(bou, dtype=np.float64),
+                int_coeffs=np.asarray(inte, dtype=np.float64)))
+        out.append(sub)
+    return out
