@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py -- PCG iterations/s + HBM GB/s on the 10M-cell lduMatrix (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full PCG iteration of the reference's loop (PCG.C:133-204: precondition,
+gSumProd, p update, Amul, gSumProd, psi/r update, gSumMag) on the 216^3 hex-box pressure
+matrix (N = 10 077 696 cells, F = 30 093 120 faces), diagonal preconditioner, with all inputs
+resident in HBM.  For N > 1 the same mesh is domain-decomposed over the ranks (strong scaling,
+one process per GPU, halo exchange + global sums on RCCL).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, lduMatrix::Amul
+(tile_kernel<OP_AMUL>): algorithmic bytes 24N+16F per launch / its average launch duration,
+measured with HIP events on the engine's stream inside the timed region.  `cpu_baseline` is the
+CPU oracle (a port of the same loop, 1 core) timed on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parts_for(n):
+    return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(n) or (1, 1, n)
+
+
+def cpu_baseline(case, iters):
+    """Oracle PCG (1 core) on the same matrix, `iters` iterations -- reported, not a target."""
+    from oracle import oracle as orc
+    S = orc.System([case])
+    S.set_accurate(False)
+    z = np.zeros(case.n_cells)
+    S.pcg(z, case.source, "diagonal", tolerance=0.0, maxIter=1)  # touch memory
+    t0 = time.perf_counter()
+    _, perf = S.pcg(z, case.source, "diagonal", tolerance=0.0, maxIter=iters - 1)
+    dt = time.perf_counter() - t0
+    return perf["nIterations"] / dt, perf["nIterations"], dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dims", type=int, nargs=3, default=[216, 216, 216])
+    ap.add_argument("--precond", default="diagonal")
+    ap.add_argument("--cpu-iters", type=int, default=int(os.environ.get("MI_BENCH_CPU_ITERS", "40")))
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        log(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}; using WORLD_SIZE")
+    n_gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    graft.build()
+    pkg = graft.load_package()
+    syn, eng = pkg.synthetic, pkg.engine
+    dev = torch.device("cuda", local_rank)
+    nx, ny, nz = args.dims
+    t0 = time.perf_counter()
+    case = syn.box_case(nx, ny, nz)
+    N, F = case.n_cells, case.n_faces
+    if rank == 0:
+        log(f"[bench] case {nx}x{ny}x{nz}: N={N} F={F} built in {time.perf_counter() - t0:.1f}s")
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    ctx = eng.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+    K, W = args.steps, args.warmup
+    amul_ms = None
+    if world == 1:
+        t0 = time.perf_counter()
+        addr = eng.Addressing(ctx, N, case.lower_addr, case.upper_addr)
+        mat = eng.Matrix(addr)
+        mat.set_coeffs(t(case.diag), t(case.upper), None)
+        src = t(case.source)
+        psi0 = torch.zeros(N, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        log(f"[bench] engine layout: {addr.stats()} in {time.perf_counter() - t0:.1f}s")
+        mat.pcg_begin(psi0, src, args.precond, tolerance=0.0, relTol=0.0, maxIter=W + K + 8, history_len=W + K + 2)
+        mat.pcg_iterate(W)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        amul_ms = mat.pcg_iterate(K, time_amul=True)  # HIP events around every Amul launch
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        perf = mat.pcg_end(None, history_len=W + K + 2)
+        assert perf["nIterations"] == W + K, perf
+        assert np.all(np.isfinite(perf["history"])) and perf["history"][-1] < perf["history"][0]
+        n_amul_cells, n_amul_faces = N, F
+    else:
+        from importlib import import_module
+        par = import_module(graft.PKG_NAME + ".parallel")
+        sub = syn.decompose_box(case, parts_for(world))[rank]
+        solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
+        solver.begin(tolerance=0.0, max_iter=W + K + 8)
+        solver.iterate(W)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        amul_ms = solver.iterate(K, time_amul=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        perf = solver.end()
+        assert perf["nIterations"] == W + K, perf
+        n_amul_cells, n_amul_faces = sub.n_cells, sub.n_faces + sum(len(i.face_cells) for i in sub.interfaces)
+
+    its = K / elapsed
+    amul_avg_s = (amul_ms / 1e3) / K
+    amul_bytes = 24 * n_amul_cells + 16 * n_amul_faces  # symmetric Amul, per launch (per rank)
+    achieved = amul_bytes / amul_avg_s / 1e9
+    out = {
+        "metric": "PCG iterations/s + HBM GB/s on 10M-cell lduMatrix at 1/2/4/8 MI355X",
+        "value": its,
+        "unit": "iterations/s",
+        "n_gpus": n_gpus,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{nx}x{ny}x{nz} hex box (N={N}, F={F}), scalar PCG + {args.precond} preconditioner, "
+                        f"symmetric pressure-like lduMatrix, {n_gpus}xMI355X",
+            "cells": N, "faces": F, "parallelism": f"domain-decomposition {parts_for(world)}" if world > 1 else "single GPU",
+            "pcg_algorithmic_GBps": (160 * N + 16 * F) * its / 1e9,
+        },
+        "roofline": {
+            "kernel": "tile_kernel<OP_AMUL> (lduMatrix::Amul)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": amul_bytes,
+            "avg_launch_us": amul_avg_s * 1e6,
+            "traffic": float(os.environ["MI_BENCH_TRAFFIC"]) if os.environ.get("MI_BENCH_TRAFFIC") else None,
+        },
+    }
+    if rank == 0:
+        if not args.no_cpu:
+            v, n_it, dt = cpu_baseline(case, args.cpu_iters)
+            out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": 1, "kind": "port",
+                                   "sample": f"{n_it} PCG iterations (diagonal) of the same {nx}x{ny}x{nz} matrix in {dt:.1f}s, "
+                                             "oracle/ldu_oracle.c, gcc -O3, one core"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

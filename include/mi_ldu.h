@@ -1,0 +1,233 @@
+/*
+ * mi_ldu.h -- C ABI of the MI355X-native lduMatrix / fvMatrix compute engine.
+ *
+ * This is the drop-in boundary for the hot path of SimFlowCFD/RapidCFD-dev
+ * (SURVEY.md section 8b).  The reference has no FFI: the path sits behind
+ * OpenFOAM's run-time selection tables (lduMatrix::solver / preconditioner /
+ * smoother, lduMatrix.H:141-185,297-341,438-460) and the lduMatrix member
+ * functions.  A maintainer binds this ABI from a C++ shim that registers the
+ * same run-time names (INTEGRATION.md shows the stub); the C++ host mirror of
+ * those classes lives in rapidcfd-dev_amd/foam/.
+ *
+ * Conventions
+ *   - scalar = double, label = int32_t (reference defaults: etc/bashrc:76,
+ *     primitives/ints/label/label.H:57-66).
+ *   - Pointers named *_dev are DEVICE pointers owned by the caller (the
+ *     reference's gpuList<T> storage, gpuList.H:23-112); *_host are host
+ *     pointers.  The engine never frees caller memory.
+ *   - Vectors passed across this ABI are in the CALLER's cell/face order.
+ *     The engine keeps its own tiled order internally; the
+ *     *_engine entry points work on vectors already in engine order.
+ *   - Every function returns MI_OK (0) or a negative error code; the message
+ *     is available from mi_last_error().  The reference aborts the process
+ *     instead (FatalError / CUDA_CALL, DeviceConfig.H:6-11); the shim turns a
+ *     non-zero status into FatalError.
+ *   - One context per GPU / per rank, not thread-safe (the reference is one
+ *     host thread per MPI rank, argList.C:775-811).
+ *   - There is no CPU fallback: every compute entry point needs a gfx950
+ *     device and fails with MI_ERR_DEVICE otherwise.
+ *
+ * All paths in citations are relative to /root/reference/src/OpenFOAM/matrices/lduMatrix/
+ * unless they start with src/.
+ */
+#ifndef MI_LDU_H
+#define MI_LDU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_ctx_s *mi_ctx_t;
+typedef struct mi_addr_s *mi_addr_t;
+typedef struct mi_matrix_s *mi_matrix_t;
+
+enum {
+    MI_OK = 0,
+    MI_ERR_ARG = -1,
+    MI_ERR_DEVICE = -2,   /* no gfx950 device / HIP failure */
+    MI_ERR_ALLOC = -3,
+    MI_ERR_STATE = -4,    /* e.g. coefficients not bound */
+    MI_ERR_LIMIT = -5     /* mesh exceeds a tile-format limit */
+};
+
+/* preconditioner names of lduMatrix::preconditioner::New
+ * (lduMatrix/lduMatrixPreconditioner.C:67-158).  DIC/DILU resolve to AINV in
+ * the reference (preconditioners/DICPreconditioner/DICPreconditioner.C:42-58). */
+enum { MI_PRECOND_NONE = 0, MI_PRECOND_DIAGONAL = 1, MI_PRECOND_AINV = 2 };
+
+/* solverPerformance (src/OpenFOAM/matrices/LduMatrix/LduMatrix/SolverPerformance.H) */
+typedef struct {
+    double initialResidual;
+    double finalResidual;
+    double normFactor;
+    int32_t nIterations;
+    int32_t converged;
+    int32_t singular;
+    int32_t reserved;
+} mi_solver_perf;
+
+/* lduMatrix::solver::readControls (lduMatrix/lduMatrixSolver.C:167-173) */
+typedef struct {
+    double tolerance; /* default 1e-6 */
+    double relTol;    /* default 0    */
+    int32_t maxIter;  /* default 1000 */
+    int32_t minIter;  /* default 0    */
+} mi_solver_controls;
+
+/* ---- context (replaces src/OpenFOAM/device/DeviceConfig.{H,C}, DeviceStream) ---- */
+/* stream: a hipStream_t created by the caller (e.g. torch's current stream) or NULL
+ * for the engine's own stream.                                                     */
+int mi_ctx_create(int device, void *hip_stream, mi_ctx_t *out);
+int mi_ctx_destroy(mi_ctx_t ctx);
+int mi_ctx_synchronize(mi_ctx_t ctx);
+const char *mi_last_error(void);
+/* 1 if a usable gfx950 device is visible to this process, else 0 */
+int mi_device_available(void);
+
+/* ---- addressing (replaces lduAddressing demand-driven tables,
+ *      lduAddressing/lduAddressing.H:128-145, .C:169-344; K23 in SURVEY.md) ----
+ * lower/upper: host mirrors of lowerAddr/upperAddr (fvMeshLduAddressing.H:165-181),
+ *   faces in OpenFOAM upper-triangular order is NOT required, only lower<upper.
+ * patches: coupled (processor) interfaces, patch p has patch_sizes[p] faces whose
+ *   internal cells are patch_face_cells_host[p][...] (fvMeshLduAddressing.H:113-120).
+ * Builds the tiled engine layout once per mesh.                                   */
+int mi_addr_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
+                   const int32_t *lower_addr_host, const int32_t *upper_addr_host,
+                   int32_t n_patches, const int32_t *patch_sizes,
+                   const int32_t *const *patch_face_cells_host, mi_addr_t *out);
+int mi_addr_destroy(mi_addr_t addr);
+int32_t mi_addr_n_cells(mi_addr_t addr);
+int32_t mi_addr_n_faces(mi_addr_t addr);
+int32_t mi_addr_n_tiles(mi_addr_t addr);
+/* number of halo ("external") cells appended after the n_cells owned cells in
+ * engine-order vectors: sum of patch sizes                                       */
+int32_t mi_addr_n_ext(mi_addr_t addr);
+/* engine->caller cell permutation (n_cells ints) */
+int mi_addr_cell_perm(mi_addr_t addr, int32_t *engine_to_caller_host);
+/* layout statistics: [0]=tiles [1]=slots total [2]=entries total (padded)
+ * [3]=halo entries total [4]=max cells/tile [5]=max slots/tile [6]=max halo/tile
+ * [7]=LDS bytes per workgroup (symmetric)                                        */
+int mi_addr_stats(mi_addr_t addr, int64_t stats[8]);
+
+/* ---- matrix (replaces lduMatrix storage + lowerSort()/upperSort() caches,
+ *      lduMatrix/lduMatrix.C:221-472; K22 calcSortCoeffs) ---- */
+int mi_matrix_create(mi_addr_t addr, mi_matrix_t *out);
+int mi_matrix_destroy(mi_matrix_t m);
+/* Bind new coefficient values ("coefficients changed" epoch; the reference
+ * invalidates lowerSortPtr_ in every mutator, lduMatrix.C:235,266).
+ * lower_dev == NULL => symmetric (lower aliases upper, lduMatrix.C:328-345).
+ * Copies into the engine's tiled layout; the caller arrays are not retained.    */
+int mi_matrix_set_coeffs(mi_matrix_t m, const double *diag_dev, const double *upper_dev,
+                         const double *lower_dev);
+/* interfaceBouCoeffs / interfaceIntCoeffs of coupled patch p (device pointers,
+ * patch_sizes[p] values each; int_coeffs_dev may be NULL for symmetric matrices). */
+int mi_matrix_set_interface_coeffs(mi_matrix_t m, int32_t patch, const double *bou_coeffs_dev,
+                                   const double *int_coeffs_dev);
+
+/* ---- halo (replaces init/updateMatrixInterfaces + processorFvPatchField
+ *      gather/scatter, lduMatrixUpdateMatrixInterfaces.C:30-276,
+ *      src/finiteVolume/fields/fvPatchFields/constraint/processor/processorFvPatchScalarField.C:36-170) ----
+ * pack: send_dev[patch_offset[p]+i] = x[patch_face_cells[p][i]] for all patches
+ *       (K5 fvPatchTemplates.C:49-63), x in engine order.
+ * The received neighbour values are written by the caller (RCCL recv / peer copy)
+ * straight into the ext region x_engine[n_cells .. n_cells+n_ext).              */
+int mi_halo_pack_engine(mi_addr_t addr, const double *x_engine_dev, double *send_dev);
+int mi_addr_patch_offsets(mi_addr_t addr, int32_t *offsets_host /* n_patches+1 */);
+
+/* ---- vector layout helpers ---- */
+int mi_vec_to_engine(mi_addr_t addr, const double *x_caller_dev, double *x_engine_dev);
+int mi_vec_from_engine(mi_addr_t addr, const double *x_engine_dev, double *x_caller_dev);
+
+/* ---- SpMV family, caller order (lduMatrix::Amul/Tmul lduMatrixATmul.C:183-342,
+ *      sumA :345-395, residual :397-496, H1 :533-554, H lduMatrixOperations.C:130-154,
+ *      faceH lduMatrixTemplates.C:110-148) ----
+ * Interface (halo) terms use ext values previously placed with mi_set_ext (single
+ * process: none).                                                                 */
+int mi_amul(mi_matrix_t m, const double *psi_dev, double *Apsi_dev);
+int mi_tmul(mi_matrix_t m, const double *psi_dev, double *Tpsi_dev);
+int mi_sumA(mi_matrix_t m, double *sumA_dev);
+int mi_residual(mi_matrix_t m, const double *psi_dev, const double *source_dev, double *rA_dev);
+int mi_H(mi_matrix_t m, const double *psi_dev, double *H_dev);
+int mi_H1(mi_matrix_t m, double *H1_dev);
+int mi_faceH(mi_matrix_t m, const double *psi_dev, double *faceH_dev);
+/* neighbour values for the coupled patches, caller patch order, n_ext doubles */
+int mi_matrix_set_ext(mi_matrix_t m, const double *ext_values_dev);
+
+/* ---- SpMV family, engine order (inner loops of the solvers; what bench.py times) ----
+ * vectors are n_cells + n_ext long; which: 0 = all tiles, 1 = interior tiles only
+ * (no ext reference), 2 = boundary tiles only (after the halo has arrived).       */
+int mi_amul_engine(mi_matrix_t m, const double *psi_e, double *Apsi_e, int which);
+int mi_tmul_engine(mi_matrix_t m, const double *psi_e, double *Tpsi_e, int which);
+
+/* ---- preconditioners (lduMatrix::preconditioner::precondition / preconditionT,
+ *      diagonalPreconditioner.C:45-89, AINVPreconditioner.C:49-120) ---- */
+int mi_precondition(mi_matrix_t m, int kind, int transpose, const double *rA_dev, double *wA_dev);
+
+/* ---- smoother (lduMatrix::smoother::smooth; JacobiSmoother.C:39-148; the
+ *      reference's "GaussSeidel" is this Jacobi with omega 0.9) ---- */
+int mi_jacobi_smooth(mi_matrix_t m, double omega, double *psi_dev, const double *source_dev,
+                     int32_t n_sweeps);
+
+/* ---- field reductions (gpuFieldCommonFunctions.C:351-367,420-440,492-511) ----
+ * deterministic fixed-tree device reductions; result returned to the host.       */
+int mi_sum(mi_ctx_t ctx, const double *a_dev, int64_t n, double *out_host);
+int mi_sum_prod(mi_ctx_t ctx, const double *a_dev, const double *b_dev, int64_t n, double *out_host);
+int mi_sum_mag(mi_ctx_t ctx, const double *a_dev, int64_t n, double *out_host);
+
+/* ---- whole solvers (lduMatrix::solver::solve; PCG.C:68-208, PBiCG.C:67-246,
+ *      PBiCGStab.C:67-300, smoothSolver.C:77-196).  psi in/out, caller order.
+ * residual_history_host (may be NULL) receives the normalised residual after
+ * every iteration, [0] = initial; history_len entries at most.                    */
+int mi_pcg_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
+                 const mi_solver_controls *controls, int precond,
+                 mi_solver_perf *perf_out, double *residual_history_host, int32_t history_len);
+/* The same PCG as a session, for callers that want to overlap or time it
+ * themselves (bench.py): begin = PCG.C:85-121 (A.psi, rA, normFactor, initial
+ * residual); iterate = enqueue n_iters bodies of the do-loop (PCG.C:133-204) on
+ * the context's stream WITHOUT synchronising -- bodies past convergence are
+ * device-side no-ops, so the result equals the reference loop; end = fetch psi,
+ * solverPerformance and the residual history.  If amul_ms_sum != NULL, every
+ * Amul launch of this call is bracketed by HIP events on the stream and the sum
+ * of their durations is returned (this synchronises).                           */
+int mi_pcg_begin(mi_matrix_t m, const double *psi0_dev, const double *source_dev,
+                 const mi_solver_controls *controls, int precond, int32_t history_len);
+int mi_pcg_iterate(mi_matrix_t m, int32_t n_iters, float *amul_ms_sum);
+int mi_pcg_end(mi_matrix_t m, double *psi_out_dev, mi_solver_perf *perf_out,
+               double *residual_history_host, int32_t history_len);
+
+int mi_pbicg_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
+                   const mi_solver_controls *controls, int precond,
+                   mi_solver_perf *perf_out, double *residual_history_host, int32_t history_len);
+/* replicate_quirk != 0 keeps the reference's psi += omega*yA (PBiCGStab.C:263-270) */
+int mi_pbicgstab_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
+                       const mi_solver_controls *controls, int precond, int replicate_quirk,
+                       mi_solver_perf *perf_out, double *residual_history_host, int32_t history_len);
+int mi_smooth_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
+                    const mi_solver_controls *controls, double omega, int32_t n_sweeps,
+                    mi_solver_perf *perf_out, double *residual_history_host, int32_t history_len);
+
+/* ---- benchmark hooks: run `iters` PCG iterations (engine order, no convergence
+ * exit, same kernels as mi_pcg_solve) and `reps` Amuls back to back, timed with
+ * HIP events on the context's stream; milliseconds returned.                      */
+int mi_bench_amul(mi_matrix_t m, int32_t reps, float *ms_out);
+int mi_bench_pcg_iters(mi_matrix_t m, const double *source_dev, int32_t iters, int precond,
+                       float *ms_out, float *amul_ms_out);
+
+/* ---- host-only layout inspection (no device; used by the CPU-side tests to
+ * verify the tiling by interpreting the tables).  name is one of e2c, c2e,
+ * tileCellStart, tileSlotStart, tileHaloStart, haloCell, tileSliceStart,
+ * sliceEntryStart, entries (uint32), slotFace, extSlot, interiorTiles,
+ * boundaryTiles, patchOffset, patchFaceCellsE, faceSlot (all int32 otherwise). */
+int mi_layout_build_host(int32_t n_cells, int32_t n_faces, const int32_t *lower_addr_host,
+                         const int32_t *upper_addr_host, int32_t n_patches, const int32_t *patch_sizes,
+                         const int32_t *const *patch_face_cells_host, int32_t tile_cells,
+                         int32_t slot_cap, void **layout_out);
+int mi_layout_array(void *layout, const char *name, const void **data, int64_t *len);
+int mi_layout_free(void *layout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_LDU_H */

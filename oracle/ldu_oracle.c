@@ -677,6 +677,10 @@ static scalar *valloc(const orc_system *s) { return (scalar *)calloc((size_t)(s-
 
 static void hist_put(scalar *hist, int histLen, int k, scalar v) { if (hist && k < histLen) hist[k] = v; }
 
+/* Vector updates (lduMatrixSolverFunctors.H:7-44, lduMatrixFunctors.H:186-301) are
+ * written as one fused multiply-add each: a*x+y contracts to an FMA under nvcc's
+ * default -fmad=true, and the HIP engine issues the same fma explicitly.        */
+
 /* PCG: solvers/PCG/PCG.C:68-208.  hist[k] = normalised residual after k
  * iterations (hist[0] = initial).                                           */
 void orc_pcg_solve(const orc_system *s, scalar *psi, const scalar *source,
@@ -706,14 +710,14 @@ void orc_pcg_solve(const orc_system *s, scalar *psi, const scalar *source,
                 memcpy(pA, wA, sizeof(scalar) * (size_t)n);
             } else {
                 scalar beta = wArA / wArAold;
-                for (i = 0; i < n; i++) pA[i] = wA[i] + beta * pA[i];
+                for (i = 0; i < n; i++) pA[i] = fma(beta, pA[i], wA[i]);
             }
             orc_amul(s, pA, wA);
             scalar wApA = g_sum_prod(s, wA, pA);
             if (check_singularity(perf, fabs(wApA) / normFactor)) break;
             scalar alpha = wArA / wApA;
-            for (i = 0; i < n; i++) psi[i] = psi[i] + alpha * pA[i];
-            for (i = 0; i < n; i++) rA[i] = rA[i] - alpha * wA[i];
+            for (i = 0; i < n; i++) psi[i] = fma(alpha, pA[i], psi[i]);
+            for (i = 0; i < n; i++) rA[i] = fma(-alpha, wA[i], rA[i]);
             perf->finalResidual = g_sum_mag(s, rA) / normFactor;
             hist_put(hist, histLen, perf->nIterations + 1, perf->finalResidual);
         } while ((perf->nIterations++ < ctl->maxIter && !check_convergence(perf, ctl)) ||
@@ -755,17 +759,17 @@ void orc_pbicg_solve(const orc_system *s, scalar *psi, const scalar *source,
                 memcpy(pT, wT, sizeof(scalar) * (size_t)n);
             } else {
                 scalar beta = wArT / wArTold;
-                for (i = 0; i < n; i++) pA[i] = wA[i] + beta * pA[i];
-                for (i = 0; i < n; i++) pT[i] = wT[i] + beta * pT[i];
+                for (i = 0; i < n; i++) pA[i] = fma(beta, pA[i], wA[i]);
+                for (i = 0; i < n; i++) pT[i] = fma(beta, pT[i], wT[i]);
             }
             orc_amul(s, pA, wA);
             orc_tmul(s, pT, wT);
             scalar wApT = g_sum_prod(s, wA, pT);
             if (check_singularity(perf, fabs(wApT) / normFactor)) break;
             scalar alpha = wArT / wApT;
-            for (i = 0; i < n; i++) psi[i] = psi[i] + alpha * pA[i];
-            for (i = 0; i < n; i++) rA[i] = rA[i] - alpha * wA[i];
-            for (i = 0; i < n; i++) rT[i] = rT[i] - alpha * wT[i];
+            for (i = 0; i < n; i++) psi[i] = fma(alpha, pA[i], psi[i]);
+            for (i = 0; i < n; i++) rA[i] = fma(-alpha, wA[i], rA[i]);
+            for (i = 0; i < n; i++) rT[i] = fma(-alpha, wT[i], rT[i]);
             perf->finalResidual = g_sum_mag(s, rA) / normFactor;
             hist_put(hist, histLen, perf->nIterations + 1, perf->finalResidual);
         } while ((perf->nIterations++ < ctl->maxIter && !check_convergence(perf, ctl)) ||
@@ -810,18 +814,18 @@ void orc_pbicgstab_solve(const orc_system *s, scalar *psi, const scalar *source,
                 if (check_singularity(perf, fabs(omega))) break;
                 const scalar beta = (rA0rA / rA0rAold) * (alpha / omega);
                 for (i = 0; i < n; i++) {
-                    scalar result1 = pA[i] - omega * AyA[i];
-                    pA[i] = rA[i] + beta * result1;
+                    scalar result1 = fma(-omega, AyA[i], pA[i]);
+                    pA[i] = fma(beta, result1, rA[i]);
                 }
             }
             precondition(s, P, 0, pA, yA);
             orc_amul(s, yA, AyA);
             const scalar rA0AyA = g_sum_prod(s, rA0, AyA);
             alpha = rA0rA / rA0AyA;
-            for (i = 0; i < n; i++) sA[i] = rA[i] - alpha * AyA[i];
+            for (i = 0; i < n; i++) sA[i] = fma(-alpha, AyA[i], rA[i]);
             perf->finalResidual = g_sum_mag(s, sA) / normFactor;
             if (check_convergence(perf, ctl)) {
-                for (i = 0; i < n; i++) psi[i] = psi[i] + alpha * yA[i];
+                for (i = 0; i < n; i++) psi[i] = fma(alpha, yA[i], psi[i]);
                 perf->nIterations++;
                 hist_put(hist, histLen, perf->nIterations, perf->finalResidual);
                 early = 1;
@@ -831,10 +835,10 @@ void orc_pbicgstab_solve(const orc_system *s, scalar *psi, const scalar *source,
             orc_amul(s, zA, tA);
             const scalar tAtA = g_sum_prod(s, tA, tA);
             omega = g_sum_prod(s, tA, sA) / tAtA;
-            for (i = 0; i < n; i++) psi[i] = psi[i] + alpha * yA[i];
-            if (replicateQuirk) for (i = 0; i < n; i++) psi[i] = psi[i] + omega * yA[i];
-            else                for (i = 0; i < n; i++) psi[i] = psi[i] + omega * zA[i];
-            for (i = 0; i < n; i++) rA[i] = sA[i] - omega * tA[i];
+            for (i = 0; i < n; i++) psi[i] = fma(alpha, yA[i], psi[i]);
+            if (replicateQuirk) for (i = 0; i < n; i++) psi[i] = fma(omega, yA[i], psi[i]);
+            else                for (i = 0; i < n; i++) psi[i] = fma(omega, zA[i], psi[i]);
+            for (i = 0; i < n; i++) rA[i] = fma(-omega, tA[i], sA[i]);
             perf->finalResidual = g_sum_mag(s, rA) / normFactor;
             hist_put(hist, histLen, perf->nIterations + 1, perf->finalResidual);
         } while ((perf->nIterations++ < ctl->maxIter && !check_convergence(perf, ctl)) ||

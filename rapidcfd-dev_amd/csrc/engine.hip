@@ -1,0 +1,1054 @@
+// engine.hip -- C-ABI (include/mi_ldu.h) of the MI355X-native lduMatrix engine.
+// Host-side orchestration only; all arithmetic is in kernels.hip.hpp.
+// There is no CPU fallback: without a gfx950 device every compute entry point
+// returns MI_ERR_DEVICE.
+#include "../../include/mi_ldu.h"
+#include "kernels.hip.hpp"
+#include "tiling.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mi;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(MI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+#define MICHK(expr) do { int r__ = (expr); if (r__ != MI_OK) return r__; } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    int alloc(size_t count)
+    {
+        if (count == n && p) return MI_OK;
+        release();
+        if (hipMalloc((void**)&p, (count ? count : 1) * sizeof(T)) != hipSuccess) { p = nullptr; return fail(MI_ERR_ALLOC, "hipMalloc failed"); }
+        n = count;
+        return MI_OK;
+    }
+    int upload(const std::vector<T>& v, hipStream_t s)
+    {
+        MICHK(alloc(v.size()));
+        if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        return MI_OK;
+    }
+};
+
+int env_int(const char* name, int def)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : def;
+}
+
+} // namespace
+
+struct mi_ctx_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    DevBuf<double> partial;  // 4 * RG
+    DevBuf<double> scalars;  // small device scalars
+    DevBuf<PcgState> state;
+    PcgState* hostState = nullptr; // pinned
+    double* hostScal = nullptr;    // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int amulBS = 256;
+};
+
+struct mi_addr_s {
+    mi_ctx_s* ctx = nullptr;
+    TileLayout L; // host copy (big vectors are dropped after upload except the permutations)
+    DevBuf<int32_t> e2c, c2e, tileCellStart, tileSlotStart, tileHaloStart, haloCell, tileSliceStart, sliceEntryStart;
+    DevBuf<uint32_t> entries;
+    DevBuf<int32_t> slotFace, extSlot, interiorTiles, boundaryTiles, patchFaceCellsE, faceSlot, lowerAddr, upperAddr;
+    std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
+    int32_t nInterior = 0, nBoundary = 0;
+    int64_t nEntries = 0, nHaloTot = 0;
+};
+
+struct mi_matrix_s {
+    mi_addr_s* addr = nullptr;
+    DevBuf<double> diagE, upE, lowE, rD;
+    bool asym = false, bound = false, rDValid = false;
+    std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
+    DevBuf<double> hist;
+    int histLen = 0;
+    // running PCG session (mi_pcg_begin/iterate/end)
+    int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
+    bool pcgActive = false;
+    std::vector<hipEvent_t> evPool;
+    ~mi_matrix_s() { for (auto* w : work) delete w; for (auto e : evPool) (void)hipEventDestroy(e); }
+    int vec(size_t k, double** out)
+    {
+        while (work.size() <= k) work.push_back(new DevBuf<double>());
+        const size_t need = (size_t)addr->L.nCells + (size_t)addr->L.nExt;
+        if (work[k]->n != need) {
+            MICHK(work[k]->alloc(need));
+            HIPCHK(hipMemsetAsync(work[k]->p, 0, need * sizeof(double), addr->ctx->stream));
+        }
+        *out = work[k]->p;
+        return MI_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mi_device_available(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
+{
+    if (!out) return fail(MI_ERR_ARG, "out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MI_ERR_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+    if (device < 0 || device >= n) return fail(MI_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MI_ERR_DEVICE, std::string("engine is built for gfx950 only, found ") + prop.gcnArchName);
+    mi_ctx_s* c = new mi_ctx_s();
+    c->device = device;
+    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(MI_ERR_DEVICE, "hipStreamCreate failed"); } c->ownStream = true; }
+    int r = c->partial.alloc(4 * RG);
+    if (r == MI_OK) r = c->scalars.alloc(16);
+    if (r == MI_OK) r = c->state.alloc(1);
+    if (r != MI_OK) { delete c; return r; }
+    if (hipHostMalloc((void**)&c->hostState, sizeof(PcgState)) != hipSuccess ||
+        hipHostMalloc((void**)&c->hostScal, 16 * sizeof(double)) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c; return fail(MI_ERR_DEVICE, "pinned host / event allocation failed");
+    }
+    c->amulBS = env_int("MI_AMUL_BS", 256);
+    if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 256;
+    *out = c;
+    return MI_OK;
+}
+
+extern "C" int mi_ctx_destroy(mi_ctx_t c)
+{
+    if (!c) return MI_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->hostState) (void)hipHostFree(c->hostState);
+    if (c->hostScal) (void)hipHostFree(c->hostScal);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ownStream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return MI_OK;
+}
+
+extern "C" int mi_ctx_synchronize(mi_ctx_t c)
+{
+    if (!c) return fail(MI_ERR_ARG, "ctx is NULL");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// addressing
+// ---------------------------------------------------------------------------
+extern "C" int mi_addr_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
+                              const int32_t* lower, const int32_t* upper, int32_t n_patches,
+                              const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
+                              mi_addr_t* out)
+{
+    if (!ctx || !out || (n_faces > 0 && (!lower || !upper)) || n_patches < 0)
+        return fail(MI_ERR_ARG, "mi_addr_create: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    mi_addr_s* a = new mi_addr_s();
+    a->ctx = ctx;
+    TileParams prm;
+    prm.tileCells = env_int("MI_TILE_CELLS", 1024);
+    prm.slotCap = env_int("MI_TILE_SLOTS", 4094);
+    const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L);
+    if (!err.empty()) { delete a; return fail(MI_ERR_LIMIT, "mi_addr_create: " + err); }
+    TileLayout& L = a->L;
+    hipStream_t s = ctx->stream;
+    int r = MI_OK;
+#define UP(buf, vec) if (r == MI_OK) r = a->buf.upload(vec, s)
+    UP(e2c, L.e2c); UP(c2e, L.c2e); UP(tileCellStart, L.tileCellStart); UP(tileSlotStart, L.tileSlotStart);
+    UP(tileHaloStart, L.tileHaloStart); UP(haloCell, L.haloCell); UP(tileSliceStart, L.tileSliceStart);
+    UP(sliceEntryStart, L.sliceEntryStart); UP(entries, L.entries); UP(slotFace, L.slotFace);
+    UP(extSlot, L.extSlot); UP(interiorTiles, L.interiorTiles); UP(boundaryTiles, L.boundaryTiles);
+    UP(patchFaceCellsE, L.patchFaceCellsE); UP(faceSlot, L.faceSlot);
+#undef UP
+    if (r != MI_OK) { delete a; return r; }
+    if (hipStreamSynchronize(s) != hipSuccess) { delete a; return fail(MI_ERR_DEVICE, "upload failed"); }
+    a->nInterior = (int32_t)L.interiorTiles.size();
+    a->nBoundary = (int32_t)L.boundaryTiles.size();
+    a->nEntries = (int64_t)L.entries.size();
+    a->nHaloTot = (int64_t)L.haloCell.size();
+    a->lowerHost.assign(lower, lower + n_faces);
+    a->upperHost.assign(upper, upper + n_faces);
+    // drop the big host tables that only the device needs
+    std::vector<uint32_t>().swap(L.entries);
+    std::vector<int32_t>().swap(L.slotFace);
+    std::vector<int32_t>().swap(L.haloCell);
+    std::vector<int32_t>().swap(L.sliceEntryStart);
+    std::vector<int32_t>().swap(L.faceSlot);
+    *out = a;
+    return MI_OK;
+}
+
+extern "C" int mi_addr_destroy(mi_addr_t a) { delete a; return MI_OK; }
+extern "C" int32_t mi_addr_n_cells(mi_addr_t a) { return a ? a->L.nCells : 0; }
+extern "C" int32_t mi_addr_n_faces(mi_addr_t a) { return a ? a->L.nFaces : 0; }
+extern "C" int32_t mi_addr_n_tiles(mi_addr_t a) { return a ? a->L.nTiles : 0; }
+extern "C" int32_t mi_addr_n_ext(mi_addr_t a) { return a ? a->L.nExt : 0; }
+
+extern "C" int mi_addr_cell_perm(mi_addr_t a, int32_t* e2c_host)
+{
+    if (!a || !e2c_host) return fail(MI_ERR_ARG, "mi_addr_cell_perm: bad argument");
+    memcpy(e2c_host, a->L.e2c.data(), sizeof(int32_t) * (size_t)a->L.nCells);
+    return MI_OK;
+}
+
+extern "C" int mi_addr_patch_offsets(mi_addr_t a, int32_t* off)
+{
+    if (!a || !off) return fail(MI_ERR_ARG, "mi_addr_patch_offsets: bad argument");
+    memcpy(off, a->L.patchOffset.data(), sizeof(int32_t) * a->L.patchOffset.size());
+    return MI_OK;
+}
+
+static size_t lds_bytes(const TileLayout& L, bool asym, bool ainv, int32_t* offLow, int32_t* offX, int32_t* offRD)
+{
+    const int32_t slots = (L.maxSlots + 3) & ~1; // even
+    const int32_t xlen = ((L.maxCells + 63) & ~63) + L.maxHalo + 2;
+    int32_t off = slots;
+    *offLow = off; if (asym) off += slots;
+    *offX = off; off += (xlen + 1) & ~1;
+    *offRD = off; if (ainv) off += (xlen + 1) & ~1;
+    return (size_t)off * sizeof(double);
+}
+
+extern "C" int mi_addr_stats(mi_addr_t a, int64_t st[8])
+{
+    if (!a || !st) return fail(MI_ERR_ARG, "mi_addr_stats: bad argument");
+    int32_t o1, o2, o3;
+    st[0] = a->L.nTiles; st[1] = a->L.totalSlots; st[2] = a->nEntries; st[3] = a->nHaloTot;
+    st[4] = a->L.maxCells; st[5] = a->L.maxSlots; st[6] = a->L.maxHalo;
+    st[7] = (int64_t)lds_bytes(a->L, false, false, &o1, &o2, &o3);
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// matrix
+// ---------------------------------------------------------------------------
+extern "C" int mi_matrix_create(mi_addr_t a, mi_matrix_t* out)
+{
+    if (!a || !out) return fail(MI_ERR_ARG, "mi_matrix_create: bad argument");
+    HIPCHK(hipSetDevice(a->ctx->device));
+    mi_matrix_s* m = new mi_matrix_s();
+    m->addr = a;
+    int r = m->diagE.alloc((size_t)a->L.nCells);
+    if (r == MI_OK) r = m->upE.alloc((size_t)a->L.totalSlots);
+    if (r != MI_OK) { delete m; return r; }
+    if (hipMemsetAsync(m->upE.p, 0, sizeof(double) * (size_t)a->L.totalSlots, a->ctx->stream) != hipSuccess) { delete m; return fail(MI_ERR_DEVICE, "memset failed"); }
+    *out = m;
+    return MI_OK;
+}
+
+extern "C" int mi_matrix_destroy(mi_matrix_t m)
+{
+    if (m) { (void)hipSetDevice(m->addr->ctx->device); (void)hipStreamSynchronize(m->addr->ctx->stream); delete m; }
+    return MI_OK;
+}
+
+extern "C" int mi_matrix_set_coeffs(mi_matrix_t m, const double* diag, const double* upper, const double* lower)
+{
+    if (!m || !diag || (!upper && m->addr->L.nFaces > 0)) return fail(MI_ERR_ARG, "mi_matrix_set_coeffs: bad argument");
+    mi_addr_s* a = m->addr;
+    hipStream_t s = a->ctx->stream;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    const bool asym = (lower != nullptr);
+    if (asym && m->lowE.n != (size_t)a->L.totalSlots) {
+        MICHK(m->lowE.alloc((size_t)a->L.totalSlots));
+        // interface slots of a previously symmetric matrix: lower side mirrors upper until re-set
+        HIPCHK(hipMemcpyAsync(m->lowE.p, m->upE.p, sizeof(double) * (size_t)a->L.totalSlots, hipMemcpyDeviceToDevice, s));
+    }
+    m->asym = asym;
+    k_gather_perm<<<RG, RB, 0, s>>>(diag, a->e2c.p, m->diagE.p, a->L.nCells);
+    k_fill_slots<<<2048, 256, 0, s>>>(upper, lower, a->slotFace.p, m->upE.p, asym ? m->lowE.p : nullptr, a->L.totalSlots);
+    HIPCHK(hipGetLastError());
+    m->bound = true;
+    m->rDValid = false;
+    return MI_OK;
+}
+
+extern "C" int mi_matrix_set_interface_coeffs(mi_matrix_t m, int32_t patch, const double* bou, const double* inte)
+{
+    if (!m || !bou || patch < 0 || patch >= m->addr->L.nPatches) return fail(MI_ERR_ARG, "mi_matrix_set_interface_coeffs: bad argument");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    const int32_t off = a->L.patchOffset[patch], n = a->L.patchOffset[(size_t)patch + 1] - off;
+    if (n == 0) return MI_OK;
+    k_fill_iface<<<(n + 255) / 256, 256, 0, a->ctx->stream>>>(bou, inte, a->extSlot.p + off, m->upE.p, m->asym ? m->lowE.p : nullptr, n);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tile kernel launch
+// ---------------------------------------------------------------------------
+namespace {
+
+template <int OP, bool ASYM, bool TRANS>
+int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
+{
+    hipStream_t s = m->addr->ctx->stream;
+    const int bs = m->addr->ctx->amulBS;
+    if (nTiles <= 0) return MI_OK;
+#define MI_LAUNCH(BS)                                                                                                   \
+    {                                                                                                                   \
+        static bool attr##BS = false;                                                                                   \
+        if (!attr##BS) {                                                                                                \
+            HIPCHK(hipFuncSetAttribute((const void*)tile_kernel<OP, ASYM, TRANS, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr##BS = true;                                                                                            \
+        }                                                                                                               \
+        tile_kernel<OP, ASYM, TRANS, BS><<<nTiles, BS, lds, s>>>(args);                                                 \
+    }
+    if (bs == 1024) MI_LAUNCH(1024)
+    else if (bs == 512) MI_LAUNCH(512)
+    else MI_LAUNCH(256)
+#undef MI_LAUNCH
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+// which: 0 all tiles, 1 interior only, 2 boundary only
+template <int OP>
+int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, const double* rD, double* y,
+                double omega, int which)
+{
+    mi_addr_s* a = m->addr;
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound (mi_matrix_set_coeffs)");
+    TileArgs t;
+    t.tileCellStart = a->tileCellStart.p; t.tileSlotStart = a->tileSlotStart.p; t.tileHaloStart = a->tileHaloStart.p;
+    t.haloCell = a->haloCell.p; t.tileSliceStart = a->tileSliceStart.p; t.sliceEntryStart = a->sliceEntryStart.p;
+    t.entries = a->entries.p;
+    t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
+    t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega;
+    const size_t lds = lds_bytes(a->L, m->asym, OP == OP_AINV, &t.offLow, &t.offX, &t.offRD);
+    if (lds > 160 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 160 KiB of LDS");
+    int nTiles = a->L.nTiles;
+    t.tileList = nullptr;
+    if (which == 1) { t.tileList = a->interiorTiles.p; nTiles = a->nInterior; }
+    else if (which == 2) { t.tileList = a->boundaryTiles.p; nTiles = a->nBoundary; }
+    if (m->asym) {
+        if (trans) return launch_tile_bs<OP, true, true>(m, t, nTiles, lds);
+        return launch_tile_bs<OP, true, false>(m, t, nTiles, lds);
+    }
+    return launch_tile_bs<OP, false, false>(m, t, nTiles, lds);
+}
+
+int ensure_rD(mi_matrix_s* m)
+{
+    if (m->rDValid) return MI_OK;
+    mi_addr_s* a = m->addr;
+    const size_t need = (size_t)a->L.nCells + (size_t)a->L.nExt;
+    if (m->rD.n != need) {
+        MICHK(m->rD.alloc(need));
+        HIPCHK(hipMemsetAsync(m->rD.p, 0, need * sizeof(double), a->ctx->stream));
+    }
+    k_recip<<<RG, RB, 0, a->ctx->stream>>>(m->rD.p, m->diagE.p, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    m->rDValid = true;
+    return MI_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// layout helpers, halo
+// ---------------------------------------------------------------------------
+extern "C" int mi_vec_to_engine(mi_addr_t a, const double* x, double* xe)
+{
+    if (!a || !x || !xe) return fail(MI_ERR_ARG, "mi_vec_to_engine: bad argument");
+    HIPCHK(hipSetDevice(a->ctx->device));
+    k_gather_perm<<<RG, RB, 0, a->ctx->stream>>>(x, a->e2c.p, xe, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_vec_from_engine(mi_addr_t a, const double* xe, double* x)
+{
+    if (!a || !x || !xe) return fail(MI_ERR_ARG, "mi_vec_from_engine: bad argument");
+    HIPCHK(hipSetDevice(a->ctx->device));
+    k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(xe, a->e2c.p, x, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_halo_pack_engine(mi_addr_t a, const double* xe, double* send)
+{
+    if (!a || !xe || (!send && a->L.nExt > 0)) return fail(MI_ERR_ARG, "mi_halo_pack_engine: bad argument");
+    if (a->L.nExt == 0) return MI_OK;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    k_halo_pack<<<(a->L.nExt + 255) / 256, 256, 0, a->ctx->stream>>>(xe, a->patchFaceCellsE.p, send, a->L.nExt);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// SpMV family
+// ---------------------------------------------------------------------------
+extern "C" int mi_amul_engine(mi_matrix_t m, const double* psi_e, double* Apsi_e, int which)
+{
+    if (!m || !psi_e || !Apsi_e) return fail(MI_ERR_ARG, "mi_amul_engine: bad argument");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    return launch_tile<OP_AMUL>(m, false, psi_e, nullptr, nullptr, Apsi_e, 0.0, which);
+}
+extern "C" int mi_tmul_engine(mi_matrix_t m, const double* psi_e, double* Tpsi_e, int which)
+{
+    if (!m || !psi_e || !Tpsi_e) return fail(MI_ERR_ARG, "mi_tmul_engine: bad argument");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    return launch_tile<OP_AMUL>(m, true, psi_e, nullptr, nullptr, Tpsi_e, 0.0, which);
+}
+
+extern "C" int mi_matrix_set_ext(mi_matrix_t m, const double* ext)
+{
+    if (!m) return fail(MI_ERR_ARG, "mi_matrix_set_ext: bad argument");
+    const int32_t nExt = m->addr->L.nExt;
+    if (nExt == 0) return MI_OK;
+    if (!ext) return fail(MI_ERR_ARG, "mi_matrix_set_ext: ext is NULL");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    double* v0;
+    MICHK(m->vec(0, &v0));
+    HIPCHK(hipMemcpyAsync(v0 + m->addr->L.nCells, ext, sizeof(double) * (size_t)nExt, hipMemcpyDeviceToDevice, m->addr->ctx->stream));
+    return MI_OK;
+}
+
+namespace {
+// caller-order wrapper: x -> engine (work 0, keeps the ext tail), op -> work 1, -> caller
+template <int OP>
+int caller_op(mi_matrix_s* m, bool trans, const double* x, const double* b, double* y)
+{
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    double *v0, *v1, *v2 = nullptr;
+    MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1));
+    if (x) k_gather_perm<<<RG, RB, 0, s>>>(x, a->e2c.p, v0, a->L.nCells);
+    if (b) { MICHK(m->vec(2, &v2)); k_gather_perm<<<RG, RB, 0, s>>>(b, a->e2c.p, v2, a->L.nCells); }
+    MICHK(launch_tile<OP>(m, trans, v0, v2, nullptr, v1, 0.0, 0));
+    k_scatter_perm<<<RG, RB, 0, s>>>(v1, a->e2c.p, y, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+} // namespace
+
+extern "C" int mi_amul(mi_matrix_t m, const double* psi, double* Apsi)
+{
+    if (!m || !psi || !Apsi) return fail(MI_ERR_ARG, "mi_amul: bad argument");
+    return caller_op<OP_AMUL>(m, false, psi, nullptr, Apsi);
+}
+extern "C" int mi_tmul(mi_matrix_t m, const double* psi, double* Tpsi)
+{
+    if (!m || !psi || !Tpsi) return fail(MI_ERR_ARG, "mi_tmul: bad argument");
+    return caller_op<OP_AMUL>(m, true, psi, nullptr, Tpsi);
+}
+extern "C" int mi_sumA(mi_matrix_t m, double* sumA)
+{
+    if (!m || !sumA) return fail(MI_ERR_ARG, "mi_sumA: bad argument");
+    return caller_op<OP_SUMA>(m, false, nullptr, nullptr, sumA);
+}
+extern "C" int mi_residual(mi_matrix_t m, const double* psi, const double* source, double* rA)
+{
+    if (!m || !psi || !source || !rA) return fail(MI_ERR_ARG, "mi_residual: bad argument");
+    return caller_op<OP_RESIDUAL>(m, false, psi, source, rA);
+}
+extern "C" int mi_H(mi_matrix_t m, const double* psi, double* H)
+{
+    if (!m || !psi || !H) return fail(MI_ERR_ARG, "mi_H: bad argument");
+    return caller_op<OP_H>(m, false, psi, nullptr, H);
+}
+extern "C" int mi_H1(mi_matrix_t m, double* H1)
+{
+    if (!m || !H1) return fail(MI_ERR_ARG, "mi_H1: bad argument");
+    return caller_op<OP_H1>(m, false, nullptr, nullptr, H1);
+}
+
+extern "C" int mi_faceH(mi_matrix_t m, const double* psi, double* faceH)
+{
+    if (!m || !psi || !faceH) return fail(MI_ERR_ARG, "mi_faceH: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    if (a->lowerAddr.n != (size_t)a->L.nFaces) { MICHK(a->lowerAddr.upload(a->lowerHost, s)); MICHK(a->upperAddr.upload(a->upperHost, s)); }
+    const int nF = a->L.nFaces;
+    if (nF == 0) return MI_OK;
+    k_faceH<<<2048, 256, 0, s>>>(psi, a->lowerAddr.p, a->upperAddr.p, a->faceSlot.p, m->upE.p, m->asym ? m->lowE.p : m->upE.p, faceH, nF);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_precondition(mi_matrix_t m, int kind, int transpose, const double* rA, double* wA)
+{
+    if (!m || !rA || !wA) return fail(MI_ERR_ARG, "mi_precondition: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    double *v0, *v1;
+    MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1));
+    k_gather_perm<<<RG, RB, 0, s>>>(rA, a->e2c.p, v0, a->L.nCells);
+    if (kind == MI_PRECOND_NONE) {
+        HIPCHK(hipMemcpyAsync(v1, v0, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s));
+    } else if (kind == MI_PRECOND_DIAGONAL) {
+        MICHK(ensure_rD(m));
+        k_mul<<<RG, RB, 0, s>>>(v1, m->rD.p, v0, a->L.nCells);
+    } else if (kind == MI_PRECOND_AINV) {
+        MICHK(ensure_rD(m));
+        MICHK(launch_tile<OP_AINV>(m, transpose != 0, v0, nullptr, m->rD.p, v1, 0.0, 0));
+    } else return fail(MI_ERR_ARG, "unknown preconditioner kind");
+    k_scatter_perm<<<RG, RB, 0, s>>>(v1, a->e2c.p, wA, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_jacobi_smooth(mi_matrix_t m, double omega, double* psi, const double* source, int32_t n_sweeps)
+{
+    if (!m || !psi || !source || n_sweeps < 0) return fail(MI_ERR_ARG, "mi_jacobi_smooth: bad argument");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    double *v0, *v1, *v2;
+    MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1)); MICHK(m->vec(2, &v2));
+    k_gather_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, v0, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, v2, a->L.nCells);
+    double *cur = v0, *nxt = v1;
+    for (int sw = 0; sw < n_sweeps; ++sw) {
+        // ping-pong instead of the reference's `psi = Apsi` copy (JacobiSmoother.C:146)
+        if (a->L.nExt > 0 && sw > 0)
+            HIPCHK(hipMemcpyAsync(cur + a->L.nCells, nxt + a->L.nCells, sizeof(double) * (size_t)a->L.nExt, hipMemcpyDeviceToDevice, s));
+        MICHK(launch_tile<OP_JACOBI>(m, false, cur, v2, nullptr, nxt, omega, 0));
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    k_scatter_perm<<<RG, RB, 0, s>>>(cur, a->e2c.p, psi, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// reductions (host result)
+// ---------------------------------------------------------------------------
+namespace {
+template <int KIND>
+int reduce_host(mi_ctx_s* c, const double* a, const double* b, int64_t n, double* out)
+{
+    if (!c || !a || !out || n < 0) return fail(MI_ERR_ARG, "reduction: bad argument");
+    if (!aligned16(a) || (b && !aligned16(b))) return fail(MI_ERR_ARG, "reduction inputs must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    k_reduce<KIND><<<RG, RB, 0, c->stream>>>(a, b, n, c->partial.p);
+    k_reduce_final<<<1, RB, 0, c->stream>>>(c->partial.p, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->hostScal, c->scalars.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c->hostScal[0];
+    return MI_OK;
+}
+} // namespace
+
+extern "C" int mi_sum(mi_ctx_t c, const double* a, int64_t n, double* out) { return reduce_host<RED_SUM>(c, a, nullptr, n, out); }
+extern "C" int mi_sum_prod(mi_ctx_t c, const double* a, const double* b, int64_t n, double* out)
+{
+    if (!b) return fail(MI_ERR_ARG, "mi_sum_prod: b is NULL");
+    return reduce_host<RED_PROD>(c, a, b, n, out);
+}
+extern "C" int mi_sum_mag(mi_ctx_t c, const double* a, int64_t n, double* out) { return reduce_host<RED_MAG>(c, a, nullptr, n, out); }
+
+// ---------------------------------------------------------------------------
+// solvers
+// ---------------------------------------------------------------------------
+namespace {
+
+// engine-order preconditioner application
+int precond_engine(mi_matrix_s* m, int kind, bool transpose, const double* r, double* w)
+{
+    mi_addr_s* a = m->addr;
+    hipStream_t s = a->ctx->stream;
+    const int64_t n = a->L.nCells;
+    if (kind == MI_PRECOND_NONE) { HIPCHK(hipMemcpyAsync(w, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s)); return MI_OK; }
+    MICHK(ensure_rD(m));
+    if (kind == MI_PRECOND_DIAGONAL) { k_mul<<<RG, RB, 0, s>>>(w, m->rD.p, r, n); HIPCHK(hipGetLastError()); return MI_OK; }
+    if (kind == MI_PRECOND_AINV) return launch_tile<OP_AINV>(m, transpose, r, nullptr, m->rD.p, w, 0.0, 0);
+    return fail(MI_ERR_ARG, "unknown preconditioner kind");
+}
+
+// host-visible scalar reduction on engine vectors
+template <int KIND>
+int reduce_sync(mi_matrix_s* m, const double* a, const double* b, double* out)
+{
+    mi_ctx_s* c = m->addr->ctx;
+    k_reduce<KIND><<<RG, RB, 0, c->stream>>>(a, b, (int64_t)m->addr->L.nCells, c->partial.p);
+    k_reduce_final<<<1, RB, 0, c->stream>>>(c->partial.p, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->hostScal, c->scalars.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c->hostScal[0];
+    return MI_OK;
+}
+
+// common start of every solver (PCG.C:91-121 and siblings): given psi_e, src_e:
+//   wA = A psi ; rA = src - wA ; normFactor ; initial residual ; convergence test.
+// Leaves the result in the device PcgState; tmp is scratch (the reference passes pA).
+int solve_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* psi_e, const double* src_e,
+                   double* wA, double* rA, double* tmp, int histLen)
+{
+    mi_addr_s* a = m->addr;
+    mi_ctx_s* c = a->ctx;
+    hipStream_t s = c->stream;
+    const int64_t n = a->L.nCells;
+    if (m->hist.n < (size_t)(histLen > 0 ? histLen : 1)) MICHK(m->hist.alloc((size_t)(histLen > 0 ? histLen : 1)));
+    m->histLen = histLen;
+    PcgState h;
+    memset(&h, 0, sizeof(h));
+    h.tolerance = ctl->tolerance; h.relTol = ctl->relTol; h.maxIter = ctl->maxIter; h.minIter = ctl->minIter;
+    *c->hostState = h;
+    HIPCHK(hipMemcpyAsync(c->state.p, c->hostState, sizeof(PcgState), hipMemcpyHostToDevice, s));
+    MICHK(launch_tile<OP_AMUL>(m, false, psi_e, nullptr, nullptr, wA, 0.0, 0));
+    k_sub<<<RG, RB, 0, s>>>(rA, src_e, wA, n);
+    MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, tmp, 0.0, 0));
+    // gAverage(psi) (gpuFieldCommonFunctions.C:611-634): needs the host for the division by N
+    double sumPsi = 0;
+    MICHK(reduce_sync<RED_SUM>(m, psi_e, nullptr, &sumPsi));
+    const double avg = sumPsi / (double)n;
+    k_normfactor<<<RG, RB, 0, s>>>(wA, src_e, tmp, avg, n, c->partial.p);
+    k_reduce<RED_MAG><<<RG, RB, 0, s>>>(rA, nullptr, n, c->partial.p + RG);
+    k_solve_init<<<1, RB, 0, s>>>(c->state.p, c->partial.p, c->partial.p + RG, m->hist.p, histLen);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+int fetch_state(mi_ctx_s* c)
+{
+    HIPCHK(hipMemcpyAsync(c->hostState, c->state.p, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+void fill_perf(const PcgState& h, mi_solver_perf* p)
+{
+    p->initialResidual = h.initialResidual; p->finalResidual = h.finalResidual; p->normFactor = h.normFactor;
+    p->nIterations = h.nIterations; p->converged = h.converged; p->singular = h.singular; p->reserved = 0;
+}
+
+int copy_hist(mi_matrix_s* m, double* hist_host, int len, int nIter)
+{
+    if (!hist_host || len <= 0) return MI_OK;
+    int cnt = nIter + 1; if (cnt > len) cnt = len; if (cnt > m->histLen) cnt = m->histLen;
+    if (cnt > 0) {
+        HIPCHK(hipMemcpyAsync(hist_host, m->hist.p, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, m->addr->ctx->stream));
+        HIPCHK(hipStreamSynchronize(m->addr->ctx->stream));
+    }
+    return MI_OK;
+}
+
+// enqueue PCG iteration bodies it0 .. it0+count-1 (no host sync)
+int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool timeAmul)
+{
+    mi_addr_s* a = m->addr;
+    mi_ctx_s* c = a->ctx;
+    hipStream_t s = c->stream;
+    const int64_t n = a->L.nCells;
+    double *psi, *src, *pA, *wA, *rA;
+    MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
+    double* P1 = c->partial.p; double* P2 = c->partial.p + RG; double* P3 = c->partial.p + 2 * RG;
+    if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
+    for (int it = it0; it < it0 + count; ++it) {
+        if (precond == MI_PRECOND_AINV) {
+            MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0));
+            k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rA, n, P1); // not gated by done: harmless, P1 unused afterwards
+        } else if (precond == MI_PRECOND_DIAGONAL) {
+            k_pcg_precond_dot<true><<<RG, RB, 0, s>>>(c->state.p, m->rD.p, rA, wA, n, P1);
+        } else {
+            k_pcg_precond_dot<false><<<RG, RB, 0, s>>>(c->state.p, nullptr, rA, wA, n, P1);
+        }
+        k_pcg_update_p<<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, pA, n);
+        if (timeAmul) {
+            while (m->evPool.size() < (size_t)(2 * (it - it0 + 1))) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); m->evPool.push_back(e); }
+            HIPCHK(hipEventRecord(m->evPool[(size_t)2 * (it - it0)], s));
+        }
+        MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0));
+        if (timeAmul) HIPCHK(hipEventRecord(m->evPool[(size_t)2 * (it - it0) + 1], s));
+        k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, pA, n, P2);
+        k_pcg_update_psi_r<<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, psi, rA, n, P3);
+        k_pcg_final<<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
+    }
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+} // namespace
+
+// ---- PCG session API (used by mi_pcg_solve and by bench.py) ----------------
+extern "C" int mi_pcg_begin(mi_matrix_t m, const double* psi0, const double* source,
+                            const mi_solver_controls* ctl, int precond, int32_t history_len)
+{
+    if (!m || !psi0 || !source || !ctl) return fail(MI_ERR_ARG, "mi_pcg_begin: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    double *psi, *src, *pA, *wA, *rA;
+    MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
+    k_gather_perm<<<RG, RB, 0, s>>>(psi0, a->e2c.p, psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    MICHK(solve_prologue(m, ctl, psi, src, wA, rA, pA, history_len));
+    m->pcgIt = 0; m->pcgPrecond = precond; m->pcgActive = true;
+    return MI_OK;
+}
+
+extern "C" int mi_pcg_iterate(mi_matrix_t m, int32_t n_iters, float* amul_ms_sum)
+{
+    if (!m || !m->pcgActive || n_iters < 0) return fail(MI_ERR_STATE, "mi_pcg_iterate: no active PCG session");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    MICHK(pcg_enqueue(m, m->pcgIt, n_iters, m->pcgPrecond, amul_ms_sum != nullptr));
+    m->pcgIt += n_iters;
+    if (amul_ms_sum) {
+        HIPCHK(hipStreamSynchronize(m->addr->ctx->stream));
+        float tot = 0;
+        for (int i = 0; i < n_iters; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, m->evPool[(size_t)2 * i], m->evPool[(size_t)2 * i + 1])); tot += ms; }
+        *amul_ms_sum = tot;
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_pcg_end(mi_matrix_t m, double* psi_out, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
+{
+    if (!m || !m->pcgActive) return fail(MI_ERR_STATE, "mi_pcg_end: no active PCG session");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    double* psi;
+    MICHK(m->vec(3, &psi));
+    if (psi_out) k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(psi, a->e2c.p, psi_out, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    MICHK(fetch_state(a->ctx));
+    if (perf) fill_perf(*a->ctx->hostState, perf);
+    MICHK(copy_hist(m, hist_host, hist_len, a->ctx->hostState->nIterations));
+    m->pcgActive = false;
+    return MI_OK;
+}
+
+extern "C" int mi_pcg_solve(mi_matrix_t m, double* psi, const double* source, const mi_solver_controls* ctl,
+                            int precond, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
+{
+    if (!m || !psi || !source || !ctl) return fail(MI_ERR_ARG, "mi_pcg_solve: bad argument");
+    const int histLen = ctl->maxIter + 2;
+    MICHK(mi_pcg_begin(m, psi, source, ctl, precond, histLen));
+    mi_ctx_s* c = m->addr->ctx;
+    MICHK(fetch_state(c));
+    const int batch = env_int("MI_PCG_BATCH", 16);
+    // bodies run for it = 0 .. maxIter inclusive at most (nIterations++ < maxIter, PCG.C:197-204)
+    while (!c->hostState->done && m->pcgIt <= ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0)) {
+        MICHK(mi_pcg_iterate(m, batch, nullptr));
+        MICHK(fetch_state(c));
+    }
+    return mi_pcg_end(m, psi, perf, hist_host, hist_len);
+}
+
+// ---- host-synchronous Krylov solvers for the asymmetric path -----------------
+namespace {
+struct HostPerf {
+    double initialResidual = 0, finalResidual = 0, normFactor = 0;
+    int nIterations = 0, converged = 0, singular = 0;
+    double tolerance, relTol; int maxIter, minIter;
+    bool checkConvergence()
+    {
+        converged = (finalResidual < tolerance) || (relTol > SP_SMALL && finalResidual < relTol * initialResidual);
+        return converged != 0;
+    }
+    bool checkSingularity(double v) { singular = (v < SP_VSMALL); return singular != 0; }
+};
+
+int finish_host(mi_matrix_s* m, const HostPerf& hp, const std::vector<double>& hist, double* psi_e, double* psi_out,
+                mi_solver_perf* perf, double* hist_host, int hist_len)
+{
+    mi_addr_s* a = m->addr;
+    k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(psi_e, a->e2c.p, psi_out, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(a->ctx->stream));
+    if (perf) {
+        perf->initialResidual = hp.initialResidual; perf->finalResidual = hp.finalResidual; perf->normFactor = hp.normFactor;
+        perf->nIterations = hp.nIterations; perf->converged = hp.converged; perf->singular = hp.singular; perf->reserved = 0;
+    }
+    if (hist_host) for (int i = 0; i < hist_len && i < (int)hist.size(); ++i) hist_host[i] = hist[(size_t)i];
+    return MI_OK;
+}
+
+int host_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* psi_e, const double* src_e,
+                  double* wA, double* rA, double* tmp, HostPerf& hp, std::vector<double>& hist)
+{
+    MICHK(solve_prologue(m, ctl, psi_e, src_e, wA, rA, tmp, 1));
+    MICHK(fetch_state(m->addr->ctx));
+    const PcgState& h = *m->addr->ctx->hostState;
+    hp.tolerance = ctl->tolerance; hp.relTol = ctl->relTol; hp.maxIter = ctl->maxIter; hp.minIter = ctl->minIter;
+    hp.normFactor = h.normFactor; hp.initialResidual = h.initialResidual; hp.finalResidual = h.finalResidual;
+    hist.clear(); hist.push_back(hp.initialResidual);
+    return MI_OK;
+}
+} // namespace
+
+extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* source, const mi_solver_controls* ctl,
+                              int precond, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
+{
+    if (!m || !psi_io || !source || !ctl) return fail(MI_ERR_ARG, "mi_pbicg_solve: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    const int64_t n = a->L.nCells;
+    double *psi, *src, *pA, *wA, *rA, *pT, *wT, *rT;
+    MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
+    MICHK(m->vec(8, &pT)); MICHK(m->vec(9, &wT)); MICHK(m->vec(10, &rT));
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    HostPerf hp; std::vector<double> hist;
+    MICHK(host_prologue(m, ctl, psi, src, wA, rA, pA, hp, hist));
+    MICHK(launch_tile<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0, 0));
+    k_sub<<<RG, RB, 0, s>>>(rT, src, wT, n);
+    double wArT = SP_GREAT, wArTold = wArT;
+    if (hp.minIter > 0 || !hp.checkConvergence()) {
+        do {
+            wArTold = wArT;
+            MICHK(precond_engine(m, precond, false, rA, wA));
+            MICHK(precond_engine(m, precond, true, rT, wT));
+            MICHK(reduce_sync<RED_PROD>(m, wA, rT, &wArT));
+            if (hp.nIterations == 0) {
+                HIPCHK(hipMemcpyAsync(pA, wA, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(pT, wT, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+            } else {
+                const double beta = wArT / wArTold;
+                k_xpsy<<<RG, RB, 0, s>>>(pA, wA, beta, pA, n);
+                k_xpsy<<<RG, RB, 0, s>>>(pT, wT, beta, pT, n);
+            }
+            MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0));
+            MICHK(launch_tile<OP_AMUL>(m, true, pT, nullptr, nullptr, wT, 0.0, 0));
+            double wApT = 0;
+            MICHK(reduce_sync<RED_PROD>(m, wA, pT, &wApT));
+            if (hp.checkSingularity(fabs(wApT) / hp.normFactor)) break;
+            const double alpha = wArT / wApT;
+            k_xpsy<<<RG, RB, 0, s>>>(psi, psi, alpha, pA, n);
+            k_xpsy<<<RG, RB, 0, s>>>(rA, rA, -alpha, wA, n);
+            k_xpsy<<<RG, RB, 0, s>>>(rT, rT, -alpha, wT, n);
+            double sm = 0;
+            MICHK(reduce_sync<RED_MAG>(m, rA, nullptr, &sm));
+            hp.finalResidual = sm / hp.normFactor;
+            hist.push_back(hp.finalResidual);
+        } while ((hp.nIterations++ < hp.maxIter && !hp.checkConvergence()) || hp.nIterations < hp.minIter);
+    }
+    return finish_host(m, hp, hist, psi, psi_io, perf, hist_host, hist_len);
+}
+
+extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* source, const mi_solver_controls* ctl,
+                                  int precond, int replicate_quirk, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
+{
+    if (!m || !psi_io || !source || !ctl) return fail(MI_ERR_ARG, "mi_pbicgstab_solve: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    const int64_t n = a->L.nCells;
+    double *psi, *src, *pA, *yA, *rA, *AyA, *sA, *zA, *tA, *rA0, *res1;
+    MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &yA)); MICHK(m->vec(7, &rA));
+    MICHK(m->vec(8, &AyA)); MICHK(m->vec(9, &sA)); MICHK(m->vec(10, &zA)); MICHK(m->vec(11, &tA)); MICHK(m->vec(12, &rA0));
+    MICHK(m->vec(13, &res1));
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    HostPerf hp; std::vector<double> hist;
+    MICHK(host_prologue(m, ctl, psi, src, yA, rA, pA, hp, hist));
+    if (hp.minIter > 0 || !hp.checkConvergence()) {
+        HIPCHK(hipMemcpyAsync(rA0, rA, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        double rA0rA = 0, alpha = 0, omega = 0;
+        do {
+            const double rA0rAold = rA0rA;
+            MICHK(reduce_sync<RED_PROD>(m, rA0, rA, &rA0rA));
+            if (hp.checkSingularity(fabs(rA0rA))) break;
+            if (hp.nIterations == 0) {
+                HIPCHK(hipMemcpyAsync(pA, rA, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+            } else {
+                if (hp.checkSingularity(fabs(omega))) break;
+                const double beta = (rA0rA / rA0rAold) * (alpha / omega);
+                k_xpsy<<<RG, RB, 0, s>>>(res1, pA, -omega, AyA, n); // result1 = pA - omega*AyA
+                k_xpsy<<<RG, RB, 0, s>>>(pA, rA, beta, res1, n);    // pA = rA + beta*result1
+            }
+            MICHK(precond_engine(m, precond, false, pA, yA));
+            MICHK(launch_tile<OP_AMUL>(m, false, yA, nullptr, nullptr, AyA, 0.0, 0));
+            double rA0AyA = 0;
+            MICHK(reduce_sync<RED_PROD>(m, rA0, AyA, &rA0AyA));
+            alpha = rA0rA / rA0AyA;
+            k_xpsy<<<RG, RB, 0, s>>>(sA, rA, -alpha, AyA, n);
+            double sm = 0;
+            MICHK(reduce_sync<RED_MAG>(m, sA, nullptr, &sm));
+            hp.finalResidual = sm / hp.normFactor;
+            if (hp.checkConvergence()) {
+                k_xpsy<<<RG, RB, 0, s>>>(psi, psi, alpha, yA, n);
+                hp.nIterations++;
+                hist.push_back(hp.finalResidual);
+                return finish_host(m, hp, hist, psi, psi_io, perf, hist_host, hist_len);
+            }
+            MICHK(precond_engine(m, precond, false, sA, zA));
+            MICHK(launch_tile<OP_AMUL>(m, false, zA, nullptr, nullptr, tA, 0.0, 0));
+            double tAtA = 0, tAsA = 0;
+            MICHK(reduce_sync<RED_PROD>(m, tA, tA, &tAtA));
+            MICHK(reduce_sync<RED_PROD>(m, tA, sA, &tAsA));
+            omega = tAsA / tAtA;
+            k_xpsy<<<RG, RB, 0, s>>>(psi, psi, alpha, yA, n);
+            k_xpsy<<<RG, RB, 0, s>>>(psi, psi, omega, replicate_quirk ? yA : zA, n);
+            k_xpsy<<<RG, RB, 0, s>>>(rA, sA, -omega, tA, n);
+            MICHK(reduce_sync<RED_MAG>(m, rA, nullptr, &sm));
+            hp.finalResidual = sm / hp.normFactor;
+            hist.push_back(hp.finalResidual);
+        } while ((hp.nIterations++ < hp.maxIter && !hp.checkConvergence()) || hp.nIterations < hp.minIter);
+    }
+    return finish_host(m, hp, hist, psi, psi_io, perf, hist_host, hist_len);
+}
+
+extern "C" int mi_smooth_solve(mi_matrix_t m, double* psi_io, const double* source, const mi_solver_controls* ctl,
+                               double omega, int32_t n_sweeps, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
+{
+    if (!m || !psi_io || !source || !ctl || n_sweeps == 0) return fail(MI_ERR_ARG, "mi_smooth_solve: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    const int64_t n = a->L.nCells;
+    double *psi, *src, *tmp, *wA, *rA, *psi2;
+    MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &tmp)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
+    MICHK(m->vec(8, &psi2));
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    HostPerf hp; std::vector<double> hist;
+    hp.tolerance = ctl->tolerance; hp.relTol = ctl->relTol; hp.maxIter = ctl->maxIter; hp.minIter = ctl->minIter;
+    double *cur = psi, *nxt = psi2;
+    auto sweeps = [&](int cnt) -> int {
+        for (int sw = 0; sw < cnt; ++sw) {
+            MICHK(launch_tile<OP_JACOBI>(m, false, cur, src, nullptr, nxt, omega, 0));
+            double* t = cur; cur = nxt; nxt = t;
+        }
+        return MI_OK;
+    };
+    if (n_sweeps < 0) { // smoothSolver.C:87-110
+        MICHK(sweeps(-n_sweeps));
+        hp.nIterations -= n_sweeps;
+    } else {
+        MICHK(host_prologue(m, ctl, psi, src, wA, rA, tmp, hp, hist));
+        if (hp.minIter > 0 || !hp.checkConvergence()) {
+            do {
+                MICHK(sweeps(n_sweeps));
+                MICHK(launch_tile<OP_RESIDUAL>(m, false, cur, src, nullptr, rA, 0.0, 0));
+                double sm = 0;
+                MICHK(reduce_sync<RED_MAG>(m, rA, nullptr, &sm));
+                hp.finalResidual = sm / hp.normFactor;
+                hist.push_back(hp.finalResidual);
+            } while (((hp.nIterations += n_sweeps) < hp.maxIter && !hp.checkConvergence()) || hp.nIterations < hp.minIter);
+        }
+    }
+    return finish_host(m, hp, hist, cur, psi_io, perf, hist_host, hist_len);
+}
+
+// ---------------------------------------------------------------------------
+// benchmark hooks
+// ---------------------------------------------------------------------------
+extern "C" int mi_bench_amul(mi_matrix_t m, int32_t reps, float* ms_out)
+{
+    if (!m || reps <= 0 || !ms_out) return fail(MI_ERR_ARG, "mi_bench_amul: bad argument");
+    mi_ctx_s* c = m->addr->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    double *x, *y;
+    MICHK(m->vec(5, &x)); MICHK(m->vec(6, &y));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; ++i) MICHK(launch_tile<OP_AMUL>(m, false, x, nullptr, nullptr, y, 0.0, 0));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
+    return MI_OK;
+}
+
+extern "C" int mi_bench_pcg_iters(mi_matrix_t m, const double* source, int32_t iters, int precond, float* ms_out, float* amul_ms_out)
+{
+    if (!m || !source || iters <= 0 || !ms_out) return fail(MI_ERR_ARG, "mi_bench_pcg_iters: bad argument");
+    mi_ctx_s* c = m->addr->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    mi_solver_controls ctl; ctl.tolerance = 0; ctl.relTol = 0; ctl.maxIter = iters + 16; ctl.minIter = 0;
+    double* zero;
+    MICHK(m->vec(14, &zero));
+    // psi0 = 0 in caller order == 0 in engine order
+    MICHK(mi_pcg_begin(m, zero, source, &ctl, precond, 1));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    MICHK(pcg_enqueue(m, 0, iters, precond, false));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
+    m->pcgActive = false;
+    if (amul_ms_out) { float t = 0; MICHK(mi_bench_amul(m, iters, &t)); *amul_ms_out = t; }
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-only layout inspection (no device needed): lets tests verify the tiling
+// on a CPU-only box by interpreting the tables themselves.  Not a compute path.
+// ---------------------------------------------------------------------------
+extern "C" int mi_layout_build_host(int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper,
+                                    int32_t n_patches, const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
+                                    int32_t tile_cells, int32_t slot_cap, void** out)
+{
+    if (!out) return fail(MI_ERR_ARG, "mi_layout_build_host: out is NULL");
+    TileLayout* L = new TileLayout();
+    TileParams prm;
+    if (tile_cells > 0) prm.tileCells = tile_cells;
+    if (slot_cap > 0) prm.slotCap = slot_cap;
+    const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, *L);
+    if (!err.empty()) { delete L; return fail(MI_ERR_LIMIT, "mi_layout_build_host: " + err); }
+    *out = L;
+    return MI_OK;
+}
+
+extern "C" int mi_layout_array(void* handle, const char* name, const void** data, int64_t* len)
+{
+    if (!handle || !name || !data || !len) return fail(MI_ERR_ARG, "mi_layout_array: bad argument");
+    TileLayout* L = static_cast<TileLayout*>(handle);
+    const std::string n(name);
+#define ARR(field) if (n == #field) { *data = L->field.data(); *len = (int64_t)L->field.size(); return MI_OK; }
+    ARR(e2c) ARR(c2e) ARR(tileCellStart) ARR(tileSlotStart) ARR(tileHaloStart) ARR(haloCell) ARR(tileSliceStart)
+    ARR(sliceEntryStart) ARR(entries) ARR(slotFace) ARR(extSlot) ARR(interiorTiles) ARR(boundaryTiles)
+    ARR(patchOffset) ARR(patchFaceCellsE) ARR(faceSlot)
+#undef ARR
+    return fail(MI_ERR_ARG, "mi_layout_array: unknown array " + n);
+}
+
+extern "C" int mi_layout_free(void* handle) { delete static_cast<TileLayout*>(handle); return MI_OK; }

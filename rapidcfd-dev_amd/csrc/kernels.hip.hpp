@@ -1,0 +1,469 @@
+// kernels.hip.hpp -- hand-written gfx950 (CDNA4) kernels of the lduMatrix hot path.
+//
+// Design (DESIGN.md "Kernels"): everything here is HBM-bandwidth bound
+// (0.19 flop/byte), so there is no MFMA; the work is organised so that every
+// HBM byte is touched once with wide coalesced loads and all irregular
+// (gather) accesses happen in LDS:
+//   * tile_kernel: one workgroup per tile.  Streams the tile's face
+//     coefficients (each symmetric coefficient ONCE) and the tile's psi + halo
+//     into LDS, then each wavefront walks 64 rows with a uniform trip count,
+//     reading the {slot, other} entries coalesced and gathering from LDS.
+//     The row sum is the same fma chain, in the same order, as the reference's
+//     matrixMultiplyFunctor (lduMatrixATmul.C:42-138) => bit-identical to the
+//     oracle.  Template OP selects Amul/Tmul, sumA, residual, H, H1, the AINV
+//     preconditioner (AINVPreconditionerF.H:41-99) and the Jacobi smoother
+//     (JacobiSmootherF.H:50-108) -- K1,K2,K3,K6,K8,K18 of SURVEY.md 2.3.
+//   * streaming vector kernels with fused reductions (K7,K9-K13): 16-byte
+//     loads, fixed block->chunk mapping, wavefront butterfly on ds_swizzle,
+//     so every reduction is deterministic run to run.
+// Compiled with -ffp-contract=off: every fused multiply-add is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+constexpr int RG = 1024;      // blocks of every streaming/reduction kernel (fixed => deterministic)
+constexpr int RB = 256;       // threads per block of the streaming kernels
+
+// ---------------------------------------------------------------------------
+// wavefront (64 lanes) sum: xor butterfly.  Steps 1..16 stay inside a 32-lane
+// half and use ds_swizzle in bit-mask mode (and=0x1f, or=0, xor=m : offset =
+// 0x1f | m<<10); the last step crosses the halves with a DPP-free bpermute.
+// Every lane ends with the same bits (a+b is commutative).
+// ---------------------------------------------------------------------------
+template <int XORMASK>
+__device__ __forceinline__ double swz_xor(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x1f | (XORMASK << 10));
+    hi = __builtin_amdgcn_ds_swizzle(hi, 0x1f | (XORMASK << 10));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += swz_xor<1>(v);
+    v += swz_xor<2>(v);
+    v += swz_xor<4>(v);
+    v += swz_xor<8>(v);
+    v += swz_xor<16>(v);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// block sum for BS threads; result valid in every thread; red = BS/64 doubles of LDS.
+template <int BS>
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads(); // protect red from a previous use
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < BS / 64; ++w) t += red[w];
+    return t;
+}
+
+// sum of the RG per-block partials, computed redundantly by every block (same
+// order everywhere => every block sees the same bits).
+__device__ __forceinline__ double sum_partials(const double* __restrict__ partial, double* red)
+{
+    double v = 0;
+#pragma unroll
+    for (int k = 0; k < RG / RB; ++k) v += partial[threadIdx.x + k * RB];
+    return block_sum<RB>(v, red);
+}
+
+// ---------------------------------------------------------------------------
+// tile kernel
+// ---------------------------------------------------------------------------
+enum { OP_AMUL = 0, OP_SUMA = 1, OP_RESIDUAL = 2, OP_H = 3, OP_H1 = 4, OP_AINV = 5, OP_JACOBI = 6 };
+
+struct TileArgs {
+    const int32_t* tileCellStart;
+    const int32_t* tileSlotStart;
+    const int32_t* tileHaloStart;
+    const int32_t* haloCell;
+    const int32_t* tileSliceStart;
+    const int32_t* sliceEntryStart;
+    const uint32_t* entries;
+    const int32_t* tileList; // nullptr => identity
+    const double* diag;
+    const double* up;
+    const double* low;
+    const double* x;  // psi (Amul, residual, H, Jacobi) or r (AINV)
+    const double* b;  // source (residual, Jacobi)
+    const double* rD; // AINV
+    double* y;
+    double omega;
+    int32_t offLow, offX, offRD; // LDS offsets in doubles
+};
+
+// cooperative global -> LDS staging, 4 loads in flight per lane
+template <int BS, class T>
+__device__ __forceinline__ void stage_copy(const T* __restrict__ src, T* __restrict__ dst, int n, int tid)
+{
+    int k = tid;
+    for (; k + 3 * BS < n; k += 4 * BS) {
+        const T v0 = src[k], v1 = src[k + BS], v2 = src[k + 2 * BS], v3 = src[k + 3 * BS];
+        dst[k] = v0; dst[k + BS] = v1; dst[k + 2 * BS] = v2; dst[k + 3 * BS] = v3;
+    }
+    for (; k < n; k += BS) dst[k] = src[k];
+}
+template <int BS>
+__device__ __forceinline__ void stage_gather(const double* __restrict__ x, const int32_t* __restrict__ idx,
+                                             double* __restrict__ dst, int n, int tid)
+{
+    int k = tid;
+    for (; k + BS < n; k += 2 * BS) {
+        const int i0 = idx[k], i1 = idx[k + BS];
+        const double v0 = x[i0], v1 = x[i1];
+        dst[k] = v0; dst[k + BS] = v1;
+    }
+    for (; k < n; k += BS) dst[k] = x[idx[k]];
+}
+
+template <int OP, bool ASYM, bool TRANS, int BS>
+__global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* cU = smem;
+    double* cL = smem + a.offLow;
+    double* xs = smem + a.offX;
+    double* rDs = smem + a.offRD;
+
+    // XCD-aware mapping: hardware places block b on XCD b%8; give each XCD a
+    // contiguous run of tiles so that neighbouring tiles (which share halo
+    // cells) hit the same L2.  Speed only, never correctness.
+    int t;
+    {
+        const int b = blockIdx.x, per = gridDim.x >> 3;
+        t = (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;
+    }
+    if (a.tileList) t = a.tileList[t];
+
+    const int tid = threadIdx.x;
+    const int c0 = a.tileCellStart[t], nc = a.tileCellStart[t + 1] - c0;
+    const int s0 = a.tileSlotStart[t], ns = a.tileSlotStart[t + 1] - s0; // even
+    const int h0 = a.tileHaloStart[t], nh = a.tileHaloStart[t + 1] - h0;
+    constexpr bool NEEDX = (OP != OP_SUMA && OP != OP_H1);
+
+    // ---- stage: coefficients (16-byte coalesced), psi, halo -------------------
+    // All global loads of a phase are issued before the first LDS store (4-deep
+    // unroll) so that every wave keeps several KiB in flight.
+    stage_copy<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid);
+    if (ASYM) stage_copy<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid);
+    if (NEEDX) {
+        stage_copy<BS>(a.x + c0, xs, nc, tid);
+        stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
+        if (OP == OP_AINV) {
+            stage_copy<BS>(a.rD + c0, rDs, nc, tid);
+            stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
+        }
+    }
+    __syncthreads();
+
+    // ---- rows: one wavefront per 64-row slice, uniform trip count -------------
+    const int sl0 = a.tileSliceStart[t], nsl = a.tileSliceStart[t + 1] - sl0;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int s = wave; s < nsl; s += BS / 64) {
+        const int e0 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s]);
+        const int e1 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s + 1]);
+        const int width = (e1 - e0) >> 6;
+        const int i = s * 64 + lane;
+        const bool live = i < nc;
+        const int gi = c0 + (live ? i : 0);
+        const double xi = (NEEDX && live) ? xs[i] : 0.0;
+        double acc;
+        if (OP == OP_AMUL) acc = a.diag[gi] * xi;
+        else if (OP == OP_SUMA) acc = a.diag[gi];
+        else if (OP == OP_RESIDUAL) acc = a.b[gi] - a.diag[gi] * xi;
+        else acc = 0.0;
+        const uint32_t* ent = a.entries + e0 + lane;
+#pragma unroll 2
+        for (int j = 0; j < width; ++j) {
+            const uint32_t en = ent[j * 64];
+            const int o = en & 0xFFFFu;
+            const int sl = (en >> 16) & 0x7FFFu;
+            double c;
+            if (ASYM) c = (((en >> 31) != 0u) != TRANS) ? cL[sl] : cU[sl];
+            else c = cU[sl];
+            if (OP == OP_AMUL || OP == OP_JACOBI) acc = fma(c, xs[o], acc);
+            else if (OP == OP_SUMA) acc += c;
+            else if (OP == OP_RESIDUAL || OP == OP_H) acc = fma(-c, xs[o], acc);
+            else if (OP == OP_H1) acc -= c;
+            else if (OP == OP_AINV) acc = fma(c * rDs[o], xs[o], acc);
+        }
+        if (live) {
+            if (OP == OP_AINV) a.y[gi] = rDs[i] * (xi - acc);
+            else if (OP == OP_JACOBI) {
+                const double rD = 1.0 / a.diag[gi];
+                const double extra = (1 - a.omega) * xi + a.omega * rD * a.b[gi];
+                a.y[gi] = extra - a.omega * rD * acc;
+            } else a.y[gi] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// layout kernels
+// ---------------------------------------------------------------------------
+__global__ void k_gather_perm(const double* __restrict__ in, const int32_t* __restrict__ perm, double* __restrict__ out, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[perm[i]];
+}
+__global__ void k_scatter_perm(const double* __restrict__ in, const int32_t* __restrict__ perm, double* __restrict__ out, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[perm[i]] = in[i];
+}
+// caller coefficients -> engine slots (K22 calcSortCoeffs, lduMatrix.C:388-401, generalised)
+__global__ void k_fill_slots(const double* __restrict__ upper, const double* __restrict__ lower,
+                             const int32_t* __restrict__ slotFace, double* __restrict__ upE,
+                             double* __restrict__ lowE, int64_t nSlots)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nSlots; k += (int64_t)gridDim.x * blockDim.x) {
+        const int f = slotFace[k];
+        if (f >= 0) { upE[k] = upper[f]; if (lowE) lowE[k] = lower[f]; }
+        else if (f == -1) { upE[k] = 0.0; if (lowE) lowE[k] = 0.0; }
+        // f <= -2: interface slot, owned by k_fill_iface
+    }
+}
+__global__ void k_fill_iface(const double* __restrict__ bou, const double* __restrict__ inte,
+                             const int32_t* __restrict__ extSlot, double* __restrict__ upE,
+                             double* __restrict__ lowE, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int k = extSlot[i];
+        upE[k] = -bou[i];
+        if (lowE) lowE[k] = inte ? -inte[i] : -bou[i];
+    }
+}
+__global__ void k_halo_pack(const double* __restrict__ x, const int32_t* __restrict__ cells, double* __restrict__ send, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) send[i] = x[cells[i]];
+}
+__global__ void k_faceH(const double* __restrict__ psi, const int32_t* __restrict__ lo, const int32_t* __restrict__ up,
+                        const int32_t* __restrict__ faceSlot, const double* __restrict__ upE,
+                        const double* __restrict__ lowE, double* __restrict__ out, int nFaces)
+{
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nFaces; f += gridDim.x * blockDim.x) {
+        const int k = faceSlot[f];
+        out[f] = upE[k] * psi[up[f]] - lowE[k] * psi[lo[f]];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// streaming vector kernels.  Fixed grid RG x RB; block b owns the contiguous
+// chunk [b*chunk, (b+1)*chunk) (chunk even), threads walk it in double2.
+// ---------------------------------------------------------------------------
+struct Chunk { int64_t lo, hi; };
+__device__ __forceinline__ Chunk my_chunk(int64_t n)
+{
+    int64_t chunk = (n + RG - 1) / RG;
+    chunk = (chunk + 1) & ~int64_t(1);
+    Chunk c;
+    c.lo = (int64_t)blockIdx.x * chunk; if (c.lo > n) c.lo = n;
+    c.hi = c.lo + chunk; if (c.hi > n) c.hi = n;
+    return c;
+}
+// iterate pairs then the odd tail; body2 sees an even-aligned index i (use 16-byte
+// loads at i), body1 the single trailing element of an odd-length chunk.
+template <class F2, class F1>
+__device__ __forceinline__ void chunk_loop(int64_t n, F2 body2, F1 body1)
+{
+    const Chunk ck = my_chunk(n);
+    const int64_t np = (ck.hi - ck.lo) >> 1;
+#pragma unroll 4
+    for (int64_t q = threadIdx.x; q < np; q += RB) body2(ck.lo + 2 * q);
+    if (((ck.hi - ck.lo) & 1) && threadIdx.x == 0) body1(ck.hi - 1);
+}
+__device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return *reinterpret_cast<const double2*>(p + i); }
+__device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { *reinterpret_cast<double2*>(p + i) = v; }
+
+enum { RED_SUM = 0, RED_PROD = 1, RED_MAG = 2 };
+template <int KIND>
+__global__ __launch_bounds__(RB) void k_reduce(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ partial)
+{
+    __shared__ double red[RB / 64];
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 x = ld2(a, i);
+          if (KIND == RED_SUM) { acc0 += x.x; acc1 += x.y; }
+          else if (KIND == RED_MAG) { acc0 += fabs(x.x); acc1 += fabs(x.y); }
+          else { const double2 y = ld2(b, i); acc0 = fma(x.x, y.x, acc0); acc1 = fma(x.y, y.y, acc1); } },
+        [&](int64_t i) { const double x = a[i];
+          if (KIND == RED_SUM) acc0 += x; else if (KIND == RED_MAG) acc0 += fabs(x); else acc0 = fma(x, b[i], acc0); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(RB) void k_reduce_final(const double* __restrict__ partial, double* __restrict__ out)
+{
+    __shared__ double red[RB / 64];
+    const double t = sum_partials(partial, red);
+    if (threadIdx.x == 0) *out = t;
+}
+
+// out = a + s*b  (one explicit fma; s by value)
+__global__ __launch_bounds__(RB) void k_xpsy(double* __restrict__ out, const double* __restrict__ a, double s, const double* __restrict__ b, int64_t n)
+{
+    chunk_loop(n, [&](int64_t i) { const double2 x = ld2(a, i), y = ld2(b, i); st2(out, i, make_double2(fma(s, y.x, x.x), fma(s, y.y, x.y))); },
+        [&](int64_t i) { out[i] = fma(s, b[i], a[i]); });
+}
+// out = a - b
+__global__ __launch_bounds__(RB) void k_sub(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n)
+{
+    chunk_loop(n, [&](int64_t i) { const double2 x = ld2(a, i), y = ld2(b, i); st2(out, i, make_double2(x.x - y.x, x.y - y.y)); },
+        [&](int64_t i) { out[i] = a[i] - b[i]; });
+}
+// out = a * b   (diagonal precondition, diagonalPreconditioner.C:74-89)
+__global__ __launch_bounds__(RB) void k_mul(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b, int64_t n)
+{
+    chunk_loop(n, [&](int64_t i) { const double2 x = ld2(a, i), y = ld2(b, i); st2(out, i, make_double2(x.x * y.x, x.y * y.y)); },
+        [&](int64_t i) { out[i] = a[i] * b[i]; });
+}
+// out = 1/a   (rD, diagonalPreconditioner.C:61-67)
+__global__ __launch_bounds__(RB) void k_recip(double* __restrict__ out, const double* __restrict__ a, int64_t n)
+{
+    chunk_loop(n, [&](int64_t i) { const double2 x = ld2(a, i); st2(out, i, make_double2(1.0 / x.x, 1.0 / x.y)); },
+        [&](int64_t i) { out[i] = 1.0 / a[i]; });
+}
+// normFactor partials (lduMatrixSolver.C:183-202): |Apsi - avg*sumA| + |b - avg*sumA|
+__global__ __launch_bounds__(RB) void k_normfactor(const double* __restrict__ Apsi, const double* __restrict__ src,
+                                                   const double* __restrict__ sumA, double avg, int64_t n, double* __restrict__ partial)
+{
+    __shared__ double red[RB / 64];
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 A = ld2(Apsi, i), b = ld2(src, i), s = ld2(sumA, i);
+          const double t0 = avg * s.x, t1 = avg * s.y;
+          acc0 += fabs(A.x - t0) + fabs(b.x - t0); acc1 += fabs(A.y - t1) + fabs(b.y - t1); },
+        [&](int64_t i) { const double t0 = avg * sumA[i]; acc0 += fabs(Apsi[i] - t0) + fabs(src[i] - t0); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident PCG pipeline (PCG.C:133-204).  The host only enqueues; all
+// scalars (wArA, beta, wApA, alpha, residual, loop condition) live in PcgState.
+// Every kernel starts with `if (st->done) return;` so iterations enqueued past
+// convergence are no-ops and the result is exactly the reference's loop.
+// ---------------------------------------------------------------------------
+struct PcgState {
+    double wArA[2];  // indexed by iteration parity
+    double alpha, wApA;
+    double normFactor, initialResidual, finalResidual;
+    double tolerance, relTol;
+    int32_t maxIter, minIter;
+    int32_t nIterations, done, converged, singular;
+};
+
+constexpr double SP_SMALL = 1e-20, SP_VSMALL = 1e-300, SP_GREAT = 1e20; // SolverPerformance.H:269-275
+
+__device__ __forceinline__ bool sp_converged(const PcgState* st, double res)
+{
+    // SolverPerformance.C:60-92
+    return (res < st->tolerance) || (st->relTol > SP_SMALL && res < st->relTol * st->initialResidual);
+}
+
+// wA = rD*rA (or rA), partial1 = sum wA*rA     [precondition + gSumProd, PCG.C:139-142]
+template <bool HAVE_RD>
+__global__ __launch_bounds__(RB) void k_pcg_precond_dot(const PcgState* __restrict__ st, const double* __restrict__ rD,
+                                                        const double* __restrict__ rA, double* __restrict__ wA,
+                                                        int64_t n, double* __restrict__ partial)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 r = ld2(rA, i); double2 w = r;
+          if (HAVE_RD) { const double2 d = ld2(rD, i); w.x = d.x * r.x; w.y = d.y * r.y; }
+          st2(wA, i, w); acc0 = fma(w.x, r.x, acc0); acc1 = fma(w.y, r.y, acc1); },
+        [&](int64_t i) { const double r = rA[i]; const double w = HAVE_RD ? rD[i] * r : r; wA[i] = w; acc0 = fma(w, r, acc0); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// wArA = sum(partial1); beta = wArA/wArAold; pA = wA (+ beta*pA)      [PCG.C:144-160]
+__global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
+                                                     const double* __restrict__ wA, double* __restrict__ pA, int64_t n)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double wArA = sum_partials(partial1, red);
+    if (it == 0) {
+        chunk_loop(n, [&](int64_t i) { st2(pA, i, ld2(wA, i)); },
+        [&](int64_t i) { pA[i] = wA[i]; });
+    } else {
+        const double beta = wArA / st->wArA[(it & 1) ^ 1];
+        chunk_loop(n, [&](int64_t i) { const double2 w = ld2(wA, i), p = ld2(pA, i); st2(pA, i, make_double2(fma(beta, p.x, w.x), fma(beta, p.y, w.y))); },
+        [&](int64_t i) { pA[i] = fma(beta, pA[i], wA[i]); });
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->wArA[it & 1] = wArA;
+}
+
+// wApA = sum(partial2); singular? ; alpha; psi += alpha pA; rA -= alpha wA; partial3 = sum|rA|  [PCG.C:166-195]
+__global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
+                                                         const double* __restrict__ pA, const double* __restrict__ wA,
+                                                         double* __restrict__ psi, double* __restrict__ rA, int64_t n,
+                                                         double* __restrict__ partial3)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double wApA = sum_partials(partial2, red);
+    if (fabs(wApA) / st->normFactor < SP_VSMALL) { // checkSingularity, SolverPerformance.C:32-44
+        // every block takes this branch; only later kernels read done/singular
+        if (threadIdx.x == 0) partial3[blockIdx.x] = -1.0; // marks "singular" for k_pcg_final
+        return;
+    }
+    const double alpha = st->wArA[it & 1] / wApA;
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 p = ld2(pA, i), w = ld2(wA, i); double2 x = ld2(psi, i), r = ld2(rA, i);
+          x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y);
+          r.x = fma(-alpha, w.x, r.x); r.y = fma(-alpha, w.y, r.y);
+          st2(psi, i, x); st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y); },
+        [&](int64_t i) { psi[i] = fma(alpha, pA[i], psi[i]); const double r = fma(-alpha, wA[i], rA[i]); rA[i] = r; acc0 += fabs(r); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial3[blockIdx.x] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->alpha = alpha; st->wApA = wApA; }
+}
+
+// residual, history, do-while condition                                  [PCG.C:195-204]
+__global__ __launch_bounds__(RB) void k_pcg_final(PcgState* __restrict__ st, int it, const double* __restrict__ partial3,
+                                                  double* __restrict__ hist, int histLen)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const bool sing = partial3[0] < 0.0; // sum|r| partials are never negative
+    const double s = sum_partials(partial3, red);
+    if (threadIdx.x != 0) return;
+    if (sing) { st->singular = 1; st->done = 1; return; } // `break`: nIterations not incremented
+    const double res = s / st->normFactor;
+    st->finalResidual = res;
+    if (it + 1 < histLen) hist[it + 1] = res;
+    st->nIterations = it + 1;
+    const bool conv = sp_converged(st, res);
+    st->converged = conv;
+    const bool cont = (it < st->maxIter && !conv) || (it + 1 < st->minIter);
+    if (!cont) st->done = 1;
+}
+
+// start of a solve: normFactor, initial residual, first convergence test   [PCG.C:105-121]
+__global__ __launch_bounds__(RB) void k_solve_init(PcgState* __restrict__ st, const double* __restrict__ partialNF,
+                                                   const double* __restrict__ partialR, double* __restrict__ hist, int histLen)
+{
+    __shared__ double red[RB / 64];
+    const double nf = sum_partials(partialNF, red) + SP_SMALL;
+    const double sr = sum_partials(partialR, red);
+    if (threadIdx.x != 0) return;
+    st->normFactor = nf;
+    const double res = sr / nf;
+    st->initialResidual = res; st->finalResidual = res;
+    if (histLen > 0) hist[0] = res;
+    st->nIterations = 0; st->singular = 0;
+    st->wArA[0] = SP_GREAT; st->wArA[1] = SP_GREAT;
+    const bool conv = sp_converged(st, res);
+    st->converged = conv;
+    st->done = (st->minIter > 0 || !conv) ? 0 : 1;
+}
+
+} // namespace mi

@@ -1,0 +1,287 @@
+// tiling.cpp -- see tiling.hpp.  Host code, runs once per mesh (the reference
+// also builds its addressing tables and its GAMG agglomeration once per mesh
+// and caches them: lduAddressing.C:169-400, GAMGAgglomeration.C:132-182).
+#include "tiling.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace mi {
+
+namespace {
+
+// One level of the multilevel clustering graph (CSR, undirected, both directions stored).
+struct Graph {
+    int32_t n = 0;
+    std::vector<int64_t> xadj;
+    std::vector<int32_t> adj;
+    std::vector<int32_t> ew;   // edge weight = number of mesh faces between the clusters
+    std::vector<int32_t> vw;   // cells in cluster
+    std::vector<int32_t> vinc; // face incidences of the cluster's cells (internal counted twice)
+    std::vector<int32_t> vint; // faces internal to the cluster
+};
+
+// Heavy-edge matching with size caps; returns number of coarse vertices and cmap.
+int32_t match_level(const Graph& g, int32_t cellCap, int32_t slotCap, std::vector<int32_t>& cmap)
+{
+    const int32_t n = g.n;
+    std::vector<int32_t> match(n, -1);
+    cmap.assign(n, -1);
+    int32_t nc = 0;
+    for (int32_t v = 0; v < n; ++v) {
+        if (match[v] >= 0) continue;
+        int32_t best = -1, bw = 0;
+        for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
+            const int32_t u = g.adj[e];
+            if (u == v || match[u] >= 0) continue;
+            if (g.vw[v] + g.vw[u] > cellCap) continue;
+            const int32_t slots = g.vinc[v] + g.vinc[u] - (g.vint[v] + g.vint[u] + g.ew[e]);
+            if (slots > slotCap) continue;
+            if (g.ew[e] > bw) { bw = g.ew[e]; best = u; }
+        }
+        if (best >= 0) { match[v] = best; match[best] = v; cmap[v] = cmap[best] = nc++; }
+        else           { match[v] = v; cmap[v] = nc++; }
+    }
+    return nc;
+}
+
+void coarsen(const Graph& g, const std::vector<int32_t>& cmap, int32_t nc, Graph& c)
+{
+    c.n = nc;
+    c.vw.assign(nc, 0); c.vinc.assign(nc, 0); c.vint.assign(nc, 0);
+    // members of each coarse vertex (1 or 2)
+    std::vector<int32_t> first(nc, -1), second(nc, -1);
+    for (int32_t v = 0; v < g.n; ++v) {
+        const int32_t cv = cmap[v];
+        if (first[cv] < 0) first[cv] = v; else second[cv] = v;
+        c.vw[cv] += g.vw[v]; c.vinc[cv] += g.vinc[v]; c.vint[cv] += g.vint[v];
+    }
+    c.xadj.assign((size_t)nc + 1, 0);
+    c.adj.clear(); c.ew.clear();
+    c.adj.reserve(g.adj.size()); c.ew.reserve(g.adj.size());
+    std::vector<int64_t> pos(nc, -1); // position of neighbour cu in the current row
+    for (int32_t cv = 0; cv < nc; ++cv) {
+        const int64_t rowStart = (int64_t)c.adj.size();
+        for (int k = 0; k < 2; ++k) {
+            const int32_t v = k ? second[cv] : first[cv];
+            if (v < 0) continue;
+            for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
+                const int32_t cu = cmap[g.adj[e]];
+                if (cu == cv) { if (k == 0) c.vint[cv] += g.ew[e]; continue; } // edge inside the pair
+                if (pos[cu] >= rowStart) c.ew[pos[cu]] += g.ew[e];
+                else { pos[cu] = (int64_t)c.adj.size(); c.adj.push_back(cu); c.ew.push_back(g.ew[e]); }
+            }
+        }
+        // keep neighbours in ascending id order: deterministic tie-breaking in match_level
+        const int64_t rowEnd = (int64_t)c.adj.size();
+        const int64_t len = rowEnd - rowStart;
+        if (len > 1) {
+            std::vector<std::pair<int32_t, int32_t>> tmp((size_t)len);
+            for (int64_t i = 0; i < len; ++i) tmp[(size_t)i] = {c.adj[rowStart + i], c.ew[rowStart + i]};
+            std::sort(tmp.begin(), tmp.end());
+            for (int64_t i = 0; i < len; ++i) { c.adj[rowStart + i] = tmp[(size_t)i].first; c.ew[rowStart + i] = tmp[(size_t)i].second; }
+        }
+        for (int64_t i = rowStart; i < rowEnd; ++i) pos[c.adj[i]] = -1;
+        c.xadj[(size_t)cv + 1] = rowEnd;
+    }
+}
+
+} // namespace
+
+std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* lower,
+                              const int32_t* upper, int32_t nPatches,
+                              const int32_t* patchSizes, const int32_t* const* patchFaceCells,
+                              const TileParams& prm, TileLayout& L)
+{
+    if (nCells <= 0) return "n_cells must be positive";
+    if (prm.slotCap > 32766) return "slotCap exceeds the 15-bit slot field";
+    for (int32_t f = 0; f < nFaces; ++f) {
+        if (lower[f] < 0 || upper[f] >= nCells || lower[f] >= upper[f])
+            return "addressing must satisfy 0 <= lowerAddr[f] < upperAddr[f] < nCells";
+    }
+    L = TileLayout();
+    L.nCells = nCells; L.nFaces = nFaces; L.nPatches = nPatches;
+    L.patchOffset.assign((size_t)nPatches + 1, 0);
+    for (int32_t p = 0; p < nPatches; ++p) L.patchOffset[(size_t)p + 1] = L.patchOffset[p] + patchSizes[p];
+    L.nExt = L.patchOffset[nPatches];
+
+    // ---- per-cell face lists in the reference's row order -------------------
+    // owner side: faces with lower==c ascending (ownerStartAddr); neighbour side:
+    // faces with upper==c in losort order (stable sort by upper) -- lduAddressing.C:169-344
+    std::vector<int32_t> ownStart((size_t)nCells + 1, 0), neiStart((size_t)nCells + 1, 0);
+    for (int32_t f = 0; f < nFaces; ++f) { ownStart[(size_t)lower[f] + 1]++; neiStart[(size_t)upper[f] + 1]++; }
+    for (int32_t c = 0; c < nCells; ++c) { ownStart[(size_t)c + 1] += ownStart[c]; neiStart[(size_t)c + 1] += neiStart[c]; }
+    std::vector<int32_t> ownFaces((size_t)nFaces), neiFaces((size_t)nFaces);
+    {
+        std::vector<int32_t> co(ownStart.begin(), ownStart.end() - 1), cn(neiStart.begin(), neiStart.end() - 1);
+        for (int32_t f = 0; f < nFaces; ++f) { ownFaces[(size_t)co[lower[f]]++] = f; neiFaces[(size_t)cn[upper[f]]++] = f; }
+    }
+    // patch faces per cell (patch order, then face order)
+    std::vector<int32_t> pfStart((size_t)nCells + 1, 0), pfList((size_t)L.nExt);
+    for (int32_t p = 0; p < nPatches; ++p)
+        for (int32_t i = 0; i < patchSizes[p]; ++i) {
+            const int32_t c = patchFaceCells[p][i];
+            if (c < 0 || c >= nCells) return "patch faceCells out of range";
+            pfStart[(size_t)c + 1]++;
+        }
+    for (int32_t c = 0; c < nCells; ++c) pfStart[(size_t)c + 1] += pfStart[c];
+    {
+        std::vector<int32_t> cp(pfStart.begin(), pfStart.end() - 1);
+        for (int32_t p = 0; p < nPatches; ++p)
+            for (int32_t i = 0; i < patchSizes[p]; ++i)
+                pfList[(size_t)cp[patchFaceCells[p][i]]++] = L.patchOffset[p] + i;
+    }
+
+    // ---- multilevel heavy-edge clustering ------------------------------------
+    std::vector<int32_t> part((size_t)nCells);
+    std::iota(part.begin(), part.end(), 0);
+    int32_t nClusters = nCells;
+    {
+        Graph g;
+        g.n = nCells;
+        g.xadj.assign((size_t)nCells + 1, 0);
+        for (int32_t c = 0; c < nCells; ++c)
+            g.xadj[(size_t)c + 1] = g.xadj[c] + (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]);
+        g.adj.resize((size_t)2 * nFaces); g.ew.assign((size_t)2 * nFaces, 1);
+        g.vw.assign(nCells, 1); g.vint.assign(nCells, 0); g.vinc.resize(nCells);
+        for (int32_t c = 0; c < nCells; ++c) {
+            int64_t k = g.xadj[c];
+            for (int32_t j = ownStart[c]; j < ownStart[(size_t)c + 1]; ++j) g.adj[(size_t)k++] = upper[ownFaces[j]];
+            for (int32_t j = neiStart[c]; j < neiStart[(size_t)c + 1]; ++j) g.adj[(size_t)k++] = lower[neiFaces[j]];
+            g.vinc[c] = (int32_t)(g.xadj[(size_t)c + 1] - g.xadj[c]) + (pfStart[(size_t)c + 1] - pfStart[c]);
+            if (g.vinc[c] > prm.slotCap) return "a single cell has more faces than a tile can hold";
+        }
+        // multi-edges (two faces between the same cell pair) are legal in LDU addressing; merge them
+        std::vector<int32_t> cmap;
+        for (int level = 0; level < 64; ++level) {
+            const int32_t nc = match_level(g, prm.tileCells, prm.slotCap, cmap);
+            if (nc == g.n) break;
+            for (int32_t c = 0; c < nCells; ++c) part[c] = cmap[part[c]];
+            Graph cg;
+            coarsen(g, cmap, nc, cg);
+            g = std::move(cg);
+            nClusters = nc;
+        }
+    }
+
+    // ---- order tiles by their smallest caller cell, cells inside a tile ascending ----
+    const int32_t nT = nClusters;
+    L.nTiles = nT;
+    {
+        std::vector<int32_t> tileMin((size_t)nT, INT32_MAX);
+        for (int32_t c = nCells - 1; c >= 0; --c) tileMin[part[c]] = c;
+        std::vector<int32_t> order((size_t)nT);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return tileMin[a] < tileMin[b]; });
+        std::vector<int32_t> rank((size_t)nT);
+        for (int32_t i = 0; i < nT; ++i) rank[order[i]] = i;
+        for (int32_t c = 0; c < nCells; ++c) part[c] = rank[part[c]];
+    }
+    L.tileCellStart.assign((size_t)nT + 1, 0);
+    for (int32_t c = 0; c < nCells; ++c) L.tileCellStart[(size_t)part[c] + 1]++;
+    for (int32_t t = 0; t < nT; ++t) L.tileCellStart[(size_t)t + 1] += L.tileCellStart[t];
+    L.e2c.resize(nCells); L.c2e.resize(nCells);
+    {
+        std::vector<int32_t> cur(L.tileCellStart.begin(), L.tileCellStart.end() - 1);
+        for (int32_t c = 0; c < nCells; ++c) { const int32_t e = cur[part[c]]++; L.e2c[e] = c; L.c2e[c] = e; }
+    }
+
+    // ---- slots, halos, row entries --------------------------------------------
+    L.tileSlotStart.assign((size_t)nT + 1, 0);
+    L.tileHaloStart.assign((size_t)nT + 1, 0);
+    L.tileSliceStart.assign((size_t)nT + 1, 0);
+    L.sliceEntryStart.clear(); L.sliceEntryStart.push_back(0);
+    L.slotFace.clear(); L.haloCell.clear(); L.entries.clear();
+    L.slotFace.reserve((size_t)nFaces + nFaces / 4 + 16);
+    L.entries.reserve((size_t)2 * nFaces + nCells);
+    L.extSlot.assign((size_t)L.nExt, -1);
+    L.faceSlot.assign((size_t)nFaces, -1);
+    L.patchFaceCellsE.resize((size_t)L.nExt);
+    for (int32_t p = 0; p < nPatches; ++p)
+        for (int32_t i = 0; i < patchSizes[p]; ++i)
+            L.patchFaceCellsE[(size_t)L.patchOffset[p] + i] = L.c2e[patchFaceCells[p][i]];
+
+    std::vector<int32_t> faceLocalSlot((size_t)nFaces, -1); // slot (tile-local) of internal face, valid within current tile
+    std::vector<int32_t> haloStamp((size_t)nCells + L.nExt, -1), haloIdx((size_t)nCells + L.nExt, 0);
+    std::vector<uint32_t> rowEnt;        // entries of the rows of the current tile, row-major
+    std::vector<int32_t> rowEntStart;
+
+    for (int32_t t = 0; t < nT; ++t) {
+        const int32_t cs = L.tileCellStart[t], ce = L.tileCellStart[(size_t)t + 1], nc = ce - cs;
+        const int64_t slotBase = (int64_t)L.slotFace.size();
+        const int32_t haloBase = (int32_t)L.haloCell.size();
+        int32_t nSlots = 0, nHalo = 0;
+        bool boundary = false;
+        rowEnt.clear(); rowEntStart.assign(1, 0);
+
+        auto halo_of = [&](int32_t engineCell) -> int32_t {
+            if (haloStamp[engineCell] != t) { haloStamp[engineCell] = t; haloIdx[engineCell] = nHalo++; L.haloCell.push_back(engineCell); }
+            return nc + haloIdx[engineCell];
+        };
+        for (int32_t e = cs; e < ce; ++e) {
+            const int32_t c = L.e2c[e];
+            // owner side, ascending face id: row uses upper[f], other = upper cell
+            for (int32_t j = ownStart[c]; j < ownStart[(size_t)c + 1]; ++j) {
+                const int32_t f = ownFaces[j], o = upper[f];
+                int32_t slot, other;
+                if (part[o] == t) { slot = nSlots++; faceLocalSlot[f] = slot; L.slotFace.push_back(f); other = L.c2e[o] - cs; L.faceSlot[f] = (int32_t)(slotBase + slot); }
+                else { slot = nSlots++; L.slotFace.push_back(f); other = halo_of(L.c2e[o]); if (L.faceSlot[f] < 0) L.faceSlot[f] = (int32_t)(slotBase + slot); }
+                rowEnt.push_back((uint32_t)other | ((uint32_t)slot << 16));
+            }
+            // neighbour side, losort order: row uses lower[f], other = lower cell
+            for (int32_t j = neiStart[c]; j < neiStart[(size_t)c + 1]; ++j) {
+                const int32_t f = neiFaces[j], o = lower[f];
+                int32_t slot, other;
+                if (part[o] == t) { slot = faceLocalSlot[f]; other = L.c2e[o] - cs; } // owner (smaller id) was visited first
+                else { slot = nSlots++; L.slotFace.push_back(f); other = halo_of(L.c2e[o]); if (L.faceSlot[f] < 0) L.faceSlot[f] = (int32_t)(slotBase + slot); }
+                rowEnt.push_back((uint32_t)other | ((uint32_t)slot << 16) | 0x80000000u);
+            }
+            // coupled interfaces in patch order
+            for (int32_t j = pfStart[c]; j < pfStart[(size_t)c + 1]; ++j) {
+                const int32_t x = pfList[j];
+                const int32_t slot = nSlots++;
+                L.slotFace.push_back(-(2 + x));
+                L.extSlot[x] = (int32_t)(slotBase + slot);
+                const int32_t other = halo_of(nCells + x);
+                boundary = true;
+                rowEnt.push_back((uint32_t)other | ((uint32_t)slot << 16));
+            }
+            rowEntStart.push_back((int32_t)rowEnt.size());
+        }
+        if (nSlots > 32766 || nc + nHalo > 65535) return "tile exceeds the entry field widths";
+        // zero slot + pad the segment to an even length (16-byte aligned double2 loads)
+        L.slotFace.push_back(-1); // the zero slot, local index nSlots
+        if ((L.slotFace.size() & 1u) != 0) L.slotFace.push_back(-1);
+        L.tileSlotStart[(size_t)t + 1] = (int32_t)L.slotFace.size();
+        L.tileHaloStart[(size_t)t + 1] = (int32_t)L.haloCell.size();
+        (void)haloBase;
+        // slices of 64 rows, column-major, padded with {zero slot, other 0}
+        const uint32_t padEnt = ((uint32_t)nSlots << 16);
+        const int32_t nSl = (nc + 63) / 64;
+        for (int32_t s = 0; s < nSl; ++s) {
+            const int32_t r0 = s * 64, r1 = std::min(nc, r0 + 64);
+            int32_t width = 0;
+            for (int32_t r = r0; r < r1; ++r) width = std::max(width, rowEntStart[(size_t)r + 1] - rowEntStart[r]);
+            const size_t base = L.entries.size();
+            L.entries.resize(base + (size_t)width * 64, padEnt);
+            for (int32_t r = r0; r < r1; ++r) {
+                const int32_t len = rowEntStart[(size_t)r + 1] - rowEntStart[r];
+                for (int32_t j = 0; j < len; ++j) L.entries[base + (size_t)j * 64 + (r - r0)] = rowEnt[(size_t)rowEntStart[r] + j];
+            }
+            L.sliceEntryStart.push_back((int32_t)L.entries.size());
+        }
+        L.tileSliceStart[(size_t)t + 1] = L.tileSliceStart[t] + nSl;
+        L.maxCells = std::max(L.maxCells, nc);
+        L.maxSlots = std::max(L.maxSlots, nSlots + 2);
+        L.maxHalo = std::max(L.maxHalo, nHalo);
+        (boundary ? L.boundaryTiles : L.interiorTiles).push_back(t);
+        if (L.entries.size() > (size_t)INT32_MAX - 4096 || L.slotFace.size() > (size_t)INT32_MAX - 4096)
+            return "mesh too large for 32-bit layout offsets";
+    }
+    L.nSlices = L.tileSliceStart[nT];
+    L.totalSlots = (int64_t)L.slotFace.size();
+    return std::string();
+}
+
+} // namespace mi

@@ -1,0 +1,58 @@
+// tiling.hpp -- host-side construction of the engine's tiled LDU layout.
+//
+// Replaces the reference's demand-driven lduAddressing tables (losort,
+// ownerStart, losortStart, ownerSortAddr, patchSort*; lduAddressing.H:128-145,
+// lduAddressing.C:169-400 -- K23 in SURVEY.md) with a layout designed for
+// MI355X: cells are clustered into compact tiles (<= TILE_CELLS cells) by
+// multilevel heavy-edge matching on the face graph, renumbered tile by tile,
+// and every tile gets
+//   * a contiguous "slot" segment of face coefficients (each internal face once,
+//     cut faces once per side) that one workgroup streams into LDS with wide
+//     coalesced loads,
+//   * a halo list (cells of other tiles / other ranks it reads),
+//   * per-row entry lists {slot, other cell, side} stored in 64-row slices
+//     column-major so a wavefront reads them coalesced and loops uniformly.
+// Entries of a row are ordered exactly like the reference's row gather
+// (lduMatrixATmul.C:90-136: upper faces ascending, then lower faces in losort
+// order, then the coupled interfaces in patch order) so the floating-point
+// summation order is preserved.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mi {
+
+struct TileLayout {
+    int32_t nCells = 0, nFaces = 0, nExt = 0, nTiles = 0, nSlices = 0;
+    int32_t nPatches = 0;
+    std::vector<int32_t> e2c, c2e;        // engine<->caller cell permutation
+    std::vector<int32_t> tileCellStart;   // [nTiles+1] engine cell range
+    std::vector<int32_t> tileSlotStart;   // [nTiles+1] slot range (starts are even)
+    std::vector<int32_t> tileHaloStart;   // [nTiles+1]
+    std::vector<int32_t> haloCell;        // engine index; >= nCells means ext cell
+    std::vector<int32_t> tileSliceStart;  // [nTiles+1]
+    std::vector<int32_t> sliceEntryStart; // [nSlices+1]
+    std::vector<uint32_t> entries;        // other | slot<<16 | isLower<<31
+    std::vector<int32_t> slotFace;        // caller face id; -1 = padding; <= -2 : interface slot -(2+ext)
+    std::vector<int32_t> extSlot;         // [nExt] slot of each interface face
+    std::vector<int32_t> interiorTiles, boundaryTiles;
+    std::vector<int32_t> patchOffset;     // [nPatches+1]
+    std::vector<int32_t> patchFaceCellsE; // [nExt] engine cell of each patch face
+    std::vector<int32_t> faceSlot;        // [nFaces] a slot that holds caller face f (for faceH)
+    int32_t maxCells = 0, maxSlots = 0, maxHalo = 0;
+    int64_t totalSlots = 0;
+};
+
+struct TileParams {
+    int32_t tileCells = 1024; // max cells per tile
+    int32_t slotCap = 4094;   // max coefficient slots per tile
+};
+
+// returns empty string on success, else an error message
+std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* lower,
+                              const int32_t* upper, int32_t nPatches,
+                              const int32_t* patchSizes, const int32_t* const* patchFaceCells,
+                              const TileParams& prm, TileLayout& out);
+
+} // namespace mi

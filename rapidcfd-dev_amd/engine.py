@@ -1,0 +1,310 @@
+"""ctypes binding of the C ABI (include/mi_ldu.h) plus a thin object layer.
+
+PyTorch is only plumbing here: device memory (``torch.Tensor.data_ptr()``),
+the current HIP stream and ``torch.distributed``.  All arithmetic happens in
+``librapidcfd_amd.so`` (hand-written gfx950 kernels).  There is no CPU
+fallback: constructing a :class:`Context` without a gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librapidcfd_amd.so")
+_lib = None
+
+PRECOND = {"none": 0, "diagonal": 1, "AINV": 2,
+           # lduMatrixPreconditioner.C:58-61, DICPreconditioner.C:42-58: DIC/DILU resolve to AINV
+           "DIC": 2, "DILU": 2, "FDIC": 2}
+
+
+class MiError(RuntimeError):
+    pass
+
+
+class SolverPerf(C.Structure):
+    _fields_ = [("initialResidual", C.c_double), ("finalResidual", C.c_double),
+                ("normFactor", C.c_double), ("nIterations", C.c_int32),
+                ("converged", C.c_int32), ("singular", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SolverControls(C.Structure):
+    _fields_ = [("tolerance", C.c_double), ("relTol", C.c_double),
+                ("maxIter", C.c_int32), ("minIter", C.c_int32)]
+
+
+# every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
+SYMBOLS = [
+    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
+    "mi_addr_create", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
+    "mi_addr_n_ext", "mi_addr_cell_perm", "mi_addr_stats", "mi_addr_patch_offsets",
+    "mi_matrix_create", "mi_matrix_destroy", "mi_matrix_set_coeffs", "mi_matrix_set_interface_coeffs",
+    "mi_matrix_set_ext", "mi_halo_pack_engine", "mi_vec_to_engine", "mi_vec_from_engine",
+    "mi_amul", "mi_tmul", "mi_sumA", "mi_residual", "mi_H", "mi_H1", "mi_faceH",
+    "mi_amul_engine", "mi_tmul_engine", "mi_precondition", "mi_jacobi_smooth",
+    "mi_sum", "mi_sum_prod", "mi_sum_mag",
+    "mi_pcg_solve", "mi_pcg_begin", "mi_pcg_iterate", "mi_pcg_end",
+    "mi_pbicg_solve", "mi_pbicgstab_solve", "mi_smooth_solve",
+    "mi_bench_amul", "mi_bench_pcg_iters",
+    "mi_layout_build_host", "mi_layout_array", "mi_layout_free",
+]
+
+
+def host_layout(n_cells, lower_addr, upper_addr, patch_face_cells=(), tile_cells=0, slot_cap=0) -> dict:
+    """Build the tiled layout on the host only and return its tables as numpy arrays (tests)."""
+    lo = np.ascontiguousarray(lower_addr, dtype=np.int32)
+    up = np.ascontiguousarray(upper_addr, dtype=np.int32)
+    patches = [np.ascontiguousarray(p, dtype=np.int32) for p in patch_face_cells]
+    npatch = len(patches)
+    sizes = (C.c_int32 * max(npatch, 1))(*[p.shape[0] for p in patches])
+    ptrs = (C.POINTER(C.c_int32) * max(npatch, 1))(*[p.ctypes.data_as(C.POINTER(C.c_int32)) for p in patches])
+    h = C.c_void_p()
+    _chk(lib().mi_layout_build_host(C.c_int32(n_cells), C.c_int32(lo.shape[0]),
+                                    lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    C.c_int32(npatch), sizes, ptrs, C.c_int32(tile_cells), C.c_int32(slot_cap), C.byref(h)))
+    out = {}
+    try:
+        for name in ("e2c", "c2e", "tileCellStart", "tileSlotStart", "tileHaloStart", "haloCell", "tileSliceStart",
+                     "sliceEntryStart", "entries", "slotFace", "extSlot", "interiorTiles", "boundaryTiles",
+                     "patchOffset", "patchFaceCellsE", "faceSlot"):
+            data, ln = C.c_void_p(), C.c_int64()
+            _chk(lib().mi_layout_array(h, name.encode(), C.byref(data), C.byref(ln)))
+            dt = np.uint32 if name == "entries" else np.int32
+            if ln.value:
+                buf = (C.c_char * (ln.value * 4)).from_address(data.value)
+                out[name] = np.frombuffer(buf, dtype=dt).copy()
+            else:
+                out[name] = np.zeros(0, dtype=dt)
+    finally:
+        lib().mi_layout_free(h)
+    return out
+
+
+def lib():
+    """Load the native library; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mi_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise MiError(f"mi error {rc}: {lib().mi_last_error().decode()}")
+
+
+def device_available() -> bool:
+    return bool(lib().mi_device_available())
+
+
+def _ptr(t) -> C.c_void_p:
+    """Device pointer of a contiguous float64 torch tensor (or None)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 8, "need contiguous float64"
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    def __init__(self, device: int = 0, stream_handle: Optional[int] = None):
+        self.h = C.c_void_p()
+        _chk(lib().mi_ctx_create(int(device), C.c_void_p(stream_handle or 0), C.byref(self.h)))
+        self.device = device
+
+    def synchronize(self):
+        _chk(lib().mi_ctx_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            lib().mi_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    # field reductions -------------------------------------------------------
+    def _red(self, fn, a, b=None):
+        out = C.c_double()
+        if b is None:
+            _chk(getattr(lib(), fn)(self.h, _ptr(a), C.c_int64(a.numel()), C.byref(out)))
+        else:
+            _chk(getattr(lib(), fn)(self.h, _ptr(a), _ptr(b), C.c_int64(a.numel()), C.byref(out)))
+        return out.value
+
+    def sum(self, a):
+        return self._red("mi_sum", a)
+
+    def sum_mag(self, a):
+        return self._red("mi_sum_mag", a)
+
+    def sum_prod(self, a, b):
+        return self._red("mi_sum_prod", a, b)
+
+
+class Addressing:
+    """lduAddressing: host lowerAddr/upperAddr + coupled-patch faceCells -> tiled engine layout."""
+
+    def __init__(self, ctx: Context, n_cells: int, lower_addr, upper_addr, patch_face_cells: Sequence = ()):
+        self.ctx = ctx
+        lo = np.ascontiguousarray(lower_addr, dtype=np.int32)
+        up = np.ascontiguousarray(upper_addr, dtype=np.int32)
+        self._patches = [np.ascontiguousarray(p, dtype=np.int32) for p in patch_face_cells]
+        npatch = len(self._patches)
+        sizes = (C.c_int32 * max(npatch, 1))(*[p.shape[0] for p in self._patches])
+        ptrs = (C.POINTER(C.c_int32) * max(npatch, 1))(*[p.ctypes.data_as(C.POINTER(C.c_int32)) for p in self._patches])
+        self.h = C.c_void_p()
+        _chk(lib().mi_addr_create(ctx.h, C.c_int32(n_cells), C.c_int32(lo.shape[0]),
+                                  lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  C.c_int32(npatch), sizes, ptrs, C.byref(self.h)))
+        self.n_cells = n_cells
+        self.n_faces = int(lo.shape[0])
+        self.n_ext = int(lib().mi_addr_n_ext(self.h))
+        self.n_tiles = int(lib().mi_addr_n_tiles(self.h))
+
+    def cell_perm(self) -> np.ndarray:
+        out = np.empty(self.n_cells, dtype=np.int32)
+        _chk(lib().mi_addr_cell_perm(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def patch_offsets(self) -> np.ndarray:
+        out = np.empty(len(self._patches) + 1, dtype=np.int32)
+        _chk(lib().mi_addr_patch_offsets(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def stats(self) -> dict:
+        st = (C.c_int64 * 8)()
+        _chk(lib().mi_addr_stats(self.h, st))
+        keys = ["tiles", "slots", "entries", "halo", "max_cells", "max_slots", "max_halo", "lds_bytes_sym"]
+        return dict(zip(keys, [int(v) for v in st]))
+
+    def to_engine(self, x, out):
+        _chk(lib().mi_vec_to_engine(self.h, _ptr(x), _ptr(out)))
+
+    def from_engine(self, xe, out):
+        _chk(lib().mi_vec_from_engine(self.h, _ptr(xe), _ptr(out)))
+
+    def halo_pack(self, xe, send):
+        _chk(lib().mi_halo_pack_engine(self.h, _ptr(xe), _ptr(send)))
+
+    def close(self):
+        if self.h:
+            lib().mi_addr_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Matrix:
+    """lduMatrix coefficients bound to an :class:`Addressing`."""
+
+    def __init__(self, addr: Addressing):
+        self.addr = addr
+        self.h = C.c_void_p()
+        _chk(lib().mi_matrix_create(addr.h, C.byref(self.h)))
+
+    def set_coeffs(self, diag, upper, lower=None):
+        _chk(lib().mi_matrix_set_coeffs(self.h, _ptr(diag), _ptr(upper), _ptr(lower)))
+
+    def set_interface_coeffs(self, patch: int, bou, inte=None):
+        _chk(lib().mi_matrix_set_interface_coeffs(self.h, C.c_int32(patch), _ptr(bou), _ptr(inte)))
+
+    def set_ext(self, ext):
+        _chk(lib().mi_matrix_set_ext(self.h, _ptr(ext)))
+
+    # SpMV family (caller order) ---------------------------------------------
+    def amul(self, psi, out):
+        _chk(lib().mi_amul(self.h, _ptr(psi), _ptr(out)))
+
+    def tmul(self, psi, out):
+        _chk(lib().mi_tmul(self.h, _ptr(psi), _ptr(out)))
+
+    def sumA(self, out):
+        _chk(lib().mi_sumA(self.h, _ptr(out)))
+
+    def residual(self, psi, source, out):
+        _chk(lib().mi_residual(self.h, _ptr(psi), _ptr(source), _ptr(out)))
+
+    def H(self, psi, out):
+        _chk(lib().mi_H(self.h, _ptr(psi), _ptr(out)))
+
+    def H1(self, out):
+        _chk(lib().mi_H1(self.h, _ptr(out)))
+
+    def faceH(self, psi, out):
+        _chk(lib().mi_faceH(self.h, _ptr(psi), _ptr(out)))
+
+    # engine order -------------------------------------------------------------
+    def amul_engine(self, psi_e, out_e, which: int = 0):
+        _chk(lib().mi_amul_engine(self.h, _ptr(psi_e), _ptr(out_e), int(which)))
+
+    def tmul_engine(self, psi_e, out_e, which: int = 0):
+        _chk(lib().mi_tmul_engine(self.h, _ptr(psi_e), _ptr(out_e), int(which)))
+
+    def precondition(self, kind: str, rA, wA, transpose: bool = False):
+        _chk(lib().mi_precondition(self.h, PRECOND[kind], int(transpose), _ptr(rA), _ptr(wA)))
+
+    def jacobi_smooth(self, psi, source, n_sweeps: int, omega: float = 0.9):
+        _chk(lib().mi_jacobi_smooth(self.h, C.c_double(omega), _ptr(psi), _ptr(source), C.c_int32(n_sweeps)))
+
+    # solvers -------------------------------------------------------------------
+    def _solve(self, fn, psi, source, extra, tolerance, relTol, maxIter, minIter):
+        ctl = SolverControls(tolerance, relTol, maxIter, minIter)
+        perf = SolverPerf()
+        hist_len = maxIter + 2
+        hist = np.full(hist_len, np.nan)
+        _chk(getattr(lib(), fn)(self.h, _ptr(psi), _ptr(source), C.byref(ctl), *extra, C.byref(perf),
+                                hist.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(hist_len)))
+        out = {k: getattr(perf, k) for k, _ in SolverPerf._fields_ if k != "reserved"}
+        out["history"] = hist[: min(hist_len, max(perf.nIterations, 0) + 1)].copy()
+        return out
+
+    def pcg(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):
+        return self._solve("mi_pcg_solve", psi, source, (C.c_int(PRECOND[precond]),), tolerance, relTol, maxIter, minIter)
+
+    def pbicg(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):
+        return self._solve("mi_pbicg_solve", psi, source, (C.c_int(PRECOND[precond]),), tolerance, relTol, maxIter, minIter)
+
+    def pbicgstab(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0,
+                  replicate_quirk=True):
+        return self._solve("mi_pbicgstab_solve", psi, source, (C.c_int(PRECOND[precond]), C.c_int(int(replicate_quirk))),
+                           tolerance, relTol, maxIter, minIter)
+
+    def smooth_solve(self, psi, source, n_sweeps=1, omega=0.9, tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):
+        return self._solve("mi_smooth_solve", psi, source, (C.c_double(omega), C.c_int32(n_sweeps)),
+                           tolerance, relTol, maxIter, minIter)
+
+    # PCG session (bench) -------------------------------------------------------
+    def pcg_begin(self, psi0, source, precond="diagonal", tolerance=0.0, relTol=0.0, maxIter=1000, minIter=0,
+                  history_len=0):
+        ctl = SolverControls(tolerance, relTol, maxIter, minIter)
+        _chk(lib().mi_pcg_begin(self.h, _ptr(psi0), _ptr(source), C.byref(ctl), C.c_int(PRECOND[precond]),
+                                C.c_int32(history_len)))
+
+    def pcg_iterate(self, n_iters: int, time_amul: bool = False) -> Optional[float]:
+        if time_amul:
+            ms = C.c_float()
+            _chk(lib().mi_pcg_iterate(self.h, C.c_int32(n_iters), C.byref(ms)))
+            return ms.value
+        _chk(lib().mi_pcg_iterate(self.h, C.c_int32(n_iters), None))
+        return None
+
+    def pcg_end(self, psi_out=None, history_len=0):
+        perf = SolverPerf()
+        hist = np.full(max(history_len, 1), np.nan)
+        _chk(lib().mi_pcg_end(self.h, _ptr(psi_out), C.byref(perf), hist.ctypes.data_as(C.POINTER(C.c_double)),
+                              C.c_int32(history_len)))
+        out = {k: getattr(perf, k) for k, _ in SolverPerf._fields_ if k != "reserved"}
+        out["history"] = hist[: min(history_len, perf.nIterations + 1)].copy()
+        return out
+
+    def bench_amul(self, reps: int) -> float:
+        ms = C.c_float()
+        _chk(lib().mi_bench_amul(self.h, C.c_int32(reps), C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            lib().mi_matrix_destroy(self.h)
+            self.h = C.c_void_p()

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    graft.build()  # compiles the HIP engine (cross-compiles without a GPU) and the oracle
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def orc(pkg):
+    from oracle import oracle
+    return oracle
+
+
+def random_graph_case(pkg, n=700, extra=2.5, seed=3, symmetric=True):
+    """Ragged non-box LDU addressing: a random connected graph with varying row lengths."""
+    syn = pkg.synthetic
+    nf_target = int(n * extra)
+    u = syn.splitmix_uniform(seed, 2 * nf_target + 2 * n)
+    a = (u[:nf_target] * n).astype(np.int64)
+    b = (u[nf_target:2 * nf_target] * n).astype(np.int64)
+    chain = np.arange(n - 1)
+    lo = np.concatenate([np.minimum(a, b), chain])
+    up = np.concatenate([np.maximum(a, b), chain + 1])
+    keep = lo != up
+    pairs = np.unique(np.stack([lo[keep], up[keep]], axis=1), axis=0)  # sorted by (lower, upper): upper-triangular order
+    lo, up = pairs[:, 0].astype(np.int32), pairs[:, 1].astype(np.int32)
+    nf = lo.shape[0]
+    c = syn.splitmix_uniform(seed + 1, 2 * nf)
+    upper = -(0.2 + c[:nf])
+    lower = None if symmetric else -(0.2 + c[nf:])
+    diag = np.zeros(n)
+    np.subtract.at(diag, lo, upper if symmetric else lower)
+    np.subtract.at(diag, up, upper)
+    diag += 0.05 + syn.splitmix_uniform(seed + 2, n)
+    source = syn.splitmix_uniform(seed + 3, n) - 0.5
+    return syn.LduCase(n, lo, up, diag, upper, lower, source)

@@ -1,0 +1,128 @@
+"""CPU: the host-side tiling (rapidcfd-dev_amd/csrc/tiling.cpp) is verified by interpreting
+its tables in numpy -- exactly what tile_kernel does on the GPU -- and comparing with the oracle."""
+import numpy as np
+import pytest
+
+from conftest import random_graph_case
+
+
+def interpret_amul(L, case, x, ext=None, bou=None, transpose=False):
+    """numpy re-enactment of tile_kernel<OP_AMUL> over the layout tables."""
+    n = case.n_cells
+    e2c = L["e2c"]
+    xe = np.concatenate([x[e2c], ext if ext is not None else np.zeros(0)])
+    slot_face = L["slotFace"]
+    up = np.zeros(slot_face.shape[0]); lo = np.zeros(slot_face.shape[0])
+    internal = slot_face >= 0
+    lower_c = case.upper if case.lower is None else case.lower
+    up[internal] = case.upper[slot_face[internal]]
+    lo[internal] = lower_c[slot_face[internal]]
+    if bou is not None:
+        up[L["extSlot"]] = -bou
+        lo[L["extSlot"]] = -bou
+    ye = np.zeros(n)
+    nT = L["tileCellStart"].shape[0] - 1
+    for t in range(nT):
+        c0, c1 = L["tileCellStart"][t], L["tileCellStart"][t + 1]
+        s0 = L["tileSlotStart"][t]
+        h0, h1 = L["tileHaloStart"][t], L["tileHaloStart"][t + 1]
+        xs = np.concatenate([xe[c0:c1], xe[L["haloCell"][h0:h1]]])
+        nc = c1 - c0
+        for s in range(L["tileSliceStart"][t], L["tileSliceStart"][t + 1]):
+            e0, e1 = L["sliceEntryStart"][s], L["sliceEntryStart"][s + 1]
+            ent = L["entries"][e0:e1].reshape(-1, 64)
+            r0 = (s - L["tileSliceStart"][t]) * 64
+            rows = np.arange(r0, min(r0 + 64, nc))
+            acc = case.diag[e2c[c0 + rows]] * xs[rows]
+            for j in range(ent.shape[0]):
+                en = ent[j, : rows.shape[0]]
+                o = (en & 0xFFFF).astype(np.int64)
+                sl = ((en >> 16) & 0x7FFF).astype(np.int64)
+                is_low = (en >> 31).astype(bool)
+                coef = np.where(is_low != transpose, lo[s0 + sl], up[s0 + sl])
+                acc = acc + coef * xs[o]
+            ye[c0 + rows] = acc
+    y = np.empty(n)
+    y[e2c] = ye
+    return y
+
+
+@pytest.mark.parametrize("tile_cells", [64, 1024])
+@pytest.mark.parametrize("kind", ["box_sym", "box_asym", "graph_sym", "graph_asym", "tiny"])
+def test_layout_reproduces_amul(pkg, orc, kind, tile_cells):
+    syn, eng = pkg.synthetic, pkg.engine
+    if kind == "tiny":
+        case = syn.box_case(2, 1, 1)
+    elif kind.startswith("box"):
+        case = syn.box_case(13, 9, 7, symmetric=kind.endswith("_sym"))
+    else:
+        case = random_graph_case(pkg, 500, symmetric=kind.endswith("_sym"))
+    L = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr, tile_cells=tile_cells)
+    n = case.n_cells
+    # permutation is a bijection, tiles partition the cells, every tile respects the cap
+    assert np.array_equal(np.sort(L["e2c"]), np.arange(n))
+    assert np.array_equal(L["c2e"][L["e2c"]], np.arange(n))
+    sizes = np.diff(L["tileCellStart"])
+    assert sizes.min() >= 1 and sizes.max() <= tile_cells and sizes.sum() == n
+    assert np.all(L["tileSlotStart"] % 2 == 0)
+    # every face owns at least one slot; internal faces exactly one or two (cut)
+    cnt = np.bincount(L["slotFace"][L["slotFace"] >= 0], minlength=case.n_faces)
+    assert cnt.min() >= 1 and cnt.max() <= 2
+    assert np.array_equal(L["slotFace"][L["faceSlot"]], np.arange(case.n_faces))
+    S = orc.System([case])
+    x = syn.splitmix_uniform(21, n) - 0.5
+    ref = S.amul(x)
+    got = interpret_amul(L, case, x)
+    assert np.max(np.abs(got - ref)) <= 4e-16 * np.max(np.abs(ref)) * 8
+    gott = interpret_amul(L, case, x, transpose=True)
+    assert np.max(np.abs(gott - S.tmul(x))) <= 4e-16 * np.max(np.abs(ref)) * 8
+
+
+def test_single_cell(pkg):
+    L = pkg.engine.host_layout(1, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert L["tileCellStart"].tolist() == [0, 1]
+    assert L["entries"].shape[0] == 0
+
+
+def test_tiles_are_compact_bricks_on_a_box(pkg):
+    # multilevel heavy-edge matching must recover brick-shaped tiles on a lexicographic box:
+    # that is what makes each symmetric coefficient be read once
+    case = pkg.synthetic.box_case(32, 32, 32)
+    L = pkg.engine.host_layout(case.n_cells, case.lower_addr, case.upper_addr)
+    sizes = np.diff(L["tileCellStart"])
+    assert sizes.min() == sizes.max() == 1024
+    slots_per_row = np.diff(L["tileSlotStart"]).sum() / case.n_cells
+    halo_per_row = np.diff(L["tileHaloStart"]).sum() / case.n_cells
+    assert slots_per_row < 3.2 and halo_per_row < 0.5
+
+
+def test_interfaces_become_boundary_tiles(pkg, orc):
+    syn, eng = pkg.synthetic, pkg.engine
+    case = syn.box_case(12, 10, 8)
+    parts = syn.decompose_box(case, (2, 1, 1))
+    x = syn.splitmix_uniform(4, case.n_cells) - 0.5
+    ref = orc.System([case]).amul(x)
+    for d, sub in enumerate(parts):
+        fcs = [itf.face_cells for itf in sub.interfaces]
+        L = eng.host_layout(sub.n_cells, sub.lower_addr, sub.upper_addr, fcs, tile_cells=64)
+        n_ext = sum(len(f) for f in fcs)
+        assert L["patchOffset"][-1] == n_ext and L["extSlot"].shape[0] == n_ext
+        assert len(L["interiorTiles"]) + len(L["boundaryTiles"]) == len(L["tileCellStart"]) - 1
+        assert len(L["boundaryTiles"]) > 0 and len(L["interiorTiles"]) > 0
+        # interior tiles never reference an ext cell
+        for t in L["interiorTiles"]:
+            h = L["haloCell"][L["tileHaloStart"][t]:L["tileHaloStart"][t + 1]]
+            assert np.all(h < sub.n_cells)
+        # halo values: the neighbour's psi at its matching patch cells
+        ext = np.concatenate([x[parts[itf.nbr_domain].global_cells][parts[itf.nbr_domain].interfaces[itf.nbr_patch].face_cells]
+                              for itf in sub.interfaces])
+        bou = np.concatenate([itf.bou_coeffs for itf in sub.interfaces])
+        got = interpret_amul(L, sub, x[sub.global_cells], ext=ext, bou=bou)
+        assert np.max(np.abs(got - ref[sub.global_cells])) < 1e-15
+
+
+def test_bad_addressing_is_rejected(pkg):
+    with pytest.raises(pkg.engine.MiError):
+        pkg.engine.host_layout(4, np.array([2], np.int32), np.array([1], np.int32))  # lower >= upper
+    with pytest.raises(pkg.engine.MiError):
+        pkg.engine.host_layout(4, np.array([0], np.int32), np.array([7], np.int32))  # out of range

@@ -1,0 +1,139 @@
+"""CPU: pin the oracle with algebraic identities (parity is unpinned by the
+reference, which has no tests; these are the cross-checks available without its binary)."""
+import numpy as np
+import pytest
+
+from conftest import random_graph_case
+
+
+def dense(case):
+    n = case.n_cells
+    A = np.zeros((n, n), dtype=np.longdouble)
+    A[np.arange(n), np.arange(n)] = case.diag
+    lo, up = case.lower_addr, case.upper_addr
+    A[lo, up] = case.upper
+    A[up, lo] = case.upper if case.lower is None else case.lower
+    return A
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+@pytest.mark.parametrize("kind", ["box", "graph"])
+def test_spmv_family_against_dense(pkg, orc, symmetric, kind):
+    case = pkg.synthetic.box_case(7, 5, 4, symmetric=symmetric) if kind == "box" else random_graph_case(pkg, 300, symmetric=symmetric)
+    S = orc.System([case])
+    A = dense(case)
+    x = pkg.synthetic.splitmix_uniform(11, case.n_cells) - 0.5
+    scale = np.abs(A).sum(1).max()
+    for got, ref in [(S.amul(x), A @ x), (S.tmul(x), A.T @ x), (S.amul_faceloop(x), A @ x),
+                     (S.sumA(), A.sum(1)), (S.residual(x, case.source), case.source - A @ x),
+                     (S.H(x), -(A - np.diag(np.diag(A))) @ x), (S.H1(), -(A - np.diag(np.diag(A))).sum(1))]:
+        assert np.max(np.abs(got - ref.astype(np.float64))) < 4e-15 * scale
+    # symmetric => x'Ay == y'Ax ; Tmul(A) == Amul(A')
+    y = pkg.synthetic.splitmix_uniform(12, case.n_cells) - 0.5
+    if symmetric:
+        assert abs(y @ S.amul(x) - x @ S.amul(y)) < 1e-13 * scale
+        assert np.array_equal(S.amul(x), S.tmul(x))
+    lo, up = case.lower_addr, case.upper_addr
+    fh = S.faceH(x)
+    lower = case.upper if case.lower is None else case.lower
+    assert np.allclose(fh, case.upper * x[up] - lower * x[lo], rtol=0, atol=1e-15 * scale)
+
+
+def test_face_loop_order_vs_row_gather_order(pkg, orc):
+    # upstream OpenFOAM face loop and RapidCFD row gather agree to a few ulp (SURVEY 8c iii)
+    case = pkg.synthetic.box_case(12, 11, 10)
+    S = orc.System([case])
+    x = pkg.synthetic.splitmix_uniform(5, case.n_cells)
+    a, b = S.amul(x), S.amul_faceloop(x)
+    assert np.max(np.abs(a - b)) <= 8 * np.finfo(float).eps * np.max(np.abs(a) + 1)
+
+
+@pytest.mark.parametrize("precond", ["none", "diagonal", "AINV", "DIC_upstream"])
+def test_pcg_solves_and_history_is_consistent(pkg, orc, precond):
+    case = pkg.synthetic.box_case(10, 9, 8)
+    S = orc.System([case])
+    A = dense(case).astype(np.float64)
+    psi, perf = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=1e-9, maxIter=500)
+    assert perf["converged"] and not perf["singular"]
+    assert perf["history"].shape[0] == perf["nIterations"] + 1
+    assert perf["history"][-1] == perf["finalResidual"] < 1e-9
+    # the reported residual is the true one: sum|b - A psi| / normFactor
+    true = np.abs(case.source - A @ psi).sum() / perf["normFactor"]
+    assert abs(true - perf["finalResidual"]) < 1e-6 * perf["finalResidual"] + 1e-14
+
+
+def test_pcg_iteration_counts_ordering(pkg, orc):
+    # 7-point Laplacian sanity: stronger preconditioners need fewer iterations
+    case = pkg.synthetic.box_case(16, 16, 16)
+    S = orc.System([case])
+    it = {p: S.pcg(np.zeros(case.n_cells), case.source, p, tolerance=1e-7, maxIter=2000)[1]["nIterations"]
+          for p in ["none", "diagonal", "AINV", "DIC_upstream"]}
+    assert it["DIC_upstream"] < it["AINV"] < min(it["diagonal"], it["none"])
+
+
+@pytest.mark.parametrize("solver", ["pbicg", "pbicgstab"])
+@pytest.mark.parametrize("precond", ["diagonal", "AINV"])
+def test_asymmetric_solvers(pkg, orc, solver, precond):
+    case = pkg.synthetic.box_case(9, 8, 7, symmetric=False)
+    S = orc.System([case])
+    A = dense(case).astype(np.float64)
+    kw = dict(replicate_quirk=False) if solver == "pbicgstab" else {}
+    psi, perf = getattr(S, solver)(np.zeros(case.n_cells), case.source, precond, tolerance=1e-10, maxIter=300, **kw)
+    assert perf["converged"]
+    assert np.abs(A @ psi - case.source).sum() / perf["normFactor"] < 1e-8
+
+
+def test_max_iter_quirk_and_min_iter(pkg, orc):
+    # do { } while (nIterations++ < maxIter ...) runs maxIter+1 bodies (PCG.C:197-204)
+    case = pkg.synthetic.box_case(8, 8, 8)
+    S = orc.System([case])
+    _, perf = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=0.0, maxIter=5)
+    assert perf["nIterations"] == 6 and not perf["converged"]
+    _, perf = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e30, maxIter=50, minIter=3)
+    assert perf["nIterations"] == 3
+    _, perf = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e30, maxIter=50)
+    assert perf["nIterations"] == 0 and perf["converged"]
+
+
+def test_singular_detection(pkg, orc):
+    case = pkg.synthetic.box_case(4, 4, 4)
+    case.source[:] = 0.0  # r = 0 => wApA = 0 => singular break, no iteration counted
+    _, perf = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=0.0, maxIter=5)
+    assert perf["singular"] and perf["nIterations"] == 0
+
+
+def test_decomposed_system_matches_serial(pkg, orc):
+    # N-subdomain emulation of the one-rank-per-GPU run: same product, same PCG history
+    syn = pkg.synthetic
+    for symmetric in (True, False):
+        case = syn.box_case(10, 8, 6, symmetric=symmetric)
+        parts = syn.decompose_box(case, (2, 2, 1))
+        S, SD = orc.System([case]), orc.System(parts)
+        x = syn.splitmix_uniform(3, case.n_cells) - 0.5
+        xg = np.concatenate([x[p.global_cells] for p in parts])
+        ref = S.amul(x)
+        got = SD.amul(xg)
+        assert np.max(np.abs(got - np.concatenate([ref[p.global_cells] for p in parts]))) < 1e-15
+        reft = S.tmul(x)
+        assert np.max(np.abs(SD.tmul(xg) - np.concatenate([reft[p.global_cells] for p in parts]))) < 1e-15
+        assert np.max(np.abs(SD.sumA() - np.concatenate([S.sumA()[p.global_cells] for p in parts]))) < 1e-15
+    case = syn.box_case(10, 8, 6)
+    parts = syn.decompose_box(case, (2, 1, 2))
+    b = np.concatenate([case.source[p.global_cells] for p in parts])
+    _, p1 = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-9)
+    _, p2 = orc.System(parts).pcg(np.zeros(case.n_cells), b, "diagonal", tolerance=1e-9)
+    assert p1["nIterations"] == p2["nIterations"]
+    # a 1-ulp change of summation order in Amul is amplified by CG: per-iteration relative
+    # agreement degrades as the residual falls, agreement relative to the initial residual holds
+    assert np.max(np.abs(p1["history"] - p2["history"])) < 1e-12 * p1["history"][0]
+    assert np.max(np.abs(p1["history"] - p2["history"]) / p1["history"]) < 1e-6
+
+
+def test_jacobi_fixed_point(pkg, orc):
+    case = pkg.synthetic.box_case(6, 6, 6, dirichlet_all=True)
+    S = orc.System([case])
+    A = dense(case).astype(np.float64)
+    exact = np.linalg.solve(A, case.source)
+    assert np.max(np.abs(S.jacobi_smooth(exact, case.source, 3) - exact)) < 1e-12 * np.max(np.abs(exact))
+    x = S.jacobi_smooth(np.zeros(case.n_cells), case.source, 400)
+    assert np.max(np.abs(x - exact)) < 1e-3 * np.max(np.abs(exact))
