@@ -168,7 +168,7 @@ class System:
         getattr(lib(), fn)(self.h, _p(x, C.c_double), _p(b, C.c_double), C.byref(ctl), *extra,
                            C.byref(perf), _p(hist, C.c_double), hist_len)
         out = {k: getattr(perf, k) for k, _ in Perf._fields_}
-        out["history"] = hist[: min(hist_len, max(perf.nIterations, 0) + 1)].copy()
+        out["history"] = hist[~np.isnan(hist)].copy()
         return x, out
 
     def pcg(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):

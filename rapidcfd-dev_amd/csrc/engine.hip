@@ -70,7 +70,7 @@ struct mi_ctx_s {
     PcgState* hostState = nullptr; // pinned
     double* hostScal = nullptr;    // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int amulBS = 256;
+    int amulBS = 512;
 };
 
 struct mi_addr_s {
@@ -89,7 +89,7 @@ struct mi_matrix_s {
     DevBuf<double> diagE, upE, lowE, rD;
     bool asym = false, bound = false, rDValid = false;
     std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
-    DevBuf<double> hist;
+    DevBuf<double> hist, tilePartial;
     int histLen = 0;
     // running PCG session (mi_pcg_begin/iterate/end)
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
@@ -148,8 +148,8 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c; return fail(MI_ERR_DEVICE, "pinned host / event allocation failed");
     }
-    c->amulBS = env_int("MI_AMUL_BS", 256);
-    if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 256;
+    c->amulBS = env_int("MI_AMUL_BS", 512);
+    if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 512;
     *out = c;
     return MI_OK;
 }
@@ -333,7 +333,7 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
     {                                                                                                                   \
         static bool attr##BS = false;                                                                                   \
         if (!attr##BS) {                                                                                                \
-            HIPCHK(hipFuncSetAttribute((const void*)tile_kernel<OP, ASYM, TRANS, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)tile_kernel<OP, ASYM, TRANS, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); \
             attr##BS = true;                                                                                            \
         }                                                                                                               \
         tile_kernel<OP, ASYM, TRANS, BS><<<nTiles, BS, lds, s>>>(args);                                                 \
@@ -349,7 +349,7 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
 // which: 0 all tiles, 1 interior only, 2 boundary only
 template <int OP>
 int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, const double* rD, double* y,
-                double omega, int which)
+                double omega, int which, double* dotPartial = nullptr)
 {
     mi_addr_s* a = m->addr;
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound (mi_matrix_set_coeffs)");
@@ -358,9 +358,9 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     t.haloCell = a->haloCell.p; t.tileSliceStart = a->tileSliceStart.p; t.sliceEntryStart = a->sliceEntryStart.p;
     t.entries = a->entries.p;
     t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
-    t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega;
+    t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega; t.dotPartial = dotPartial;
     const size_t lds = lds_bytes(a->L, m->asym, OP == OP_AINV, &t.offLow, &t.offX, &t.offRD);
-    if (lds > 160 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 160 KiB of LDS");
+    if (lds > 159 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 159 KiB of LDS");
     int nTiles = a->L.nTiles;
     t.tileList = nullptr;
     if (which == 1) { t.tileList = a->interiorTiles.p; nTiles = a->nInterior; }
@@ -678,7 +678,10 @@ int copy_hist(mi_matrix_s* m, double* hist_host, int len, int nIter)
     return MI_OK;
 }
 
-// enqueue PCG iteration bodies it0 .. it0+count-1 (no host sync)
+// enqueue PCG iteration bodies it0 .. it0+count-1 (no host sync).
+// diagonal / none: 5 launches per iteration -- update_p (precondition fused), Amul (+ fused
+// gSumProd partials), fold, update_psi_r (+ next iteration's wArA partials), final.
+// AINV: the preconditioner is itself a tile pass, so wA is materialised.
 int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool timeAmul)
 {
     mi_addr_s* a = m->addr;
@@ -689,24 +692,30 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool timeAmul)
     MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
     double* P1 = c->partial.p; double* P2 = c->partial.p + RG; double* P3 = c->partial.p + 2 * RG;
     if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
+    if (m->tilePartial.n < (size_t)a->L.nTiles) MICHK(m->tilePartial.alloc((size_t)a->L.nTiles));
     for (int it = it0; it < it0 + count; ++it) {
         if (precond == MI_PRECOND_AINV) {
             MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0));
-            k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rA, n, P1); // not gated by done: harmless, P1 unused afterwards
+            k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rA, n, P1); // not gated by done: harmless
+            k_pcg_update_p<0><<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, nullptr, nullptr, pA, n);
         } else if (precond == MI_PRECOND_DIAGONAL) {
-            k_pcg_precond_dot<true><<<RG, RB, 0, s>>>(c->state.p, m->rD.p, rA, wA, n, P1);
+            k_pcg_update_p<1><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, m->rD.p, rA, pA, n);
         } else {
-            k_pcg_precond_dot<false><<<RG, RB, 0, s>>>(c->state.p, nullptr, rA, wA, n, P1);
+            k_pcg_update_p<2><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, nullptr, rA, pA, n);
         }
-        k_pcg_update_p<<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, pA, n);
         if (timeAmul) {
             while (m->evPool.size() < (size_t)(2 * (it - it0 + 1))) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); m->evPool.push_back(e); }
             HIPCHK(hipEventRecord(m->evPool[(size_t)2 * (it - it0)], s));
         }
-        MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0));
+        MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0, m->tilePartial.p));
         if (timeAmul) HIPCHK(hipEventRecord(m->evPool[(size_t)2 * (it - it0) + 1], s));
-        k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, pA, n, P2);
-        k_pcg_update_psi_r<<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, psi, rA, n, P3);
+        k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P2);
+        if (precond == MI_PRECOND_AINV)
+            k_pcg_update_psi_r<0><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
+        else if (precond == MI_PRECOND_DIAGONAL)
+            k_pcg_update_psi_r<1><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, m->rD.p, psi, rA, n, P3, P1);
+        else
+            k_pcg_update_psi_r<2><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
         k_pcg_final<<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
     }
     HIPCHK(hipGetLastError());
@@ -729,6 +738,14 @@ extern "C" int mi_pcg_begin(mi_matrix_t m, const double* psi0, const double* sou
     k_gather_perm<<<RG, RB, 0, s>>>(psi0, a->e2c.p, psi, a->L.nCells);
     k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
     MICHK(solve_prologue(m, ctl, psi, src, wA, rA, pA, history_len));
+    // wArA partials of iteration 0 (later iterations get them from k_pcg_update_psi_r)
+    if (precond == MI_PRECOND_DIAGONAL) {
+        MICHK(ensure_rD(m));
+        k_pcg_precond_dot<true><<<RG, RB, 0, s>>>(a->ctx->state.p, m->rD.p, rA, wA, a->L.nCells, a->ctx->partial.p);
+    } else if (precond == MI_PRECOND_NONE) {
+        k_pcg_precond_dot<false><<<RG, RB, 0, s>>>(a->ctx->state.p, nullptr, rA, wA, a->L.nCells, a->ctx->partial.p);
+    }
+    HIPCHK(hipGetLastError());
     m->pcgIt = 0; m->pcgPrecond = precond; m->pcgActive = true;
     return MI_OK;
 }

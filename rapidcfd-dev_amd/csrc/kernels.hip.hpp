@@ -98,6 +98,7 @@ struct TileArgs {
     const double* b;  // source (residual, Jacobi)
     const double* rD; // AINV
     double* y;
+    double* dotPartial; // Amul only: per-workgroup partial of sum(y*x) (fused gSumProd), or nullptr
     double omega;
     int32_t offLow, offX, offRD; // LDS offsets in doubles
 };
@@ -164,15 +165,42 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
             stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
         }
     }
-    __syncthreads();
 
     // ---- rows: one wavefront per 64-row slice, uniform trip count -------------
+    // The {slot, other} entries of a slice are fetched into registers one slice
+    // ahead (the first slice before the staging barrier), so the compute loop
+    // only touches LDS.
     const int sl0 = a.tileSliceStart[t], nsl = a.tileSliceStart[t + 1] - sl0;
     const int wave = tid >> 6, lane = tid & 63;
-    for (int s = wave; s < nsl; s += BS / 64) {
-        const int e0 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s]);
+    constexpr int NW = BS / 64;
+    constexpr int PRE = 8;
+    const uint32_t padEnt = (uint32_t)(ns - 1) << 16; // last slot of the segment is always 0.0
+    uint32_t ecur[PRE];
+    int wcur = 0, e0cur = 0;
+    auto fetch = [&](int s, uint32_t (&e)[PRE], int& e0, int& width) {
+        e0 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s]);
         const int e1 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s + 1]);
-        const int width = (e1 - e0) >> 6;
+        width = (e1 - e0) >> 6;
+        const uint32_t* ent = a.entries + e0 + lane;
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) e[j] = (j < width) ? ent[j * 64] : padEnt;
+    };
+    if (wave < nsl) fetch(wave, ecur, e0cur, wcur);
+    else {
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) ecur[j] = padEnt;
+    }
+    __syncthreads();
+
+    double dot = 0.0;
+    for (int s = wave; s < nsl; s += NW) {
+        uint32_t enext[PRE];
+        int wnext = 0, e0next = 0;
+        if (s + NW < nsl) fetch(s + NW, enext, e0next, wnext);
+        else {
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) enext[j] = padEnt;
+        }
         const int i = s * 64 + lane;
         const bool live = i < nc;
         const int gi = c0 + (live ? i : 0);
@@ -182,10 +210,7 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
         else if (OP == OP_SUMA) acc = a.diag[gi];
         else if (OP == OP_RESIDUAL) acc = a.b[gi] - a.diag[gi] * xi;
         else acc = 0.0;
-        const uint32_t* ent = a.entries + e0 + lane;
-#pragma unroll 2
-        for (int j = 0; j < width; ++j) {
-            const uint32_t en = ent[j * 64];
+        auto accumulate = [&](uint32_t en) {
             const int o = en & 0xFFFFu;
             const int sl = (en >> 16) & 0x7FFFu;
             double c;
@@ -196,6 +221,12 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
             else if (OP == OP_RESIDUAL || OP == OP_H) acc = fma(-c, xs[o], acc);
             else if (OP == OP_H1) acc -= c;
             else if (OP == OP_AINV) acc = fma(c * rDs[o], xs[o], acc);
+        };
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) if (j < wcur) accumulate(ecur[j]);
+        if (wcur > PRE) {
+            const uint32_t* ent = a.entries + e0cur + lane;
+            for (int j = PRE; j < wcur; ++j) accumulate(ent[j * 64]);
         }
         if (live) {
             if (OP == OP_AINV) a.y[gi] = rDs[i] * (xi - acc);
@@ -204,8 +235,25 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
                 const double extra = (1 - a.omega) * xi + a.omega * rD * a.b[gi];
                 a.y[gi] = extra - a.omega * rD * acc;
             } else a.y[gi] = acc;
+            if (OP == OP_AMUL) dot = fma(acc, xi, dot);
         }
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) ecur[j] = enext[j];
+        wcur = wnext; e0cur = e0next;
     }
+    if (OP == OP_AMUL && a.dotPartial) { // fused gSumProd(wA, pA), PCG.C:166
+        __shared__ double red[BS / 64];
+        const double tsum = block_sum<BS>(dot, red);
+        if (tid == 0) a.dotPartial[blockIdx.x] = tsum;
+    }
+}
+
+// fold n per-workgroup partials into the RG slots the consumers reduce (fixed order)
+__global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict__ in, int n, double* __restrict__ out)
+{
+    double v = 0.0;
+    for (int k = threadIdx.x; k < n; k += 1024) v += in[k];
+    out[threadIdx.x] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -384,28 +432,42 @@ __global__ __launch_bounds__(RB) void k_pcg_precond_dot(const PcgState* __restri
 }
 
 // wArA = sum(partial1); beta = wArA/wArAold; pA = wA (+ beta*pA)      [PCG.C:144-160]
+// PMODE 0: wA is stored (any preconditioner); 1: wA = rD*rA recomputed on the fly (diagonal);
+// 2: wA = rA (none) -- the precondition pass and the wA round trip through HBM are fused away.
+template <int PMODE>
 __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
-                                                     const double* __restrict__ wA, double* __restrict__ pA, int64_t n)
+                                                     const double* __restrict__ wA, const double* __restrict__ rD,
+                                                     const double* __restrict__ rA, double* __restrict__ pA, int64_t n)
 {
     if (st->done) return;
     __shared__ double red[RB / 64];
     const double wArA = sum_partials(partial1, red);
-    if (it == 0) {
-        chunk_loop(n, [&](int64_t i) { st2(pA, i, ld2(wA, i)); },
-        [&](int64_t i) { pA[i] = wA[i]; });
-    } else {
-        const double beta = wArA / st->wArA[(it & 1) ^ 1];
-        chunk_loop(n, [&](int64_t i) { const double2 w = ld2(wA, i), p = ld2(pA, i); st2(pA, i, make_double2(fma(beta, p.x, w.x), fma(beta, p.y, w.y))); },
-        [&](int64_t i) { pA[i] = fma(beta, pA[i], wA[i]); });
-    }
+    const double beta = (it == 0) ? 0.0 : wArA / st->wArA[(it & 1) ^ 1];
+    const bool first = (it == 0);
+    chunk_loop(n, [&](int64_t i) {
+            double2 w;
+            if (PMODE == 0) w = ld2(wA, i);
+            else if (PMODE == 1) { const double2 d = ld2(rD, i), r = ld2(rA, i); w = make_double2(d.x * r.x, d.y * r.y); }
+            else w = ld2(rA, i);
+            if (first) st2(pA, i, w);
+            else { const double2 p = ld2(pA, i); st2(pA, i, make_double2(fma(beta, p.x, w.x), fma(beta, p.y, w.y))); }
+        },
+        [&](int64_t i) {
+            const double w = (PMODE == 0) ? wA[i] : (PMODE == 1) ? rD[i] * rA[i] : rA[i];
+            pA[i] = first ? w : fma(beta, pA[i], w);
+        });
     if (blockIdx.x == 0 && threadIdx.x == 0) st->wArA[it & 1] = wArA;
 }
 
 // wApA = sum(partial2); singular? ; alpha; psi += alpha pA; rA -= alpha wA; partial3 = sum|rA|  [PCG.C:166-195]
+// PMODE 1/2 additionally produce partial1 = sum (M^-1 rA)*rA for the NEXT iteration's wArA
+// (precondition + gSumProd of PCG.C:139-142 fused into this pass).
+template <int PMODE>
 __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
                                                          const double* __restrict__ pA, const double* __restrict__ wA,
+                                                         const double* __restrict__ rD,
                                                          double* __restrict__ psi, double* __restrict__ rA, int64_t n,
-                                                         double* __restrict__ partial3)
+                                                         double* __restrict__ partial3, double* __restrict__ partial1)
 {
     if (st->done) return;
     __shared__ double red[RB / 64];
@@ -416,14 +478,25 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
         return;
     }
     const double alpha = st->wArA[it & 1] / wApA;
-    double acc0 = 0, acc1 = 0;
-    chunk_loop(n, [&](int64_t i) { const double2 p = ld2(pA, i), w = ld2(wA, i); double2 x = ld2(psi, i), r = ld2(rA, i);
-          x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y);
-          r.x = fma(-alpha, w.x, r.x); r.y = fma(-alpha, w.y, r.y);
-          st2(psi, i, x); st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y); },
-        [&](int64_t i) { psi[i] = fma(alpha, pA[i], psi[i]); const double r = fma(-alpha, wA[i], rA[i]); rA[i] = r; acc0 += fabs(r); });
+    double acc0 = 0, acc1 = 0, d0 = 0, d1 = 0;
+    chunk_loop(n, [&](int64_t i) {
+            const double2 p = ld2(pA, i), w = ld2(wA, i); double2 x = ld2(psi, i), r = ld2(rA, i);
+            x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y);
+            r.x = fma(-alpha, w.x, r.x); r.y = fma(-alpha, w.y, r.y);
+            st2(psi, i, x); st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y);
+            if (PMODE == 1) { const double2 d = ld2(rD, i); d0 = fma(d.x * r.x, r.x, d0); d1 = fma(d.y * r.y, r.y, d1); }
+            else if (PMODE == 2) { d0 = fma(r.x, r.x, d0); d1 = fma(r.y, r.y, d1); }
+        },
+        [&](int64_t i) {
+            psi[i] = fma(alpha, pA[i], psi[i]); const double r = fma(-alpha, wA[i], rA[i]); rA[i] = r; acc0 += fabs(r);
+            if (PMODE == 1) d0 = fma(rD[i] * r, r, d0); else if (PMODE == 2) d0 = fma(r, r, d0);
+        });
     const double t = block_sum<RB>(acc0 + acc1, red);
     if (threadIdx.x == 0) partial3[blockIdx.x] = t;
+    if (PMODE != 0) {
+        const double u = block_sum<RB>(d0 + d1, red);
+        if (threadIdx.x == 0) partial1[blockIdx.x] = u;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->alpha = alpha; st->wApA = wApA; }
 }
 

