@@ -96,7 +96,8 @@ def main():
     ctx = eng.Context(local_rank, torch.cuda.current_stream().cuda_stream)
     K, W = args.steps, args.warmup
     amul_ms = None
-    if world == 1:
+    force_dist = bool(os.environ.get("MI_BENCH_FORCE_DIST"))  # exercise the N>1 code path on one GPU
+    if world == 1 and not force_dist:
         t0 = time.perf_counter()
         addr = eng.Addressing(ctx, N, case.lower_addr, case.upper_addr)
         mat = eng.Matrix(addr)
@@ -124,16 +125,19 @@ def main():
         solver.begin(tolerance=0.0, max_iter=W + K + 8)
         solver.iterate(W)
         torch.cuda.synchronize()
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         amul_ms = solver.iterate(K, time_amul=True)
         torch.cuda.synchronize()
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         elapsed = time.perf_counter() - t0
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
         perf = solver.end()
         assert perf["nIterations"] == W + K, perf
         n_amul_cells, n_amul_faces = sub.n_cells, sub.n_faces + sum(len(i.face_cells) for i in sub.interfaces)

@@ -197,6 +197,34 @@ int mi_pcg_iterate(mi_matrix_t m, int32_t n_iters, float *amul_ms_sum);
 int mi_pcg_end(mi_matrix_t m, double *psi_out_dev, mi_solver_perf *perf_out,
                double *residual_history_host, int32_t history_len);
 
+/* ---- distributed PCG (one rank per GPU).  The reference runs the same PCG on every
+ * MPI rank and meets its neighbours in Foam::reduce (PCG.C:142,166,195 ->
+ * src/Pstream/mpi/allReduceTemplates.C:195-208) and in the processor-patch exchange inside
+ * Amul (lduMatrixUpdateMatrixInterfaces.C:30-276).  Here the device-resident pipeline is
+ * cut at exactly those points: the caller owns the engine-order vectors (n_cells + n_ext
+ * doubles each), an 8-double scalar block and the send buffer (n_ext doubles), runs the
+ * collectives (RCCL through torch.distributed) between phases, and receives the halo
+ * straight into pA[n_cells ..).  scal: [0] sum wA.rA  [1] sum|rA|  [2] sum wA.pA
+ * [3] sum psi  [4] normFactor sum.  Phases:
+ *    0  pack psi for the exchange            (then: exchange into psi ext)
+ *    1  wA=A psi, rA, sumA, scal[3]          (then: allreduce scal[3]; avg = scal[3]/N_global)
+ *    2  arg=avg: scal[4], scal[1], scal[0]   (then: allreduce scal[0..1], scal[4])
+ *    3  normFactor, initial residual, first convergence test
+ *   10  (test of it-1,) pA update, pack pA   (then: start exchange into pA ext)
+ *   11  Amul interior tiles                  (overlaps the exchange)
+ *   12  Amul boundary tiles, scal[2]         (after the exchange; then allreduce scal[2])
+ *   13  psi, rA update, scal[1], scal[0]     (then: allreduce scal[0..1])
+ *   14  convergence test of iteration `it`   (end of a batch)                           */
+int mi_dpcg_set_buffers(mi_matrix_t m, double *psi_e, double *src_e, double *pA_e, double *wA_e,
+                        double *rA_e, double *scal8, double *send_buf,
+                        const mi_solver_controls *controls, int precond, int32_t history_len);
+int mi_dpcg_phase(mi_matrix_t m, int phase, int32_t it, double arg);
+int mi_dpcg_status(mi_matrix_t m, mi_solver_perf *perf_out, int32_t *done_out,
+                   double *residual_history_host, int32_t history_len);
+/* HIP-event helpers on the context's stream (bench.py times the Amul phases with them) */
+int mi_event_record(mi_matrix_t m, int32_t idx);
+int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, float *ms_out);
+
 int mi_pbicg_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
                    const mi_solver_controls *controls, int precond,
                    mi_solver_perf *perf_out, double *residual_history_host, int32_t history_len);

@@ -84,8 +84,11 @@ struct mi_addr_s {
     int64_t nEntries = 0, nHaloTot = 0;
 };
 
+struct mi_dpcg_s { double *psi = nullptr, *src = nullptr, *pA = nullptr, *wA = nullptr, *rA = nullptr, *scal = nullptr, *send = nullptr; int precond = 0; };
+
 struct mi_matrix_s {
     mi_addr_s* addr = nullptr;
+    mi_dpcg_s dp; // buffers of a distributed PCG session (owned by the caller)
     DevBuf<double> diagE, upE, lowE, rD;
     bool asym = false, bound = false, rDValid = false;
     std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
@@ -649,7 +652,7 @@ int solve_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* 
     const double avg = sumPsi / (double)n;
     k_normfactor<<<RG, RB, 0, s>>>(wA, src_e, tmp, avg, n, c->partial.p);
     k_reduce<RED_MAG><<<RG, RB, 0, s>>>(rA, nullptr, n, c->partial.p + RG);
-    k_solve_init<<<1, RB, 0, s>>>(c->state.p, c->partial.p, c->partial.p + RG, m->hist.p, histLen);
+    k_solve_init<false><<<1, RB, 0, s>>>(c->state.p, c->partial.p, c->partial.p + RG, m->hist.p, histLen);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -716,7 +719,7 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool timeAmul)
             k_pcg_update_psi_r<1><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, m->rD.p, psi, rA, n, P3, P1);
         else
             k_pcg_update_psi_r<2><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
-        k_pcg_final<<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
+        k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
     }
     HIPCHK(hipGetLastError());
     return MI_OK;
@@ -796,6 +799,118 @@ extern "C" int mi_pcg_solve(mi_matrix_t m, double* psi, const double* source, co
         MICHK(fetch_state(c));
     }
     return mi_pcg_end(m, psi, perf, hist_host, hist_len);
+}
+
+
+// ---------------------------------------------------------------------------
+// distributed PCG: the same device-resident pipeline cut into phases at the
+// points where the reference calls Foam::reduce / exchanges processor-patch
+// values (PCG.C:142,166,195 -> allReduceTemplates.C:195-208; Amul ->
+// lduMatrixUpdateMatrixInterfaces.C:30-276).  The caller (one rank per GPU)
+// owns the engine-order vectors and the 8-double scalar block, runs the
+// collectives (RCCL) on them between phases, and receives halo values straight
+// into pA[n_cells..n_cells+n_ext).  scal: [0] sum wA.rA  [1] sum|rA|  [2] sum wA.pA
+// [3] sum psi  [4] normFactor sum.
+// ---------------------------------------------------------------------------
+
+extern "C" int mi_dpcg_set_buffers(mi_matrix_t m, double* psi_e, double* src_e, double* pA_e, double* wA_e, double* rA_e,
+                                   double* scal8, double* send_buf, const mi_solver_controls* ctl, int precond, int32_t history_len)
+{
+    if (!m || !psi_e || !src_e || !pA_e || !wA_e || !rA_e || !scal8 || !ctl) return fail(MI_ERR_ARG, "mi_dpcg_set_buffers: bad argument");
+    if (precond != MI_PRECOND_DIAGONAL && precond != MI_PRECOND_NONE) return fail(MI_ERR_ARG, "distributed PCG supports the diagonal / none preconditioners");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_ctx_s* c = m->addr->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    m->dp.psi = psi_e; m->dp.src = src_e; m->dp.pA = pA_e; m->dp.wA = wA_e; m->dp.rA = rA_e; m->dp.scal = scal8; m->dp.send = send_buf; m->dp.precond = precond;
+    const int histLen = history_len > 0 ? history_len : 1;
+    if (m->hist.n < (size_t)histLen) MICHK(m->hist.alloc((size_t)histLen));
+    m->histLen = history_len;
+    if (m->tilePartial.n < (size_t)m->addr->L.nTiles) MICHK(m->tilePartial.alloc((size_t)m->addr->L.nTiles));
+    PcgState h; memset(&h, 0, sizeof(h));
+    h.tolerance = ctl->tolerance; h.relTol = ctl->relTol; h.maxIter = ctl->maxIter; h.minIter = ctl->minIter;
+    *c->hostState = h;
+    HIPCHK(hipMemcpyAsync(c->state.p, c->hostState, sizeof(PcgState), hipMemcpyHostToDevice, c->stream));
+    if (precond == MI_PRECOND_DIAGONAL) MICHK(ensure_rD(m));
+    return MI_OK;
+}
+
+// phases: see include/mi_ldu.h
+extern "C" int mi_dpcg_phase(mi_matrix_t m, int phase, int32_t it, double arg)
+{
+    if (!m || !m->dp.psi) return fail(MI_ERR_STATE, "mi_dpcg_phase: call mi_dpcg_set_buffers first");
+    mi_addr_s* a = m->addr;
+    mi_ctx_s* c = a->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t n = a->L.nCells;
+    const mi_dpcg_s& B = m->dp;
+    double* P = c->partial.p; // scratch partial slots
+    auto finalize = [&](const double* partial, double* dst) { k_reduce_final<<<1, RB, 0, s>>>(partial, dst); };
+    switch (phase) {
+    case 0: // prologue: gather psi at the coupled patches for the exchange
+        MICHK(mi_halo_pack_engine(a, B.psi, B.send));
+        break;
+    case 1: // wA = A psi ; rA = src - wA ; sumA ; local sum(psi)
+        MICHK(launch_tile<OP_AMUL>(m, false, B.psi, nullptr, nullptr, B.wA, 0.0, 0));
+        k_sub<<<RG, RB, 0, s>>>(B.rA, B.src, B.wA, n);
+        MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, B.pA, 0.0, 0));
+        k_reduce<RED_SUM><<<RG, RB, 0, s>>>(B.psi, nullptr, n, P);
+        finalize(P, B.scal + 3);
+        break;
+    case 2: // arg = global average of psi: normFactor partial, sum|rA|, first wArA
+        k_normfactor<<<RG, RB, 0, s>>>(B.wA, B.src, B.pA, arg, n, P);
+        finalize(P, B.scal + 4);
+        k_reduce<RED_MAG><<<RG, RB, 0, s>>>(B.rA, nullptr, n, P + RG);
+        finalize(P + RG, B.scal + 1);
+        if (B.precond == MI_PRECOND_DIAGONAL) k_pcg_precond_dot<true><<<RG, RB, 0, s>>>(c->state.p, m->rD.p, B.rA, B.wA, n, P + 2 * RG);
+        else k_pcg_precond_dot<false><<<RG, RB, 0, s>>>(c->state.p, nullptr, B.rA, B.wA, n, P + 2 * RG);
+        finalize(P + 2 * RG, B.scal + 0);
+        break;
+    case 3: // after the allreduce of scal[0,1,4]
+        k_solve_init<true><<<1, RB, 0, s>>>(c->state.p, B.scal + 4, B.scal + 1, m->hist.p, m->histLen);
+        break;
+    case 10: // iteration `it`: (residual test of it-1,) pA update, pack pA for the exchange
+        if (it > 0) k_pcg_final<true><<<1, RB, 0, s>>>(c->state.p, it - 1, B.scal + 1, m->hist.p, m->histLen);
+        if (B.precond == MI_PRECOND_DIAGONAL) k_pcg_update_p<1, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 0, nullptr, m->rD.p, B.rA, B.pA, n);
+        else k_pcg_update_p<2, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 0, nullptr, nullptr, B.rA, B.pA, n);
+        MICHK(mi_halo_pack_engine(a, B.pA, B.send));
+        break;
+    case 11: // interior tiles: overlap with the halo exchange
+        MICHK(launch_tile<OP_AMUL>(m, false, B.pA, nullptr, nullptr, B.wA, 0.0, 1, m->tilePartial.p));
+        break;
+    case 12: // boundary tiles (halo has arrived) + local sum wA.pA
+        MICHK(launch_tile<OP_AMUL>(m, false, B.pA, nullptr, nullptr, B.wA, 0.0, 2, m->tilePartial.p + a->nInterior));
+        k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P);
+        finalize(P, B.scal + 2);
+        break;
+    case 13: // after the allreduce of scal[2]: psi, rA updates; local sum|rA| and next wArA
+        if (B.precond == MI_PRECOND_DIAGONAL)
+            k_pcg_update_psi_r<1, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 2, B.pA, B.wA, m->rD.p, B.psi, B.rA, n, P + RG, P + 2 * RG);
+        else
+            k_pcg_update_psi_r<2, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 2, B.pA, B.wA, nullptr, B.psi, B.rA, n, P + RG, P + 2 * RG);
+        finalize(P + RG, B.scal + 1);
+        finalize(P + 2 * RG, B.scal + 0);
+        break;
+    case 14: // residual test of the last enqueued iteration (after the allreduce of scal[0,1])
+        k_pcg_final<true><<<1, RB, 0, s>>>(c->state.p, it, B.scal + 1, m->hist.p, m->histLen);
+        break;
+    default:
+        return fail(MI_ERR_ARG, "mi_dpcg_phase: unknown phase");
+    }
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" int mi_dpcg_status(mi_matrix_t m, mi_solver_perf* perf, int32_t* done, double* hist_host, int32_t hist_len)
+{
+    if (!m || !perf) return fail(MI_ERR_ARG, "mi_dpcg_status: bad argument");
+    mi_ctx_s* c = m->addr->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    MICHK(fetch_state(c));
+    fill_perf(*c->hostState, perf);
+    if (done) *done = c->hostState->done;
+    MICHK(copy_hist(m, hist_host, hist_len, c->hostState->nIterations));
+    return MI_OK;
 }
 
 // ---- host-synchronous Krylov solvers for the asymmetric path -----------------
@@ -1069,3 +1184,21 @@ extern "C" int mi_layout_array(void* handle, const char* name, const void** data
 }
 
 extern "C" int mi_layout_free(void* handle) { delete static_cast<TileLayout*>(handle); return MI_OK; }
+
+// HIP-event pair helpers for callers that time a kernel range on the engine's stream
+// (bench.py brackets the Amul phases of the distributed path).
+extern "C" int mi_event_record(mi_matrix_t m, int32_t idx)
+{
+    if (!m || idx < 0) return fail(MI_ERR_ARG, "mi_event_record: bad argument");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    while (m->evPool.size() <= (size_t)idx) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); m->evPool.push_back(ev); }
+    HIPCHK(hipEventRecord(m->evPool[(size_t)idx], m->addr->ctx->stream));
+    return MI_OK;
+}
+extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, float* ms)
+{
+    if (!m || !ms || idx0 < 0 || idx1 < 0 || (size_t)idx0 >= m->evPool.size() || (size_t)idx1 >= m->evPool.size()) return fail(MI_ERR_ARG, "mi_event_elapsed_ms: bad argument");
+    HIPCHK(hipEventSynchronize(m->evPool[(size_t)idx1]));
+    HIPCHK(hipEventElapsedTime(ms, m->evPool[(size_t)idx0], m->evPool[(size_t)idx1]));
+    return MI_OK;
+}

@@ -434,14 +434,14 @@ __global__ __launch_bounds__(RB) void k_pcg_precond_dot(const PcgState* __restri
 // wArA = sum(partial1); beta = wArA/wArAold; pA = wA (+ beta*pA)      [PCG.C:144-160]
 // PMODE 0: wA is stored (any preconditioner); 1: wA = rD*rA recomputed on the fly (diagonal);
 // 2: wA = rA (none) -- the precondition pass and the wA round trip through HBM are fused away.
-template <int PMODE>
+template <int PMODE, bool DIST = false>
 __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
                                                      const double* __restrict__ wA, const double* __restrict__ rD,
                                                      const double* __restrict__ rA, double* __restrict__ pA, int64_t n)
 {
     if (st->done) return;
     __shared__ double red[RB / 64];
-    const double wArA = sum_partials(partial1, red);
+    const double wArA = DIST ? partial1[0] : sum_partials(partial1, red); // DIST: global sum from the allreduce
     const double beta = (it == 0) ? 0.0 : wArA / st->wArA[(it & 1) ^ 1];
     const bool first = (it == 0);
     chunk_loop(n, [&](int64_t i) {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
 // wApA = sum(partial2); singular? ; alpha; psi += alpha pA; rA -= alpha wA; partial3 = sum|rA|  [PCG.C:166-195]
 // PMODE 1/2 additionally produce partial1 = sum (M^-1 rA)*rA for the NEXT iteration's wArA
 // (precondition + gSumProd of PCG.C:139-142 fused into this pass).
-template <int PMODE>
+template <int PMODE, bool DIST = false>
 __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
                                                          const double* __restrict__ pA, const double* __restrict__ wA,
                                                          const double* __restrict__ rD,
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
 {
     if (st->done) return;
     __shared__ double red[RB / 64];
-    const double wApA = sum_partials(partial2, red);
+    const double wApA = DIST ? partial2[0] : sum_partials(partial2, red);
     if (fabs(wApA) / st->normFactor < SP_VSMALL) { // checkSingularity, SolverPerformance.C:32-44
         // every block takes this branch; only later kernels read done/singular
         if (threadIdx.x == 0) partial3[blockIdx.x] = -1.0; // marks "singular" for k_pcg_final
@@ -501,13 +501,14 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
 }
 
 // residual, history, do-while condition                                  [PCG.C:195-204]
+template <bool DIST = false>
 __global__ __launch_bounds__(RB) void k_pcg_final(PcgState* __restrict__ st, int it, const double* __restrict__ partial3,
                                                   double* __restrict__ hist, int histLen)
 {
     if (st->done) return;
     __shared__ double red[RB / 64];
     const bool sing = partial3[0] < 0.0; // sum|r| partials are never negative
-    const double s = sum_partials(partial3, red);
+    const double s = DIST ? partial3[0] : sum_partials(partial3, red);
     if (threadIdx.x != 0) return;
     if (sing) { st->singular = 1; st->done = 1; return; } // `break`: nIterations not incremented
     const double res = s / st->normFactor;
@@ -521,12 +522,13 @@ __global__ __launch_bounds__(RB) void k_pcg_final(PcgState* __restrict__ st, int
 }
 
 // start of a solve: normFactor, initial residual, first convergence test   [PCG.C:105-121]
+template <bool DIST = false>
 __global__ __launch_bounds__(RB) void k_solve_init(PcgState* __restrict__ st, const double* __restrict__ partialNF,
                                                    const double* __restrict__ partialR, double* __restrict__ hist, int histLen)
 {
     __shared__ double red[RB / 64];
-    const double nf = sum_partials(partialNF, red) + SP_SMALL;
-    const double sr = sum_partials(partialR, red);
+    const double nf = (DIST ? partialNF[0] : sum_partials(partialNF, red)) + SP_SMALL;
+    const double sr = DIST ? partialR[0] : sum_partials(partialR, red);
     if (threadIdx.x != 0) return;
     st->normFactor = nf;
     const double res = sr / nf;

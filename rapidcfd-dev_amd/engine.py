@@ -51,6 +51,7 @@ SYMBOLS = [
     "mi_pbicg_solve", "mi_pbicgstab_solve", "mi_smooth_solve",
     "mi_bench_amul", "mi_bench_pcg_iters",
     "mi_layout_build_host", "mi_layout_array", "mi_layout_free",
+    "mi_dpcg_set_buffers", "mi_dpcg_phase", "mi_dpcg_status", "mi_event_record", "mi_event_elapsed_ms",
 ]
 
 
@@ -298,6 +299,36 @@ class Matrix:
         out = {k: getattr(perf, k) for k, _ in SolverPerf._fields_ if k != "reserved"}
         out["history"] = hist[: min(history_len, perf.nIterations + 1)].copy()
         return out
+
+    # distributed PCG phases (parallel.py) -----------------------------------------
+    def dpcg_set_buffers(self, psi_e, src_e, pA_e, wA_e, rA_e, scal8, send_buf, precond="diagonal",
+                         tolerance=0.0, relTol=0.0, maxIter=1000, minIter=0, history_len=0):
+        ctl = SolverControls(tolerance, relTol, maxIter, minIter)
+        _chk(lib().mi_dpcg_set_buffers(self.h, _ptr(psi_e), _ptr(src_e), _ptr(pA_e), _ptr(wA_e), _ptr(rA_e),
+                                       _ptr(scal8), _ptr(send_buf), C.byref(ctl), C.c_int(PRECOND[precond]),
+                                       C.c_int32(history_len)))
+
+    def dpcg_phase(self, phase: int, it: int = 0, arg: float = 0.0):
+        _chk(lib().mi_dpcg_phase(self.h, int(phase), C.c_int32(it), C.c_double(arg)))
+
+    def dpcg_status(self, history_len=0):
+        perf = SolverPerf()
+        done = C.c_int32()
+        hist = np.full(max(history_len, 1), np.nan)
+        _chk(lib().mi_dpcg_status(self.h, C.byref(perf), C.byref(done), hist.ctypes.data_as(C.POINTER(C.c_double)),
+                                  C.c_int32(history_len)))
+        out = {k: getattr(perf, k) for k, _ in SolverPerf._fields_ if k != "reserved"}
+        out["done"] = int(done.value)
+        out["history"] = hist[~np.isnan(hist)].copy()
+        return out
+
+    def event_record(self, idx: int):
+        _chk(lib().mi_event_record(self.h, C.c_int32(idx)))
+
+    def event_elapsed_ms(self, i0: int, i1: int) -> float:
+        ms = C.c_float()
+        _chk(lib().mi_event_elapsed_ms(self.h, C.c_int32(i0), C.c_int32(i1), C.byref(ms)))
+        return ms.value
 
     def bench_amul(self, reps: int) -> float:
         ms = C.c_float()

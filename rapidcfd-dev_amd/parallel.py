@@ -1,0 +1,196 @@
+"""One-rank-per-GPU domain-decomposed PCG.
+
+The reference runs one MPI rank per GPU; every rank executes the same PCG and
+meets the others in ``Foam::reduce`` (three scalar all-reduces per iteration,
+PCG.C:142,166,195 -> src/Pstream/mpi/allReduceTemplates.C:195-208) and in the
+processor-patch exchange inside every ``Amul``
+(lduMatrixUpdateMatrixInterfaces.C:30-276, processorFvPatchScalarField.C:36-170,
+host-staged MPI_Isend/Irecv by default).
+
+MI355X-native form: the device-resident PCG pipeline of the engine is cut into
+phases at exactly those points (``mi_dpcg_phase``); between phases this driver
+issues RCCL collectives through ``torch.distributed`` on tensors that ARE the
+engine's buffers (no staging copies):
+
+* halo: the pack kernel writes the patch-internal values of ``pA`` into the send
+  buffer; ``isend``/``irecv`` pairs (one per neighbour = one xGMI link each) run on
+  a second HIP stream and land directly in ``pA[n_cells:]`` while the interior
+  tiles of ``Amul`` run on the main stream; boundary tiles run after the wait.
+* global sums: the ``sum|rA|`` of iteration k and the ``wA.rA`` of iteration k+1
+  come out of the same pass over ``rA``, so they travel in ONE two-double
+  all-reduce; with the ``wA.pA`` all-reduce that is two collectives per iteration
+  instead of the reference's three.  The host never reads a scalar inside the loop:
+  convergence is tested on the device and polled once per batch.
+
+The arithmetic backend is pluggable (``ops``): the product backend is
+:class:`HipOps` (HIP kernels through the C ABI).  Tests inject a numpy backend to
+check the exchange/reduction logic with the ``gloo`` backend on CPU.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine as eng
+
+
+class HipOps:
+    """Per-rank state on the GPU: engine handles + the tensors the collectives act on."""
+
+    def __init__(self, ctx: "eng.Context", sub, device, precond: str = "diagonal"):
+        if sub.lower is not None:
+            raise ValueError("PCG needs a symmetric matrix")
+        self.device = device
+        self.n = sub.n_cells
+        self.addr = eng.Addressing(ctx, sub.n_cells, sub.lower_addr, sub.upper_addr,
+                                   [itf.face_cells for itf in sub.interfaces])
+        self.n_ext = self.addr.n_ext
+        self.offsets = self.addr.patch_offsets()
+        self.mat = eng.Matrix(self.addr)
+
+        def t(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+        self.mat.set_coeffs(t(sub.diag), t(sub.upper), None)
+        for p, itf in enumerate(sub.interfaces):
+            self.mat.set_interface_coeffs(p, t(itf.bou_coeffs), None)
+        nv = self.n + self.n_ext
+        z = lambda: torch.zeros(nv, dtype=torch.float64, device=device)
+        self.psi, self.src, self.pA, self.wA, self.rA = z(), z(), z(), z(), z()
+        self.scal = torch.zeros(8, dtype=torch.float64, device=device)
+        self.send = torch.zeros(max(self.n_ext, 1), dtype=torch.float64, device=device)
+        self.addr.to_engine(t(sub.source), self.src)
+        self.precond = precond
+        self._psi_out = torch.zeros(self.n, dtype=torch.float64, device=device)
+
+    def set_initial(self, psi0):
+        if psi0 is None:
+            self.psi.zero_()
+        else:
+            self.addr.to_engine(torch.from_numpy(np.ascontiguousarray(psi0)).to(self.device), self.psi)
+
+    def begin(self, **controls):
+        self.mat.dpcg_set_buffers(self.psi, self.src, self.pA, self.wA, self.rA, self.scal, self.send,
+                                  precond=self.precond, **controls)
+
+    def phase(self, k: int, it: int = 0, arg: float = 0.0):
+        self.mat.dpcg_phase(k, it, arg)
+
+    def status(self, history_len=0):
+        return self.mat.dpcg_status(history_len)
+
+    def solution(self) -> np.ndarray:
+        self.addr.from_engine(self.psi, self._psi_out)
+        torch.cuda.synchronize()
+        return self._psi_out.cpu().numpy()
+
+    def event_record(self, idx):
+        self.mat.event_record(idx)
+
+    def event_elapsed_ms(self, i0, i1):
+        return self.mat.event_elapsed_ms(i0, i1)
+
+
+class DistributedPCG:
+    """PCG over the sub-domains of all ranks; ``sub`` is this rank's LduCase with interfaces."""
+
+    def __init__(self, ctx, sub, device, precond: str = "diagonal", ops=None, n_global: Optional[int] = None):
+        self.ops = ops if ops is not None else HipOps(ctx, sub, device, precond)
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.nbrs: List[int] = [itf.nbr_domain for itf in sub.interfaces]
+        if len(set(self.nbrs)) != len(self.nbrs):
+            raise ValueError("one processor patch per neighbour rank is supported (NCCL p2p is matched per peer, in order)")
+        self.sizes = [len(itf.face_cells) for itf in sub.interfaces]
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        self.n = sub.n_cells
+        self.is_cuda = torch.device(device).type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=device) if self.is_cuda else None
+        if n_global is None:
+            ng = torch.tensor([float(self.n)], dtype=torch.float64, device=device)
+            self._allreduce(ng)
+            n_global = int(round(float(ng.item())))
+        self.n_global = n_global
+        self.it = 0
+        self.history_len = 0
+
+    # -- collectives ----------------------------------------------------------
+    def _allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def _start_exchange(self, vec):
+        """send the packed patch values, receive the neighbours' into vec[n:]; returns a waiter."""
+        if self.world == 1 or not self.nbrs:
+            return lambda: None
+        o = self.ops
+        p2p = []
+        for k, nbr in enumerate(self.nbrs):
+            a, b = int(self.offsets[k]), int(self.offsets[k + 1])
+            p2p.append(dist.P2POp(dist.isend, o.send[a:b], nbr))
+            p2p.append(dist.P2POp(dist.irecv, vec[self.n + a:self.n + b], nbr))
+        if self.is_cuda:
+            main = torch.cuda.current_stream()
+            self.comm_stream.wait_stream(main)          # the pack kernel has to finish first
+            with torch.cuda.stream(self.comm_stream):
+                for r in dist.batch_isend_irecv(p2p):
+                    r.wait()                            # stream-level wait on the comm stream only
+            return lambda: main.wait_stream(self.comm_stream)
+        reqs = dist.batch_isend_irecv(p2p)
+        return lambda: [r.wait() for r in reqs]
+
+    # -- solver ---------------------------------------------------------------
+    def begin(self, psi0=None, tolerance=1e-6, rel_tol=0.0, max_iter=1000, min_iter=0):
+        o = self.ops
+        self.history_len = max_iter + 2
+        o.set_initial(psi0)
+        o.begin(tolerance=tolerance, relTol=rel_tol, maxIter=max_iter, minIter=min_iter, history_len=self.history_len)
+        o.phase(0)
+        self._start_exchange(o.psi)()
+        o.phase(1)
+        self._allreduce(o.scal[3:4])
+        avg = float(o.scal[3].item()) / self.n_global       # gAverage(psi): the one host read of the prologue
+        o.phase(2, 0, avg)
+        self._allreduce(o.scal[0:2])
+        self._allreduce(o.scal[4:5])
+        o.phase(3)
+        self.it = 0
+        self.max_iter, self.min_iter = max_iter, min_iter
+
+    def iterate(self, n_iters: int, time_amul: bool = False):
+        """enqueue n_iters iterations (device no-ops once converged); no host synchronisation."""
+        o = self.ops
+        for k in range(n_iters):
+            it = self.it
+            o.phase(10, it)
+            wait = self._start_exchange(o.pA)
+            if time_amul:
+                o.event_record(2 * k)
+            o.phase(11, it)      # interior tiles overlap the exchange
+            wait()
+            o.phase(12, it)      # boundary tiles
+            if time_amul:
+                o.event_record(2 * k + 1)
+            self._allreduce(o.scal[2:3])
+            o.phase(13, it)
+            self._allreduce(o.scal[0:2])
+            self.it += 1
+        if n_iters > 0:
+            o.phase(14, self.it - 1)
+        if time_amul:
+            return sum(o.event_elapsed_ms(2 * k, 2 * k + 1) for k in range(n_iters))
+        return None
+
+    def end(self):
+        return self.ops.status(self.history_len)
+
+    def solve(self, psi0=None, tolerance=1e-6, rel_tol=0.0, max_iter=1000, min_iter=0, batch=16):
+        self.begin(psi0, tolerance, rel_tol, max_iter, min_iter)
+        st = self.ops.status(0)
+        while not st["done"] and self.it <= max(max_iter, min_iter):
+            self.iterate(batch)
+            st = self.ops.status(0)
+        return self.end()

@@ -249,3 +249,73 @@ def test_full_size_properties(pkg, ctx):
     psi2 = torch.zeros(n, dtype=torch.float64, device="cuda:0")
     perf2 = mat.pcg(psi2, b, "diagonal", tolerance=0.0, maxIter=60)
     assert np.array_equal(perf2["history"], perf["history"]) and torch.equal(psi, psi2)
+
+
+@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 2)])
+def test_decomposed_pcg_on_one_gpu(pkg, orc, ctx, parts):
+    """N sub-domains emulated on one GPU: the distributed phases (mi_dpcg_phase), interface slots,
+    interior/boundary tile split and halo pack, with the exchange done by device copies and the
+    all-reduce by summing the ranks' scalar blocks -- against the serial oracle."""
+    from importlib import import_module
+    import __graft_entry__ as graft
+    par = import_module(graft.PKG_NAME + ".parallel")
+    syn = pkg.synthetic
+    case = syn.box_case(20, 18, 14)
+    subs = syn.decompose_box(case, parts)
+    # one engine context per emulated rank (each owns its device-side solver state), same stream
+    ctxs = [pkg.engine.Context(0, torch.cuda.current_stream().cuda_stream) for _ in subs]
+    ops = [par.HipOps(c, s, torch.device("cuda:0")) for c, s in zip(ctxs, subs)]
+    kw = dict(tolerance=1e-9, relTol=0.0, maxIter=300, minIter=0)
+
+    def exchange(field):
+        for d, s in enumerate(subs):
+            for k, itf in enumerate(s.interfaces):
+                o = ops[itf.nbr_domain]
+                a, b = int(o.offsets[itf.nbr_patch]), int(o.offsets[itf.nbr_patch + 1])
+                dst = getattr(ops[d], field)
+                a2, b2 = int(ops[d].offsets[k]), int(ops[d].offsets[k + 1])
+                dst[ops[d].n + a2: ops[d].n + b2].copy_(o.send[a:b])
+
+    def allreduce(sl):
+        tot = sum(o.scal[sl] for o in ops)
+        for o in ops:
+            o.scal[sl] = tot
+
+    for o in ops:
+        o.set_initial(None); o.begin(history_len=kw["maxIter"] + 2, **kw); o.phase(0)
+    exchange("psi")
+    for o in ops:
+        o.phase(1)
+    allreduce(slice(3, 4))
+    avg = float(ops[0].scal[3].item()) / case.n_cells
+    for o in ops:
+        o.phase(2, 0, avg)
+    allreduce(slice(0, 2)); allreduce(slice(4, 5))
+    for o in ops:
+        o.phase(3)
+    it = 0
+    while it <= kw["maxIter"]:
+        for _ in range(8):
+            for o in ops:
+                o.phase(10, it)
+            exchange("pA")
+            for o in ops:
+                o.phase(11, it); o.phase(12, it)
+            allreduce(slice(2, 3))
+            for o in ops:
+                o.phase(13, it)
+            allreduce(slice(0, 2))
+            it += 1
+        for o in ops:
+            o.phase(14, it - 1)
+        if all(o.status()["done"] for o in ops):
+            break
+    ref_psi, ref = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-9, maxIter=300)
+    psi = np.zeros(case.n_cells)
+    for o, s in zip(ops, subs):
+        st = o.status(kw["maxIter"] + 2)
+        assert st["nIterations"] == ref["nIterations"] and st["converged"] == ref["converged"]
+        assert st["history"].shape == ref["history"].shape
+        assert np.max(np.abs(st["history"] - ref["history"])) < HIST_RTOL * ref["history"][0]
+        psi[s.global_cells] = o.solution()
+    assert np.max(np.abs(psi - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
