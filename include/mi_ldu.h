@@ -42,6 +42,7 @@ extern "C" {
 typedef struct mi_ctx_s *mi_ctx_t;
 typedef struct mi_addr_s *mi_addr_t;
 typedef struct mi_matrix_s *mi_matrix_t;
+typedef struct mi_gamg_s *mi_gamg_t;
 
 enum {
     MI_OK = 0,
@@ -196,6 +197,59 @@ int mi_pcg_begin(mi_matrix_t m, const double *psi0_dev, const double *source_dev
 int mi_pcg_iterate(mi_matrix_t m, int32_t n_iters, float *amul_ms_sum);
 int mi_pcg_end(mi_matrix_t m, double *psi_out_dev, mi_solver_perf *perf_out,
                double *residual_history_host, int32_t history_len);
+
+/* ---- GAMG (solvers/GAMG/GAMGSolver.C:47-249, GAMGSolverSolve.C:59-619, GAMGSolverScale.C:59-171,
+ *      GAMGSolverAgglomerateMatrix.C:37-321, GAMGAgglomerations/.../pairGAMGAgglomerate.C:31-313,
+ *      GAMGAgglomerateLduAddressing.C:245-461, GAMGAgglomerationTemplates.C:35-308) ----
+ * mi_gamg_create builds the pair-agglomeration hierarchy once per mesh (host, cached like the
+ * reference's GAMGAgglomeration MeshObject) and one engine layout per level.
+ *   face_weights_host: [n_faces] agglomeration weights -- faceAreaPair passes
+ *     |Sf/sqrt|Sf| o (1,1.01,1.02)| (src/finiteVolume/.../faceAreaPairGAMGAgglomeration.C:54-81),
+ *     algebraicPair passes |upper|.
+ *   n_cells_in_coarsest_level: the mandatory fvSolution key (GAMGAgglomeration.C:96-99); mergeLevels 1.
+ *   forward_init: the reference's process-wide static sweep direction (pairGAMGAgglomeration.C:33),
+ *     true in a fresh process; mi_gamg_forward_out returns its value after the build.
+ * mi_gamg_solve agglomerates the level matrices from the matrix's current coefficients (the
+ * reference does this on every solver construction, GAMGSolver.C:88-97), then runs V-cycles.
+ * Smoother: Jacobi omega (the reference's "GaussSeidel", JacobiSmoother.C:34-36).  The coarsest
+ * level is solved directly (directSolveCoarsest, GAMGSolver.C:144-172) with a dense inverse kept
+ * on the device.  scaleCorrection < 0 selects the reference default (= symmetric).            */
+typedef struct {
+    double tolerance, relTol;
+    int32_t maxIter, minIter;
+    int32_t nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps;     /* 0, 1, 4 */
+    int32_t nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps;  /* 2, 1, 4 */
+    int32_t nFinestSweeps, scaleCorrection;                         /* 2, -1   */
+    double omega;                                                   /* 0.9     */
+} mi_gamg_controls;
+int mi_gamg_create(mi_addr_t fine_addr, const double *face_weights_host, int32_t n_cells_in_coarsest_level,
+                   int forward_init, mi_gamg_t *out);
+int mi_gamg_destroy(mi_gamg_t g);
+int32_t mi_gamg_n_levels(mi_gamg_t g);
+int mi_gamg_forward_out(mi_gamg_t g);
+/* out4 = {n_fine_cells, n_fine_faces, n_coarse_cells, n_coarse_faces} of coarse level `level` */
+int mi_gamg_level_sizes(mi_gamg_t g, int32_t level, int32_t out4[4]);
+int mi_gamg_solve(mi_gamg_t g, mi_matrix_t m, double *psi_dev, const double *source_dev,
+                  const mi_gamg_controls *controls, mi_solver_perf *perf_out,
+                  double *residual_history_host, int32_t history_len);
+/* level operators in the caller order of each level (restrictField / prolongField,
+ * GAMGAgglomerationTemplates.C:35-153,273-308) and the agglomerated level coefficients
+ * (GAMGSolverAgglomerateMatrix.C:218-317); used by the parity tests                          */
+int mi_gamg_restrict(mi_gamg_t g, int32_t level, const double *fine_dev, double *coarse_dev);
+int mi_gamg_prolong(mi_gamg_t g, int32_t level, const double *coarse_dev, double *fine_dev);
+int mi_gamg_level_coeffs(mi_gamg_t g, mi_matrix_t m, int32_t level, double *diag_out_dev,
+                         double *upper_out_dev, double *lower_out_dev);
+
+/* host-only inspection of the hierarchy builder (no device; CPU tests compare it with the
+ * oracle's independent restatement).  name: restrictMap, faceRestrict, faceFlip (uint8), cLower,
+ * cUpper, cellChildStart, cellChild, faceChildStart, faceChild, diagChildStart, diagChild.     */
+int mi_gamg_host_build(int32_t n_cells, int32_t n_faces, const int32_t *lower_addr_host,
+                       const int32_t *upper_addr_host, const double *face_weights_host,
+                       int32_t n_cells_in_coarsest_level, int forward_init, void **hierarchy_out);
+int32_t mi_gamg_host_n_levels(void *hierarchy);
+int mi_gamg_host_array(void *hierarchy, int32_t level, const char *name, const void **data,
+                       int64_t *len, int32_t *elem_size);
+int mi_gamg_host_free(void *hierarchy);
 
 /* ---- distributed PCG (one rank per GPU).  The reference runs the same PCG on every
  * MPI rank and meets its neighbours in Foam::reduce (PCG.C:142,166,195 ->

@@ -1,0 +1,413 @@
+/*
+ * gamg_oracle.c -- CPU ORACLE for the GAMG solver (test infrastructure, NOT product code;
+ * see the header of ldu_oracle.c: PARITY UNPINNED, the reference ships no tests).
+ *
+ * Restates, single domain (no coupled interfaces), paths relative to
+ * /root/reference/src/OpenFOAM/matrices/lduMatrix/solvers/GAMG/ :
+ *   - pair agglomeration        GAMGAgglomerations/pairGAMGAgglomeration/pairGAMGAgglomerate.C:31-313
+ *   - coarse addressing         GAMGAgglomerations/GAMGAgglomeration/GAMGAgglomerateLduAddressing.C:245-461
+ *   - face-weight restriction   GAMGAgglomerations/GAMGAgglomeration/GAMGAgglomerationTemplates.C:236-270
+ *   - level loop / stop rule    pairGAMGAgglomerate.C:46-120, GAMGAgglomeration.C:72-81 (mergeLevels 1 only)
+ *   - coarse matrices           GAMGSolverAgglomerateMatrix.C:37-321 + GAMGSolverAgglomerateMatrixF.H:9-159
+ *   - restrict / prolong        GAMGAgglomerationTemplates.C:35-153,273-308, GAMGAgglomerationF.H:9-38
+ *   - scale                     GAMGSolverScale.C:40-171
+ *   - V-cycle, solve loop       GAMGSolverSolve.C:59-474, defaults GAMGSolver.C:67-77
+ *   - coarsest level            GAMGSolverSolve.C:552-570 (direct solve; dense LU with partial pivoting
+ *                               stands in for LUscalarMatrix, src/OpenFOAM/matrices/LUscalarMatrix)
+ *   - smoother                  Jacobi omega 0.9 (= the reference's "GaussSeidel"), via ldu_oracle.c
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int32_t label;
+typedef double scalar;
+
+/* from ldu_oracle.c */
+typedef struct orc_system orc_system;
+orc_system *orc_sys_create(int nDomains);
+void orc_sys_set_domain(orc_system *s, int d, label nCells, label nFaces, const label *lower, const label *upper,
+                        const scalar *diag, const scalar *lowerC, const scalar *upperC);
+void orc_sys_destroy(orc_system *s);
+void orc_amul(const orc_system *s, const scalar *psi, scalar *Apsi);
+void orc_jacobi_smooth(const orc_system *s, scalar omega, scalar *psi, const scalar *source, int nSweeps);
+scalar orc_norm_factor(const orc_system *s, const scalar *psi, const scalar *source, const scalar *Apsi, scalar *tmp);
+scalar orc_gSumMag(const orc_system *s, const scalar *a);
+
+#define G_GREAT 1e20
+#define G_SMALL 1e-20
+#define G_VSMALL 1e-300
+
+typedef struct {
+    label nFine, nFineFaces, nCoarse, nCoarseFaces;
+    label *restrictMap;   /* [nFine] coarse cell of each fine cell */
+    label *faceRestrict;  /* [nFineFaces] coarse face, or -(coarseCell+1) for faces inside a coarse cell */
+    unsigned char *faceFlip;
+    label *cLower, *cUpper; /* coarse owner / neighbour, grouped by owner in creation order */
+} gamg_level;
+
+typedef struct {
+    int nLevels;          /* number of coarse levels */
+    gamg_level *lev;
+    int forwardOut;       /* value of the static sweep-direction flag after the build */
+} gamg_hier;
+
+/* one level of pair matching: pairGAMGAgglomerate.C:135-313 */
+static label pair_agglomerate(label nFine, label nFaces, const label *lower, const label *upper,
+                              const scalar *w, int forward, label *map)
+{
+    label *off = (label *)calloc((size_t)nFine + 1, sizeof(label));
+    label *cf = (label *)malloc(sizeof(label) * (size_t)(2 * nFaces + 1));
+    label *cnt = (label *)calloc((size_t)nFine, sizeof(label));
+    label f, c, nCoarse = 0;
+    for (f = 0; f < nFaces; f++) { off[upper[f] + 1]++; off[lower[f] + 1]++; }
+    for (c = 0; c < nFine; c++) off[c + 1] += off[c];
+    /* faces where the cell is the neighbour first, then faces where it is the owner (:176-193) */
+    for (f = 0; f < nFaces; f++) cf[off[upper[f]] + cnt[upper[f]]++] = f;
+    for (f = 0; f < nFaces; f++) cf[off[lower[f]] + cnt[lower[f]]++] = f;
+    for (c = 0; c < nFine; c++) map[c] = -1;
+    for (label k = 0; k < nFine; k++) {
+        c = forward ? k : nFine - k - 1;
+        if (map[c] >= 0) continue;
+        label match = -1; scalar best = -G_GREAT;
+        for (label j = off[c]; j < off[c + 1]; j++) {
+            f = cf[j];
+            if (map[upper[f]] < 0 && map[lower[f]] < 0 && w[f] > best) { match = f; best = w[f]; }
+        }
+        if (match >= 0) { map[upper[match]] = nCoarse; map[lower[match]] = nCoarse; nCoarse++; }
+        else {
+            label cm = -1; scalar cb = -G_GREAT;
+            for (label j = off[c]; j < off[c + 1]; j++) { f = cf[j]; if (w[f] > cb) { cm = f; cb = w[f]; } }
+            if (cm >= 0) { label a = map[upper[cm]], b = map[lower[cm]]; map[c] = a > b ? a : b; }
+        }
+    }
+    for (label k = 0; k < nFine; k++) { c = forward ? k : nFine - k - 1; if (map[c] < 0) map[c] = nCoarse++; }
+    if (!forward) { nCoarse--; for (c = 0; c < nFine; c++) map[c] = nCoarse - map[c]; nCoarse++; }
+    free(off); free(cf); free(cnt);
+    return nCoarse;
+}
+
+/* GAMGAgglomerateLduAddressing.C:245-461 */
+static void coarse_addressing(gamg_level *L, const label *lower, const label *upper)
+{
+    const label nF = L->nFineFaces, nC = L->nCoarse;
+    const label *rm = L->restrictMap;
+    label maxN = 10, f, nCF = 0;
+    label *ccn = (label *)calloc((size_t)nC, sizeof(label));
+    label *ccf = (label *)malloc(sizeof(label) * (size_t)maxN * (size_t)nC);
+    label *initNei = (label *)malloc(sizeof(label) * (size_t)(nF ? nF : 1));
+    L->faceRestrict = (label *)malloc(sizeof(label) * (size_t)(nF ? nF : 1));
+    L->faceFlip = (unsigned char *)calloc((size_t)(nF ? nF : 1), 1);
+    for (f = 0; f < nF; f++) {
+        label ru = rm[upper[f]], rl = rm[lower[f]];
+        if (ru == rl) { L->faceRestrict[f] = -(ru + 1); continue; }
+        label cOwn = ru < rl ? ru : rl, cNei = ru < rl ? rl : ru;
+        int found = 0;
+        for (label i = 0; i < ccn[cOwn]; i++)
+            if (initNei[ccf[(size_t)maxN * cOwn + i]] == cNei) { found = 1; L->faceRestrict[f] = ccf[(size_t)maxN * cOwn + i]; break; }
+        if (!found) {
+            if (ccn[cOwn] >= maxN) {
+                label oldMax = maxN; maxN *= 2;
+                ccf = (label *)realloc(ccf, sizeof(label) * (size_t)maxN * (size_t)nC);
+                for (label i = nC - 1; i >= 0; i--)
+                    for (label j = ccn[i] - 1; j >= 0; j--) ccf[(size_t)maxN * i + j] = ccf[(size_t)oldMax * i + j];
+            }
+            ccf[(size_t)maxN * cOwn + ccn[cOwn]++] = nCF;
+            initNei[nCF] = cNei;
+            L->faceRestrict[f] = nCF++;
+        }
+    }
+    L->nCoarseFaces = nCF;
+    L->cLower = (label *)malloc(sizeof(label) * (size_t)(nCF ? nCF : 1));
+    L->cUpper = (label *)malloc(sizeof(label) * (size_t)(nCF ? nCF : 1));
+    label *cmap = (label *)malloc(sizeof(label) * (size_t)(nCF ? nCF : 1));
+    label k = 0;
+    for (label c = 0; c < nC; c++)
+        for (label i = 0; i < ccn[c]; i++) {
+            label init = ccf[(size_t)maxN * c + i];
+            L->cLower[k] = c; L->cUpper[k] = initNei[init]; cmap[init] = k++;
+        }
+    for (f = 0; f < nF; f++) if (L->faceRestrict[f] >= 0) L->faceRestrict[f] = cmap[L->faceRestrict[f]];
+    for (f = 0; f < nF; f++) {
+        label cfi = L->faceRestrict[f];
+        if (cfi >= 0 && L->cLower[cfi] == rm[upper[f]] && L->cUpper[cfi] == rm[lower[f]]) L->faceFlip[f] = 1;
+    }
+    free(ccn); free(ccf); free(initNei); free(cmap);
+}
+
+gamg_hier *orc_gamg_build(label nCells, label nFaces, const label *lower, const label *upper,
+                          const scalar *faceWeights, label nCellsInCoarsestLevel, int forwardInit)
+{
+    const int maxLevels = 50; /* GAMGAgglomeration.C:94 */
+    gamg_hier *H = (gamg_hier *)calloc(1, sizeof(gamg_hier));
+    H->lev = (gamg_level *)calloc((size_t)maxLevels, sizeof(gamg_level));
+    int forward = forwardInit;
+    label nFine = nCells, nF = nFaces;
+    const label *lo = lower, *up = upper;
+    scalar *w = (scalar *)malloc(sizeof(scalar) * (size_t)(nF ? nF : 1));
+    memcpy(w, faceWeights, sizeof(scalar) * (size_t)nF);
+    while (H->nLevels < maxLevels - 1) {
+        gamg_level *L = &H->lev[H->nLevels];
+        L->nFine = nFine; L->nFineFaces = nF;
+        L->restrictMap = (label *)malloc(sizeof(label) * (size_t)nFine);
+        L->nCoarse = pair_agglomerate(nFine, nF, lo, up, w, forward, L->restrictMap);
+        forward = !forward; /* the static flag flips even when the level is then discarded (:310) */
+        if (!(L->nCoarse >= nCellsInCoarsestLevel) || L->nCoarse == nFine) { free(L->restrictMap); L->restrictMap = NULL; break; }
+        coarse_addressing(L, lo, up);
+        scalar *cw = (scalar *)calloc((size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1), sizeof(scalar));
+        for (label f = 0; f < nF; f++) if (L->faceRestrict[f] >= 0) cw[L->faceRestrict[f]] += w[f];
+        free(w); w = cw;
+        nFine = L->nCoarse; nF = L->nCoarseFaces; lo = L->cLower; up = L->cUpper;
+        H->nLevels++;
+    }
+    free(w);
+    H->forwardOut = forward;
+    return H;
+}
+
+int orc_gamg_n_levels(const gamg_hier *H) { return H->nLevels; }
+int orc_gamg_forward_out(const gamg_hier *H) { return H->forwardOut; }
+void orc_gamg_level_sizes(const gamg_hier *H, int l, label *out4)
+{
+    out4[0] = H->lev[l].nFine; out4[1] = H->lev[l].nFineFaces; out4[2] = H->lev[l].nCoarse; out4[3] = H->lev[l].nCoarseFaces;
+}
+void orc_gamg_level_maps(const gamg_hier *H, int l, label *restrictMap, label *faceRestrict, label *faceFlip,
+                         label *cLower, label *cUpper)
+{
+    const gamg_level *L = &H->lev[l];
+    label i;
+    if (restrictMap) memcpy(restrictMap, L->restrictMap, sizeof(label) * (size_t)L->nFine);
+    if (faceRestrict) memcpy(faceRestrict, L->faceRestrict, sizeof(label) * (size_t)L->nFineFaces);
+    if (faceFlip) for (i = 0; i < L->nFineFaces; i++) faceFlip[i] = L->faceFlip[i];
+    if (cLower) memcpy(cLower, L->cLower, sizeof(label) * (size_t)L->nCoarseFaces);
+    if (cUpper) memcpy(cUpper, L->cUpper, sizeof(label) * (size_t)L->nCoarseFaces);
+}
+void orc_gamg_free(gamg_hier *H)
+{
+    for (int l = 0; l < H->nLevels; l++) {
+        free(H->lev[l].restrictMap); free(H->lev[l].faceRestrict); free(H->lev[l].faceFlip);
+        free(H->lev[l].cLower); free(H->lev[l].cUpper);
+    }
+    free(H->lev); free(H);
+}
+
+/* ---- fields between levels ---------------------------------------------------------------- */
+/* restrictField: cf = 0; cf[c] = sum of ff over the children of c in ascending fine index
+ * (segmented sum over the stable sort, GAMGAgglomerationF.H:9-38)                              */
+static void restrict_field(const gamg_level *L, const scalar *ff, scalar *cf)
+{
+    label i;
+    for (i = 0; i < L->nCoarse; i++) cf[i] = 0;
+    for (i = 0; i < L->nFine; i++) cf[L->restrictMap[i]] += ff[i];
+}
+static void prolong_field(const gamg_level *L, const scalar *cf, scalar *ff)
+{
+    for (label i = 0; i < L->nFine; i++) ff[i] = cf[L->restrictMap[i]];
+}
+
+/* coarse matrix: GAMGSolverAgglomerateMatrix.C:65-72,218-317 (+F.H).  Sums run over the fine
+ * faces in ascending index (stable sort by target).                                            */
+static void agglomerate_matrix(const gamg_level *L, int asym, const scalar *fDiag, const scalar *fUpper,
+                               const scalar *fLower, scalar *cDiag, scalar *cUpper, scalar *cLower)
+{
+    label f;
+    restrict_field(L, fDiag, cDiag);
+    for (f = 0; f < L->nCoarseFaces; f++) { cUpper[f] = 0; if (asym) cLower[f] = 0; }
+    for (f = 0; f < L->nFineFaces; f++) {
+        label t = L->faceRestrict[f];
+        if (t >= 0) {
+            if (!asym) cUpper[t] += fUpper[f];
+            else if (!L->faceFlip[f]) { cUpper[t] += fUpper[f]; cLower[t] += fLower[f]; }
+            else { cUpper[t] += fLower[f]; cLower[t] += fUpper[f]; }
+        } else {
+            if (!asym) cDiag[-1 - t] += 2 * fUpper[f];
+            else cDiag[-1 - t] += fUpper[f] + fLower[f];
+        }
+    }
+}
+
+/* dense LU with partial pivoting for the coarsest level */
+static void lu_factor(int n, scalar *A, int *piv)
+{
+    for (int k = 0; k < n; k++) {
+        int p = k; scalar big = fabs(A[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; i++) if (fabs(A[(size_t)i * n + k]) > big) { big = fabs(A[(size_t)i * n + k]); p = i; }
+        piv[k] = p;
+        if (p != k) for (int j = 0; j < n; j++) { scalar t = A[(size_t)k * n + j]; A[(size_t)k * n + j] = A[(size_t)p * n + j]; A[(size_t)p * n + j] = t; }
+        for (int i = k + 1; i < n; i++) {
+            scalar m = A[(size_t)i * n + k] / A[(size_t)k * n + k];
+            A[(size_t)i * n + k] = m;
+            for (int j = k + 1; j < n; j++) A[(size_t)i * n + j] -= m * A[(size_t)k * n + j];
+        }
+    }
+}
+static void lu_solve(int n, const scalar *A, const int *piv, scalar *b)
+{
+    for (int k = 0; k < n; k++) { if (piv[k] != k) { scalar t = b[k]; b[k] = b[piv[k]]; b[piv[k]] = t; }
+        for (int i = k + 1; i < n; i++) b[i] -= A[(size_t)i * n + k] * b[k]; }
+    for (int k = n - 1; k >= 0; k--) { for (int j = k + 1; j < n; j++) b[k] -= A[(size_t)k * n + j] * b[j]; b[k] /= A[(size_t)k * n + k]; }
+}
+
+typedef struct {
+    scalar tolerance, relTol;
+    int32_t maxIter, minIter;
+    int32_t nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps;
+    int32_t nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps;
+    int32_t nFinestSweeps, scaleCorrection; /* scaleCorrection < 0: default = symmetric (GAMGSolver.C:76) */
+    scalar omega; /* Jacobi relaxation, JacobiSmoother.C:34-36 */
+} gamg_controls;
+
+typedef struct {
+    scalar initialResidual, finalResidual, normFactor;
+    int32_t nIterations, converged, singular;
+} gamg_perf;
+
+/* scale: GAMGSolverScale.C:59-171 */
+static void scale_field(const orc_system *A, const scalar *D, label n, scalar *field, scalar *Acf, const scalar *source)
+{
+    orc_amul(A, field, Acf);
+    long double num = 0, den = 0;
+    for (label i = 0; i < n; i++) { num += (long double)source[i] * field[i]; den += (long double)Acf[i] * field[i]; }
+    scalar d = (scalar)den;
+    scalar sf = (scalar)num / (d >= 0 ? d + G_VSMALL : d - G_VSMALL); /* stabilise(), Scalar.H:295-305 */
+    for (label i = 0; i < n; i++) field[i] = fma(sf, field[i], fma(-sf, Acf[i], source[i]) / D[i]);
+}
+
+static int conv_check(gamg_perf *p, const gamg_controls *c)
+{
+    p->converged = (p->finalResidual < c->tolerance) || (c->relTol > G_SMALL && p->finalResidual < c->relTol * p->initialResidual);
+    return p->converged;
+}
+
+static int imin(int a, int b) { return a < b ? a : b; }
+
+void orc_gamg_solve(const gamg_hier *H, const label *lower, const label *upper, const scalar *diag,
+                    const scalar *upperC, const scalar *lowerC /* NULL: symmetric */, scalar *psi,
+                    const scalar *source, const gamg_controls *ctl, gamg_perf *perf, scalar *hist, int histLen)
+{
+    const int nL = H->nLevels;
+    const int asym = lowerC != NULL;
+    const int doScale = ctl->scaleCorrection < 0 ? !asym : ctl->scaleCorrection;
+    const label n0 = H->lev[0].nFine;
+    memset(perf, 0, sizeof(*perf));
+    if (nL < 1) { perf->singular = 1; return; } /* reference: FatalError "No coarse levels created" */
+
+    /* ---- level matrices (GAMGSolver.C:88-97: rebuilt on every solver construction) ---- */
+    orc_system **A = (orc_system **)calloc((size_t)nL + 1, sizeof(*A));
+    scalar **D = (scalar **)calloc((size_t)nL + 1, sizeof(*D));
+    scalar **U = (scalar **)calloc((size_t)nL + 1, sizeof(*U));
+    scalar **Lw = (scalar **)calloc((size_t)nL + 1, sizeof(*Lw));
+    A[0] = orc_sys_create(1);
+    orc_sys_set_domain(A[0], 0, n0, H->lev[0].nFineFaces, lower, upper, diag, lowerC, upperC);
+    D[0] = (scalar *)diag; U[0] = (scalar *)upperC; Lw[0] = (scalar *)lowerC;
+    for (int l = 0; l < nL; l++) {
+        const gamg_level *L = &H->lev[l];
+        D[l + 1] = (scalar *)malloc(sizeof(scalar) * (size_t)L->nCoarse);
+        U[l + 1] = (scalar *)malloc(sizeof(scalar) * (size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1));
+        Lw[l + 1] = asym ? (scalar *)malloc(sizeof(scalar) * (size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1)) : NULL;
+        agglomerate_matrix(L, asym, D[l], U[l], Lw[l], D[l + 1], U[l + 1], Lw[l + 1]);
+        A[l + 1] = orc_sys_create(1);
+        orc_sys_set_domain(A[l + 1], 0, L->nCoarse, L->nCoarseFaces, L->cLower, L->cUpper, D[l + 1], Lw[l + 1], U[l + 1]);
+    }
+    /* coarsest level: dense LU (GAMGSolver.C:144-172) */
+    const gamg_level *Lc = &H->lev[nL - 1];
+    const int nc = Lc->nCoarse;
+    scalar *dense = (scalar *)calloc((size_t)nc * (size_t)nc, sizeof(scalar));
+    int *piv = (int *)malloc(sizeof(int) * (size_t)nc);
+    for (int i = 0; i < nc; i++) dense[(size_t)i * nc + i] = D[nL][i];
+    for (label f = 0; f < Lc->nCoarseFaces; f++) {
+        dense[(size_t)Lc->cLower[f] * nc + Lc->cUpper[f]] = U[nL][f];
+        dense[(size_t)Lc->cUpper[f] * nc + Lc->cLower[f]] = asym ? Lw[nL][f] : U[nL][f];
+    }
+    lu_factor(nc, dense, piv);
+
+    scalar **corr = (scalar **)calloc((size_t)nL, sizeof(*corr));
+    scalar **src = (scalar **)calloc((size_t)nL, sizeof(*src));
+    for (int l = 0; l < nL; l++) {
+        corr[l] = (scalar *)calloc((size_t)H->lev[l].nCoarse, sizeof(scalar));
+        src[l] = (scalar *)calloc((size_t)H->lev[l].nCoarse, sizeof(scalar));
+    }
+    scalar *Apsi = (scalar *)calloc((size_t)n0, sizeof(scalar));
+    scalar *fcorr = (scalar *)calloc((size_t)n0, sizeof(scalar));
+    scalar *fres = (scalar *)calloc((size_t)n0, sizeof(scalar));
+    scalar *scr1 = (scalar *)calloc((size_t)n0, sizeof(scalar));
+    scalar *scr2 = (scalar *)calloc((size_t)n0, sizeof(scalar));
+
+    /* ---- GAMGSolverSolve.C:70-94 ---- */
+    orc_amul(A[0], psi, Apsi);
+    scalar normFactor = orc_norm_factor(A[0], psi, source, Apsi, fcorr);
+    perf->normFactor = normFactor;
+    for (label i = 0; i < n0; i++) fres[i] = source[i] - Apsi[i];
+    perf->initialResidual = orc_gSumMag(A[0], fres) / normFactor;
+    perf->finalResidual = perf->initialResidual;
+    if (hist && histLen > 0) hist[0] = perf->initialResidual;
+
+    if (ctl->minIter > 0 || !conv_check(perf, ctl)) {
+        const int coarsest = nL - 1;
+        do {
+            /* ---- Vcycle (GAMGSolverSolve.C:181-474) ---- */
+            restrict_field(&H->lev[0], fres, src[0]);
+            for (int l = 0; l < coarsest; l++) {
+                const label nl = H->lev[l].nCoarse;
+                if (ctl->nPreSweeps) {
+                    memset(corr[l], 0, sizeof(scalar) * (size_t)nl);
+                    orc_jacobi_smooth(A[l + 1], ctl->omega, corr[l], src[l],
+                                      imin(ctl->nPreSweeps + ctl->preSweepsLevelMultiplier * l, ctl->maxPreSweeps));
+                    if (doScale && l < coarsest - 1) scale_field(A[l + 1], D[l + 1], nl, corr[l], scr1, src[l]);
+                    orc_amul(A[l + 1], corr[l], scr1);
+                    for (label i = 0; i < nl; i++) src[l][i] -= scr1[i];
+                }
+                restrict_field(&H->lev[l + 1], src[l], src[l + 1]);
+            }
+            memcpy(corr[coarsest], src[coarsest], sizeof(scalar) * (size_t)nc);
+            lu_solve(nc, dense, piv, corr[coarsest]);
+            for (int l = coarsest - 1; l >= 0; l--) {
+                const label nl = H->lev[l].nCoarse;
+                if (ctl->nPreSweeps) memcpy(scr2, corr[l], sizeof(scalar) * (size_t)nl);
+                prolong_field(&H->lev[l + 1], corr[l + 1], corr[l]);
+                if (doScale && l < coarsest - 1) scale_field(A[l + 1], D[l + 1], nl, corr[l], scr1, src[l]);
+                if (ctl->nPreSweeps) for (label i = 0; i < nl; i++) corr[l][i] += scr2[i];
+                orc_jacobi_smooth(A[l + 1], ctl->omega, corr[l], src[l],
+                                  imin(ctl->nPostSweeps + ctl->postSweepsLevelMultiplier * l, ctl->maxPostSweeps));
+            }
+            prolong_field(&H->lev[0], corr[0], fcorr);
+            if (doScale) scale_field(A[0], D[0], n0, fcorr, Apsi, fres);
+            for (label i = 0; i < n0; i++) psi[i] = psi[i] + fcorr[i];
+            orc_jacobi_smooth(A[0], ctl->omega, psi, source, ctl->nFinestSweeps);
+            /* ---- residual (GAMGSolverSolve.C:146-160) ---- */
+            orc_amul(A[0], psi, Apsi);
+            for (label i = 0; i < n0; i++) fres[i] = source[i] - Apsi[i];
+            perf->finalResidual = orc_gSumMag(A[0], fres) / normFactor;
+            if (hist && perf->nIterations + 1 < histLen) hist[perf->nIterations + 1] = perf->finalResidual;
+        } while ((++perf->nIterations < ctl->maxIter && !conv_check(perf, ctl)) || perf->nIterations < ctl->minIter);
+    }
+
+    for (int l = 0; l <= nL; l++) { orc_sys_destroy(A[l]); if (l) { free(D[l]); free(U[l]); free(Lw[l]); } }
+    for (int l = 0; l < nL; l++) { free(corr[l]); free(src[l]); }
+    free(A); free(D); free(U); free(Lw); free(corr); free(src); free(dense); free(piv);
+    free(Apsi); free(fcorr); free(fres); free(scr1); free(scr2);
+}
+
+/* level matrix of coarse level l+1, for unit parity tests of the engine's agglomerateMatrix kernels */
+void orc_gamg_coarse_matrix(const gamg_hier *H, int upToLevel, const scalar *diag, const scalar *upperC,
+                            const scalar *lowerC, scalar *cDiag, scalar *cUpper, scalar *cLower)
+{
+    const int asym = lowerC != NULL;
+    const scalar *d = diag, *u = upperC, *lo = lowerC;
+    scalar *pd = NULL, *pu = NULL, *pl = NULL;
+    for (int l = 0; l <= upToLevel; l++) {
+        const gamg_level *L = &H->lev[l];
+        scalar *nd = (scalar *)malloc(sizeof(scalar) * (size_t)L->nCoarse);
+        scalar *nu = (scalar *)malloc(sizeof(scalar) * (size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1));
+        scalar *nl = asym ? (scalar *)malloc(sizeof(scalar) * (size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1)) : NULL;
+        agglomerate_matrix(L, asym, d, u, lo, nd, nu, nl);
+        free(pd); free(pu); free(pl);
+        pd = nd; pu = nu; pl = nl; d = nd; u = nu; lo = nl;
+    }
+    const gamg_level *L = &H->lev[upToLevel];
+    memcpy(cDiag, pd, sizeof(scalar) * (size_t)L->nCoarse);
+    memcpy(cUpper, pu, sizeof(scalar) * (size_t)L->nCoarseFaces);
+    if (asym && cLower) memcpy(cLower, pl, sizeof(scalar) * (size_t)L->nCoarseFaces);
+    free(pd); free(pu); free(pl);
+}

@@ -189,3 +189,91 @@ class System:
                      maxIter=1000, minIter=0):
         return self._solve("orc_smooth_solve", psi, source, (C.c_double(omega), C.c_int(n_sweeps)),
                            tolerance, relTol, maxIter, minIter, maxIter + 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# GAMG (gamg_oracle.c)
+# ---------------------------------------------------------------------------------------------
+class GamgControls(C.Structure):
+    _fields_ = [("tolerance", C.c_double), ("relTol", C.c_double), ("maxIter", C.c_int32), ("minIter", C.c_int32),
+                ("nPreSweeps", C.c_int32), ("preSweepsLevelMultiplier", C.c_int32), ("maxPreSweeps", C.c_int32),
+                ("nPostSweeps", C.c_int32), ("postSweepsLevelMultiplier", C.c_int32), ("maxPostSweeps", C.c_int32),
+                ("nFinestSweeps", C.c_int32), ("scaleCorrection", C.c_int32), ("omega", C.c_double)]
+
+
+def gamg_controls(tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0, nPreSweeps=0, preSweepsLevelMultiplier=1,
+                  maxPreSweeps=4, nPostSweeps=2, postSweepsLevelMultiplier=1, maxPostSweeps=4, nFinestSweeps=2,
+                  scaleCorrection=-1, omega=0.9):
+    """defaults of GAMGSolver.C:67-77 and lduMatrixSolver.C:167-173"""
+    return GamgControls(tolerance, relTol, maxIter, minIter, nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps,
+                        nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection, omega)
+
+
+def box_face_weights(case):
+    """faceAreaPair weights |Sf/sqrt|Sf| o (1,1.01,1.02)| on the uniform hex box
+    (faceAreaPairGAMGAgglomeration.C:54-81): |Sf| = h^2 along direction d."""
+    nx, ny, nz = case.dims
+    lo, up = case.lower_addr.astype(np.int64), case.upper_addr.astype(np.int64)
+    d = up - lo
+    direction = np.where(d == 1, 0, np.where(d == nx, 1, 2))
+    if nx == 1 or ny == 1:  # degenerate boxes: recompute robustly
+        direction = np.where(d == 1, 0, np.where((d == nx) & (ny > 1), 1, 2))
+    h = 1.0 / nx
+    return h * np.array([1.0, 1.01, 1.02])[direction]
+
+
+class GamgHierarchy:
+    def __init__(self, case, face_weights, n_cells_in_coarsest_level=10, forward=True):
+        L = lib()
+        L.orc_gamg_build.restype = C.c_void_p
+        self.case = case
+        lo, up, w = _i(case.lower_addr), _i(case.upper_addr), _d(face_weights)
+        self._keep = (lo, up)
+        self.h = C.c_void_p(L.orc_gamg_build(C.c_int32(case.n_cells), C.c_int32(case.n_faces), _p(lo, C.c_int32),
+                                             _p(up, C.c_int32), _p(w, C.c_double), C.c_int32(n_cells_in_coarsest_level),
+                                             int(forward)))
+        self.n_levels = int(L.orc_gamg_n_levels(self.h))
+        self.forward_out = bool(L.orc_gamg_forward_out(self.h))
+
+    def __del__(self):
+        try:
+            lib().orc_gamg_free(self.h)
+        except Exception:
+            pass
+
+    def level(self, l):
+        s = (C.c_int32 * 4)()
+        lib().orc_gamg_level_sizes(self.h, l, s)
+        nf, nff, nc, ncf = [int(v) for v in s]
+        rm, fr, ff = np.empty(nf, np.int32), np.empty(nff, np.int32), np.empty(nff, np.int32)
+        cl, cu = np.empty(ncf, np.int32), np.empty(ncf, np.int32)
+        lib().orc_gamg_level_maps(self.h, l, _p(rm, C.c_int32), _p(fr, C.c_int32), _p(ff, C.c_int32),
+                                  _p(cl, C.c_int32), _p(cu, C.c_int32))
+        return dict(n_fine=nf, n_fine_faces=nff, n_coarse=nc, n_coarse_faces=ncf, restrict=rm, face_restrict=fr,
+                    face_flip=ff.astype(bool), lower=cl, upper=cu)
+
+    def coarse_matrix(self, up_to_level):
+        cs = self.case
+        lv = self.level(up_to_level)
+        d, u = np.empty(lv["n_coarse"]), np.empty(lv["n_coarse_faces"])
+        lo = np.empty(lv["n_coarse_faces"]) if cs.lower is not None else None
+        lib().orc_gamg_coarse_matrix(self.h, up_to_level, _p(_d(cs.diag), C.c_double), _p(_d(cs.upper), C.c_double),
+                                     _p(_d(cs.lower), C.c_double) if cs.lower is not None else None,
+                                     _p(d, C.c_double), _p(u, C.c_double), _p(lo, C.c_double) if lo is not None else None)
+        return d, u, lo
+
+    def solve(self, psi, source, **kw):
+        cs = self.case
+        ctl = gamg_controls(**kw)
+        x = _d(psi).copy()
+        b = _d(source)
+        perf = Perf()
+        hist_len = ctl.maxIter + 2
+        hist = np.full(hist_len, np.nan)
+        lo, up = self._keep
+        lib().orc_gamg_solve(self.h, _p(lo, C.c_int32), _p(up, C.c_int32), _p(_d(cs.diag), C.c_double),
+                             _p(_d(cs.upper), C.c_double), _p(_d(cs.lower), C.c_double) if cs.lower is not None else None,
+                             _p(x, C.c_double), _p(b, C.c_double), C.byref(ctl), C.byref(perf), _p(hist, C.c_double), hist_len)
+        out = {k: getattr(perf, k) for k, _ in Perf._fields_}
+        out["history"] = hist[~np.isnan(hist)].copy()
+        return x, out

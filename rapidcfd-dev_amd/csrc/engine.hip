@@ -1202,3 +1202,5 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
     HIPCHK(hipEventElapsedTime(ms, m->evPool[(size_t)idx0], m->evPool[(size_t)idx1]));
     return MI_OK;
 }
+
+#include "gamg_engine.inc"

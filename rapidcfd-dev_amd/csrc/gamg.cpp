@@ -1,0 +1,159 @@
+// gamg.cpp -- see gamg.hpp.
+#include "gamg.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <unordered_map>
+
+namespace mi {
+
+namespace {
+
+// Greedy pair matching of one level.  Visiting order and tie-breaking follow the reference
+// (strict '>' => first maximum wins; a cell's faces are listed neighbour-side first, then
+// owner-side; unmatched cells join the cluster across their heaviest face; leftovers become
+// singletons; reverse sweeps mirror the coarse numbering).
+int32_t match_pairs(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32_t* upper,
+                    const std::vector<double>& w, bool forward, std::vector<int32_t>& coarseOf)
+{
+    std::vector<int32_t> start((size_t)nFine + 1, 0);
+    for (int32_t f = 0; f < nFaces; ++f) { ++start[(size_t)upper[f] + 1]; ++start[(size_t)lower[f] + 1]; }
+    for (int32_t c = 0; c < nFine; ++c) start[(size_t)c + 1] += start[c];
+    std::vector<int32_t> faces((size_t)2 * nFaces), fill(start.begin(), start.end() - 1);
+    for (int32_t f = 0; f < nFaces; ++f) faces[(size_t)fill[upper[f]]++] = f;
+    for (int32_t f = 0; f < nFaces; ++f) faces[(size_t)fill[lower[f]]++] = f;
+
+    coarseOf.assign((size_t)nFine, -1);
+    int32_t nCoarse = 0;
+    const double NEG = -1e20;
+    for (int32_t k = 0; k < nFine; ++k) {
+        const int32_t c = forward ? k : nFine - 1 - k;
+        if (coarseOf[c] >= 0) continue;
+        int32_t pick = -1; double best = NEG;
+        for (int32_t j = start[c]; j < start[(size_t)c + 1]; ++j) {
+            const int32_t f = faces[j];
+            if (coarseOf[upper[f]] < 0 && coarseOf[lower[f]] < 0 && w[f] > best) { pick = f; best = w[f]; }
+        }
+        if (pick >= 0) { coarseOf[upper[pick]] = coarseOf[lower[pick]] = nCoarse++; continue; }
+        int32_t join = -1; double jbest = NEG;
+        for (int32_t j = start[c]; j < start[(size_t)c + 1]; ++j) {
+            const int32_t f = faces[j];
+            if (w[f] > jbest) { join = f; jbest = w[f]; }
+        }
+        if (join >= 0) coarseOf[c] = std::max(coarseOf[upper[join]], coarseOf[lower[join]]);
+    }
+    for (int32_t k = 0; k < nFine; ++k) {
+        const int32_t c = forward ? k : nFine - 1 - k;
+        if (coarseOf[c] < 0) coarseOf[c] = nCoarse++;
+    }
+    if (!forward) for (int32_t c = 0; c < nFine; ++c) coarseOf[c] = nCoarse - 1 - coarseOf[c];
+    return nCoarse;
+}
+
+// Coarse faces: one per unordered pair of distinct coarse cells, numbered so that they are
+// grouped by owner (= smaller coarse cell) and, inside an owner, in order of first appearance
+// among the fine faces -- the numbering the reference's per-cell neighbour lists produce.
+void build_coarse_faces(GamgLevelHost& L, const int32_t* lower, const int32_t* upper)
+{
+    const int32_t nF = L.nFineFaces, nC = L.nCoarse;
+    L.faceRestrict.assign((size_t)nF, 0);
+    L.faceFlip.assign((size_t)nF, 0);
+    // first pass: provisional ids in order of creation + per-owner lists
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> perOwner((size_t)nC); // (neighbour, provisional id)
+    std::vector<int32_t> provNei;
+    for (int32_t f = 0; f < nF; ++f) {
+        const int32_t ru = L.restrictMap[upper[f]], rl = L.restrictMap[lower[f]];
+        if (ru == rl) { L.faceRestrict[f] = -(ru + 1); continue; }
+        const int32_t own = std::min(ru, rl), nei = std::max(ru, rl);
+        auto& lst = perOwner[own];
+        int32_t id = -1;
+        for (auto& pr : lst) if (pr.first == nei) { id = pr.second; break; }
+        if (id < 0) { id = (int32_t)provNei.size(); provNei.push_back(nei); lst.emplace_back(nei, id); }
+        L.faceRestrict[f] = id;
+    }
+    const int32_t nCF = (int32_t)provNei.size();
+    L.nCoarseFaces = nCF;
+    L.cLower.resize(nCF); L.cUpper.resize(nCF);
+    std::vector<int32_t> finalId((size_t)nCF);
+    int32_t k = 0;
+    for (int32_t c = 0; c < nC; ++c)
+        for (auto& pr : perOwner[c]) { L.cLower[k] = c; L.cUpper[k] = pr.first; finalId[pr.second] = k++; }
+    for (int32_t f = 0; f < nF; ++f) {
+        int32_t& t = L.faceRestrict[f];
+        if (t < 0) continue;
+        t = finalId[t];
+        // flipped when the fine (lower -> upper) direction is opposite to the coarse (owner -> neighbour)
+        if (L.cLower[t] == L.restrictMap[upper[f]] && L.cUpper[t] == L.restrictMap[lower[f]]) L.faceFlip[f] = 1;
+    }
+}
+
+void segment(int32_t nTargets, const std::vector<int32_t>& target, std::vector<int32_t>& start, std::vector<int32_t>& child)
+{
+    // children of target t = all i with target[i] == t, ascending i (counting sort is stable); negatives skipped
+    start.assign((size_t)nTargets + 1, 0);
+    for (int32_t t : target) if (t >= 0) ++start[(size_t)t + 1];
+    for (int32_t t = 0; t < nTargets; ++t) start[(size_t)t + 1] += start[t];
+    child.resize((size_t)start[nTargets]);
+    std::vector<int32_t> fill(start.begin(), start.end() - 1);
+    for (int32_t i = 0; i < (int32_t)target.size(); ++i) if (target[i] >= 0) child[(size_t)fill[target[i]]++] = i;
+}
+
+} // namespace
+
+std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* lower, const int32_t* upper,
+                                 const double* faceWeights, int32_t nCellsInCoarsestLevel, bool forwardInit,
+                                 GamgHierarchyHost& H)
+{
+    if (nCells <= 0 || !faceWeights) return "bad argument";
+    H.levels.clear();
+    bool forward = forwardInit;
+    const int maxLevels = 50;
+    std::vector<double> w(faceWeights, faceWeights + nFaces);
+    int32_t nFine = nCells, nF = nFaces;
+    const int32_t *lo = lower, *up = upper;
+    while ((int)H.levels.size() < maxLevels - 1) {
+        GamgLevelHost L;
+        L.nFine = nFine; L.nFineFaces = nF;
+        L.nCoarse = match_pairs(nFine, nF, lo, up, w, forward, L.restrictMap);
+        forward = !forward;
+        if (L.nCoarse < nCellsInCoarsestLevel || L.nCoarse == nFine) break; // continueAgglomerating
+        build_coarse_faces(L, lo, up);
+        std::vector<double> cw((size_t)L.nCoarseFaces, 0.0); // restrictFaceField (host): plain summation
+        for (int32_t f = 0; f < nF; ++f) if (L.faceRestrict[f] >= 0) cw[L.faceRestrict[f]] += w[f];
+        w.swap(cw);
+        segment(L.nCoarse, L.restrictMap, L.cellChildStart, L.cellChild);
+        segment(L.nCoarseFaces, L.faceRestrict, L.faceChildStart, L.faceChild);
+        std::vector<int32_t> interior((size_t)nF);
+        for (int32_t f = 0; f < nF; ++f) interior[f] = L.faceRestrict[f] < 0 ? -1 - L.faceRestrict[f] : -1;
+        segment(L.nCoarse, interior, L.diagChildStart, L.diagChild);
+        H.levels.push_back(std::move(L));
+        GamgLevelHost& B = H.levels.back();
+        nFine = B.nCoarse; nF = B.nCoarseFaces; lo = B.cLower.data(); up = B.cUpper.data();
+    }
+    H.forwardOut = forward;
+    return std::string();
+}
+
+bool invert_dense(int n, std::vector<double>& A)
+{
+    std::vector<double> I((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) I[(size_t)i * n + i] = 1.0;
+    for (int k = 0; k < n; ++k) {
+        int p = k; double big = std::fabs(A[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; ++i) if (std::fabs(A[(size_t)i * n + k]) > big) { big = std::fabs(A[(size_t)i * n + k]); p = i; }
+        if (big == 0.0) return false;
+        if (p != k) for (int j = 0; j < n; ++j) { std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]); std::swap(I[(size_t)k * n + j], I[(size_t)p * n + j]); }
+        const double inv = 1.0 / A[(size_t)k * n + k];
+        for (int j = 0; j < n; ++j) { A[(size_t)k * n + j] *= inv; I[(size_t)k * n + j] *= inv; }
+        for (int i = 0; i < n; ++i) {
+            if (i == k) continue;
+            const double m = A[(size_t)i * n + k];
+            if (m == 0.0) continue;
+            for (int j = 0; j < n; ++j) { A[(size_t)i * n + j] -= m * A[(size_t)k * n + j]; I[(size_t)i * n + j] -= m * I[(size_t)k * n + j]; }
+        }
+    }
+    A.swap(I);
+    return true;
+}
+
+} // namespace mi

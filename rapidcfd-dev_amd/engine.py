@@ -52,7 +52,25 @@ SYMBOLS = [
     "mi_bench_amul", "mi_bench_pcg_iters",
     "mi_layout_build_host", "mi_layout_array", "mi_layout_free",
     "mi_dpcg_set_buffers", "mi_dpcg_phase", "mi_dpcg_status", "mi_event_record", "mi_event_elapsed_ms",
+    "mi_gamg_create", "mi_gamg_destroy", "mi_gamg_n_levels", "mi_gamg_forward_out", "mi_gamg_level_sizes",
+    "mi_gamg_solve", "mi_gamg_restrict", "mi_gamg_prolong", "mi_gamg_level_coeffs",
+    "mi_gamg_host_build", "mi_gamg_host_n_levels", "mi_gamg_host_array", "mi_gamg_host_free",
 ]
+
+
+class GamgControls(C.Structure):
+    _fields_ = [("tolerance", C.c_double), ("relTol", C.c_double), ("maxIter", C.c_int32), ("minIter", C.c_int32),
+                ("nPreSweeps", C.c_int32), ("preSweepsLevelMultiplier", C.c_int32), ("maxPreSweeps", C.c_int32),
+                ("nPostSweeps", C.c_int32), ("postSweepsLevelMultiplier", C.c_int32), ("maxPostSweeps", C.c_int32),
+                ("nFinestSweeps", C.c_int32), ("scaleCorrection", C.c_int32), ("omega", C.c_double)]
+
+
+def gamg_controls(tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0, nPreSweeps=0, preSweepsLevelMultiplier=1,
+                  maxPreSweeps=4, nPostSweeps=2, postSweepsLevelMultiplier=1, maxPostSweeps=4, nFinestSweeps=2,
+                  scaleCorrection=-1, omega=0.9):
+    """GAMGSolver.C:67-77 defaults"""
+    return GamgControls(tolerance, relTol, maxIter, minIter, nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps,
+                        nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection, omega)
 
 
 def host_layout(n_cells, lower_addr, upper_addr, patch_face_cells=(), tile_cells=0, slot_cap=0) -> dict:
@@ -339,3 +357,75 @@ class Matrix:
         if self.h:
             lib().mi_matrix_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class Gamg:
+    """GAMG hierarchy + solver (lduMatrix::solver 'GAMG', agglomerator faceAreaPair/algebraicPair)."""
+
+    def __init__(self, addr: Addressing, face_weights, n_cells_in_coarsest_level: int = 10, forward: bool = True):
+        self.addr = addr
+        w = np.ascontiguousarray(face_weights, dtype=np.float64)
+        self.h = C.c_void_p()
+        _chk(lib().mi_gamg_create(addr.h, w.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(n_cells_in_coarsest_level),
+                                  int(forward), C.byref(self.h)))
+        self.n_levels = int(lib().mi_gamg_n_levels(self.h))
+        self.forward_out = bool(lib().mi_gamg_forward_out(self.h))
+
+    def level_sizes(self, level: int):
+        out = (C.c_int32 * 4)()
+        _chk(lib().mi_gamg_level_sizes(self.h, C.c_int32(level), out))
+        return dict(zip(("n_fine", "n_fine_faces", "n_coarse", "n_coarse_faces"), [int(v) for v in out]))
+
+    def solve(self, mat: Matrix, psi, source, **kw):
+        ctl = gamg_controls(**kw)
+        perf = SolverPerf()
+        hist_len = ctl.maxIter + 2
+        hist = np.full(hist_len, np.nan)
+        _chk(lib().mi_gamg_solve(self.h, mat.h, _ptr(psi), _ptr(source), C.byref(ctl), C.byref(perf),
+                                 hist.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(hist_len)))
+        out = {k: getattr(perf, k) for k, _ in SolverPerf._fields_ if k != "reserved"}
+        out["history"] = hist[~np.isnan(hist)].copy()
+        return out
+
+    def restrict(self, level, fine, coarse):
+        _chk(lib().mi_gamg_restrict(self.h, C.c_int32(level), _ptr(fine), _ptr(coarse)))
+
+    def prolong(self, level, coarse, fine):
+        _chk(lib().mi_gamg_prolong(self.h, C.c_int32(level), _ptr(coarse), _ptr(fine)))
+
+    def level_coeffs(self, mat: Matrix, level, diag, upper, lower=None):
+        _chk(lib().mi_gamg_level_coeffs(self.h, mat.h, C.c_int32(level), _ptr(diag), _ptr(upper), _ptr(lower)))
+
+    def close(self):
+        if self.h:
+            lib().mi_gamg_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def gamg_host_hierarchy(n_cells, lower_addr, upper_addr, face_weights, n_cells_in_coarsest_level=10, forward=True):
+    """Host-only build of the GAMG hierarchy; returns a list of per-level dicts of numpy arrays (tests)."""
+    lo = np.ascontiguousarray(lower_addr, dtype=np.int32)
+    up = np.ascontiguousarray(upper_addr, dtype=np.int32)
+    w = np.ascontiguousarray(face_weights, dtype=np.float64)
+    h = C.c_void_p()
+    _chk(lib().mi_gamg_host_build(C.c_int32(n_cells), C.c_int32(lo.shape[0]), lo.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  up.ctypes.data_as(C.POINTER(C.c_int32)), w.ctypes.data_as(C.POINTER(C.c_double)),
+                                  C.c_int32(n_cells_in_coarsest_level), int(forward), C.byref(h)))
+    out = []
+    try:
+        for lvl in range(int(lib().mi_gamg_host_n_levels(h))):
+            d = {}
+            for name in ("restrictMap", "faceRestrict", "faceFlip", "cLower", "cUpper", "cellChildStart", "cellChild",
+                         "faceChildStart", "faceChild", "diagChildStart", "diagChild"):
+                data, ln, es = C.c_void_p(), C.c_int64(), C.c_int32()
+                _chk(lib().mi_gamg_host_array(h, C.c_int32(lvl), name.encode(), C.byref(data), C.byref(ln), C.byref(es)))
+                dt = np.uint8 if es.value == 1 else np.int32
+                if ln.value:
+                    buf = (C.c_char * (ln.value * es.value)).from_address(data.value)
+                    d[name] = np.frombuffer(buf, dtype=dt).copy()
+                else:
+                    d[name] = np.zeros(0, dtype=dt)
+            out.append(d)
+    finally:
+        lib().mi_gamg_host_free(h)
+    return out

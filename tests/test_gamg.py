@@ -1,0 +1,156 @@
+"""GAMG: oracle properties and engine-vs-oracle hierarchy (CPU); engine V-cycle parity (gpu)."""
+import numpy as np
+import pytest
+
+from conftest import random_graph_case
+
+
+def graph_weights(pkg, case):
+    return 0.5 + pkg.synthetic.splitmix_uniform(77, case.n_faces)
+
+
+@pytest.mark.parametrize("kind,ncoarsest,forward", [("box", 10, True), ("box", 50, False), ("graph", 10, True), ("box_odd", 4, True)])
+def test_engine_hierarchy_equals_oracle(pkg, orc, kind, ncoarsest, forward):
+    # two independent restatements (C in oracle/, C++ in the engine) of pairGAMGAgglomerate.C +
+    # GAMGAgglomerateLduAddressing.C must agree exactly
+    if kind == "box":
+        case = pkg.synthetic.box_case(14, 11, 9); w = orc.box_face_weights(case)
+    elif kind == "box_odd":
+        case = pkg.synthetic.box_case(7, 5, 3); w = orc.box_face_weights(case)
+    else:
+        case = random_graph_case(pkg, 800); w = graph_weights(pkg, case)
+    H = orc.GamgHierarchy(case, w, ncoarsest, forward)
+    E = pkg.engine.gamg_host_hierarchy(case.n_cells, case.lower_addr, case.upper_addr, w, ncoarsest, forward)
+    assert H.n_levels == len(E) >= 2
+    for l in range(H.n_levels):
+        o, e = H.level(l), E[l]
+        assert np.array_equal(o["restrict"], e["restrictMap"])
+        assert np.array_equal(o["lower"], e["cLower"]) and np.array_equal(o["upper"], e["cUpper"])
+        assert np.array_equal(o["face_restrict"], e["faceRestrict"])
+        assert np.array_equal(o["face_flip"], e["faceFlip"].astype(bool))
+        assert np.all(o["lower"] < o["upper"])
+        # every coarse cell has 1..n children and pairs dominate
+        cnt = np.bincount(o["restrict"], minlength=o["n_coarse"])
+        assert cnt.min() >= 1
+        assert np.array_equal(np.diff(e["cellChildStart"]), cnt)
+    assert H.level(H.n_levels - 1)["n_coarse"] >= ncoarsest
+
+
+def test_coarse_matrix_is_galerkin_by_summation(pkg, orc):
+    # piecewise-constant restriction R: coarse A = R A R^T (GAMGSolverAgglomerateMatrix.C)
+    case = pkg.synthetic.box_case(8, 7, 6, symmetric=False)
+    H = orc.GamgHierarchy(case, orc.box_face_weights(case), 8)
+    n = case.n_cells
+    A = np.zeros((n, n)); A[np.arange(n), np.arange(n)] = case.diag
+    A[case.lower_addr, case.upper_addr] = case.upper; A[case.upper_addr, case.lower_addr] = case.lower
+    for l in range(min(3, H.n_levels)):
+        lv = H.level(l)
+        R = np.zeros((lv["n_coarse"], lv["n_fine"])); R[lv["restrict"], np.arange(lv["n_fine"])] = 1.0
+        A = R @ A @ R.T
+        d, u, lo = H.coarse_matrix(l)
+        Ac = np.zeros_like(A); Ac[np.arange(len(d)), np.arange(len(d))] = d
+        Ac[lv["lower"], lv["upper"]] = u; Ac[lv["upper"], lv["lower"]] = lo
+        assert np.max(np.abs(Ac - A)) < 1e-13 * np.max(np.abs(A))
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_oracle_gamg_converges_mesh_independently(pkg, orc, symmetric):
+    its = []
+    for dims in [(12, 12, 12), (24, 24, 24)]:
+        case = pkg.synthetic.box_case(*dims, symmetric=symmetric)
+        H = orc.GamgHierarchy(case, orc.box_face_weights(case), 10)
+        psi, perf = H.solve(np.zeros(case.n_cells), case.source, tolerance=1e-7, maxIter=200)
+        assert perf["converged"]
+        r = orc.System([case]).residual(psi, case.source)
+        assert abs(np.abs(r).sum() / perf["normFactor"] - perf["finalResidual"]) < 1e-12
+        its.append(perf["nIterations"])
+    if symmetric:
+        assert abs(its[0] - its[1]) <= 4  # multigrid: iteration count (almost) independent of the mesh size
+
+
+def test_oracle_gamg_controls(pkg, orc):
+    case = pkg.synthetic.box_case(12, 10, 8)
+    H = orc.GamgHierarchy(case, orc.box_face_weights(case), 10)
+    z = np.zeros(case.n_cells)
+    _, p = H.solve(z, case.source, tolerance=0.0, maxIter=5)
+    assert p["nIterations"] == 5  # ++nIterations < maxIter (GAMGSolverSolve.C:166-174): exactly maxIter cycles
+    _, p0 = H.solve(z, case.source, tolerance=1e-6, nPreSweeps=2)
+    _, p1 = H.solve(z, case.source, tolerance=1e-6)
+    assert p0["converged"] and p0["nIterations"] < p1["nIterations"]
+    _, p2 = H.solve(z, case.source, tolerance=1e-6, scaleCorrection=0)
+    assert p2["converged"]
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["box_sym", "box_asym", "graph_sym"])
+def test_engine_gamg_operators_bit_exact(pkg, orc, name):
+    import torch
+    eng = pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    if name == "graph_sym":
+        case = random_graph_case(pkg, 2500); w = graph_weights(pkg, case)
+    else:
+        case = pkg.synthetic.box_case(20, 16, 12, symmetric=(name == "box_sym")); w = orc.box_face_weights(case)
+    H = orc.GamgHierarchy(case, w, 10)
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    G = eng.Gamg(addr, w, 10)
+    assert G.n_levels == H.n_levels and G.forward_out == H.forward_out
+    for l in range(H.n_levels):
+        lv = H.level(l)
+        assert G.level_sizes(l) == {k: lv[k] for k in ("n_fine", "n_fine_faces", "n_coarse", "n_coarse_faces")}
+        ff = pkg.synthetic.splitmix_uniform(l + 1, lv["n_fine"]) - 0.5
+        cf = torch.empty(lv["n_coarse"], dtype=torch.float64, device="cuda:0")
+        G.restrict(l, dev(ff), cf)
+        ref = np.zeros(lv["n_coarse"]); np.add.at(ref, lv["restrict"], ff)   # ascending fine index
+        assert np.array_equal(cf.cpu().numpy(), ref)
+        back = torch.empty(lv["n_fine"], dtype=torch.float64, device="cuda:0")
+        G.prolong(l, cf, back)
+        assert np.array_equal(back.cpu().numpy(), ref[lv["restrict"]])
+        d = torch.empty(lv["n_coarse"], dtype=torch.float64, device="cuda:0")
+        u = torch.empty(max(lv["n_coarse_faces"], 1), dtype=torch.float64, device="cuda:0")
+        lo = torch.empty(max(lv["n_coarse_faces"], 1), dtype=torch.float64, device="cuda:0") if case.lower is not None else None
+        G.level_coeffs(mat, l, d, u, lo)
+        rd, ru, rl = H.coarse_matrix(l)
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), rd)
+        assert np.array_equal(u.cpu().numpy()[: lv["n_coarse_faces"]], ru)
+        if lo is not None:
+            assert np.array_equal(lo.cpu().numpy()[: lv["n_coarse_faces"]], rl)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [("box_sym", {}), ("box_sym", dict(nPreSweeps=1)), ("box_sym", dict(scaleCorrection=0)),
+                                     ("box_asym", {}), ("graph_sym", {}), ("box_sym", dict(tolerance=0.0, maxIter=4)),
+                                     ("box_sym", dict(tolerance=1e30, minIter=2))])
+def test_engine_gamg_history(pkg, orc, name, kw):
+    import torch
+    eng = pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    if name == "graph_sym":
+        case = random_graph_case(pkg, 2500); w = graph_weights(pkg, case)
+    else:
+        case = pkg.synthetic.box_case(24, 20, 16, symmetric=(name == "box_sym")); w = orc.box_face_weights(case)
+    args = dict(tolerance=1e-9, maxIter=100); args.update(kw)
+    H = orc.GamgHierarchy(case, w, 10)
+    ref_psi, ref = H.solve(np.zeros(case.n_cells), case.source, **args)
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    G = eng.Gamg(addr, w, 10)
+    psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+    perf = G.solve(mat, psi, dev(case.source), **args)
+    assert perf["nIterations"] == ref["nIterations"] and perf["converged"] == ref["converged"]
+    h, hr = perf["history"], ref["history"]
+    assert h.shape == hr.shape
+    assert np.max(np.abs(h - hr)) < 1e-10 * hr[0]
+    torch.cuda.synchronize()
+    assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+    # a second solve on the cached hierarchy gives the same bits (level matrices are rebuilt, hierarchy is not)
+    psi2 = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+    perf2 = G.solve(mat, psi2, dev(case.source), **args)
+    assert np.array_equal(perf2["history"], perf["history"])
