@@ -43,6 +43,7 @@ typedef struct mi_ctx_s *mi_ctx_t;
 typedef struct mi_addr_s *mi_addr_t;
 typedef struct mi_matrix_s *mi_matrix_t;
 typedef struct mi_gamg_s *mi_gamg_t;
+typedef struct mi_patch_s *mi_patch_t;
 
 enum {
     MI_OK = 0,
@@ -239,6 +240,34 @@ int mi_gamg_restrict(mi_gamg_t g, int32_t level, const double *fine_dev, double 
 int mi_gamg_prolong(mi_gamg_t g, int32_t level, const double *coarse_dev, double *fine_dev);
 int mi_gamg_level_coeffs(mi_gamg_t g, mi_matrix_t m, int32_t level, double *diag_out_dev,
                          double *upper_out_dev, double *lower_out_dev);
+
+/* ---- fvMatrix assembly sweeps, scalar fields, caller-order device arrays ----
+ * (src/finiteVolume/finiteVolume/convectionSchemes/gaussConvectionScheme/gaussConvectionScheme.C:74-115,
+ *  .../laplacianSchemes/gaussLaplacianScheme/gaussLaplacianScheme.C:44-88,
+ *  src/OpenFOAM/matrices/lduMatrix/lduMatrix/lduMatrixOperations.C:36-106,
+ *  src/finiteVolume/fvMatrices/fvMatrix/fvMatrix.C:38-124,208-349,1087-1345,
+ *  src/finiteVolume/finiteVolume/fvc/fvcSurfaceIntegrate.C:40-96,
+ *  src/finiteVolume/interpolation/surfaceInterpolation/surfaceInterpolationScheme/surfaceInterpolationScheme.C:337-352)
+ * Every scheme is ONE fused row pass (the reference: 3-6 Thrust passes + temporaries).  They need
+ * the caller's faces owner-sorted (OpenFOAM's upper-triangular order).
+ * mi_row_face_op kind: 0 sumDiag, 1 negSumDiag, 2 sumMagOffDiag; lower_dev NULL => symmetric.
+ * mi_patch_*: a boundary patch = its faceCells; mi_patch_add applies pf per unique cell in ascending
+ * patch-face order (addToInternalField, K26): fn 0 add, 1 subtract, 2 add magnitudes.          */
+int mi_row_face_op(mi_addr_t addr, int kind, const double *lower_dev, const double *upper_dev, double *inout_dev);
+int mi_fvm_laplacian(mi_addr_t addr, const double *delta_coeffs_dev, const double *gamma_magsf_dev,
+                     double *upper_out_dev, double *diag_out_dev);
+int mi_fvm_div(mi_addr_t addr, const double *weights_dev, const double *face_flux_dev,
+               double *lower_out_dev, double *upper_out_dev, double *diag_out_dev);
+int mi_surface_integrate(mi_addr_t addr, const double *ssf_dev, const double *vol_dev_or_null, double *ivf_dev);
+int mi_face_interpolate(mi_addr_t addr, const double *lambda_dev, const double *phi_dev, double *sf_dev);
+int mi_patch_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_patch_faces, const int32_t *face_cells_host, mi_patch_t *out);
+int mi_patch_destroy(mi_patch_t patch);
+int mi_patch_add(mi_patch_t patch, const double *pf_dev, double *intf_dev, int fn);
+/* fvMatrix<scalar>::relax(alpha): coupled[p] != 0 marks processor-like patches */
+int mi_relax(mi_addr_t addr, double alpha, double *diag_dev, const double *lower_dev, const double *upper_dev,
+             double *source_dev, const double *psi_dev, int32_t n_patches, const mi_patch_t *patches,
+             const double *const *internal_coeffs_dev, const double *const *boundary_coeffs_dev,
+             const int32_t *coupled);
 
 /* host-only inspection of the hierarchy builder (no device; CPU tests compare it with the
  * oracle's independent restatement).  name: restrictMap, faceRestrict, faceFlip (uint8), cLower,

@@ -277,3 +277,76 @@ class GamgHierarchy:
         out = {k: getattr(perf, k) for k, _ in Perf._fields_}
         out["history"] = hist[~np.isnan(hist)].copy()
         return x, out
+
+
+# ---------------------------------------------------------------------------------------------
+# fvMatrix assembly sweeps (fvm_oracle.c)
+# ---------------------------------------------------------------------------------------------
+def row_face_op(kind, n_cells, lower_addr, upper_addr, lower, upper, inout):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    out = _d(inout).copy()
+    u = _d(upper)
+    l = u if lower is None else _d(lower)
+    lib().orc_row_face_op(int(kind), C.c_int32(n_cells), C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32),
+                          _p(l, C.c_double), _p(u, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def fvm_laplacian(n_cells, lower_addr, upper_addr, delta_coeffs, gamma_magsf):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    upper, diag = np.empty(lo.shape[0]), np.empty(n_cells)
+    lib().orc_fvm_laplacian(C.c_int32(n_cells), C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32),
+                            _p(_d(delta_coeffs), C.c_double), _p(_d(gamma_magsf), C.c_double), _p(upper, C.c_double), _p(diag, C.c_double))
+    return upper, diag
+
+
+def fvm_div(n_cells, lower_addr, upper_addr, weights, face_flux):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    lower, upper, diag = np.empty(lo.shape[0]), np.empty(lo.shape[0]), np.empty(n_cells)
+    lib().orc_fvm_div(C.c_int32(n_cells), C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32),
+                      _p(_d(weights), C.c_double), _p(_d(face_flux), C.c_double), _p(lower, C.c_double),
+                      _p(upper, C.c_double), _p(diag, C.c_double))
+    return lower, upper, diag
+
+
+def patch_add(face_cells, pf, intf, fn=0):
+    fc = _i(face_cells)
+    out = _d(intf).copy()
+    lib().orc_patch_add(C.c_int32(fc.shape[0]), _p(fc, C.c_int32), _p(_d(pf), C.c_double), int(fn), C.c_int32(out.shape[0]), _p(out, C.c_double))
+    return out
+
+
+def relax(n_cells, lower_addr, upper_addr, alpha, diag, lower, upper, source, psi, face_cells=(), icoeffs=(), bcoeffs=(), coupled=()):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    d, s = _d(diag).copy(), _d(source).copy()
+    u = _d(upper)
+    l = u if lower is None else _d(lower)
+    n = len(face_cells)
+    fcs = [_i(f) for f in face_cells]
+    ics = [_d(a) for a in icoeffs]
+    bcs = [_d(a) for a in bcoeffs]
+    sizes = (C.c_int32 * max(n, 1))(*[f.shape[0] for f in fcs])
+    fp = (C.POINTER(C.c_int32) * max(n, 1))(*[_p(f, C.c_int32) for f in fcs])
+    ip = (C.POINTER(C.c_double) * max(n, 1))(*[_p(a, C.c_double) for a in ics])
+    bp = (C.POINTER(C.c_double) * max(n, 1))(*[_p(a, C.c_double) for a in bcs])
+    cp = (C.c_int * max(n, 1))(*[int(c) for c in coupled])
+    lib().orc_relax(C.c_int32(n_cells), C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), C.c_double(alpha),
+                    _p(d, C.c_double), _p(l, C.c_double), _p(u, C.c_double), _p(s, C.c_double), _p(_d(psi), C.c_double),
+                    n, sizes, fp, ip, bp, cp)
+    return d, s
+
+
+def surface_integrate(n_cells, lower_addr, upper_addr, ssf, vol=None):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    out = np.empty(n_cells)
+    lib().orc_surface_integrate(C.c_int32(n_cells), C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32),
+                                _p(_d(ssf), C.c_double), _p(_d(vol), C.c_double) if vol is not None else None, _p(out, C.c_double))
+    return out
+
+
+def face_interpolate(lower_addr, upper_addr, lam, phi):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    out = np.empty(lo.shape[0])
+    lib().orc_face_interpolate(C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(_d(lam), C.c_double),
+                               _p(_d(phi), C.c_double), _p(out, C.c_double))
+    return out

@@ -6,6 +6,7 @@
 #include "kernels.hip.hpp"
 #include "tiling.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,6 +80,8 @@ struct mi_addr_s {
     DevBuf<int32_t> e2c, c2e, tileCellStart, tileSlotStart, tileHaloStart, haloCell, tileSliceStart, sliceEntryStart;
     DevBuf<uint32_t> entries;
     DevBuf<int32_t> slotFace, extSlot, interiorTiles, boundaryTiles, patchFaceCellsE, faceSlot, lowerAddr, upperAddr;
+    DevBuf<int32_t> ownerStartC, losortStartC, losortC; // caller-order row tables for the assembly sweeps (lazy)
+    DevBuf<double> relaxD0, relaxSumOff;
     std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
     int32_t nInterior = 0, nBoundary = 0;
     int64_t nEntries = 0, nHaloTot = 0;
@@ -1204,3 +1207,4 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
 }
 
 #include "gamg_engine.inc"
+#include "assembly.inc"

@@ -55,6 +55,8 @@ SYMBOLS = [
     "mi_gamg_create", "mi_gamg_destroy", "mi_gamg_n_levels", "mi_gamg_forward_out", "mi_gamg_level_sizes",
     "mi_gamg_solve", "mi_gamg_restrict", "mi_gamg_prolong", "mi_gamg_level_coeffs",
     "mi_gamg_host_build", "mi_gamg_host_n_levels", "mi_gamg_host_array", "mi_gamg_host_free",
+    "mi_row_face_op", "mi_fvm_laplacian", "mi_fvm_div", "mi_surface_integrate", "mi_face_interpolate",
+    "mi_patch_create", "mi_patch_destroy", "mi_patch_add", "mi_relax",
 ]
 
 
@@ -429,3 +431,52 @@ def gamg_host_hierarchy(n_cells, lower_addr, upper_addr, face_weights, n_cells_i
     finally:
         lib().mi_gamg_host_free(h)
     return out
+
+
+class Patch:
+    """A boundary patch (its faceCells) for the assembly sweeps."""
+
+    def __init__(self, ctx: Context, n_cells: int, face_cells):
+        fc = np.ascontiguousarray(face_cells, dtype=np.int32)
+        self.h = C.c_void_p()
+        _chk(lib().mi_patch_create(ctx.h, C.c_int32(n_cells), C.c_int32(fc.shape[0]),
+                                   fc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(self.h)))
+
+    def add(self, pf, intf, fn: int = 0):
+        _chk(lib().mi_patch_add(self.h, _ptr(pf), _ptr(intf), int(fn)))
+
+    def close(self):
+        if self.h:
+            lib().mi_patch_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Assembly:
+    """fvm::div / fvm::laplacian / negSumDiag / relax ... on caller-order arrays of an Addressing."""
+
+    def __init__(self, addr: Addressing):
+        self.addr = addr
+
+    def row_face_op(self, kind: int, lower, upper, inout):
+        _chk(lib().mi_row_face_op(self.addr.h, int(kind), _ptr(lower), _ptr(upper), _ptr(inout)))
+
+    def fvm_laplacian(self, delta_coeffs, gamma_magsf, upper_out, diag_out):
+        _chk(lib().mi_fvm_laplacian(self.addr.h, _ptr(delta_coeffs), _ptr(gamma_magsf), _ptr(upper_out), _ptr(diag_out)))
+
+    def fvm_div(self, weights, face_flux, lower_out, upper_out, diag_out):
+        _chk(lib().mi_fvm_div(self.addr.h, _ptr(weights), _ptr(face_flux), _ptr(lower_out), _ptr(upper_out), _ptr(diag_out)))
+
+    def surface_integrate(self, ssf, vol, ivf):
+        _chk(lib().mi_surface_integrate(self.addr.h, _ptr(ssf), _ptr(vol), _ptr(ivf)))
+
+    def face_interpolate(self, lam, phi, sf):
+        _chk(lib().mi_face_interpolate(self.addr.h, _ptr(lam), _ptr(phi), _ptr(sf)))
+
+    def relax(self, alpha, diag, lower, upper, source, psi, patches=(), internal_coeffs=(), boundary_coeffs=(), coupled=()):
+        n = len(patches)
+        ph = (C.c_void_p * max(n, 1))(*[p.h for p in patches])
+        ic = (C.c_void_p * max(n, 1))(*[_ptr(t) for t in internal_coeffs])
+        bc = (C.c_void_p * max(n, 1))(*[_ptr(t) for t in boundary_coeffs])
+        cp = (C.c_int32 * max(n, 1))(*[int(v) for v in coupled])
+        _chk(lib().mi_relax(self.addr.h, C.c_double(alpha), _ptr(diag), _ptr(lower), _ptr(upper), _ptr(source), _ptr(psi),
+                            C.c_int32(n), ph, ic, bc, cp))
