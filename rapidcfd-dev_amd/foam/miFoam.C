@@ -1,0 +1,409 @@
+// miFoam.C -- see miFoam.H.  Host code only; every number is produced by the HIP engine behind
+// the C ABI (include/mi_ldu.h).  Compiled with hipcc only because device memory is managed here.
+#include "miFoam.H"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+
+namespace Foam
+{
+
+std::ostream& Info = std::cout;
+
+void FatalErrorIn(const std::string& where, const std::string& msg)
+{
+    // the reference prints "--> FOAM FATAL ERROR" and aborts (error.C); a library throws instead
+    throw error("--> FOAM FATAL ERROR:\n" + msg + "\n\n    From function " + where);
+}
+
+void miCheck(int rc, const char* where)
+{
+    if (rc != MI_OK) FatalErrorIn(where, std::string("MI355X engine error ") + std::to_string(rc) + ": " + mi_last_error());
+}
+
+#define FOAM_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) FatalErrorIn(#expr, hipGetErrorString(e_)); } while (0)
+
+// one engine context per process = per MPI rank = per GPU (argList.C:775-811 `-device N`)
+struct miEngine
+{
+    mi_ctx_t ctx;
+    miEngine() : ctx(nullptr)
+    {
+        const char* d = std::getenv("MI_DEVICE");
+        miCheck(mi_ctx_create(d ? std::atoi(d) : 0, nullptr, &ctx), "miEngine::miEngine()");
+    }
+    ~miEngine() { mi_ctx_destroy(ctx); }
+    static miEngine& New() { static miEngine e; return e; }
+};
+
+void* miDeviceAlloc(std::size_t bytes) { miEngine::New(); void* p = nullptr; FOAM_HIP(hipMalloc(&p, bytes)); return p; }
+void miDeviceFree(void* p) { (void)hipFree(p); }
+void miCopyH2D(void* d, const void* s, std::size_t n) { FOAM_HIP(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); }
+void miCopyD2H(void* d, const void* s, std::size_t n) { mi_ctx_synchronize(miEngine::New().ctx); FOAM_HIP(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); }
+void miCopyD2D(void* d, const void* s, std::size_t n) { mi_ctx_synchronize(miEngine::New().ctx); FOAM_HIP(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice)); }
+void miDeviceZero(void* p, std::size_t n) { FOAM_HIP(hipMemset(p, 0, n)); }
+
+// ---- solverPerformance ------------------------------------------------------------------------------
+const scalar solverPerformance::great_ = 1e20;
+const scalar solverPerformance::small_ = 1e-20;
+const scalar solverPerformance::vsmall_ = 1e-300;
+
+bool solverPerformance::checkConvergence(scalar tol, scalar relTol)
+{
+    converged_ = (finalResidual_ < tol) || (relTol > small_ && finalResidual_ < relTol * initialResidual_);
+    return converged_;
+}
+bool solverPerformance::checkSingularity(scalar residual) { singular_ = residual < vsmall_; return singular_; }
+void solverPerformance::print(std::ostream& os) const
+{
+    os << solverName_ << ":  Solving for " << fieldName_;
+    if (singular_) os << ":  solution singularity" << std::endl;
+    else os << ", Initial residual = " << initialResidual_ << ", Final residual = " << finalResidual_
+            << ", No Iterations " << noIterations_ << std::endl;
+}
+
+// ---- lduAddressing --------------------------------------------------------------------------------------
+lduAddressing::lduAddressing(label nCells, const labelList& lower, const labelList& upper, const std::vector<labelList>& patchAddr)
+: size_(nCells), lower_(lower), upper_(upper), patchAddr_(patchAddr), addr_(nullptr), gamg_(nullptr), gamgCoarsest_(-1)
+{
+    if (lower_.size() != upper_.size()) FatalErrorIn("lduAddressing::lduAddressing", "lowerAddr and upperAddr differ in size");
+}
+lduAddressing::~lduAddressing() { if (gamg_) mi_gamg_destroy(gamg_); if (addr_) mi_addr_destroy(addr_); }
+mi_addr_t lduAddressing::handle() const
+{
+    if (!addr_) {
+        std::vector<label> sizes; std::vector<const label*> ptrs;
+        for (const labelList& p : patchAddr_) { sizes.push_back((label)p.size()); ptrs.push_back(p.data()); }
+        miCheck(mi_addr_create(miEngine::New().ctx, size_, (label)lower_.size(), lower_.data(), upper_.data(), (label)sizes.size(),
+                               sizes.data(), ptrs.data(), &addr_), "lduAddressing::handle()");
+    }
+    return addr_;
+}
+mi_gamg_t lduAddressing::agglomeration(const scalarField& w, label nCoarsest) const
+{
+    if (gamg_ && gamgCoarsest_ != nCoarsest) { mi_gamg_destroy(gamg_); gamg_ = nullptr; }
+    if (!gamg_) {
+        if ((label)w.size() != (label)lower_.size()) FatalErrorIn("lduAddressing::agglomeration", "face weights do not match the number of faces");
+        miCheck(mi_gamg_create(handle(), w.data(), nCoarsest, 1, &gamg_), "GAMGAgglomeration::New");
+        gamgCoarsest_ = nCoarsest;
+    }
+    return gamg_;
+}
+
+// ---- lduMatrix ----------------------------------------------------------------------------------------------
+lduMatrix::lduMatrix(const lduAddressing& a)
+: lduAddr_(a), diag_(a.size()), upper_((label)a.lowerAddrHost().size()), mat_(nullptr), dirty_(true) {}
+lduMatrix::~lduMatrix() { if (mat_) mi_matrix_destroy(mat_); }
+scalargpuField& lduMatrix::lower()
+{
+    if (!lowerPtr_) lowerPtr_.reset(new scalargpuField(upper_));
+    dirty_ = true;
+    return *lowerPtr_;
+}
+void lduMatrix::sync(const FieldFieldScalar* bou, const FieldFieldScalar* inte, const lduInterfaceFieldPtrsList* ifs) const
+{
+    if (!mat_) miCheck(mi_matrix_create(lduAddr_.handle(), &mat_), "lduMatrix::sync");
+    if (dirty_) { // the reference's lowerSortPtr_ invalidation (lduMatrix.C:235,266)
+        miCheck(mi_matrix_set_coeffs(mat_, diag_.data(), upper_.data(), lowerPtr_ ? lowerPtr_->data() : nullptr), "lduMatrix::sync");
+        dirty_ = false;
+    }
+    const label nP = lduAddr_.nPatches();
+    if (nP == 0) return;
+    if (!bou || (label)bou->size() != nP || !ifs || (label)ifs->size() != nP)
+        FatalErrorIn("lduMatrix::sync", "interface coefficient lists do not match the coupled patches of the addressing");
+    scalargpuField ext(mi_addr_n_ext(lduAddr_.handle()));
+    label off = 0;
+    for (label p = 0; p < nP; ++p) {
+        const label n = (label)lduAddr_.patchAddr(p).size();
+        miCheck(mi_matrix_set_interface_coeffs(mat_, p, (*bou)[p].data(), inte && (label)inte->size() == nP ? (*inte)[p].data() : nullptr), "lduMatrix::sync");
+        if (n) miCopyD2D(ext.data() + off, (*ifs)[p]->patchNeighbourField.data(), sizeof(scalar) * n);
+        off += n;
+    }
+    miCheck(mi_matrix_set_ext(mat_, ext.data()), "lduMatrix::sync");
+    mi_ctx_synchronize(miEngine::New().ctx);
+}
+void lduMatrix::Amul(scalargpuField& Apsi, const scalargpuField& psi, const FieldFieldScalar& b, const lduInterfaceFieldPtrsList& ifs, direction) const
+{
+    sync(&b, nullptr, &ifs); miCheck(mi_amul(mat_, psi.data(), Apsi.data()), "lduMatrix::Amul");
+}
+void lduMatrix::Tmul(scalargpuField& Tpsi, const scalargpuField& psi, const FieldFieldScalar& i, const lduInterfaceFieldPtrsList& ifs, direction) const
+{
+    // Tmul uses interfaceIntCoeffs (lduMatrixATmul.C:264-342): pass them in both slots so the engine's lower side holds them
+    sync(&i, &i, &ifs); miCheck(mi_tmul(mat_, psi.data(), Tpsi.data()), "lduMatrix::Tmul");
+    dirty_ = true;
+}
+void lduMatrix::sumA(scalargpuField& s, const FieldFieldScalar& b, const lduInterfaceFieldPtrsList& ifs) const
+{
+    sync(&b, nullptr, &ifs); miCheck(mi_sumA(mat_, s.data()), "lduMatrix::sumA");
+}
+void lduMatrix::residual(scalargpuField& rA, const scalargpuField& psi, const scalargpuField& source, const FieldFieldScalar& b,
+                         const lduInterfaceFieldPtrsList& ifs, direction) const
+{
+    sync(&b, nullptr, &ifs); miCheck(mi_residual(mat_, psi.data(), source.data(), rA.data()), "lduMatrix::residual");
+}
+void lduMatrix::negSumDiag() { miCheck(mi_row_face_op(lduAddr_.handle(), 1, lowerPtr_ ? lowerPtr_->data() : nullptr, upper_.data(), diag_.data()), "lduMatrix::negSumDiag"); dirty_ = true; }
+void lduMatrix::sumDiag() { miCheck(mi_row_face_op(lduAddr_.handle(), 0, lowerPtr_ ? lowerPtr_->data() : nullptr, upper_.data(), diag_.data()), "lduMatrix::sumDiag"); dirty_ = true; }
+void lduMatrix::sumMagOffDiag(scalargpuField& s) const { miCheck(mi_row_face_op(lduAddr_.handle(), 2, lowerPtr_ ? lowerPtr_->data() : nullptr, upper_.data(), s.data()), "lduMatrix::sumMagOffDiag"); }
+
+// ---- preconditioner names (lduMatrixPreconditioner.C:36-65) ---------------------------------------------------
+word lduMatrix::preconditioner::getName(const dictionary& d)
+{
+    word name = d.lookup("preconditioner");
+    // DIC / DILU (and friends) are replaced by the approximate inverse in the reference
+    // (DICPreconditioner.C:42-58, DILUPreconditioner.C:42-58): the reported name becomes AINV
+    if (name == "DIC" || name == "DILU" || name == "FDIC" || name == "GAMG") name = "AINV";
+    return name;
+}
+int lduMatrix::preconditioner::kind(const word& n)
+{
+    if (n == "none") return MI_PRECOND_NONE;
+    if (n == "diagonal") return MI_PRECOND_DIAGONAL;
+    if (n == "AINV") return MI_PRECOND_AINV;
+    FatalErrorIn("lduMatrix::preconditioner::New", "Unknown preconditioner " + n + "\n\nValid preconditioners are :\n(AINV DIC DILU diagonal none)");
+}
+
+// ---- solver base + factory --------------------------------------------------------------------------------------
+std::map<word, lduMatrix::solver::ctor>& lduMatrix::solver::symMatrixConstructorTable() { static std::map<word, ctor> t; return t; }
+std::map<word, lduMatrix::solver::ctor>& lduMatrix::solver::asymMatrixConstructorTable() { static std::map<word, ctor> t; return t; }
+
+lduMatrix::solver::solver(const word& fieldName, const lduMatrix& matrix, const FieldFieldScalar& b, const FieldFieldScalar& i,
+                          const lduInterfaceFieldPtrsList& ifs, const dictionary& d)
+: fieldName_(fieldName), matrix_(matrix), interfaceBouCoeffs_(b), interfaceIntCoeffs_(i), interfaces_(ifs), controlDict_(d)
+{
+    readControls();
+}
+void lduMatrix::solver::readControls()
+{
+    maxIter_ = controlDict_.lookupOrDefault<label>("maxIter", 1000);
+    minIter_ = controlDict_.lookupOrDefault<label>("minIter", 0);
+    tolerance_ = controlDict_.lookupOrDefault<scalar>("tolerance", 1e-6);
+    relTol_ = controlDict_.lookupOrDefault<scalar>("relTol", 0);
+}
+
+namespace
+{
+word tableNames(const std::map<word, lduMatrix::solver::ctor>& t)
+{
+    word s = "(";
+    for (auto& kv : t) s += kv.first + " ";
+    if (s.size() > 1) s.pop_back();
+    return s + ")";
+}
+mi_solver_controls controlsOf(scalar tol, scalar relTol, label maxIter, label minIter) { mi_solver_controls c = {tol, relTol, maxIter, minIter}; return c; }
+solverPerformance perfOf(const word& solverName, const word& fieldName, const mi_solver_perf& r)
+{
+    return solverPerformance(solverName, fieldName, r.initialResidual, r.finalResidual, r.nIterations, r.converged != 0, r.singular != 0);
+}
+void requireUncoupled(const lduInterfaceFieldPtrsList& ifs, const char* who)
+{
+    if (!ifs.empty()) FatalErrorIn(who, "coupled interfaces inside a whole-solver call need the distributed driver (mi_dpcg_phase / parallel.py)");
+}
+} // namespace
+
+// diagonalSolver (solvers/diagonalSolver/diagonalSolver.C): psi = source/diag
+class diagonalSolver : public lduMatrix::solver
+{
+public:
+    using lduMatrix::solver::solver;
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    {
+        std::vector<scalar> d = matrix_.diag().asHost(), s = source.asHost();
+        for (std::size_t i = 0; i < d.size(); ++i) s[i] /= d[i];
+        psi = s;
+        return solverPerformance("diagonalSolver", fieldName_, 0, 0, 0, true, false);
+    }
+};
+
+autoPtr<lduMatrix::solver> lduMatrix::solver::New(const word& fieldName, const lduMatrix& matrix, const FieldFieldScalar& b,
+                                                  const FieldFieldScalar& i, const lduInterfaceFieldPtrsList& ifs, const dictionary& d)
+{
+    const word name = d.lookup("solver");
+    if (matrix.diagonal()) return autoPtr<solver>(new diagonalSolver(fieldName, matrix, b, i, ifs, d));
+    const bool sym = matrix.symmetric();
+    auto& table = sym ? symMatrixConstructorTable() : asymMatrixConstructorTable();
+    auto it = table.find(name);
+    if (it == table.end())
+        FatalErrorIn("lduMatrix::solver::New", "Unknown " + word(sym ? "symmetric" : "asymmetric") + " matrix solver " + name +
+                     "\n\nValid " + word(sym ? "symmetric" : "asymmetric") + " matrix solvers are :\n" + tableNames(table));
+    return it->second(fieldName, matrix, b, i, ifs, d);
+}
+
+// ---- concrete solvers, registered under the reference's run-time names ---------------------------------------------
+class PCG : public lduMatrix::solver
+{
+public:
+    using lduMatrix::solver::solver;
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    {
+        requireUncoupled(interfaces_, "PCG::solve");
+        const word pre = lduMatrix::preconditioner::getName(controlDict_);
+        const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
+        mi_solver_perf r;
+        miCheck(mi_pcg_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
+                             lduMatrix::preconditioner::kind(pre), &r, nullptr, 0), "PCG::solve");
+        return perfOf(pre + "PCG", fieldName_, r); // PCG.C:75-80
+    }
+};
+class PBiCG : public lduMatrix::solver
+{
+public:
+    using lduMatrix::solver::solver;
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    {
+        requireUncoupled(interfaces_, "PBiCG::solve");
+        const word pre = lduMatrix::preconditioner::getName(controlDict_);
+        const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
+        mi_solver_perf r;
+        miCheck(mi_pbicg_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
+                               lduMatrix::preconditioner::kind(pre), &r, nullptr, 0), "PBiCG::solve");
+        return perfOf(pre + "PBiCG", fieldName_, r);
+    }
+};
+class PBiCGStab : public lduMatrix::solver
+{
+public:
+    using lduMatrix::solver::solver;
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    {
+        requireUncoupled(interfaces_, "PBiCGStab::solve");
+        const word pre = lduMatrix::preconditioner::getName(controlDict_);
+        const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
+        mi_solver_perf r;
+        // keep the reference's `psi += omega*yA` (PBiCGStab.C:263-270) unless the case asks for the textbook update
+        const int quirk = controlDict_.lookupOrDefault<label>("textbookOmegaUpdate", 0) ? 0 : 1;
+        miCheck(mi_pbicgstab_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
+                                   lduMatrix::preconditioner::kind(pre), quirk, &r, nullptr, 0), "PBiCGStab::solve");
+        return perfOf(pre + "PBiCGStab", fieldName_, r);
+    }
+};
+class smoothSolver : public lduMatrix::solver
+{
+public:
+    using lduMatrix::solver::solver;
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    {
+        requireUncoupled(interfaces_, "smoothSolver::solve");
+        const word sm = controlDict_.lookup("smoother");
+        if (sm != "GaussSeidel" && sm != "Jacobi") // GaussSeidelSmoother.C:43-66: GaussSeidel IS Jacobi in the reference
+            FatalErrorIn("lduMatrix::smoother::New", "Unknown smoother " + sm + "\n\nValid smoothers are :\n(GaussSeidel Jacobi)");
+        const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
+        mi_solver_perf r;
+        miCheck(mi_smooth_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
+                                controlDict_.lookupOrDefault<scalar>("omega", 0.9), controlDict_.lookupOrDefault<label>("nSweeps", 1),
+                                &r, nullptr, 0), "smoothSolver::solve");
+        return perfOf("smoothSolver", fieldName_, r);
+    }
+};
+class GAMGSolver : public lduMatrix::solver
+{
+public:
+    using lduMatrix::solver::solver;
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    {
+        requireUncoupled(interfaces_, "GAMGSolver::solve");
+        const word agg = controlDict_.lookupOrDefault<word>("agglomerator", "faceAreaPair");
+        const label nCoarsest = controlDict_.lookupOrDefault<label>("nCellsInCoarsestLevel", -1);
+        if (nCoarsest < 0) FatalErrorIn("GAMGAgglomeration::GAMGAgglomeration", "keyword nCellsInCoarsestLevel is undefined in dictionary"); // GAMGAgglomeration.C:96-99
+        if (!controlDict_.found("mergeLevels")) FatalErrorIn("pairGAMGAgglomeration::pairGAMGAgglomeration", "keyword mergeLevels is undefined in dictionary");
+        if (controlDict_.lookupOrDefault<label>("mergeLevels", 1) != 1) FatalErrorIn("GAMGSolver", "mergeLevels != 1 is not supported yet");
+        const word sm = controlDict_.lookupOrDefault<word>("smoother", "GaussSeidel");
+        if (sm != "GaussSeidel" && sm != "Jacobi") FatalErrorIn("lduMatrix::smoother::New", "Unknown smoother " + sm);
+        scalarField w;
+        if (agg == "algebraicPair") { w = matrix_.upper().asHost(); for (scalar& v : w) v = std::fabs(v); } // algebraicPairGAMGAgglomeration.C:47-61
+        else if (agg == "faceAreaPair") {
+            const word key = "faceAreaPairWeights";  // supplied by the mesh layer (faceAreaPairGAMGAgglomeration.C:54-81)
+            if (!faceWeights_) FatalErrorIn("faceAreaPairGAMGAgglomeration", "no face-area weights registered for this mesh (" + key + ")");
+            w = *faceWeights_;
+        } else FatalErrorIn("GAMGAgglomeration::New", "Unknown GAMGAgglomeration type " + agg);
+        mi_gamg_t g = matrix_.lduAddr().agglomeration(w, nCoarsest);
+        mi_gamg_controls c;
+        c.tolerance = tolerance_; c.relTol = relTol_; c.maxIter = maxIter_; c.minIter = minIter_;
+        c.nPreSweeps = controlDict_.lookupOrDefault<label>("nPreSweeps", 0);
+        c.preSweepsLevelMultiplier = controlDict_.lookupOrDefault<label>("preSweepsLevelMultiplier", 1);
+        c.maxPreSweeps = controlDict_.lookupOrDefault<label>("maxPreSweeps", 4);
+        c.nPostSweeps = controlDict_.lookupOrDefault<label>("nPostSweeps", 2);
+        c.postSweepsLevelMultiplier = controlDict_.lookupOrDefault<label>("postSweepsLevelMultiplier", 1);
+        c.maxPostSweeps = controlDict_.lookupOrDefault<label>("maxPostSweeps", 4);
+        c.nFinestSweeps = controlDict_.lookupOrDefault<label>("nFinestSweeps", 2);
+        c.scaleCorrection = controlDict_.found("scaleCorrection") ? controlDict_.lookupOrDefault<label>("scaleCorrection", 1) : -1;
+        c.omega = controlDict_.lookupOrDefault<scalar>("omega", 0.9);
+        mi_solver_perf r;
+        miCheck(mi_gamg_solve(g, matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c, &r, nullptr, 0), "GAMGSolver::solve");
+        return perfOf("GAMG", fieldName_, r);
+    }
+    static const scalarField* faceWeights_;
+};
+const scalarField* GAMGSolver::faceWeights_ = nullptr;
+void setFaceAreaPairWeights(const scalarField* w) { GAMGSolver::faceWeights_ = w; }
+
+// static registration objects, as in PCG.C:36-37 etc.
+static lduMatrix::solver::addsymMatrixConstructorToTable<PCG> addPCGSymMatrixConstructorToTable_("PCG");
+static lduMatrix::solver::addasymMatrixConstructorToTable<PBiCG> addPBiCGAsymMatrixConstructorToTable_("PBiCG");
+static lduMatrix::solver::addasymMatrixConstructorToTable<PBiCGStab> addPBiCGStabAsymMatrixConstructorToTable_("PBiCGStab");
+static lduMatrix::solver::addsymMatrixConstructorToTable<PBiCGStab> addPBiCGStabSymMatrixConstructorToTable_("PBiCGStab");
+static lduMatrix::solver::addsymMatrixConstructorToTable<smoothSolver> addsmoothSolverSymMatrixConstructorToTable_("smoothSolver");
+static lduMatrix::solver::addasymMatrixConstructorToTable<smoothSolver> addsmoothSolverAsymMatrixConstructorToTable_("smoothSolver");
+static lduMatrix::solver::addsymMatrixConstructorToTable<GAMGSolver> addGAMGSolverMatrixConstructorToTable_("GAMG");
+static lduMatrix::solver::addasymMatrixConstructorToTable<GAMGSolver> addGAMGAsymSolverMatrixConstructorToTable_("GAMG");
+
+// ---- fvScalarMatrix -----------------------------------------------------------------------------------------------------
+fvScalarMatrix::fvScalarMatrix(const word& psiName, const lduAddressing& a, const std::vector<labelList>& pfc, const std::vector<bool>& coupled)
+: lduMatrix(a), psiName_(psiName), source_(a.size()), patchFaceCells_(pfc), patchCoupled_(coupled)
+{
+    for (const labelList& p : pfc) { internalCoeffs_.emplace_back((label)p.size()); boundaryCoeffs_.emplace_back((label)p.size()); }
+    patches_.assign(pfc.size(), nullptr);
+}
+fvScalarMatrix::~fvScalarMatrix() { for (mi_patch_t p : patches_) if (p) mi_patch_destroy(p); }
+static mi_patch_t patchOf(std::vector<mi_patch_t>& cache, std::size_t k, label nCells, const labelList& fc)
+{
+    if (!cache[k]) miCheck(mi_patch_create(miEngine::New().ctx, nCells, (label)fc.size(), fc.data(), &cache[k]), "fvPatch::faceCells");
+    return cache[k];
+}
+void fvScalarMatrix::addBoundaryDiag(scalargpuField& diag) const
+{
+    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p)
+        miCheck(mi_patch_add(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]), internalCoeffs_[p].data(), diag.data(), 0), "fvMatrix::addBoundaryDiag");
+}
+void fvScalarMatrix::addBoundarySource(scalargpuField& source) const
+{
+    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p)
+        if (!patchCoupled_[p])
+            miCheck(mi_patch_add(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]), boundaryCoeffs_[p].data(), source.data(), 0), "fvMatrix::addBoundarySource");
+}
+void fvScalarMatrix::relax(scalar alpha, const scalargpuField& psi)
+{
+    std::vector<mi_patch_t> ph; std::vector<const double*> ic, bc; std::vector<int32_t> cp;
+    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p) {
+        ph.push_back(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]));
+        ic.push_back(internalCoeffs_[p].data()); bc.push_back(boundaryCoeffs_[p].data()); cp.push_back(patchCoupled_[p] ? 1 : 0);
+    }
+    miCheck(mi_relax(lduAddr().handle(), alpha, diag().data(), asymmetric() ? lower().data() : nullptr, upper().data(), source_.data(), psi.data(),
+                     (label)ph.size(), ph.data(), ic.data(), bc.data(), cp.data()), "fvMatrix::relax");
+}
+solverPerformance fvScalarMatrix::solve(scalargpuField& psi, const dictionary& solverControls)
+{
+    // fvScalarMatrix.C:142-192: saveDiag; addBoundaryDiag; totalSource = source + boundary; solver::New()->solve; restore
+    scalargpuField saveDiag(diag());
+    addBoundaryDiag(diag());
+    scalargpuField totalSource(source_);
+    addBoundarySource(totalSource);
+    FieldFieldScalar noCoeffs; lduInterfaceFieldPtrsList noInterfaces;
+    solverPerformance perf = lduMatrix::solver::New(psiName_, *this, noCoeffs, noCoeffs, noInterfaces, solverControls)->solve(psi, totalSource);
+    perf.print(Info);
+    diag() = saveDiag;
+    return perf;
+}
+
+void fvm::laplacian(fvScalarMatrix& M, const scalargpuField& deltaCoeffs, const scalargpuField& gammaMagSf)
+{
+    miCheck(mi_fvm_laplacian(M.lduAddr().handle(), deltaCoeffs.data(), gammaMagSf.data(), M.upper().data(), M.diag().data()), "fvm::laplacian");
+}
+void fvm::div(fvScalarMatrix& M, const scalargpuField& weights, const scalargpuField& faceFlux)
+{
+    scalargpuField& lower = M.lower();
+    miCheck(mi_fvm_div(M.lduAddr().handle(), weights.data(), faceFlux.data(), lower.data(), M.upper().data(), M.diag().data()), "fvm::div");
+}
+
+} // namespace Foam

@@ -1,0 +1,113 @@
+// pEqnFoam.C -- a miniature of the solver applications' pressure / momentum steps, written against
+// the OpenFOAM-style interface of miFoam.H exactly the way icoFoam.C:75-92 is written against
+// OpenFOAM: assemble with fvm::laplacian / fvm::div, solve through lduMatrix::solver::New with an
+// fvSolution-style dictionary, print the solverPerformance line.  tests/test_foam_mirror.py runs it
+// on the GPU box and checks every printed number against the oracle.
+//
+// usage: pEqnFoam nx ny nz
+#include "miFoam.H"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iomanip>
+
+using namespace Foam;
+
+static double splitmixUniform(uint64_t seed, uint64_t i)
+{   // rapidcfd-dev_amd/synthetic.py::splitmix_uniform
+    uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+int main(int argc, char** argv)
+{
+    try {
+        const int nx = argc > 1 ? atoi(argv[1]) : 16, ny = argc > 2 ? atoi(argv[2]) : 16, nz = argc > 3 ? atoi(argv[3]) : 16;
+        const label n = nx * ny * nz;
+        const scalar h = 1.0 / nx;
+        // blockMesh-like box: owner-sorted internal faces, six boundary patches
+        labelList lower, upper; std::vector<int> dir;
+        for (label c = 0; c < n; ++c) {
+            const int i = c % nx, j = (c / nx) % ny, k = c / (nx * ny);
+            if (i < nx - 1) { lower.push_back(c); upper.push_back(c + 1); dir.push_back(0); }
+            if (j < ny - 1) { lower.push_back(c); upper.push_back(c + nx); dir.push_back(1); }
+            if (k < nz - 1) { lower.push_back(c); upper.push_back(c + nx * ny); dir.push_back(2); }
+        }
+        const label nf = (label)lower.size();
+        std::vector<labelList> patches(6);
+        for (label c = 0; c < n; ++c) {
+            const int i = c % nx, j = (c / nx) % ny, k = c / (nx * ny);
+            if (i == 0) patches[0].push_back(c);
+            if (i == nx - 1) patches[1].push_back(c);
+            if (j == 0) patches[2].push_back(c);
+            if (j == ny - 1) patches[3].push_back(c);
+            if (k == 0) patches[4].push_back(c);
+            if (k == nz - 1) patches[5].push_back(c);
+        }
+        lduAddressing addr(n, lower, upper);
+        scalarField faceAreaWeights(nf);
+        const double wdir[3] = {1.0, 1.01, 1.02};
+        for (label f = 0; f < nf; ++f) faceAreaWeights[f] = h * wdir[dir[f]];
+        setFaceAreaPairWeights(&faceAreaWeights);
+
+        Info << std::setprecision(17);
+        Info << "Create mesh: " << n << " cells, " << nf << " internal faces" << std::endl;
+
+        // ---- pEqn: fvm::laplacian(1, p) == source, p fixedValue on patch 0 (x-min) ----
+        scalarField delta(nf, 1.0 / h), gam(nf), src(n);
+        for (label f = 0; f < nf; ++f) gam[f] = h * h * (1.0 + 0.1 * splitmixUniform(12345, f));
+        for (label c = 0; c < n; ++c) src[c] = (2.0 * splitmixUniform(777, c) - 1.0) * h * h * h;
+        fvScalarMatrix pEqn("p", addr, patches, std::vector<bool>(6, false));
+        fvm::laplacian(pEqn, scalargpuField(delta), scalargpuField(gam));
+        pEqn.source() = src;
+        pEqn.internalCoeffs()[0] = scalarField(patches[0].size(), -2.0 * h); // fixedValue: -gamma*|Sf|*2/h
+        const char* pre[] = {"diagonal", "DIC", "none"};
+        for (const char* p : pre) {
+            scalargpuField psi(n);
+            pEqn.solve(psi, dictionary{{"solver", "PCG"}, {"preconditioner", p}, {"tolerance", "1e-08"}, {"relTol", "0"}});
+        }
+        {
+            scalargpuField psi(n);
+            pEqn.solve(psi, dictionary{{"solver", "GAMG"}, {"smoother", "GaussSeidel"}, {"agglomerator", "faceAreaPair"},
+                                       {"nCellsInCoarsestLevel", "10"}, {"mergeLevels", "1"}, {"tolerance", "1e-08"}, {"relTol", "0"},
+                                       {"cacheAgglomeration", "true"}});
+        }
+        {
+            scalargpuField psi(n);
+            pEqn.solve(psi, dictionary{{"solver", "smoothSolver"}, {"smoother", "GaussSeidel"}, {"nSweeps", "2"}, {"tolerance", "1e-03"}, {"maxIter", "400"}});
+        }
+        // ---- UEqn-like: ddt + fvm::div(phi) - fvm::laplacian(nu): asymmetric, PBiCG / PBiCGStab ----
+        {
+            scalarField wts(nf), phi(nf);
+            for (label f = 0; f < nf; ++f) { phi[f] = dir[f] == 0 ? 0.3 * h * h : 0.0; wts[f] = 1.0; } // upwind, flow in +x
+            fvScalarMatrix conv("Ux", addr, patches, std::vector<bool>(6, false));
+            fvm::div(conv, scalargpuField(wts), scalargpuField(phi));
+            // UEqn = ddt + conv - lap, assembled on the host side of the mirror (lduMatrix::operator+=/-= are whole-array axpys)
+            std::vector<scalar> cl = conv.lower().asHost(), cu = conv.upper().asHost(), cd = conv.diag().asHost();
+            std::vector<scalar> lu = pEqn.upper().asHost(), ld = pEqn.diag().asHost();
+            for (label f = 0; f < nf; ++f) { cl[f] -= lu[f]; cu[f] -= lu[f]; }
+            for (label c = 0; c < n; ++c) cd[c] = cd[c] - ld[c] + h * h * h / 1e-3;
+            fvScalarMatrix UEqn("Ux", addr, patches, std::vector<bool>(6, false));
+            UEqn.lower() = cl; UEqn.upper() = cu; UEqn.diag() = cd; UEqn.source() = src;
+            UEqn.internalCoeffs()[0] = scalarField(patches[0].size(), 2.0 * h);
+            for (const char* s : {"PBiCG", "PBiCGStab"}) {
+                scalargpuField psi(n);
+                UEqn.solve(psi, dictionary{{"solver", s}, {"preconditioner", "DILU"}, {"tolerance", "1e-10"}, {"relTol", "0"}});
+            }
+            scalargpuField psi(n);
+            UEqn.relax(0.7, psi);
+            UEqn.solve(psi, dictionary{{"solver", "PBiCG"}, {"preconditioner", "diagonal"}, {"tolerance", "1e-10"}, {"relTol", "0"}});
+        }
+        // ---- error behaviour: unknown run-time name lists the valid ones (lduMatrixSolver.C:84-100) ----
+        try {
+            scalargpuField psi(n);
+            pEqn.solve(psi, dictionary{{"solver", "PCGG"}, {"preconditioner", "DIC"}});
+        } catch (const Foam::error& e) { Info << e.what() << std::endl; }
+        Info << "End" << std::endl;
+        return 0;
+    } catch (const Foam::error& e) { std::cerr << e.what() << std::endl; return 1; }
+}

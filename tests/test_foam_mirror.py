@@ -1,0 +1,76 @@
+"""The compiled C++ host mirror of the OpenFOAM interface (rapidcfd-dev_amd/foam): CPU checks that it
+builds, links the C ABI and carries the reference's run-time names; the gpu test runs the miniature
+solver application and checks every printed solverPerformance line against the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "rapidcfd-dev_amd")
+
+
+def test_mirror_builds_and_registers_reference_names(pkg):
+    assert os.path.exists(os.path.join(PKG, "libmiFoam.so")) and os.path.exists(os.path.join(PKG, "pEqnFoam"))
+    src = open(os.path.join(PKG, "foam", "miFoam.C")).read()
+    for name in ("PCG", "PBiCG", "PBiCGStab", "smoothSolver", "GAMG"):
+        assert re.search(r'MatrixConstructorToTable_\("%s"\)' % name, src), name
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(PKG, "libmiFoam.so")], capture_output=True, text=True).stdout
+    assert "lduMatrix" in syms and "solver" in syms
+    # the mirror computes nothing itself: it has no kernels, only calls into the C ABI
+    assert "__global__" not in src and "mi_pcg_solve" in src
+
+
+LINE = re.compile(r"^(\w+):  Solving for (\w+), Initial residual = (\S+), Final residual = (\S+), No Iterations (\d+)")
+
+
+@pytest.mark.gpu
+def test_pEqnFoam_matches_oracle(pkg, orc):
+    dims = (12, 10, 8)
+    out = subprocess.run([os.path.join(PKG, "pEqnFoam"), *map(str, dims)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    lines = [LINE.match(l) for l in out.stdout.splitlines()]
+    got = [(m.group(1), m.group(2), float(m.group(3)), float(m.group(4)), int(m.group(5))) for m in lines if m]
+    syn = pkg.synthetic
+    case = syn.box_case(*dims)           # addressing + source as in the application
+    n, nf, h = case.n_cells, case.n_faces, 1.0 / dims[0]
+    gam = h * h * (1.0 + 0.1 * syn.splitmix_uniform(12345, nf))
+    upper, diag = orc.fvm_laplacian(n, case.lower_addr, case.upper_addr, np.full(nf, 1.0 / h), gam)
+    xmin = np.nonzero(np.arange(n) % dims[0] == 0)[0]
+    pdiag = orc.patch_add(xmin, np.full(xmin.shape[0], -2.0 * h), diag, 0)
+    src = case.source
+    P = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, pdiag, upper, None, src)])
+    z = np.zeros(n)
+    exp = []
+    for pre, name in (("diagonal", "diagonalPCG"), ("AINV", "AINVPCG"), ("none", "nonePCG")):
+        _, p = P.pcg(z, src, pre, tolerance=1e-8); exp.append((name, "p", p))
+    H = orc.GamgHierarchy(syn.LduCase(n, case.lower_addr, case.upper_addr, pdiag, upper, None, src, dims=dims),
+                          orc.box_face_weights(case), 10)
+    _, p = H.solve(z, src, tolerance=1e-8); exp.append(("GAMG", "p", p))
+    _, p = P.smooth_solve(z, src, n_sweeps=2, tolerance=1e-3, maxIter=400); exp.append(("smoothSolver", "p", p))
+    # UEqn = ddt + div(phi) - laplacian
+    direction = np.where(case.upper_addr - case.lower_addr == 1, 0, 1)
+    phi = np.where(direction == 0, 0.3 * h * h, 0.0)
+    cl, cu, cd = orc.fvm_div(n, case.lower_addr, case.upper_addr, np.ones(nf), phi)
+    ul, uu = cl - upper, cu - upper
+    ud = cd - diag + h ** 3 / 1e-3
+    ud_solve = orc.patch_add(xmin, np.full(xmin.shape[0], 2.0 * h), ud, 0)
+    U = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, ud_solve, uu, ul, src)])
+    _, p = U.pbicg(z, src, "AINV", tolerance=1e-10); exp.append(("AINVPBiCG", "Ux", p))
+    _, p = U.pbicgstab(z, src, "AINV", tolerance=1e-10, replicate_quirk=True); exp.append(("AINVPBiCGStab", "Ux", p))
+    rd, rs = orc.relax(n, case.lower_addr, case.upper_addr, 0.7, ud, ul, uu, src, z, [xmin], [np.full(xmin.shape[0], 2.0 * h)],
+                       [np.zeros(xmin.shape[0])], [0])
+    rd_solve = orc.patch_add(xmin, np.full(xmin.shape[0], 2.0 * h), rd, 0)
+    UR = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, rd_solve, uu, ul, rs)])
+    _, p = UR.pbicg(z, rs, "diagonal", tolerance=1e-10); exp.append(("diagonalPBiCG", "Ux", p))
+    assert len(got) == len(exp), out.stdout
+    for (gname, gfield, gi, gf, gn), (ename, efield, p) in zip(got, exp):
+        assert (gname, gfield) == (ename, efield)
+        assert gn == p["nIterations"], (gname, gn, p["nIterations"])
+        assert abs(gi - p["initialResidual"]) < 1e-12 and abs(gf - p["finalResidual"]) < 1e-10
+    # error behaviour of the run-time selection table (lduMatrixSolver.C:84-100)
+    assert "Unknown symmetric matrix solver PCGG" in out.stdout and "Valid symmetric matrix solvers are" in out.stdout
+    assert re.search(r"\(GAMG PBiCGStab PCG smoothSolver\)", out.stdout)
+    assert out.stdout.strip().endswith("End")
