@@ -72,6 +72,7 @@ struct mi_ctx_s {
     double* hostScal = nullptr;    // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int amulBS = 512;
+    int tileFlags = 0;
 };
 
 struct mi_addr_s {
@@ -154,6 +155,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c; return fail(MI_ERR_DEVICE, "pinned host / event allocation failed");
     }
+    c->tileFlags = env_int("MI_TILE_FLAGS", 0);
     c->amulBS = env_int("MI_AMUL_BS", 512);
     if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 512;
     *out = c;
@@ -364,7 +366,7 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     t.haloCell = a->haloCell.p; t.tileSliceStart = a->tileSliceStart.p; t.sliceEntryStart = a->sliceEntryStart.p;
     t.entries = a->entries.p;
     t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
-    t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega; t.dotPartial = dotPartial;
+    t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega; t.dotPartial = dotPartial; t.flags = a->ctx->tileFlags;
     const size_t lds = lds_bytes(a->L, m->asym, OP == OP_AINV, &t.offLow, &t.offX, &t.offRD);
     if (lds > 159 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 159 KiB of LDS");
     int nTiles = a->L.nTiles;

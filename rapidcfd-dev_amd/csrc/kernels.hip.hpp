@@ -101,9 +101,20 @@ struct TileArgs {
     double* dotPartial; // Amul only: per-workgroup partial of sum(y*x) (fused gSumProd), or nullptr
     double omega;
     int32_t offLow, offX, offRD; // LDS offsets in doubles
+    int32_t flags;               // bit0: non-temporal coefficient loads, bit1: non-temporal entry loads, bit2: nt result stores
 };
 
 // cooperative global -> LDS staging, 4 loads in flight per lane
+template <bool NT, class T>
+__device__ __forceinline__ T ldg(const T* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ double2 ldg2(const double2* p, bool nt)
+{
+    if (!nt) return *p;
+    const double* q = reinterpret_cast<const double*>(p);
+    typedef double dvec2 __attribute__((ext_vector_type(2)));
+    const dvec2 v = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(q));
+    return make_double2(v.x, v.y);
+}
 template <int BS, class T>
 __device__ __forceinline__ void stage_copy(const T* __restrict__ src, T* __restrict__ dst, int n, int tid)
 {
@@ -113,6 +124,17 @@ __device__ __forceinline__ void stage_copy(const T* __restrict__ src, T* __restr
         dst[k] = v0; dst[k + BS] = v1; dst[k + 2 * BS] = v2; dst[k + 3 * BS] = v3;
     }
     for (; k < n; k += BS) dst[k] = src[k];
+}
+// streamed-once data (coefficients): non-temporal loads so they do not displace psi/halo lines in L2
+template <int BS>
+__device__ __forceinline__ void stage_copy_nt(const double2* __restrict__ src, double2* __restrict__ dst, int n, int tid, bool nt)
+{
+    int k = tid;
+    for (; k + 3 * BS < n; k += 4 * BS) {
+        const double2 v0 = ldg2(src + k, nt), v1 = ldg2(src + k + BS, nt), v2 = ldg2(src + k + 2 * BS, nt), v3 = ldg2(src + k + 3 * BS, nt);
+        dst[k] = v0; dst[k + BS] = v1; dst[k + 2 * BS] = v2; dst[k + 3 * BS] = v3;
+    }
+    for (; k < n; k += BS) dst[k] = ldg2(src + k, nt);
 }
 template <int BS>
 __device__ __forceinline__ void stage_gather(const double* __restrict__ x, const int32_t* __restrict__ idx,
@@ -155,8 +177,9 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
     // ---- stage: coefficients (16-byte coalesced), psi, halo -------------------
     // All global loads of a phase are issued before the first LDS store (4-deep
     // unroll) so that every wave keeps several KiB in flight.
-    stage_copy<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid);
-    if (ASYM) stage_copy<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid);
+    const bool nt = (a.flags & 1) != 0;
+    stage_copy_nt<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid, nt);
+    if (ASYM) stage_copy_nt<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid, nt);
     if (NEEDX) {
         stage_copy<BS>(a.x + c0, xs, nc, tid);
         stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
         width = (e1 - e0) >> 6;
         const uint32_t* ent = a.entries + e0 + lane;
 #pragma unroll
-        for (int j = 0; j < PRE; ++j) e[j] = (j < width) ? ent[j * 64] : padEnt;
+        for (int j = 0; j < PRE; ++j) e[j] = (j < width) ? ((a.flags & 2) ? __builtin_nontemporal_load(ent + j * 64) : ent[j * 64]) : padEnt;
     };
     if (wave < nsl) fetch(wave, ecur, e0cur, wcur);
     else {
@@ -234,7 +257,8 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
                 const double rD = 1.0 / a.diag[gi];
                 const double extra = (1 - a.omega) * xi + a.omega * rD * a.b[gi];
                 a.y[gi] = extra - a.omega * rD * acc;
-            } else a.y[gi] = acc;
+            } else if (a.flags & 4) __builtin_nontemporal_store(acc, a.y + gi);
+            else a.y[gi] = acc;
             if (OP == OP_AMUL) dot = fma(acc, xi, dot);
         }
 #pragma unroll
