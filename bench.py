@@ -94,9 +94,12 @@ def main():
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
     # one explicit HIP stream shared by torch (copies, RCCL collectives) and the engine's kernels
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx = eng.Context(local_rank, stream.cuda_stream)
+    if os.environ.get("MI_BENCH_NULL_STREAM"):   # A/B hook: engine-owned stream next to torch's legacy default stream
+        ctx = eng.Context(local_rank, None)
+    else:
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        ctx = eng.Context(local_rank, stream.cuda_stream)
     K, W = args.steps, args.warmup
     amul_ms = None
     force_dist = bool(os.environ.get("MI_BENCH_FORCE_DIST"))  # exercise the N>1 code path on one GPU

@@ -116,6 +116,10 @@ class DistributedPCG:
         self.n_global = n_global
         self.it = 0
         self.history_len = 0
+        # views and p2p descriptors are built once: nothing is allocated inside the iteration loop
+        o = self.ops
+        self._s01, self._s2, self._s3, self._s4 = o.scal[0:2], o.scal[2:3], o.scal[3:4], o.scal[4:5]
+        self._p2p = {}
 
     # -- collectives ----------------------------------------------------------
     def _allreduce(self, t):
@@ -127,11 +131,14 @@ class DistributedPCG:
         if self.world == 1 or not self.nbrs:
             return lambda: None
         o = self.ops
-        p2p = []
-        for k, nbr in enumerate(self.nbrs):
-            a, b = int(self.offsets[k]), int(self.offsets[k + 1])
-            p2p.append(dist.P2POp(dist.isend, o.send[a:b], nbr))
-            p2p.append(dist.P2POp(dist.irecv, vec[self.n + a:self.n + b], nbr))
+        p2p = self._p2p.get(id(vec))
+        if p2p is None:
+            p2p = []
+            for k, nbr in enumerate(self.nbrs):
+                a, b = int(self.offsets[k]), int(self.offsets[k + 1])
+                p2p.append(dist.P2POp(dist.isend, o.send[a:b], nbr))
+                p2p.append(dist.P2POp(dist.irecv, vec[self.n + a:self.n + b], nbr))
+            self._p2p[id(vec)] = p2p
         if self.is_cuda:
             main = torch.cuda.current_stream()
             self.comm_stream.wait_stream(main)          # the pack kernel has to finish first
@@ -151,11 +158,11 @@ class DistributedPCG:
         o.phase(0)
         self._start_exchange(o.psi)()
         o.phase(1)
-        self._allreduce(o.scal[3:4])
+        self._allreduce(self._s3)
         avg = float(o.scal[3].item()) / self.n_global       # gAverage(psi): the one host read of the prologue
         o.phase(2, 0, avg)
-        self._allreduce(o.scal[0:2])
-        self._allreduce(o.scal[4:5])
+        self._allreduce(self._s01)
+        self._allreduce(self._s4)
         o.phase(3)
         self.it = 0
         self.max_iter, self.min_iter = max_iter, min_iter
@@ -174,9 +181,9 @@ class DistributedPCG:
             o.phase(12, it)      # boundary tiles
             if time_amul:
                 o.event_record(2 * k + 1)
-            self._allreduce(o.scal[2:3])
+            self._allreduce(self._s2)
             o.phase(13, it)
-            self._allreduce(o.scal[0:2])
+            self._allreduce(self._s01)
             self.it += 1
         if n_iters > 0:
             o.phase(14, self.it - 1)
