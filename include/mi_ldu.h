@@ -323,6 +323,8 @@ int mi_smooth_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
  * exit, same kernels as mi_pcg_solve) and `reps` Amuls back to back, timed with
  * HIP events on the context's stream; milliseconds returned.                      */
 int mi_bench_amul(mi_matrix_t m, int32_t reps, float *ms_out);
+/* diagnostic: resident Amul workgroups per CU as the HIP runtime computes it, LDS bytes per workgroup, block size */
+int mi_debug_occupancy(mi_matrix_t m, int32_t *blocks_per_cu, int32_t *lds_bytes_out, int32_t *block_size);
 int mi_bench_pcg_iters(mi_matrix_t m, const double *source_dev, int32_t iters, int precond,
                        float *ms_out, float *amul_ms_out);
 

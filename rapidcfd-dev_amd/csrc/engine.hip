@@ -1121,6 +1121,25 @@ extern "C" int mi_smooth_solve(mi_matrix_t m, double* psi_io, const double* sour
 // ---------------------------------------------------------------------------
 // benchmark hooks
 // ---------------------------------------------------------------------------
+// diagnostic: resident workgroups per CU of the Amul kernel as the runtime sees it (LDS / VGPR limits)
+extern "C" int mi_debug_occupancy(mi_matrix_t m, int32_t* blocks_per_cu, int32_t* lds_bytes_out, int32_t* block_size)
+{
+    if (!m || !blocks_per_cu) return fail(MI_ERR_ARG, "mi_debug_occupancy: bad argument");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    int32_t o1, o2, o3;
+    const size_t lds = lds_bytes(a->L, m->asym, false, &o1, &o2, &o3);
+    const int bs = a->ctx->amulBS;
+    int nb = 0;
+    if (bs == 1024) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, 1024>, 1024, lds));
+    else if (bs == 512) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, 512>, 512, lds));
+    else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, 256>, 256, lds));
+    *blocks_per_cu = nb;
+    if (lds_bytes_out) *lds_bytes_out = (int32_t)lds;
+    if (block_size) *block_size = bs;
+    return MI_OK;
+}
+
 extern "C" int mi_bench_amul(mi_matrix_t m, int32_t reps, float* ms_out)
 {
     if (!m || reps <= 0 || !ms_out) return fail(MI_ERR_ARG, "mi_bench_amul: bad argument");

@@ -49,7 +49,7 @@ SYMBOLS = [
     "mi_sum", "mi_sum_prod", "mi_sum_mag",
     "mi_pcg_solve", "mi_pcg_begin", "mi_pcg_iterate", "mi_pcg_end",
     "mi_pbicg_solve", "mi_pbicgstab_solve", "mi_smooth_solve",
-    "mi_bench_amul", "mi_bench_pcg_iters",
+    "mi_bench_amul", "mi_bench_pcg_iters", "mi_debug_occupancy",
     "mi_layout_build_host", "mi_layout_array", "mi_layout_free",
     "mi_dpcg_set_buffers", "mi_dpcg_phase", "mi_dpcg_status", "mi_event_record", "mi_event_elapsed_ms",
     "mi_gamg_create", "mi_gamg_destroy", "mi_gamg_n_levels", "mi_gamg_forward_out", "mi_gamg_level_sizes",
@@ -349,6 +349,11 @@ class Matrix:
         ms = C.c_float()
         _chk(lib().mi_event_elapsed_ms(self.h, C.c_int32(i0), C.c_int32(i1), C.byref(ms)))
         return ms.value
+
+    def occupancy(self):
+        b, l, s = C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(lib().mi_debug_occupancy(self.h, C.byref(b), C.byref(l), C.byref(s)))
+        return dict(blocks_per_cu=b.value, lds_bytes=l.value, block_size=s.value)
 
     def bench_amul(self, reps: int) -> float:
         ms = C.c_float()

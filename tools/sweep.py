@@ -35,6 +35,7 @@ for tile in tiles:
         mat = eng.Matrix(addr)
         mat.set_coeffs(diag, upper, None)
         st = addr.stats()
+        occ = mat.occupancy()
         mat.bench_amul(5)
         ms = min(mat.bench_amul(50) for _ in range(3)) / 50
         psi0 = torch.zeros(N, dtype=torch.float64, device=dev)
@@ -45,7 +46,7 @@ for tile in tiles:
         gbs = (24 * N + 16 * F) / (ms * 1e-3) / 1e9
         r = dict(tile=tile, bs=bs, amul_us=ms * 1e3, amul_GBs=gbs, frac=gbs / 8000, pcg_ms=pcg_ms, its=1e3 / pcg_ms,
                  pcg_GBs=(160 * N + 16 * F) / (pcg_ms * 1e-3) / 1e9, lds=st["lds_bytes_sym"], slots_per_row=st["slots"] / N,
-                 halo_per_row=st["halo"] / N, entries_per_row=st["entries"] / N)
+                 halo_per_row=st["halo"] / N, occ=occ["blocks_per_cu"], entries_per_row=st["entries"] / N)
         print(json.dumps(r), flush=True)
         res.append(r)
         mat.close(); addr.close(); ctx.close()
