@@ -73,6 +73,7 @@ struct mi_ctx_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int amulBS = 512;
     int tileFlags = 0;
+    int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
 };
 
 struct mi_addr_s {
@@ -156,6 +157,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
         delete c; return fail(MI_ERR_DEVICE, "pinned host / event allocation failed");
     }
     c->tileFlags = env_int("MI_TILE_FLAGS", 0);
+    c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 512);
     if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 512;
     *out = c;
@@ -701,15 +703,16 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool timeAmul)
     double* P1 = c->partial.p; double* P2 = c->partial.p + RG; double* P3 = c->partial.p + 2 * RG;
     if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
     if (m->tilePartial.n < (size_t)a->L.nTiles) MICHK(m->tilePartial.alloc((size_t)a->L.nTiles));
+    const bool fuse = c->fuseFinal && precond != MI_PRECOND_AINV;
     for (int it = it0; it < it0 + count; ++it) {
         if (precond == MI_PRECOND_AINV) {
             MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0));
             k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rA, n, P1); // not gated by done: harmless
-            k_pcg_update_p<0><<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, nullptr, nullptr, pA, n);
+            k_pcg_update_p<0><<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, nullptr, nullptr, pA, n); // AINV path keeps k_pcg_final (P1 is rewritten before it)
         } else if (precond == MI_PRECOND_DIAGONAL) {
-            k_pcg_update_p<1><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, m->rD.p, rA, pA, n);
+            k_pcg_update_p<1><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, m->rD.p, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen);
         } else {
-            k_pcg_update_p<2><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, nullptr, rA, pA, n);
+            k_pcg_update_p<2><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, nullptr, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen);
         }
         if (timeAmul) {
             while (m->evPool.size() < (size_t)(2 * (it - it0 + 1))) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); m->evPool.push_back(e); }
@@ -724,8 +727,11 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool timeAmul)
             k_pcg_update_psi_r<1><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, m->rD.p, psi, rA, n, P3, P1);
         else
             k_pcg_update_psi_r<2><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
-        k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
+        // diagonal / none: the convergence test of this iteration is fused into the next k_pcg_update_p
+        if (!fuse) k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
     }
+    // test of the last enqueued iteration (idempotent: the next batch's first kernel repeats it)
+    if (count > 0 && fuse) k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it0 + count - 1, P3, m->hist.p, m->histLen);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }

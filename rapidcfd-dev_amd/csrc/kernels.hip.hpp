@@ -458,13 +458,39 @@ __global__ __launch_bounds__(RB) void k_pcg_precond_dot(const PcgState* __restri
 // wArA = sum(partial1); beta = wArA/wArAold; pA = wA (+ beta*pA)      [PCG.C:144-160]
 // PMODE 0: wA is stored (any preconditioner); 1: wA = rD*rA recomputed on the fly (diagonal);
 // 2: wA = rA (none) -- the precondition pass and the wA round trip through HBM are fused away.
+// Fused into the head of this kernel (single-GPU path, partial3 != nullptr): the convergence test of
+// iteration it-1 (k_pcg_final) -- every block evaluates it redundantly from the same partials, block 0
+// records it; a separate launch per iteration is saved.
+__device__ __forceinline__ bool pcg_test_previous(PcgState* __restrict__ st, int itPrev, const double* __restrict__ partial3,
+                                                  double* __restrict__ hist, int histLen, double* red)
+{
+    const bool sing = partial3[0] < 0.0; // sum|r| partials are never negative
+    const double s = sum_partials(partial3, red);
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (sing) { if (lead) { st->singular = 1; st->done = 1; } return false; } // `break`: nIterations not incremented
+    const double res = s / st->normFactor;
+    const bool conv = sp_converged(st, res);
+    const bool cont = (itPrev < st->maxIter && !conv) || (itPrev + 1 < st->minIter);
+    if (lead) {
+        st->finalResidual = res;
+        if (itPrev + 1 < histLen) hist[itPrev + 1] = res;
+        st->nIterations = itPrev + 1;
+        st->converged = conv;
+        if (!cont) st->done = 1;
+    }
+    return cont;
+}
+
 template <int PMODE, bool DIST = false>
 __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
                                                      const double* __restrict__ wA, const double* __restrict__ rD,
-                                                     const double* __restrict__ rA, double* __restrict__ pA, int64_t n)
+                                                     const double* __restrict__ rA, double* __restrict__ pA, int64_t n,
+                                                     const double* __restrict__ partial3 = nullptr, double* __restrict__ hist = nullptr,
+                                                     int histLen = 0)
 {
     if (st->done) return;
     __shared__ double red[RB / 64];
+    if (!DIST && partial3 && it > 0 && !pcg_test_previous(st, it - 1, partial3, hist, histLen, red)) return;
     const double wArA = DIST ? partial1[0] : sum_partials(partial1, red); // DIST: global sum from the allreduce
     const double beta = (it == 0) ? 0.0 : wArA / st->wArA[(it & 1) ^ 1];
     const bool first = (it == 0);
