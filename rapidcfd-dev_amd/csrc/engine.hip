@@ -71,7 +71,7 @@ struct mi_ctx_s {
     PcgState* hostState = nullptr; // pinned
     double* hostScal = nullptr;    // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int amulBS = 512;
+    int amulBS = 0;
     int tileFlags = 0;
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
 };
@@ -158,8 +158,8 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     }
     c->tileFlags = env_int("MI_TILE_FLAGS", 0);
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
-    c->amulBS = env_int("MI_AMUL_BS", 512);
-    if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 512;
+    c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
+    if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 0;
     *out = c;
     return MI_OK;
 }
@@ -337,7 +337,11 @@ template <int OP, bool ASYM, bool TRANS>
 int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
 {
     hipStream_t s = m->addr->ctx->stream;
-    const int bs = m->addr->ctx->amulBS;
+    // residency: three 512-thread workgroups per CU while a tile needs <= 53 KiB of LDS; with more LDS
+    // (asymmetric matrices, AINV) only two fit, and 1024 threads keep the CU at 32 waves (measured:
+    // asymmetric Amul 254 -> 211 us on the 216^3 box)
+    int bs = m->addr->ctx->amulBS;
+    if (bs == 0) bs = (lds > 53 * 1024) ? 1024 : 512;
     if (nTiles <= 0) return MI_OK;
 #define MI_LAUNCH(BS)                                                                                                   \
     {                                                                                                                   \
@@ -1135,7 +1139,7 @@ extern "C" int mi_debug_occupancy(mi_matrix_t m, int32_t* blocks_per_cu, int32_t
     HIPCHK(hipSetDevice(a->ctx->device));
     int32_t o1, o2, o3;
     const size_t lds = lds_bytes(a->L, m->asym, false, &o1, &o2, &o3);
-    const int bs = a->ctx->amulBS;
+    const int bs = a->ctx->amulBS ? a->ctx->amulBS : ((lds > 53 * 1024) ? 1024 : 512);
     int nb = 0;
     if (bs == 1024) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, 1024>, 1024, lds));
     else if (bs == 512) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, 512>, 512, lds));
