@@ -63,6 +63,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    # Only the JSON line may reach stdout: libraries (RCCL prints a version banner through C stdio at exit)
+    # write to fd 1 behind Python's back, so fd 1 is pointed at stderr and the JSON goes to a private copy.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -75,8 +81,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("MI_BENCH_FORCE_DIST") == "2":  # "2": also run the RCCL calls on a 1-rank group
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     graft.build()
@@ -186,8 +193,8 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": 1, "kind": "port",
                                    "sample": f"{n_it} PCG iterations (diagonal) of the same {nx}x{ny}x{nz} matrix in {dt:.1f}s, "
                                              "oracle/ldu_oracle.c, gcc -O3, one core"}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

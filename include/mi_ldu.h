@@ -248,8 +248,9 @@ int mi_gamg_level_coeffs(mi_gamg_t g, mi_matrix_t m, int32_t level, double *diag
  *  src/finiteVolume/fvMatrices/fvMatrix/fvMatrix.C:38-124,208-349,1087-1345,
  *  src/finiteVolume/finiteVolume/fvc/fvcSurfaceIntegrate.C:40-96,
  *  src/finiteVolume/interpolation/surfaceInterpolation/surfaceInterpolationScheme/surfaceInterpolationScheme.C:337-352)
- * Every scheme is ONE fused row pass (the reference: 3-6 Thrust passes + temporaries).  They need
- * the caller's faces owner-sorted (OpenFOAM's upper-triangular order).
+ * Every scheme is one streaming face pass + one row pass whose own-face reads are staged through LDS
+ * (the reference: 3-6 Thrust passes + temporaries).  They need the caller's faces owner-sorted
+ * (OpenFOAM's upper-triangular order); face fields 16-byte aligned.
  * mi_row_face_op kind: 0 sumDiag, 1 negSumDiag, 2 sumMagOffDiag; lower_dev NULL => symmetric.
  * mi_patch_*: a boundary patch = its faceCells; mi_patch_add applies pf per unique cell in ascending
  * patch-face order (addToInternalField, K26): fn 0 add, 1 subtract, 2 add magnitudes.          */

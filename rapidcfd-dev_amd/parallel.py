@@ -123,7 +123,7 @@ class DistributedPCG:
 
     # -- collectives ----------------------------------------------------------
     def _allreduce(self, t):
-        if self.world > 1:
+        if dist.is_initialized():  # also on a 1-rank group: same RCCL code path as N > 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     def _start_exchange(self, vec):

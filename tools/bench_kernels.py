@@ -52,8 +52,8 @@ psi = x.clone()
 timeit("Jacobi smooth, 2 sweeps (caller order)", lambda: A.jacobi_smooth(psi, b, 2), 2 * (32 * N + 16 * F), note="incl. 3 permutation passes")
 timeit("gSumProd (deterministic reduction)", lambda: ctx.sum_prod(x, b), 16 * N, note="includes host read-back")
 timeit("set_coeffs symmetric (caller -> slots)", lambda: A.set_coeffs(fd, fu, None), 16 * N + 16 * F, note="K22 calcSortCoeffs analogue, once per assembled matrix")
-timeit("fvm::laplacian fused", lambda: asm.fvm_laplacian(ff, fw, fu, fd), 8 * N + 24 * F + 8 * N, note="reads delta,gamma; writes upper, diag; + row tables")
-timeit("fvm::div fused", lambda: asm.fvm_div(fw, ff, fl, fu, fd), 8 * N + 32 * F + 8 * N, note="reads w,phi; writes lower, upper, diag")
+timeit("fvm::laplacian (face pass + row pass)", lambda: asm.fvm_laplacian(ff, fw, fu, fd), 8 * N + 24 * F + 8 * N, note="reads delta,gamma; writes upper, diag; + row tables")
+timeit("fvm::div (face pass + row pass)", lambda: asm.fvm_div(fw, ff, fl, fu, fd), 8 * N + 32 * F + 8 * N, note="reads w,phi; writes lower, upper, diag")
 timeit("negSumDiag", lambda: asm.row_face_op(1, fl, fu, fd), 16 * N + 16 * F)
 timeit("fvc::surfaceIntegrate", lambda: asm.surface_integrate(ff, None, y), 8 * N + 8 * F)
 timeit("face interpolate", lambda: asm.face_interpolate(fw, x, fu), 8 * N + 16 * F + 8 * F)
