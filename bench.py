@@ -109,6 +109,7 @@ def main():
         ctx = eng.Context(local_rank, stream.cuda_stream)
     K, W = args.steps, args.warmup
     amul_ms = None
+    host_enqueue_us = None
     force_dist = bool(os.environ.get("MI_BENCH_FORCE_DIST"))  # exercise the N>1 code path on one GPU
     if world == 1 and not force_dist:
         t0 = time.perf_counter()
@@ -143,6 +144,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         amul_ms = solver.iterate(K, time_amul=True)
+        host_enqueue_us = 1e6 * (time.perf_counter() - t0) / K   # host time to enqueue one iteration (incl. collectives)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -177,6 +179,7 @@ def main():
                         f"symmetric pressure-like lduMatrix, {n_gpus}xMI355X",
             "cells": N, "faces": F, "parallelism": f"domain-decomposition {parts_for(world)}" if world > 1 else "single GPU",
             "pcg_algorithmic_GBps": (160 * N + 16 * F) * its / 1e9,
+            "host_enqueue_us_per_step": host_enqueue_us,
         },
         "roofline": {
             "kernel": "tile_kernel<OP_AMUL> (lduMatrix::Amul)",

@@ -319,3 +319,45 @@ def test_decomposed_pcg_on_one_gpu(pkg, orc, ctx, parts):
         assert np.max(np.abs(st["history"] - ref["history"])) < HIST_RTOL * ref["history"][0]
         psi[s.global_cells] = o.solution()
     assert np.max(np.abs(psi - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+def test_error_behaviour_of_the_abi(pkg, ctx):
+    """status codes instead of the reference's abort(): bad arguments, unbound matrix, bad addressing."""
+    eng, syn = pkg.engine, pkg.synthetic
+    case = syn.box_case(6, 5, 4)
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    mat = eng.Matrix(addr)
+    x = dev(syn.splitmix_uniform(1, case.n_cells)); y = torch.empty_like(x)
+    with pytest.raises(eng.MiError, match="not bound"):
+        mat.amul(x, y)                                   # MI_ERR_STATE: coefficients never bound
+    with pytest.raises(eng.MiError, match="not bound"):
+        mat.pcg(y, x)
+    with pytest.raises(eng.MiError, match="lowerAddr"):
+        eng.Addressing(ctx, 4, np.array([3], np.int32), np.array([1], np.int32))
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None)
+    with pytest.raises(eng.MiError, match="unknown preconditioner|bad argument"):
+        pkg.engine._chk(pkg.engine.lib().mi_precondition(mat.h, 99, 0, pkg.engine._ptr(x), pkg.engine._ptr(y)))
+    with pytest.raises(eng.MiError, match="bad argument"):
+        pkg.engine._chk(pkg.engine.lib().mi_amul(mat.h, None, pkg.engine._ptr(y)))
+    with pytest.raises(eng.MiError):
+        eng.Gamg(addr, np.ones(case.n_faces), n_cells_in_coarsest_level=10 ** 6)   # "No coarse levels created" (GAMGSolver.C:175-190)
+
+
+def test_star_mesh_long_rows(pkg, orc, ctx):
+    # rows with 300 faces: exercises the beyond-register-prefetch path of the tile kernel
+    n = 301
+    lo = np.zeros(n - 1, np.int32); up = np.arange(1, n, dtype=np.int32)
+    syn = pkg.synthetic
+    upper = -(0.1 + syn.splitmix_uniform(1, n - 1)); lower = -(0.1 + syn.splitmix_uniform(4, n - 1))
+    diag = np.zeros(n); np.subtract.at(diag, lo, lower); np.subtract.at(diag, up, upper); diag += 0.5
+    case = syn.LduCase(n, lo, up, diag, upper, lower, syn.splitmix_uniform(2, n))
+    _, mat = make(pkg, ctx, case)
+    S = orc.System([case])
+    x = syn.splitmix_uniform(3, n)
+    out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+    mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    perf = mat.pbicgstab(psi, dev(case.source), "DILU", tolerance=1e-12, maxIter=100)
+    _, ref = S.pbicgstab(np.zeros(n), case.source, "AINV", tolerance=1e-12, maxIter=100)
+    assert perf["nIterations"] == ref["nIterations"]

@@ -126,3 +126,39 @@ def test_bad_addressing_is_rejected(pkg):
         pkg.engine.host_layout(4, np.array([2], np.int32), np.array([1], np.int32))  # lower >= upper
     with pytest.raises(pkg.engine.MiError):
         pkg.engine.host_layout(4, np.array([0], np.int32), np.array([7], np.int32))  # out of range
+
+
+def test_layout_property_random_graphs(pkg, orc):
+    """property test: any LDU addressing (ragged rows, multi-degree hubs, odd tile caps) -> the interpreted
+    tile tables reproduce A*x and A^T*x of the oracle."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=25, deadline=None)
+    @given(n=st.integers(2, 400), extra=st.floats(0.0, 4.0), seed=st.integers(0, 10_000),
+           tile=st.sampled_from([3, 17, 64, 200, 1024]), sym=st.booleans())
+    def run(n, extra, seed, tile, sym):
+        case = random_graph_case(pkg, n, extra=extra, seed=seed, symmetric=sym)
+        L = pkg.engine.host_layout(case.n_cells, case.lower_addr, case.upper_addr, tile_cells=tile)
+        assert np.diff(L["tileCellStart"]).max() <= tile
+        S = orc.System([case])
+        x = pkg.synthetic.splitmix_uniform(seed + 7, n) - 0.5
+        ref = S.amul(x)
+        tol = 1e-14 * max(np.max(np.abs(ref)), 1e-300)
+        assert np.max(np.abs(interpret_amul(L, case, x) - ref)) <= tol
+        assert np.max(np.abs(interpret_amul(L, case, x, transpose=True) - S.tmul(x))) <= tol
+
+    run()
+
+
+def test_hub_cell_with_many_faces(pkg, orc):
+    # a star: one cell connected to 300 others (polyhedral "hub"): rows longer than the register-prefetch depth
+    n = 301
+    lo = np.zeros(n - 1, np.int32); up = np.arange(1, n, dtype=np.int32)
+    syn = pkg.synthetic
+    upper = -(0.1 + syn.splitmix_uniform(1, n - 1))
+    diag = np.zeros(n); np.subtract.at(diag, lo, upper); np.subtract.at(diag, up, upper); diag += 0.5
+    case = syn.LduCase(n, lo, up, diag, upper, None, syn.splitmix_uniform(2, n))
+    L = pkg.engine.host_layout(n, lo, up, tile_cells=64)
+    x = syn.splitmix_uniform(3, n)
+    ref = orc.System([case]).amul(x)
+    assert np.max(np.abs(interpret_amul(L, case, x) - ref)) < 1e-12
