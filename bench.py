@@ -39,6 +39,19 @@ def parts_for(n):
     return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(n) or (1, 1, n)
 
 
+def traffic_from_profile(nx, ny, nz, n_gpus):
+    """HBM bytes per Amul launch from the committed rocprofv3 PMC passes (profiles/traffic_latest.json: FETCH_SIZE x 2 +
+    WRITE_SIZE as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read inside this process, so the value is the
+    one measured on this exact workload/layout; null for any other configuration."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        if rec.get("workload") == f"{nx}x{ny}x{nz}" and rec.get("n_gpus") == n_gpus:
+            return float(rec["amul_traffic_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(case, iters):
     """Oracle PCG (1 core) on the same matrix, `iters` iterations -- reported, not a target."""
     from oracle import oracle as orc
@@ -185,9 +198,9 @@ def main():
             "kernel": "tile_kernel<OP_AMUL> (lduMatrix::Amul)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": amul_bytes,
+            "algorithmic_bytes_per_launch": amul_bytes, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_g_rocprof_summary_final.md)",
             "avg_launch_us": amul_avg_s * 1e6,
-            "traffic": float(os.environ["MI_BENCH_TRAFFIC"]) if os.environ.get("MI_BENCH_TRAFFIC") else None,
+            "traffic": traffic_from_profile(nx, ny, nz, n_gpus),
         },
     }
     if rank == 0:
