@@ -377,8 +377,8 @@ __global__ __launch_bounds__(RB) void k_reduce_final(const double* __restrict__ 
     if (threadIdx.x == 0) *out = t;
 }
 
-// out = a + s*b  (one explicit fma; s by value)
-__global__ __launch_bounds__(RB) void k_xpsy(double* __restrict__ out, const double* __restrict__ a, double s, const double* __restrict__ b, int64_t n)
+// out = a + s*b  (one explicit fma; s by value).  out may alias a or b element-wise (in-place updates), hence no __restrict__ on them
+__global__ __launch_bounds__(RB) void k_xpsy(double* out, const double* a, double s, const double* b, int64_t n)
 {
     chunk_loop(n, [&](int64_t i) { const double2 x = ld2(a, i), y = ld2(b, i); st2(out, i, make_double2(fma(s, y.x, x.x), fma(s, y.y, x.y))); },
         [&](int64_t i) { out[i] = fma(s, b[i], a[i]); });

@@ -102,6 +102,29 @@ int main(int argc, char** argv)
             UEqn.relax(0.7, psi);
             UEqn.solve(psi, dictionary{{"solver", "PBiCG"}, {"preconditioner", "diagonal"}, {"tolerance", "1e-10"}, {"relTol", "0"}});
         }
+        // ---- UEqn as a vector equation: fvMatrix<vector>::solveSegregated, per-component boundary coefficients ----
+        {
+            scalarField wts(nf, 1.0), phi(nf);
+            for (label f = 0; f < nf; ++f) phi[f] = dir[f] == 0 ? 0.3 * h * h : 0.0;
+            fvScalarMatrix conv("U", addr, patches, std::vector<bool>(6, false));
+            fvm::div(conv, scalargpuField(wts), scalargpuField(phi));
+            std::vector<scalar> cl = conv.lower().asHost(), cu = conv.upper().asHost(), cd = conv.diag().asHost();
+            std::vector<scalar> lu = pEqn.upper().asHost(), ld = pEqn.diag().asHost();
+            for (label f = 0; f < nf; ++f) { cl[f] -= lu[f]; cu[f] -= lu[f]; }
+            for (label c = 0; c < n; ++c) cd[c] = cd[c] - ld[c] + h * h * h / 1e-3;
+            fvVectorMatrix UEqn("U", addr, patches, std::vector<bool>(6, false));
+            UEqn.lower() = cl; UEqn.upper() = cu; UEqn.diag() = cd;
+            for (int d = 0; d < 3; ++d) {
+                scalarField s(n);
+                for (label c = 0; c < n; ++c) s[c] = (2.0 * splitmixUniform(900 + d, c) - 1.0) * h * h * h;
+                UEqn.source().component(d) = s;
+                UEqn.internalCoeffs()[0].component(d) = scalarField(patches[0].size(), (2.0 + d) * h);   // differs per component
+                UEqn.boundaryCoeffs()[1].component(d) = scalarField(patches[1].size(), 0.01 * (d + 1) * h * h * h);
+            }
+            vectorgpuField U(n);
+            solverPerformance sp = UEqn.solve(U, dictionary{{"solver", "PBiCG"}, {"preconditioner", "DILU"}, {"tolerance", "1e-10"}, {"relTol", "0"}});
+            Info << "solveSegregated max: " << sp.solverName() << " " << sp.initialResidual() << " " << sp.finalResidual() << " " << sp.nIterations() << std::endl;
+        }
         // ---- error behaviour: unknown run-time name lists the valid ones (lduMatrixSolver.C:84-100) ----
         try {
             scalargpuField psi(n);

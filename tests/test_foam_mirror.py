@@ -65,6 +65,19 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     rd_solve = orc.patch_add(xmin, np.full(xmin.shape[0], 2.0 * h), rd, 0)
     UR = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, rd_solve, uu, ul, rs)])
     _, p = UR.pbicg(z, rs, "diagonal", tolerance=1e-10); exp.append(("diagonalPBiCG", "Ux", p))
+    # fvMatrix<vector>::solveSegregated: three component systems, per-component boundary coefficients
+    xmax = np.nonzero(np.arange(n) % dims[0] == dims[0] - 1)[0]
+    worst = dict(i=0.0, f=0.0, n=0)
+    for d, cname in enumerate("xyz"):
+        sd = (2.0 * syn.splitmix_uniform(900 + d, n) - 1.0) * h ** 3
+        sd = orc.patch_add(xmax, np.full(xmax.shape[0], 0.01 * (d + 1) * h ** 3), sd, 0)          # addBoundarySource
+        dd = orc.patch_add(xmin, np.full(xmin.shape[0], (2.0 + d) * h), ud, 0)                       # addBoundaryDiag(cmpt)
+        _, p = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, dd, uu, ul, sd)]).pbicg(z, sd, "AINV", tolerance=1e-10)
+        exp.append(("AINVPBiCG", "U" + cname, p))
+        worst = dict(i=max(worst["i"], p["initialResidual"]), f=max(worst["f"], p["finalResidual"]), n=max(worst["n"], p["nIterations"]))
+    m = re.search(r"solveSegregated max: (\w+) (\S+) (\S+) (\d+)", out.stdout)
+    assert m and m.group(1) == "AINVPBiCG" and int(m.group(4)) == worst["n"]
+    assert abs(float(m.group(2)) - worst["i"]) < 1e-12 and abs(float(m.group(3)) - worst["f"]) < 1e-10
     assert len(got) == len(exp), out.stdout
     for (gname, gfield, gi, gf, gn), (ename, efield, p) in zip(got, exp):
         assert (gname, gfield) == (ename, efield)
