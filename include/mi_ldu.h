@@ -99,6 +99,16 @@ int mi_addr_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
                    const int32_t *lower_addr_host, const int32_t *upper_addr_host,
                    int32_t n_patches, const int32_t *patch_sizes,
                    const int32_t *const *patch_face_cells_host, mi_addr_t *out);
+/* Same, with LOCAL coupled patches (cyclic, cyclicLduInterfaceField: lduAddressing/lduInterfaceFields/
+ * cyclicLduInterfaceField, src/finiteVolume/fields/fvPatchFields/constraint/cyclic): patch_nbr_cells_host[p] != NULL
+ * gives, face by face, the local cell on the other side of patch p (the neighbour patch's faceCells in matching
+ * order); the update result[faceCells] -= coeffs*psi[nbrCells] then needs no exchange and every solver entry
+ * point works on such a matrix.  NULL entries are processor patches (ext region).                              */
+int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
+                           const int32_t *lower_addr_host, const int32_t *upper_addr_host,
+                           int32_t n_patches, const int32_t *patch_sizes,
+                           const int32_t *const *patch_face_cells_host,
+                           const int32_t *const *patch_nbr_cells_host, mi_addr_t *out);
 int mi_addr_destroy(mi_addr_t addr);
 int32_t mi_addr_n_cells(mi_addr_t addr);
 int32_t mi_addr_n_faces(mi_addr_t addr);
@@ -336,7 +346,8 @@ int mi_bench_pcg_iters(mi_matrix_t m, const double *source_dev, int32_t iters, i
  * boundaryTiles, patchOffset, patchFaceCellsE, faceSlot (all int32 otherwise). */
 int mi_layout_build_host(int32_t n_cells, int32_t n_faces, const int32_t *lower_addr_host,
                          const int32_t *upper_addr_host, int32_t n_patches, const int32_t *patch_sizes,
-                         const int32_t *const *patch_face_cells_host, int32_t tile_cells,
+                         const int32_t *const *patch_face_cells_host,
+                         const int32_t *const *patch_nbr_cells_host_or_null, int32_t tile_cells,
                          int32_t slot_cap, void **layout_out);
 int mi_layout_array(void *layout, const char *name, const void **data, int64_t *len);
 int mi_layout_free(void *layout);

@@ -200,9 +200,12 @@ static void update_interfaces(const orc_system *s, int d, int useIntCoeffs,
         const scalar *psiN = psiAll + nb->offset;
         const scalar *co = useIntCoeffs ? me->intCoeffs : me->bouCoeffs;
         for (i = 0; i < me->nFaces; i++) {
-            scalar value = (coeffSign * co[i]) * psiN[ot->faceCells[i]];
-            if (negate) resultDom[me->faceCells[i]] += value;
-            else        resultDom[me->faceCells[i]] -= value;
+            /* one fused multiply-add per face, like every other term of the row
+             * (the contraction nvcc applies to  result -= coeffs*pnf  in the functor) */
+            const scalar cs = coeffSign * co[i];
+            const scalar pn = psiN[ot->faceCells[i]];
+            scalar *r = &resultDom[me->faceCells[i]];
+            *r = negate ? fma(cs, pn, *r) : fma(-cs, pn, *r);
         }
     }
 }

@@ -79,13 +79,13 @@ struct mi_ctx_s {
 struct mi_addr_s {
     mi_ctx_s* ctx = nullptr;
     TileLayout L; // host copy (big vectors are dropped after upload except the permutations)
-    DevBuf<int32_t> e2c, c2e, tileCellStart, tileSlotStart, tileHaloStart, haloCell, tileSliceStart, sliceEntryStart;
+    DevBuf<int32_t> e2c, c2e, tileCellStart, tileSlotStart, tileIfaceSlot0, tileHaloStart, haloCell, tileSliceStart, sliceEntryStart;
     DevBuf<uint32_t> entries;
     DevBuf<int32_t> slotFace, extSlot, interiorTiles, boundaryTiles, patchFaceCellsE, faceSlot, lowerAddr, upperAddr;
     DevBuf<int32_t> ownerStartC, losortStartC, losortC; // caller-order row tables for the assembly sweeps (lazy)
     DevBuf<double> relaxD0, relaxSumOff;
     std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
-    int32_t nInterior = 0, nBoundary = 0;
+    int32_t nInterior = 0, nBoundary = 0, nLocalPatches = 0;
     int64_t nEntries = 0, nHaloTot = 0;
 };
 
@@ -188,10 +188,23 @@ extern "C" int mi_ctx_synchronize(mi_ctx_t c)
 // ---------------------------------------------------------------------------
 // addressing
 // ---------------------------------------------------------------------------
+extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
+                                      const int32_t* lower, const int32_t* upper, int32_t n_patches,
+                                      const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
+                                      const int32_t* const* patch_nbr_cells, mi_addr_t* out);
+
 extern "C" int mi_addr_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
                               const int32_t* lower, const int32_t* upper, int32_t n_patches,
                               const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
                               mi_addr_t* out)
+{
+    return mi_addr_create_coupled(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, nullptr, out);
+}
+
+extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
+                                      const int32_t* lower, const int32_t* upper, int32_t n_patches,
+                                      const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
+                                      const int32_t* const* patch_nbr_cells, mi_addr_t* out)
 {
     if (!ctx || !out || (n_faces > 0 && (!lower || !upper)) || n_patches < 0)
         return fail(MI_ERR_ARG, "mi_addr_create: bad argument");
@@ -201,13 +214,15 @@ extern "C" int mi_addr_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
     TileParams prm;
     prm.tileCells = env_int("MI_TILE_CELLS", 1024);
     prm.slotCap = env_int("MI_TILE_SLOTS", 4094);
-    const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L);
+    const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L, patch_nbr_cells);
     if (!err.empty()) { delete a; return fail(MI_ERR_LIMIT, "mi_addr_create: " + err); }
+    a->nLocalPatches = 0;
+    if (patch_nbr_cells) for (int32_t p = 0; p < n_patches; ++p) if (patch_nbr_cells[p]) a->nLocalPatches++;
     TileLayout& L = a->L;
     hipStream_t s = ctx->stream;
     int r = MI_OK;
 #define UP(buf, vec) if (r == MI_OK) r = a->buf.upload(vec, s)
-    UP(e2c, L.e2c); UP(c2e, L.c2e); UP(tileCellStart, L.tileCellStart); UP(tileSlotStart, L.tileSlotStart);
+    UP(e2c, L.e2c); UP(c2e, L.c2e); UP(tileCellStart, L.tileCellStart); UP(tileSlotStart, L.tileSlotStart); UP(tileIfaceSlot0, L.tileIfaceSlot0);
     UP(tileHaloStart, L.tileHaloStart); UP(haloCell, L.haloCell); UP(tileSliceStart, L.tileSliceStart);
     UP(sliceEntryStart, L.sliceEntryStart); UP(entries, L.entries); UP(slotFace, L.slotFace);
     UP(extSlot, L.extSlot); UP(interiorTiles, L.interiorTiles); UP(boundaryTiles, L.boundaryTiles);
@@ -368,7 +383,7 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     mi_addr_s* a = m->addr;
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound (mi_matrix_set_coeffs)");
     TileArgs t;
-    t.tileCellStart = a->tileCellStart.p; t.tileSlotStart = a->tileSlotStart.p; t.tileHaloStart = a->tileHaloStart.p;
+    t.tileCellStart = a->tileCellStart.p; t.tileSlotStart = a->tileSlotStart.p; t.tileIfaceSlot0 = a->tileIfaceSlot0.p; t.tileHaloStart = a->tileHaloStart.p;
     t.haloCell = a->haloCell.p; t.tileSliceStart = a->tileSliceStart.p; t.sliceEntryStart = a->sliceEntryStart.p;
     t.entries = a->entries.p;
     t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
@@ -1191,14 +1206,14 @@ extern "C" int mi_bench_pcg_iters(mi_matrix_t m, const double* source, int32_t i
 // ---------------------------------------------------------------------------
 extern "C" int mi_layout_build_host(int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper,
                                     int32_t n_patches, const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
-                                    int32_t tile_cells, int32_t slot_cap, void** out)
+                                    const int32_t* const* patch_nbr_cells, int32_t tile_cells, int32_t slot_cap, void** out)
 {
     if (!out) return fail(MI_ERR_ARG, "mi_layout_build_host: out is NULL");
     TileLayout* L = new TileLayout();
     TileParams prm;
     if (tile_cells > 0) prm.tileCells = tile_cells;
     if (slot_cap > 0) prm.slotCap = slot_cap;
-    const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, *L);
+    const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, *L, patch_nbr_cells);
     if (!err.empty()) { delete L; return fail(MI_ERR_LIMIT, "mi_layout_build_host: " + err); }
     *out = L;
     return MI_OK;
@@ -1210,7 +1225,7 @@ extern "C" int mi_layout_array(void* handle, const char* name, const void** data
     TileLayout* L = static_cast<TileLayout*>(handle);
     const std::string n(name);
 #define ARR(field) if (n == #field) { *data = L->field.data(); *len = (int64_t)L->field.size(); return MI_OK; }
-    ARR(e2c) ARR(c2e) ARR(tileCellStart) ARR(tileSlotStart) ARR(tileHaloStart) ARR(haloCell) ARR(tileSliceStart)
+    ARR(e2c) ARR(c2e) ARR(tileCellStart) ARR(tileSlotStart) ARR(tileIfaceSlot0) ARR(tileHaloStart) ARR(haloCell) ARR(tileSliceStart)
     ARR(sliceEntryStart) ARR(entries) ARR(slotFace) ARR(extSlot) ARR(interiorTiles) ARR(boundaryTiles)
     ARR(patchOffset) ARR(patchFaceCellsE) ARR(faceSlot)
 #undef ARR

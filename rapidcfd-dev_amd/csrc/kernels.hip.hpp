@@ -85,6 +85,7 @@ enum { OP_AMUL = 0, OP_SUMA = 1, OP_RESIDUAL = 2, OP_H = 3, OP_H1 = 4, OP_AINV =
 struct TileArgs {
     const int32_t* tileCellStart;
     const int32_t* tileSlotStart;
+    const int32_t* tileIfaceSlot0;
     const int32_t* tileHaloStart;
     const int32_t* haloCell;
     const int32_t* tileSliceStart;
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
     const int c0 = a.tileCellStart[t], nc = a.tileCellStart[t + 1] - c0;
     const int s0 = a.tileSlotStart[t], ns = a.tileSlotStart[t + 1] - s0; // even
     const int h0 = a.tileHaloStart[t], nh = a.tileHaloStart[t + 1] - h0;
+    const int ifs0 = (OP == OP_JACOBI || OP == OP_AINV) ? a.tileIfaceSlot0[t] : 0; // first interface slot of the tile
     constexpr bool NEEDX = (OP != OP_SUMA && OP != OP_H1);
 
     // ---- stage: coefficients (16-byte coalesced), psi, halo -------------------
@@ -228,7 +230,8 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
         const bool live = i < nc;
         const int gi = c0 + (live ? i : 0);
         const double xi = (NEEDX && live) ? xs[i] : 0.0;
-        double acc;
+        double acc, accI = 0.0;
+        if (OP == OP_JACOBI) accI = a.b[gi];
         if (OP == OP_AMUL) acc = a.diag[gi] * xi;
         else if (OP == OP_SUMA) acc = a.diag[gi];
         else if (OP == OP_RESIDUAL) acc = a.b[gi] - a.diag[gi] * xi;
@@ -239,11 +242,13 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
             double c;
             if (ASYM) c = (((en >> 31) != 0u) != TRANS) ? cL[sl] : cU[sl];
             else c = cU[sl];
-            if (OP == OP_AMUL || OP == OP_JACOBI) acc = fma(c, xs[o], acc);
+            if (OP == OP_JACOBI) { // coupled patches go to bPrime, faces to the row sum (JacobiSmoother.C:75-93, JacobiSmootherF.H)
+                if (sl >= ifs0) accI = fma(-c, xs[o], accI); else acc = fma(c, xs[o], acc);
+            } else if (OP == OP_AMUL) acc = fma(c, xs[o], acc);
             else if (OP == OP_SUMA) acc += c;
             else if (OP == OP_RESIDUAL || OP == OP_H) acc = fma(-c, xs[o], acc);
             else if (OP == OP_H1) acc -= c;
-            else if (OP == OP_AINV) acc = fma(c * rDs[o], xs[o], acc);
+            else if (OP == OP_AINV) { if (sl < ifs0) acc = fma(c * rDs[o], xs[o], acc); } // faces only (AINVPreconditioner.C)
         };
 #pragma unroll
         for (int j = 0; j < PRE; ++j) if (j < wcur) accumulate(ecur[j]);
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
             if (OP == OP_AINV) a.y[gi] = rDs[i] * (xi - acc);
             else if (OP == OP_JACOBI) {
                 const double rD = 1.0 / a.diag[gi];
-                const double extra = (1 - a.omega) * xi + a.omega * rD * a.b[gi];
+                const double extra = (1 - a.omega) * xi + a.omega * rD * accI;
                 a.y[gi] = extra - a.omega * rD * acc;
             } else if (a.flags & 4) __builtin_nontemporal_store(acc, a.y + gi);
             else a.y[gi] = acc;

@@ -92,7 +92,7 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, int32_t nc, Graph
 std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* lower,
                               const int32_t* upper, int32_t nPatches,
                               const int32_t* patchSizes, const int32_t* const* patchFaceCells,
-                              const TileParams& prm, TileLayout& L)
+                              const TileParams& prm, TileLayout& L, const int32_t* const* patchNbrCells)
 {
     if (nCells <= 0) return "n_cells must be positive";
     if (prm.slotCap > 32766) return "slotCap exceeds the 15-bit slot field";
@@ -132,6 +132,17 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
             for (int32_t i = 0; i < patchSizes[p]; ++i)
                 pfList[(size_t)cp[patchFaceCells[p][i]]++] = L.patchOffset[p] + i;
     }
+
+    // local coupled patches (cyclic): caller cell on the other side of every interface face, or -1 (ext region)
+    std::vector<int32_t> ifaceLocalNbr((size_t)L.nExt, -1);
+    if (patchNbrCells)
+        for (int32_t p = 0; p < nPatches; ++p)
+            if (patchNbrCells[p])
+                for (int32_t i = 0; i < patchSizes[p]; ++i) {
+                    const int32_t c = patchNbrCells[p][i];
+                    if (c < 0 || c >= nCells) return "cyclic patch neighbour cells out of range";
+                    ifaceLocalNbr[(size_t)L.patchOffset[p] + i] = c;
+                }
 
     // ---- multilevel heavy-edge clustering ------------------------------------
     std::vector<int32_t> part((size_t)nCells);
@@ -189,6 +200,8 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
 
     // ---- slots, halos, row entries --------------------------------------------
     L.tileSlotStart.assign((size_t)nT + 1, 0);
+    L.tileIfaceSlot0.assign((size_t)nT, 0);
+    std::vector<int32_t> ifaceEnt, ifaceX;
     L.tileHaloStart.assign((size_t)nT + 1, 0);
     L.tileSliceStart.assign((size_t)nT + 1, 0);
     L.sliceEntryStart.clear(); L.sliceEntryStart.push_back(0);
@@ -214,6 +227,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         int32_t nSlots = 0, nHalo = 0;
         bool boundary = false;
         rowEnt.clear(); rowEntStart.assign(1, 0);
+        ifaceEnt.clear(); ifaceX.clear();
 
         auto halo_of = [&](int32_t engineCell) -> int32_t {
             if (haloStamp[engineCell] != t) { haloStamp[engineCell] = t; haloIdx[engineCell] = nHalo++; L.haloCell.push_back(engineCell); }
@@ -239,15 +253,26 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
             }
             // coupled interfaces in patch order
             for (int32_t j = pfStart[c]; j < pfStart[(size_t)c + 1]; ++j) {
+                // interface slots are numbered after all face slots of the tile (second pass below) so that
+                // a kernel can tell them apart with one compare: slot >= tileIfaceSlot0[t]
                 const int32_t x = pfList[j];
-                const int32_t slot = nSlots++;
-                L.slotFace.push_back(-(2 + x));
-                L.extSlot[x] = (int32_t)(slotBase + slot);
-                const int32_t other = halo_of(nCells + x);
-                boundary = true;
+                const int32_t slot = 0;
+                ifaceEnt.push_back((int32_t)rowEnt.size()); ifaceX.push_back(x);
+                int32_t other;
+                const int32_t nb = ifaceLocalNbr[x];
+                if (nb < 0) { other = halo_of(nCells + x); boundary = true; }      // remote: value arrives in the ext region
+                else if (part[nb] == t) other = L.c2e[nb] - cs;                      // cyclic partner inside this tile
+                else other = halo_of(L.c2e[nb]);                                     // cyclic partner in another tile
                 rowEnt.push_back((uint32_t)other | ((uint32_t)slot << 16));
             }
             rowEntStart.push_back((int32_t)rowEnt.size());
+        }
+        L.tileIfaceSlot0[t] = nSlots;
+        for (size_t k = 0; k < ifaceEnt.size(); ++k) {
+            const int32_t slot = nSlots++;
+            L.slotFace.push_back(-(2 + ifaceX[k]));
+            L.extSlot[ifaceX[k]] = (int32_t)(slotBase + slot);
+            rowEnt[(size_t)ifaceEnt[k]] |= ((uint32_t)slot << 16);
         }
         if (nSlots > 32766 || nc + nHalo > 65535) return "tile exceeds the entry field widths";
         // zero slot + pad the segment to an even length (16-byte aligned double2 loads)

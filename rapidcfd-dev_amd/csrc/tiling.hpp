@@ -29,6 +29,7 @@ struct TileLayout {
     std::vector<int32_t> e2c, c2e;        // engine<->caller cell permutation
     std::vector<int32_t> tileCellStart;   // [nTiles+1] engine cell range
     std::vector<int32_t> tileSlotStart;   // [nTiles+1] slot range (starts are even)
+    std::vector<int32_t> tileIfaceSlot0;  // [nTiles] local slot index of the first interface slot (they follow the face slots)
     std::vector<int32_t> tileHaloStart;   // [nTiles+1]
     std::vector<int32_t> haloCell;        // engine index; >= nCells means ext cell
     std::vector<int32_t> tileSliceStart;  // [nTiles+1]
@@ -53,6 +54,9 @@ struct TileParams {
 std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* lower,
                               const int32_t* upper, int32_t nPatches,
                               const int32_t* patchSizes, const int32_t* const* patchFaceCells,
-                              const TileParams& prm, TileLayout& out);
+                              const TileParams& prm, TileLayout& out,
+                              const int32_t* const* patchNbrCells = nullptr);
+// patchNbrCells[p] != nullptr marks patch p as a LOCAL coupled patch (cyclic): face i couples faceCells[i]
+// with the local cell patchNbrCells[p][i] (cyclicLduInterfaceField); nullptr = values arrive in the ext region.
 
 } // namespace mi

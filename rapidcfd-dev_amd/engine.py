@@ -40,7 +40,7 @@ class SolverControls(C.Structure):
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
-    "mi_addr_create", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
+    "mi_addr_create", "mi_addr_create_coupled", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
     "mi_addr_n_ext", "mi_addr_cell_perm", "mi_addr_stats", "mi_addr_patch_offsets",
     "mi_matrix_create", "mi_matrix_destroy", "mi_matrix_set_coeffs", "mi_matrix_set_interface_coeffs",
     "mi_matrix_set_ext", "mi_halo_pack_engine", "mi_vec_to_engine", "mi_vec_from_engine",
@@ -75,7 +75,7 @@ def gamg_controls(tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0, nPreSweep
                         nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection, omega)
 
 
-def host_layout(n_cells, lower_addr, upper_addr, patch_face_cells=(), tile_cells=0, slot_cap=0) -> dict:
+def host_layout(n_cells, lower_addr, upper_addr, patch_face_cells=(), tile_cells=0, slot_cap=0, patch_nbr_cells=()) -> dict:
     """Build the tiled layout on the host only and return its tables as numpy arrays (tests)."""
     lo = np.ascontiguousarray(lower_addr, dtype=np.int32)
     up = np.ascontiguousarray(upper_addr, dtype=np.int32)
@@ -84,13 +84,17 @@ def host_layout(n_cells, lower_addr, upper_addr, patch_face_cells=(), tile_cells
     sizes = (C.c_int32 * max(npatch, 1))(*[p.shape[0] for p in patches])
     ptrs = (C.POINTER(C.c_int32) * max(npatch, 1))(*[p.ctypes.data_as(C.POINTER(C.c_int32)) for p in patches])
     h = C.c_void_p()
+    nbrs = [None if (k >= len(patch_nbr_cells) or patch_nbr_cells[k] is None)
+            else np.ascontiguousarray(patch_nbr_cells[k], dtype=np.int32) for k in range(npatch)]
+    nptrs = (C.POINTER(C.c_int32) * max(npatch, 1))(*[q.ctypes.data_as(C.POINTER(C.c_int32)) if q is not None
+                                                       else C.POINTER(C.c_int32)() for q in nbrs])
     _chk(lib().mi_layout_build_host(C.c_int32(n_cells), C.c_int32(lo.shape[0]),
                                     lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),
-                                    C.c_int32(npatch), sizes, ptrs, C.c_int32(tile_cells), C.c_int32(slot_cap), C.byref(h)))
+                                    C.c_int32(npatch), sizes, ptrs, nptrs, C.c_int32(tile_cells), C.c_int32(slot_cap), C.byref(h)))
     out = {}
     try:
-        for name in ("e2c", "c2e", "tileCellStart", "tileSlotStart", "tileHaloStart", "haloCell", "tileSliceStart",
-                     "sliceEntryStart", "entries", "slotFace", "extSlot", "interiorTiles", "boundaryTiles",
+        for name in ("e2c", "c2e", "tileCellStart", "tileSlotStart", "tileIfaceSlot0", "tileHaloStart", "haloCell",
+                     "tileSliceStart", "sliceEntryStart", "entries", "slotFace", "extSlot", "interiorTiles", "boundaryTiles",
                      "patchOffset", "patchFaceCellsE", "faceSlot"):
             data, ln = C.c_void_p(), C.c_int64()
             _chk(lib().mi_layout_array(h, name.encode(), C.byref(data), C.byref(ln)))
@@ -169,7 +173,9 @@ class Context:
 class Addressing:
     """lduAddressing: host lowerAddr/upperAddr + coupled-patch faceCells -> tiled engine layout."""
 
-    def __init__(self, ctx: Context, n_cells: int, lower_addr, upper_addr, patch_face_cells: Sequence = ()):
+    def __init__(self, ctx: Context, n_cells: int, lower_addr, upper_addr, patch_face_cells: Sequence = (),
+                 patch_nbr_cells: Sequence = ()):
+        """patch_nbr_cells[p] (optional): local cells across patch p => cyclic (local) coupling; None => processor patch"""
         self.ctx = ctx
         lo = np.ascontiguousarray(lower_addr, dtype=np.int32)
         up = np.ascontiguousarray(upper_addr, dtype=np.int32)
@@ -178,9 +184,13 @@ class Addressing:
         sizes = (C.c_int32 * max(npatch, 1))(*[p.shape[0] for p in self._patches])
         ptrs = (C.POINTER(C.c_int32) * max(npatch, 1))(*[p.ctypes.data_as(C.POINTER(C.c_int32)) for p in self._patches])
         self.h = C.c_void_p()
-        _chk(lib().mi_addr_create(ctx.h, C.c_int32(n_cells), C.c_int32(lo.shape[0]),
-                                  lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),
-                                  C.c_int32(npatch), sizes, ptrs, C.byref(self.h)))
+        self._nbrs = [None if (k >= len(patch_nbr_cells) or patch_nbr_cells[k] is None)
+                      else np.ascontiguousarray(patch_nbr_cells[k], dtype=np.int32) for k in range(npatch)]
+        nptrs = (C.POINTER(C.c_int32) * max(npatch, 1))(*[q.ctypes.data_as(C.POINTER(C.c_int32)) if q is not None
+                                                           else C.POINTER(C.c_int32)() for q in self._nbrs])
+        _chk(lib().mi_addr_create_coupled(ctx.h, C.c_int32(n_cells), C.c_int32(lo.shape[0]),
+                                          lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          C.c_int32(npatch), sizes, ptrs, nptrs, C.byref(self.h)))
         self.n_cells = n_cells
         self.n_faces = int(lo.shape[0])
         self.n_ext = int(lib().mi_addr_n_ext(self.h))

@@ -210,3 +210,29 @@ def decompose_box(case: LduCase, parts) -> List[LduCase]:
                 int_coeffs=np.asarray(inte, dtype=np.float64)))
         out.append(sub)
     return out
+
+
+def add_cyclic_y(case: LduCase, kappa_scale: float = 1.0, asym_shift: float = 0.0) -> LduCase:
+    """Make the box periodic in y: the y-min and y-max boundary patches become a cyclic pair
+    (cyclicFvPatchField / cyclicLduInterfaceField: the neighbour values are local cells).  Face i of the
+    y-min patch couples with face i of the y-max patch; coupling kappa = h*kappa_scale enters the diagonal
+    (internalCoeffs, what addBoundaryDiag folds in) and the interface coefficients (boundaryCoeffs = -offdiag).
+    Returned case: same addressing, two interfaces that reference each other inside domain 0."""
+    import copy
+    nx, ny, nz = case.dims
+    c = np.arange(case.n_cells, dtype=np.int64)
+    j = (c // nx) % ny
+    ymin = np.nonzero(j == 0)[0].astype(np.int32)
+    ymax = np.nonzero(j == ny - 1)[0].astype(np.int32)
+    h = 1.0 / nx
+    sign = 1.0 if case.lower is None else -1.0      # offdiag sign of the base matrix (sym: +h, asym: -nu*h)
+    kappa = sign * h * kappa_scale * np.ones(ymin.shape[0])
+    out = copy.copy(case)
+    out.diag = case.diag.copy()
+    np.subtract.at(out.diag, ymin, kappa)
+    np.subtract.at(out.diag, ymax, kappa)
+    out.interfaces = [
+        Interface(nbr_domain=0, nbr_patch=1, face_cells=ymin, bou_coeffs=-kappa, int_coeffs=-(kappa - sign * asym_shift * h)),
+        Interface(nbr_domain=0, nbr_patch=0, face_cells=ymax, bou_coeffs=-(kappa - sign * asym_shift * h), int_coeffs=-kappa),
+    ]
+    return out

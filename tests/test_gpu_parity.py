@@ -361,3 +361,36 @@ def test_star_mesh_long_rows(pkg, orc, ctx):
     perf = mat.pbicgstab(psi, dev(case.source), "DILU", tolerance=1e-12, maxIter=100)
     _, ref = S.pbicgstab(np.zeros(n), case.source, "AINV", tolerance=1e-12, maxIter=100)
     assert perf["nIterations"] == ref["nIterations"]
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_cyclic_interfaces(pkg, orc, ctx, symmetric):
+    """cyclic (local coupled) patches: every operator and whole solvers, single process, against the oracle."""
+    syn, eng = pkg.synthetic, pkg.engine
+    case = syn.add_cyclic_y(syn.box_case(18, 12, 10, symmetric=symmetric), asym_shift=0.0 if symmetric else 0.25)
+    fcs = [i.face_cells for i in case.interfaces]
+    nbrs = [case.interfaces[i.nbr_patch].face_cells for i in case.interfaces]
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, fcs, nbrs)
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    for p, itf in enumerate(case.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if symmetric else dev(itf.int_coeffs))
+    S = orc.System([case])
+    n = case.n_cells
+    x = syn.splitmix_uniform(3, n) - 0.5
+    out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+    mat.sumA(out); assert np.array_equal(host(out), S.sumA())
+    mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
+    psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 2)
+    assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 2))   # interface terms enter bPrime, like the reference
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    if symmetric:
+        perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=1e-9, maxIter=500)
+        ref_psi, ref = S.pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-9, maxIter=500)
+    else:
+        mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
+        perf = mat.pbicg(psi, dev(case.source), "DILU", tolerance=1e-10, maxIter=300)
+        ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV", tolerance=1e-10, maxIter=300)
+    _check_hist(perf, ref)
+    assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))

@@ -162,3 +162,26 @@ def test_hub_cell_with_many_faces(pkg, orc):
     x = syn.splitmix_uniform(3, n)
     ref = orc.System([case]).amul(x)
     assert np.max(np.abs(interpret_amul(L, case, x) - ref)) < 1e-12
+
+
+def test_cyclic_patches_are_local_couplings(pkg, orc):
+    # cyclic pair (y-periodic box): interface slots point at local cells, no tile depends on the ext region
+    syn, eng = pkg.synthetic, pkg.engine
+    for symmetric in (True, False):
+        case = syn.add_cyclic_y(syn.box_case(9, 6, 5, symmetric=symmetric), asym_shift=0.0 if symmetric else 0.3)
+        fcs = [i.face_cells for i in case.interfaces]
+        nbrs = [case.interfaces[i.nbr_patch].face_cells for i in case.interfaces]
+        L = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr, fcs, tile_cells=64, patch_nbr_cells=nbrs)
+        assert len(L["boundaryTiles"]) == 0
+        assert np.all(L["haloCell"] < case.n_cells)
+        # interface slots close every tile's slot segment
+        for t in range(len(L["tileIfaceSlot0"])):
+            s0, s1 = L["tileSlotStart"][t], L["tileSlotStart"][t + 1]
+            sf = L["slotFace"][s0:s1]
+            k = L["tileIfaceSlot0"][t]
+            assert np.all(sf[:k] >= 0) and np.all(sf[k:] < 0)
+        x = syn.splitmix_uniform(8, case.n_cells) - 0.5
+        S = orc.System([case])
+        bou = np.concatenate([i.bou_coeffs for i in case.interfaces])
+        got = interpret_amul(L, case, x, ext=np.zeros(len(bou)), bou=bou)
+        assert np.max(np.abs(got - S.amul(x))) < 1e-15
