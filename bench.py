@@ -123,6 +123,7 @@ def main():
     K, W = args.steps, args.warmup
     amul_ms = None
     host_enqueue_us = None
+    host_loop = "single-GPU device-resident pipeline (mi_pcg_iterate)"
     force_dist = bool(os.environ.get("MI_BENCH_FORCE_DIST"))  # exercise the N>1 code path on one GPU
     if world == 1 and not force_dist:
         t0 = time.perf_counter()
@@ -149,6 +150,7 @@ def main():
         par = import_module(graft.PKG_NAME + ".parallel")
         sub = syn.decompose_box(case, parts_for(world))[rank]
         solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
+        host_loop = {"native": "C++ loop over RCCL (mi_dpcg_comm_iterate)", "torch": "torch.distributed loop (parallel.py)"}[solver.driver]
         solver.begin(tolerance=0.0, max_iter=W + K + 8)
         solver.iterate(W)
         torch.cuda.synchronize()
@@ -157,7 +159,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         amul_ms = solver.iterate(K, time_amul=True)
-        host_enqueue_us = 1e6 * (time.perf_counter() - t0) / K   # host time to enqueue one iteration (incl. collectives)
+        host_enqueue_us = 1e6 * solver.last_enqueue_s / K   # host time to enqueue one iteration (incl. collectives)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -192,7 +194,7 @@ def main():
                         f"symmetric pressure-like lduMatrix, {n_gpus}xMI355X",
             "cells": N, "faces": F, "parallelism": f"domain-decomposition {parts_for(world)}" if world > 1 else "single GPU",
             "pcg_algorithmic_GBps": (160 * N + 16 * F) * its / 1e9,
-            "host_enqueue_us_per_step": host_enqueue_us,
+            "host_enqueue_us_per_step": host_enqueue_us, "host_loop": host_loop,
         },
         "roofline": {
             "kernel": "tile_kernel<OP_AMUL> (lduMatrix::Amul)",

@@ -44,6 +44,7 @@ typedef struct mi_addr_s *mi_addr_t;
 typedef struct mi_matrix_s *mi_matrix_t;
 typedef struct mi_gamg_s *mi_gamg_t;
 typedef struct mi_patch_s *mi_patch_t;
+typedef struct mi_comm_s *mi_comm_t;
 
 enum {
     MI_OK = 0,
@@ -315,6 +316,26 @@ int mi_dpcg_set_buffers(mi_matrix_t m, double *psi_e, double *src_e, double *pA_
 int mi_dpcg_phase(mi_matrix_t m, int phase, int32_t it, double arg);
 int mi_dpcg_status(mi_matrix_t m, mi_solver_perf *perf_out, int32_t *done_out,
                    double *residual_history_host, int32_t history_len);
+/* ---- RCCL communicator and the C++ host loop of the distributed PCG.  Replaces the reference's MPI layer
+ * on this path (src/Pstream/mpi/UPstream.C, allReduceTemplates.C:195-208, UIPread.C/UOPwrite.C as used by
+ * processorFvPatchScalarField.C:36-170): one rank per GPU, all-reduces on the engine's stream, halo
+ * send/recv on a second stream so Amul's interior tiles overlap the exchange.  RCCL is bound at run time;
+ * its absence is an error here (MI_ERR_DEVICE), never a fallback.
+ *   id: 128 bytes from mi_comm_unique_id on rank 0, distributed to all ranks by the launcher (any channel).
+ *   mi_dpcg_comm_begin: prologue up to the first convergence test (PCG.C:75-118); buffers and controls
+ *     come from mi_dpcg_set_buffers.  reduce/halo may be the same communicator; two let the halo traffic
+ *     and the scalar all-reduces progress independently.  patch_rank[p] = rank on the other side of
+ *     processor patch p; patch_nbr_patch[p] = index of the matching patch on that rank (NULL = same index).
+ *   mi_dpcg_comm_iterate: enqueue n_iters iterations without host synchronisation; poll with
+ *     mi_dpcg_status.  record_amul_events != 0 brackets the Amul phases of the k-th enqueued iteration
+ *     with the events 2k, 2k+1 of the matrix (mi_event_elapsed_ms).                                   */
+int mi_comm_unique_id(void *id_out, int32_t len);
+int mi_comm_create(mi_ctx_t ctx, int32_t n_ranks, int32_t rank, const void *id, mi_comm_t *out);
+int mi_comm_destroy(mi_comm_t comm);
+int mi_comm_allreduce_sum(mi_comm_t comm, double *buf_dev, int64_t n);
+int mi_dpcg_comm_begin(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,
+                       const int32_t *patch_nbr_patch_or_null, int64_t n_global_cells);
+int mi_dpcg_comm_iterate(mi_matrix_t m, int32_t n_iters, int32_t record_amul_events);
 /* HIP-event helpers on the context's stream (bench.py times the Amul phases with them) */
 int mi_event_record(mi_matrix_t m, int32_t idx);
 int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, float *ms_out);

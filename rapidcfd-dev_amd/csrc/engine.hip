@@ -86,6 +86,7 @@ struct mi_addr_s {
     DevBuf<double> relaxD0, relaxSumOff;
     std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
     int32_t nInterior = 0, nBoundary = 0, nLocalPatches = 0;
+    std::vector<char> patchIsLocal; // [nPatches] cyclic (local) coupled patch: no exchange
     int64_t nEntries = 0, nHaloTot = 0;
 };
 
@@ -103,7 +104,8 @@ struct mi_matrix_s {
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
     bool pcgActive = false;
     std::vector<hipEvent_t> evPool;
-    ~mi_matrix_s() { for (auto* w : work) delete w; for (auto e : evPool) (void)hipEventDestroy(e); }
+    struct mi_dpcg_comm_s* dpc = nullptr; // C++-driven distributed session (comm.inc)
+    ~mi_matrix_s();
     int vec(size_t k, double** out)
     {
         while (work.size() <= k) work.push_back(new DevBuf<double>());
@@ -217,7 +219,8 @@ extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
     const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L, patch_nbr_cells);
     if (!err.empty()) { delete a; return fail(MI_ERR_LIMIT, "mi_addr_create: " + err); }
     a->nLocalPatches = 0;
-    if (patch_nbr_cells) for (int32_t p = 0; p < n_patches; ++p) if (patch_nbr_cells[p]) a->nLocalPatches++;
+    a->patchIsLocal.assign((size_t)std::max(n_patches, 0), 0);
+    if (patch_nbr_cells) for (int32_t p = 0; p < n_patches; ++p) if (patch_nbr_cells[p]) { a->nLocalPatches++; a->patchIsLocal[(size_t)p] = 1; }
     TileLayout& L = a->L;
     hipStream_t s = ctx->stream;
     int r = MI_OK;
@@ -900,9 +903,9 @@ extern "C" int mi_dpcg_phase(mi_matrix_t m, int phase, int32_t it, double arg)
         k_solve_init<true><<<1, RB, 0, s>>>(c->state.p, B.scal + 4, B.scal + 1, m->hist.p, m->histLen);
         break;
     case 10: // iteration `it`: (residual test of it-1,) pA update, pack pA for the exchange
-        if (it > 0) k_pcg_final<true><<<1, RB, 0, s>>>(c->state.p, it - 1, B.scal + 1, m->hist.p, m->histLen);
-        if (B.precond == MI_PRECOND_DIAGONAL) k_pcg_update_p<1, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 0, nullptr, m->rD.p, B.rA, B.pA, n);
-        else k_pcg_update_p<2, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 0, nullptr, nullptr, B.rA, B.pA, n);
+        // the residual test of iteration it-1 (PCG.C:195-204) rides at the head of the pA update, like on one GPU
+        if (B.precond == MI_PRECOND_DIAGONAL) k_pcg_update_p<1, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 0, nullptr, m->rD.p, B.rA, B.pA, n, B.scal + 1, m->hist.p, m->histLen);
+        else k_pcg_update_p<2, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 0, nullptr, nullptr, B.rA, B.pA, n, B.scal + 1, m->hist.p, m->histLen);
         MICHK(mi_halo_pack_engine(a, B.pA, B.send));
         break;
     case 11: // interior tiles: overlap with the halo exchange
@@ -910,16 +913,14 @@ extern "C" int mi_dpcg_phase(mi_matrix_t m, int phase, int32_t it, double arg)
         break;
     case 12: // boundary tiles (halo has arrived) + local sum wA.pA
         MICHK(launch_tile<OP_AMUL>(m, false, B.pA, nullptr, nullptr, B.wA, 0.0, 2, m->tilePartial.p + a->nInterior));
-        k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P);
-        finalize(P, B.scal + 2);
+        k_fold_final<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, B.scal + 2);
         break;
     case 13: // after the allreduce of scal[2]: psi, rA updates; local sum|rA| and next wArA
         if (B.precond == MI_PRECOND_DIAGONAL)
             k_pcg_update_psi_r<1, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 2, B.pA, B.wA, m->rD.p, B.psi, B.rA, n, P + RG, P + 2 * RG);
         else
             k_pcg_update_psi_r<2, true><<<RG, RB, 0, s>>>(c->state.p, it, B.scal + 2, B.pA, B.wA, nullptr, B.psi, B.rA, n, P + RG, P + 2 * RG);
-        finalize(P + RG, B.scal + 1);
-        finalize(P + 2 * RG, B.scal + 0);
+        k_reduce_final2<<<2, RB, 0, s>>>(P + RG, B.scal + 1, P + 2 * RG, B.scal + 0);
         break;
     case 14: // residual test of the last enqueued iteration (after the allreduce of scal[0,1])
         k_pcg_final<true><<<1, RB, 0, s>>>(c->state.p, it, B.scal + 1, m->hist.p, m->histLen);
@@ -1254,3 +1255,16 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
 
 #include "gamg_engine.inc"
 #include "assembly.inc"
+#include "comm.inc"
+
+mi_matrix_s::~mi_matrix_s()
+{
+    for (auto* w : work) delete w;
+    for (auto e : evPool) (void)hipEventDestroy(e);
+    if (dpc) {
+        if (dpc->commStream) (void)hipStreamDestroy(dpc->commStream);
+        if (dpc->evPack) (void)hipEventDestroy(dpc->evPack);
+        if (dpc->evHalo) (void)hipEventDestroy(dpc->evHalo);
+        delete dpc;
+    }
+}

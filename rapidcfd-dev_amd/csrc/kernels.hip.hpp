@@ -375,6 +375,40 @@ __global__ __launch_bounds__(RB) void k_reduce(const double* __restrict__ a, con
     const double t = block_sum<RB>(acc0 + acc1, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
+// k_fold_partials followed by k_reduce_final in one launch, same summation order (distributed path:
+// the local sum wA.pA goes straight into the all-reduce buffer)
+__global__ __launch_bounds__(1024) void k_fold_final(const double* __restrict__ in, int n, double* __restrict__ out)
+{
+    __shared__ double folded[RG];
+    __shared__ double red[RB / 64];
+    double v = 0.0;
+    for (int k = threadIdx.x; k < n; k += 1024) v += in[k];
+    folded[threadIdx.x] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x < RB) {
+#pragma unroll
+        for (int k = 0; k < RG / RB; ++k) t += folded[threadIdx.x + k * RB];
+    }
+    t = wave_sum(t);
+    const int wave = threadIdx.x >> 6;
+    if (wave < RB / 64 && (threadIdx.x & 63) == 0) red[wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = red[0];
+#pragma unroll
+        for (int w = 1; w < RB / 64; ++w) r += red[w];
+        *out = r;
+    }
+}
+// two final reductions in one launch (block b reduces partial_b into out_b)
+__global__ __launch_bounds__(RB) void k_reduce_final2(const double* __restrict__ partialA, double* __restrict__ outA,
+                                                      const double* __restrict__ partialB, double* __restrict__ outB)
+{
+    __shared__ double red[RB / 64];
+    const double t = sum_partials(blockIdx.x == 0 ? partialA : partialB, red);
+    if (threadIdx.x == 0) *(blockIdx.x == 0 ? outA : outB) = t;
+}
 __global__ __launch_bounds__(RB) void k_reduce_final(const double* __restrict__ partial, double* __restrict__ out)
 {
     __shared__ double red[RB / 64];
@@ -466,11 +500,12 @@ __global__ __launch_bounds__(RB) void k_pcg_precond_dot(const PcgState* __restri
 // Fused into the head of this kernel (single-GPU path, partial3 != nullptr): the convergence test of
 // iteration it-1 (k_pcg_final) -- every block evaluates it redundantly from the same partials, block 0
 // records it; a separate launch per iteration is saved.
+template <bool DIST>
 __device__ __forceinline__ bool pcg_test_previous(PcgState* __restrict__ st, int itPrev, const double* __restrict__ partial3,
                                                   double* __restrict__ hist, int histLen, double* red)
 {
     const bool sing = partial3[0] < 0.0; // sum|r| partials are never negative
-    const double s = sum_partials(partial3, red);
+    const double s = DIST ? partial3[0] : sum_partials(partial3, red); // DIST: global sum from the allreduce
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (sing) { if (lead) { st->singular = 1; st->done = 1; } return false; } // `break`: nIterations not incremented
     const double res = s / st->normFactor;
@@ -495,7 +530,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
 {
     if (st->done) return;
     __shared__ double red[RB / 64];
-    if (!DIST && partial3 && it > 0 && !pcg_test_previous(st, it - 1, partial3, hist, histLen, red)) return;
+    if (partial3 && it > 0 && !pcg_test_previous<DIST>(st, it - 1, partial3, hist, histLen, red)) return;
     const double wArA = DIST ? partial1[0] : sum_partials(partial1, red); // DIST: global sum from the allreduce
     const double beta = (it == 0) ? 0.0 : wArA / st->wArA[(it & 1) ^ 1];
     const bool first = (it == 0);

@@ -39,6 +39,8 @@ class SolverControls(C.Structure):
 
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
+    "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
+    "mi_dpcg_comm_iterate",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
     "mi_addr_create", "mi_addr_create_coupled", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
     "mi_addr_n_ext", "mi_addr_cell_perm", "mi_addr_stats", "mi_addr_patch_offsets",
@@ -227,6 +229,30 @@ class Addressing:
             self.h = C.c_void_p()
 
 
+class Comm:
+    """RCCL communicator of one rank (mi_comm_*).  ``unique_id()`` on rank 0, ship the 128 bytes to every rank."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        _chk(lib().mi_comm_unique_id(buf, C.c_int32(128)))
+        return bytes(buf)
+
+    def __init__(self, ctx: "Context", n_ranks: int, rank: int, uid: bytes):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.n_ranks, self.rank = n_ranks, rank
+        _chk(lib().mi_comm_create(ctx.h, C.c_int32(n_ranks), C.c_int32(rank), C.c_char_p(uid), C.byref(self.h)))
+
+    def allreduce_sum(self, t):
+        _chk(lib().mi_comm_allreduce_sum(self.h, _ptr(t), C.c_int64(t.numel())))
+
+    def close(self):
+        if self.h:
+            lib().mi_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Matrix:
     """lduMatrix coefficients bound to an :class:`Addressing`."""
 
@@ -351,6 +377,16 @@ class Matrix:
         out["done"] = int(done.value)
         out["history"] = hist[~np.isnan(hist)].copy()
         return out
+
+    def dpcg_comm_begin(self, reduce: "Comm", halo: "Comm", patch_rank, patch_nbr_patch=None, n_global=0):
+        pr = np.ascontiguousarray(patch_rank, dtype=np.int32)
+        pn = None if patch_nbr_patch is None else np.ascontiguousarray(patch_nbr_patch, dtype=np.int32)
+        I32 = C.POINTER(C.c_int32)
+        _chk(lib().mi_dpcg_comm_begin(self.h, reduce.h, halo.h, pr.ctypes.data_as(I32) if pr.size else I32(),
+                                      pn.ctypes.data_as(I32) if pn is not None and pn.size else I32(), C.c_int64(n_global)))
+
+    def dpcg_comm_iterate(self, n_iters: int, time_amul: bool = False):
+        _chk(lib().mi_dpcg_comm_iterate(self.h, C.c_int32(n_iters), C.c_int32(1 if time_amul else 0)))
 
     def event_record(self, idx: int):
         _chk(lib().mi_event_record(self.h, C.c_int32(idx)))

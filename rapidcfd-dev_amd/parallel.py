@@ -28,6 +28,7 @@ check the exchange/reduction logic with the ``gloo`` backend on CPU.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -102,7 +103,12 @@ class DistributedPCG:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.nbrs: List[int] = [itf.nbr_domain for itf in sub.interfaces]
-        if len(set(self.nbrs)) != len(self.nbrs):
+        self.nbr_patches: List[int] = [itf.nbr_patch for itf in sub.interfaces]
+        # host loop: "native" = the engine's C++ loop calling RCCL directly (mi_dpcg_comm_*), "torch" = this
+        # module's loop over torch.distributed.  Both run the same device phases; the injected test backend
+        # (numpy over gloo) always uses the torch loop.
+        self.driver = "torch" if ops is not None or torch.device(device).type != "cuda" else os.environ.get("MI_DPCG_DRIVER", "native")
+        if self.driver == "torch" and len(set(self.nbrs)) != len(self.nbrs):
             raise ValueError("one processor patch per neighbour rank is supported (NCCL p2p is matched per peer, in order)")
         self.sizes = [len(itf.face_cells) for itf in sub.interfaces]
         self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
@@ -120,6 +126,17 @@ class DistributedPCG:
         o = self.ops
         self._s01, self._s2, self._s3, self._s4 = o.scal[0:2], o.scal[2:3], o.scal[3:4], o.scal[4:5]
         self._p2p = {}
+        self.comms = None
+        if self.driver == "native":
+            ids = [None]
+            if self.rank == 0:
+                ids = [[eng.Comm.unique_id(), eng.Comm.unique_id()]]
+            if dist.is_initialized() and self.world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            one = os.environ.get("MI_DPCG_ONE_COMM", "0") == "1"
+            reduce_c = eng.Comm(ctx, self.world, self.rank, ids[0][0])
+            halo_c = reduce_c if one else eng.Comm(ctx, self.world, self.rank, ids[0][1])
+            self.comms = (reduce_c, halo_c)
 
     # -- collectives ----------------------------------------------------------
     def _allreduce(self, t):
@@ -155,6 +172,11 @@ class DistributedPCG:
         self.history_len = max_iter + 2
         o.set_initial(psi0)
         o.begin(tolerance=tolerance, relTol=rel_tol, maxIter=max_iter, minIter=min_iter, history_len=self.history_len)
+        self.it = 0
+        self.max_iter, self.min_iter = max_iter, min_iter
+        if self.driver == "native":
+            o.mat.dpcg_comm_begin(self.comms[0], self.comms[1], self.nbrs, self.nbr_patches, self.n_global)
+            return
         o.phase(0)
         self._start_exchange(o.psi)()
         o.phase(1)
@@ -170,6 +192,15 @@ class DistributedPCG:
     def iterate(self, n_iters: int, time_amul: bool = False):
         """enqueue n_iters iterations (device no-ops once converged); no host synchronisation."""
         o = self.ops
+        import time
+        t0 = time.perf_counter()
+        if self.driver == "native":
+            o.mat.dpcg_comm_iterate(n_iters, time_amul)
+            self.it += n_iters
+            self.last_enqueue_s = time.perf_counter() - t0   # host time to enqueue (no synchronisation inside)
+            if time_amul:
+                return sum(o.event_elapsed_ms(2 * k, 2 * k + 1) for k in range(n_iters))
+            return None
         for k in range(n_iters):
             it = self.it
             o.phase(10, it)
@@ -187,6 +218,7 @@ class DistributedPCG:
             self.it += 1
         if n_iters > 0:
             o.phase(14, self.it - 1)
+        self.last_enqueue_s = time.perf_counter() - t0
         if time_amul:
             return sum(o.event_elapsed_ms(2 * k, 2 * k + 1) for k in range(n_iters))
         return None

@@ -394,3 +394,23 @@ def test_cyclic_interfaces(pkg, orc, ctx, symmetric):
         ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV", tolerance=1e-10, maxIter=300)
     _check_hist(perf, ref)
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+def test_native_rccl_loop_self_exchange(pkg, orc, ctx):
+    """C++ host loop over RCCL (mi_dpcg_comm_*) on a 1-rank communicator: the y-periodic box is posed with two
+    PROCESSOR patches whose neighbour rank is this rank, so pack -> ncclSend/ncclRecv -> ext region -> boundary
+    tiles and the scalar all-reduces all run for real; the oracle solves the same system as one domain."""
+    syn, par = pkg.synthetic, pkg.parallel
+    case = syn.add_cyclic_y(syn.box_case(20, 16, 12, symmetric=True))
+    S = orc.System([case])
+    ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-9, maxIter=400)
+    solver = par.DistributedPCG(ctx, case, "cuda:0", precond="diagonal", n_global=case.n_cells)
+    assert solver.driver == "native"
+    st = solver.solve(tolerance=1e-9, max_iter=400)
+    _check_hist(st, ref)
+    got = solver.ops.solution()
+    assert np.max(np.abs(got - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+    # raw all-reduce on the communicator
+    t = torch.arange(5, dtype=torch.float64, device="cuda:0")
+    solver.comms[0].allreduce_sum(t); torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(5, dtype=torch.float64))
