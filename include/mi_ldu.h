@@ -333,6 +333,15 @@ int mi_comm_unique_id(void *id_out, int32_t len);
 int mi_comm_create(mi_ctx_t ctx, int32_t n_ranks, int32_t rank, const void *id, mi_comm_t *out);
 int mi_comm_destroy(mi_comm_t comm);
 int mi_comm_allreduce_sum(mi_comm_t comm, double *buf_dev, int64_t n);
+/* Attach communicators to a matrix: from here on it behaves like the reference's lduMatrix on a decomposed
+ * case -- mi_amul/tmul/residual/H/jacobi_smooth exchange the processor-patch values themselves
+ * (init/updateMatrixInterfaces), every global sum inside the solvers is all-reduced, and
+ * mi_pcg_solve / mi_pbicg_solve / mi_pbicgstab_solve / mi_smooth_solve solve the GLOBAL system; all ranks call
+ * them together, like the MPI ranks of the reference.  (mi_pcg_solve: diagonal/none run the device-resident
+ * phase pipeline, AINV a host-stepped loop.)  GAMG is not communicator-aware yet.                          */
+int mi_matrix_attach_comm(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,
+                          const int32_t *patch_nbr_patch_or_null, int64_t n_global_cells);
+int mi_matrix_detach_comm(mi_matrix_t m);
 int mi_dpcg_comm_begin(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,
                        const int32_t *patch_nbr_patch_or_null, int64_t n_global_cells);
 int mi_dpcg_comm_iterate(mi_matrix_t m, int32_t n_iters, int32_t record_amul_events);

@@ -104,7 +104,8 @@ struct mi_matrix_s {
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
     bool pcgActive = false;
     std::vector<hipEvent_t> evPool;
-    struct mi_dpcg_comm_s* dpc = nullptr; // C++-driven distributed session (comm.inc)
+    struct mi_dpcg_comm_s* dpc = nullptr; // attached RCCL communicators + exchange plan (comm.inc)
+    DevBuf<double> sendBuf, dscal;         // halo send buffer / scalar block of engine-driven distributed solves
     ~mi_matrix_s();
     int vec(size_t k, double** out)
     {
@@ -118,6 +119,17 @@ struct mi_matrix_s {
         return MI_OK;
     }
 };
+
+// communicator hooks (comm.inc): with a communicator attached to the matrix every operator that reads the
+// coupled-patch neighbour values exchanges them itself and every global sum is all-reduced over the ranks
+bool comm_remote(const mi_matrix_s* m);                         // attached and has processor patches
+bool comm_attached(const mi_matrix_s* m);
+int64_t comm_n_global(const mi_matrix_s* m);                     // global cell count (gAverage)
+int comm_exchange_start(mi_matrix_s* m, const double* send, double* vec);
+int comm_exchange_wait(mi_matrix_s* m);
+int comm_allreduce(mi_matrix_s* m, double* dev, size_t n);
+int pcg_solve_attached(mi_matrix_s* m, double* psi_io, const double* source, const mi_solver_controls* ctl, int precond,
+                       mi_solver_perf* perf, double* hist_host, int32_t hist_len);
 
 // ---------------------------------------------------------------------------
 // context
@@ -421,6 +433,25 @@ int ensure_rD(mi_matrix_s* m)
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Tile operator over all tiles.  With a communicator attached the neighbour values of the processor patches
+// are exchanged here (init/updateMatrixInterfaces, lduMatrixUpdateMatrixInterfaces.C:30-276): pack, send/recv
+// on the halo stream into x's ext region, interior tiles meanwhile, boundary tiles after the wait.  Without
+// one the ext region holds whatever the caller placed there (mi_matrix_set_ext).
+template <int OP>
+int tile_op(mi_matrix_s* m, bool trans, const double* x, const double* b, const double* rD, double* y, double omega,
+            double* dotPartial = nullptr)
+{
+    constexpr bool readsNbr = (OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_JACOBI);
+    if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial);
+    mi_addr_s* a = m->addr;
+    if (m->sendBuf.n < (size_t)a->L.nExt) MICHK(m->sendBuf.alloc((size_t)a->L.nExt));
+    MICHK(mi_halo_pack_engine(a, x, m->sendBuf.p));
+    MICHK(comm_exchange_start(m, m->sendBuf.p, const_cast<double*>(x)));
+    MICHK(launch_tile<OP>(m, trans, x, b, rD, y, omega, 1, dotPartial));
+    MICHK(comm_exchange_wait(m));
+    return launch_tile<OP>(m, trans, x, b, rD, y, omega, 2, dotPartial ? dotPartial + a->nInterior : nullptr);
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -495,7 +526,7 @@ int caller_op(mi_matrix_s* m, bool trans, const double* x, const double* b, doub
     MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1));
     if (x) k_gather_perm<<<RG, RB, 0, s>>>(x, a->e2c.p, v0, a->L.nCells);
     if (b) { MICHK(m->vec(2, &v2)); k_gather_perm<<<RG, RB, 0, s>>>(b, a->e2c.p, v2, a->L.nCells); }
-    MICHK(launch_tile<OP>(m, trans, v0, v2, nullptr, v1, 0.0, 0));
+    MICHK(tile_op<OP>(m, trans, v0, v2, nullptr, v1, 0.0));
     k_scatter_perm<<<RG, RB, 0, s>>>(v1, a->e2c.p, y, a->L.nCells);
     HIPCHK(hipGetLastError());
     return MI_OK;
@@ -585,9 +616,9 @@ extern "C" int mi_jacobi_smooth(mi_matrix_t m, double omega, double* psi, const 
     double *cur = v0, *nxt = v1;
     for (int sw = 0; sw < n_sweeps; ++sw) {
         // ping-pong instead of the reference's `psi = Apsi` copy (JacobiSmoother.C:146)
-        if (a->L.nExt > 0 && sw > 0)
+        if (a->L.nExt > 0 && sw > 0 && !comm_remote(m))
             HIPCHK(hipMemcpyAsync(cur + a->L.nCells, nxt + a->L.nCells, sizeof(double) * (size_t)a->L.nExt, hipMemcpyDeviceToDevice, s));
-        MICHK(launch_tile<OP_JACOBI>(m, false, cur, v2, nullptr, nxt, omega, 0));
+        MICHK(tile_op<OP_JACOBI>(m, false, cur, v2, nullptr, nxt, omega));
         double* t = cur; cur = nxt; nxt = t;
     }
     k_scatter_perm<<<RG, RB, 0, s>>>(cur, a->e2c.p, psi, a->L.nCells);
@@ -649,6 +680,7 @@ int reduce_sync(mi_matrix_s* m, const double* a, const double* b, double* out)
     k_reduce<KIND><<<RG, RB, 0, c->stream>>>(a, b, (int64_t)m->addr->L.nCells, c->partial.p);
     k_reduce_final<<<1, RB, 0, c->stream>>>(c->partial.p, c->scalars.p);
     HIPCHK(hipGetLastError());
+    if (comm_attached(m)) MICHK(comm_allreduce(m, c->scalars.p, 1)); // Foam::reduce(..., sumOp<scalar>())
     HIPCHK(hipMemcpyAsync(c->hostScal, c->scalars.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = c->hostScal[0];
@@ -672,15 +704,20 @@ int solve_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* 
     h.tolerance = ctl->tolerance; h.relTol = ctl->relTol; h.maxIter = ctl->maxIter; h.minIter = ctl->minIter;
     *c->hostState = h;
     HIPCHK(hipMemcpyAsync(c->state.p, c->hostState, sizeof(PcgState), hipMemcpyHostToDevice, s));
-    MICHK(launch_tile<OP_AMUL>(m, false, psi_e, nullptr, nullptr, wA, 0.0, 0));
+    MICHK(tile_op<OP_AMUL>(m, false, psi_e, nullptr, nullptr, wA, 0.0));
     k_sub<<<RG, RB, 0, s>>>(rA, src_e, wA, n);
     MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, tmp, 0.0, 0));
     // gAverage(psi) (gpuFieldCommonFunctions.C:611-634): needs the host for the division by N
     double sumPsi = 0;
     MICHK(reduce_sync<RED_SUM>(m, psi_e, nullptr, &sumPsi));
-    const double avg = sumPsi / (double)n;
+    const double avg = sumPsi / (double)(comm_attached(m) ? comm_n_global(m) : n);
     k_normfactor<<<RG, RB, 0, s>>>(wA, src_e, tmp, avg, n, c->partial.p);
     k_reduce<RED_MAG><<<RG, RB, 0, s>>>(rA, nullptr, n, c->partial.p + RG);
+    if (comm_attached(m)) { // the two sums are global (lduMatrixSolver.C:182-236, gSumMag)
+        k_reduce_final2<<<2, RB, 0, s>>>(c->partial.p, c->scalars.p + 1, c->partial.p + RG, c->scalars.p + 2);
+        MICHK(comm_allreduce(m, c->scalars.p + 1, 2));
+        k_solve_init<true><<<1, RB, 0, s>>>(c->state.p, c->scalars.p + 1, c->scalars.p + 2, m->hist.p, histLen);
+    } else
     k_solve_init<false><<<1, RB, 0, s>>>(c->state.p, c->partial.p, c->partial.p + RG, m->hist.p, histLen);
     HIPCHK(hipGetLastError());
     return MI_OK;
@@ -766,6 +803,7 @@ extern "C" int mi_pcg_begin(mi_matrix_t m, const double* psi0, const double* sou
 {
     if (!m || !psi0 || !source || !ctl) return fail(MI_ERR_ARG, "mi_pcg_begin: bad argument");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    if (comm_attached(m)) return fail(MI_ERR_STATE, "mi_pcg_begin: a communicator is attached; use mi_pcg_solve or the mi_dpcg_* session");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
     hipStream_t s = a->ctx->stream;
@@ -821,6 +859,8 @@ extern "C" int mi_pcg_solve(mi_matrix_t m, double* psi, const double* source, co
                             int precond, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
 {
     if (!m || !psi || !source || !ctl) return fail(MI_ERR_ARG, "mi_pcg_solve: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    if (comm_attached(m)) return pcg_solve_attached(m, psi, source, ctl, precond, perf, hist_host, hist_len);
     const int histLen = ctl->maxIter + 2;
     MICHK(mi_pcg_begin(m, psi, source, ctl, precond, histLen));
     mi_ctx_s* c = m->addr->ctx;
@@ -1002,7 +1042,7 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
     k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
     HostPerf hp; std::vector<double> hist;
     MICHK(host_prologue(m, ctl, psi, src, wA, rA, pA, hp, hist));
-    MICHK(launch_tile<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0, 0));
+    MICHK(tile_op<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0));
     k_sub<<<RG, RB, 0, s>>>(rT, src, wT, n);
     double wArT = SP_GREAT, wArTold = wArT;
     if (hp.minIter > 0 || !hp.checkConvergence()) {
@@ -1019,8 +1059,8 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
                 k_xpsy<<<RG, RB, 0, s>>>(pA, wA, beta, pA, n);
                 k_xpsy<<<RG, RB, 0, s>>>(pT, wT, beta, pT, n);
             }
-            MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0));
-            MICHK(launch_tile<OP_AMUL>(m, true, pT, nullptr, nullptr, wT, 0.0, 0));
+            MICHK(tile_op<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0));
+            MICHK(tile_op<OP_AMUL>(m, true, pT, nullptr, nullptr, wT, 0.0));
             double wApT = 0;
             MICHK(reduce_sync<RED_PROD>(m, wA, pT, &wApT));
             if (hp.checkSingularity(fabs(wApT) / hp.normFactor)) break;
@@ -1070,7 +1110,7 @@ extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* s
                 k_xpsy<<<RG, RB, 0, s>>>(pA, rA, beta, res1, n);    // pA = rA + beta*result1
             }
             MICHK(precond_engine(m, precond, false, pA, yA));
-            MICHK(launch_tile<OP_AMUL>(m, false, yA, nullptr, nullptr, AyA, 0.0, 0));
+            MICHK(tile_op<OP_AMUL>(m, false, yA, nullptr, nullptr, AyA, 0.0));
             double rA0AyA = 0;
             MICHK(reduce_sync<RED_PROD>(m, rA0, AyA, &rA0AyA));
             alpha = rA0rA / rA0AyA;
@@ -1085,7 +1125,7 @@ extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* s
                 return finish_host(m, hp, hist, psi, psi_io, perf, hist_host, hist_len);
             }
             MICHK(precond_engine(m, precond, false, sA, zA));
-            MICHK(launch_tile<OP_AMUL>(m, false, zA, nullptr, nullptr, tA, 0.0, 0));
+            MICHK(tile_op<OP_AMUL>(m, false, zA, nullptr, nullptr, tA, 0.0));
             double tAtA = 0, tAsA = 0;
             MICHK(reduce_sync<RED_PROD>(m, tA, tA, &tAtA));
             MICHK(reduce_sync<RED_PROD>(m, tA, sA, &tAsA));
@@ -1120,7 +1160,7 @@ extern "C" int mi_smooth_solve(mi_matrix_t m, double* psi_io, const double* sour
     double *cur = psi, *nxt = psi2;
     auto sweeps = [&](int cnt) -> int {
         for (int sw = 0; sw < cnt; ++sw) {
-            MICHK(launch_tile<OP_JACOBI>(m, false, cur, src, nullptr, nxt, omega, 0));
+            MICHK(tile_op<OP_JACOBI>(m, false, cur, src, nullptr, nxt, omega));
             double* t = cur; cur = nxt; nxt = t;
         }
         return MI_OK;
@@ -1133,7 +1173,7 @@ extern "C" int mi_smooth_solve(mi_matrix_t m, double* psi_io, const double* sour
         if (hp.minIter > 0 || !hp.checkConvergence()) {
             do {
                 MICHK(sweeps(n_sweeps));
-                MICHK(launch_tile<OP_RESIDUAL>(m, false, cur, src, nullptr, rA, 0.0, 0));
+                MICHK(tile_op<OP_RESIDUAL>(m, false, cur, src, nullptr, rA, 0.0));
                 double sm = 0;
                 MICHK(reduce_sync<RED_MAG>(m, rA, nullptr, &sm));
                 hp.finalResidual = sm / hp.normFactor;

@@ -40,7 +40,7 @@ class SolverControls(C.Structure):
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
-    "mi_dpcg_comm_iterate",
+    "mi_dpcg_comm_iterate", "mi_matrix_attach_comm", "mi_matrix_detach_comm",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
     "mi_addr_create", "mi_addr_create_coupled", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
     "mi_addr_n_ext", "mi_addr_cell_perm", "mi_addr_stats", "mi_addr_patch_offsets",
@@ -377,6 +377,19 @@ class Matrix:
         out["done"] = int(done.value)
         out["history"] = hist[~np.isnan(hist)].copy()
         return out
+
+    def attach_comm(self, reduce: "Comm", halo: "Comm", patch_rank, patch_nbr_patch=None, n_global=0):
+        """decomposed-case behaviour for every operator and solver of this matrix (mi_matrix_attach_comm)"""
+        pr = np.ascontiguousarray(patch_rank, dtype=np.int32)
+        pn = None if patch_nbr_patch is None else np.ascontiguousarray(patch_nbr_patch, dtype=np.int32)
+        I32 = C.POINTER(C.c_int32)
+        _chk(lib().mi_matrix_attach_comm(self.h, reduce.h, halo.h, pr.ctypes.data_as(I32) if pr.size else I32(),
+                                         pn.ctypes.data_as(I32) if pn is not None and pn.size else I32(), C.c_int64(n_global)))
+        self._comms = (reduce, halo)
+
+    def detach_comm(self):
+        _chk(lib().mi_matrix_detach_comm(self.h))
+        self._comms = None
 
     def dpcg_comm_begin(self, reduce: "Comm", halo: "Comm", patch_rank, patch_nbr_patch=None, n_global=0):
         pr = np.ascontiguousarray(patch_rank, dtype=np.int32)

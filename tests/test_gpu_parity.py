@@ -414,3 +414,46 @@ def test_native_rccl_loop_self_exchange(pkg, orc, ctx):
     t = torch.arange(5, dtype=torch.float64, device="cuda:0")
     solver.comms[0].allreduce_sum(t); torch.cuda.synchronize()
     assert torch.equal(t.cpu(), torch.arange(5, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_attached_comm_operators_and_solvers(pkg, orc, ctx, symmetric):
+    """mi_matrix_attach_comm on a 1-rank RCCL communicator.  The y-periodic box is posed with PROCESSOR patches whose
+    neighbour rank is this rank: every operator exchanges its halo through ncclSend/ncclRecv and every solver
+    all-reduces its sums, exactly the code an N-rank run executes; the oracle treats the same system as one domain."""
+    syn, eng = pkg.synthetic, pkg.engine
+    case = syn.add_cyclic_y(syn.box_case(18, 12, 10, symmetric=symmetric), asym_shift=0.0 if symmetric else 0.25)
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, [i.face_cells for i in case.interfaces])
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    for p, itf in enumerate(case.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if symmetric else dev(itf.int_coeffs))
+    uid = eng.Comm.unique_id()
+    comm = eng.Comm(ctx, 1, 0, uid)
+    mat.attach_comm(comm, comm, [0, 0], [1, 0], n_global=case.n_cells)
+    S = orc.System([case])
+    n = case.n_cells
+    x = syn.splitmix_uniform(3, n) - 0.5
+    out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+    mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
+    mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
+    psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 3)
+    assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 3))
+
+    def run(fn_eng, fn_orc, **kw):
+        psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        perf = fn_eng(psi, dev(case.source), **kw)
+        ref_psi, ref = fn_orc(np.zeros(n), case.source, **kw)
+        _check_hist(perf, ref)
+        assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+
+    if symmetric:
+        run(mat.pcg, S.pcg, precond="diagonal", tolerance=1e-9, maxIter=500)
+        run(mat.pcg, S.pcg, precond="AINV", tolerance=1e-9, maxIter=500)
+    else:
+        run(mat.pbicg, S.pbicg, precond="AINV", tolerance=1e-10, maxIter=300)
+        run(mat.pbicgstab, S.pbicgstab, precond="diagonal", tolerance=1e-10, maxIter=300)
+    run(mat.smooth_solve, S.smooth_solve, n_sweeps=2, tolerance=1e-4, maxIter=400)
+    mat.detach_comm()
+    comm.close()
