@@ -236,6 +236,17 @@ typedef struct {
 } mi_gamg_controls;
 int mi_gamg_create(mi_addr_t fine_addr, const double *face_weights_host, int32_t n_cells_in_coarsest_level,
                    int forward_init, mi_gamg_t *out);
+/* Same for a matrix with coupled patches.  Cyclic (local) patches need no communicator (pass NULLs; mi_gamg_create
+ * does that).  Processor patches (processorGAMGInterface, solvers/GAMG/interfaces/processorGAMGInterface/
+ * processorGAMGInterface.C:54-245; GAMGAgglomerateLduAddressing.C:464-520) need the communicators the matrix is
+ * attached to: the ranks agree on when to stop (GAMGAgglomeration.C:72-81), exchange the restrict addressing of the
+ * patch cells on every level, every level matrix exchanges its own halo, the scale factors are all-reduced
+ * (GAMGSolverScale.C:104-107) and the coarsest level is the GLOBAL system (LUscalarMatrix.C:57-150) whose dense
+ * inverse every rank holds the rows of.  All ranks call create/solve together.                                  */
+int mi_gamg_create_coupled(mi_addr_t fine_addr, const double *face_weights_host,
+                           int32_t n_cells_in_coarsest_level, int forward_init, mi_comm_t reduce_or_null,
+                           mi_comm_t halo_or_null, const int32_t *patch_rank,
+                           const int32_t *patch_nbr_patch_or_null, mi_gamg_t *out);
 int mi_gamg_destroy(mi_gamg_t g);
 int32_t mi_gamg_n_levels(mi_gamg_t g);
 int mi_gamg_forward_out(mi_gamg_t g);

@@ -2,7 +2,8 @@
  * gamg_oracle.c -- CPU ORACLE for the GAMG solver (test infrastructure, NOT product code;
  * see the header of ldu_oracle.c: PARITY UNPINNED, the reference ships no tests).
  *
- * Restates, single domain (no coupled interfaces), paths relative to
+ * Restates (single domain: orc_gamg_build/solve; coupled patches and decomposed cases: orc_gamg_build_sys/solve_sys
+ * at the end of the file), paths relative to
  * /root/reference/src/OpenFOAM/matrices/lduMatrix/solvers/GAMG/ :
  *   - pair agglomeration        GAMGAgglomerations/pairGAMGAgglomeration/pairGAMGAgglomerate.C:31-313
  *   - coarse addressing         GAMGAgglomerations/GAMGAgglomeration/GAMGAgglomerateLduAddressing.C:245-461
@@ -21,12 +22,12 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef int32_t label;
-typedef double scalar;
+#include "ldu_oracle.h"
 
 /* from ldu_oracle.c */
-typedef struct orc_system orc_system;
 orc_system *orc_sys_create(int nDomains);
+int orc_sys_add_interface(orc_system *s, int d, label nbrDomain, label nbrPatch, label nFaces, const label *faceCells,
+                          const scalar *bouCoeffs, const scalar *intCoeffs);
 void orc_sys_set_domain(orc_system *s, int d, label nCells, label nFaces, const label *lower, const label *upper,
                         const scalar *diag, const scalar *lowerC, const scalar *upperC);
 void orc_sys_destroy(orc_system *s);
@@ -410,4 +411,314 @@ void orc_gamg_coarse_matrix(const gamg_hier *H, int upToLevel, const scalar *dia
     memcpy(cUpper, pu, sizeof(scalar) * (size_t)L->nCoarseFaces);
     if (asym && cLower) memcpy(cLower, pl, sizeof(scalar) * (size_t)L->nCoarseFaces);
     free(pd); free(pu); free(pl);
+}
+
+
+/* ============================================================================================
+ * Coupled patches / decomposed case: every domain of an orc_system agglomerates on its own (the
+ * reference runs pairGAMGAgglomeration per processor), the domains agree on when to stop
+ * (GAMGAgglomeration.C:72-81), every coupled patch is agglomerated from the coarse-cell ids on
+ * both of its sides (processorGAMGInterface.C:54-128, cyclicGAMGInterface.C; exchange of the ids:
+ * GAMGAgglomerateLduAddressing.C:464-520), its coefficients are summed per coarse interface face
+ * (GAMGInterface::agglomerateCoeffs), every level is again an orc_system with interfaces, the
+ * scale factors are global sums (GAMGSolverScale.C:104-107) and the coarsest level is the global
+ * system solved directly (LUscalarMatrix.C:57-150,275-400).
+ * ============================================================================================ */
+typedef struct {
+    label nFine, nCoarse;      /* patch faces on the fine / coarse side of the level */
+    label *faceRestrict;       /* [nFine] -> coarse interface face */
+    label *faceCells;          /* [nCoarse] coarse cell on this side */
+} gamg_patch;
+
+typedef struct {
+    int nDomains, nLevels, forwardOut;
+    gamg_level **lev;          /* [d][l] */
+    gamg_patch ***patch;       /* [d][l][p] */
+    int *nPatches;             /* [d] */
+} gamg_sys_hier;
+
+gamg_sys_hier *orc_gamg_build_sys(const orc_system *S, const scalar *faceWeights /* per domain, concatenated */,
+                                  label nCellsInCoarsestLevel, int forwardInit)
+{
+    const int maxLevels = 50, D = S->nDomains;
+    gamg_sys_hier *H = (gamg_sys_hier *)calloc(1, sizeof(*H));
+    H->nDomains = D;
+    H->lev = (gamg_level **)calloc((size_t)D, sizeof(*H->lev));
+    H->patch = (gamg_patch ***)calloc((size_t)D, sizeof(*H->patch));
+    H->nPatches = (int *)calloc((size_t)D, sizeof(int));
+    scalar **w = (scalar **)calloc((size_t)D, sizeof(*w));
+    const label **lo = (const label **)calloc((size_t)D, sizeof(*lo)), **up = (const label **)calloc((size_t)D, sizeof(*up));
+    label *nFine = (label *)calloc((size_t)D, sizeof(label)), *nF = (label *)calloc((size_t)D, sizeof(label));
+    label ***pfc = (label ***)calloc((size_t)D, sizeof(*pfc)); /* current fine faceCells [d][p] */
+    label **pn = (label **)calloc((size_t)D, sizeof(*pn));     /* their sizes */
+    int64_t woff = 0;
+    for (int d = 0; d < D; d++) {
+        const orc_domain *m = &S->dom[d];
+        H->lev[d] = (gamg_level *)calloc((size_t)maxLevels, sizeof(gamg_level));
+        H->patch[d] = (gamg_patch **)calloc((size_t)maxLevels, sizeof(gamg_patch *));
+        H->nPatches[d] = m->nIfaces;
+        w[d] = (scalar *)malloc(sizeof(scalar) * (size_t)(m->nFaces ? m->nFaces : 1));
+        memcpy(w[d], faceWeights + woff, sizeof(scalar) * (size_t)m->nFaces); woff += m->nFaces;
+        lo[d] = m->lower; up[d] = m->upper; nFine[d] = m->nCells; nF[d] = m->nFaces;
+        pfc[d] = (label **)calloc((size_t)(m->nIfaces ? m->nIfaces : 1), sizeof(label *));
+        pn[d] = (label *)calloc((size_t)(m->nIfaces ? m->nIfaces : 1), sizeof(label));
+        for (int p = 0; p < m->nIfaces; p++) {
+            pn[d][p] = m->ifaces[p].nFaces;
+            pfc[d][p] = (label *)malloc(sizeof(label) * (size_t)(pn[d][p] ? pn[d][p] : 1));
+            memcpy(pfc[d][p], m->ifaces[p].faceCells, sizeof(label) * (size_t)pn[d][p]);
+        }
+    }
+    int forward = forwardInit;
+    while (H->nLevels < maxLevels - 1) {
+        const int l = H->nLevels;
+        int cont = 1;
+        for (int d = 0; d < D; d++) {
+            gamg_level *L = &H->lev[d][l];
+            L->nFine = nFine[d]; L->nFineFaces = nF[d];
+            L->restrictMap = (label *)malloc(sizeof(label) * (size_t)nFine[d]);
+            L->nCoarse = pair_agglomerate(nFine[d], nF[d], lo[d], up[d], w[d], forward, L->restrictMap);
+            if (!(L->nCoarse >= nCellsInCoarsestLevel) || L->nCoarse == nFine[d]) cont = 0; /* andOp over the processors */
+        }
+        forward = !forward;
+        if (!cont) { for (int d = 0; d < D; d++) { free(H->lev[d][l].restrictMap); H->lev[d][l].restrictMap = NULL; } break; }
+        for (int d = 0; d < D; d++) {
+            gamg_level *L = &H->lev[d][l];
+            coarse_addressing(L, lo[d], up[d]);
+            scalar *cw = (scalar *)calloc((size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1), sizeof(scalar));
+            for (label f = 0; f < nF[d]; f++) if (L->faceRestrict[f] >= 0) cw[L->faceRestrict[f]] += w[d][f];
+            free(w[d]); w[d] = cw;
+        }
+        /* coupled patches: one coarse interface face per distinct (my coarse cell, neighbour's coarse cell) pair,
+         * in order of first appearance (both sides visit matching faces in the same order) */
+        for (int d = 0; d < D; d++) {
+            const orc_domain *m = &S->dom[d];
+            H->patch[d][l] = (gamg_patch *)calloc((size_t)(m->nIfaces ? m->nIfaces : 1), sizeof(gamg_patch));
+            for (int p = 0; p < m->nIfaces; p++) {
+                const int nd = m->ifaces[p].nbrDomain, np = m->ifaces[p].nbrPatch;
+                gamg_patch *P = &H->patch[d][l][p];
+                const label n = pn[d][p];
+                P->nFine = n;
+                P->faceRestrict = (label *)malloc(sizeof(label) * (size_t)(n ? n : 1));
+                P->faceCells = (label *)malloc(sizeof(label) * (size_t)(n ? n : 1));
+                label *nbr = (label *)malloc(sizeof(label) * (size_t)(n ? n : 1));
+                label nc = 0;
+                for (label i = 0; i < n; i++) {
+                    const label mine = H->lev[d][l].restrictMap[pfc[d][p][i]];
+                    const label theirs = H->lev[nd][l].restrictMap[pfc[nd][np][i]];
+                    label k;
+                    for (k = 0; k < nc; k++) if (P->faceCells[k] == mine && nbr[k] == theirs) break;
+                    if (k == nc) { P->faceCells[nc] = mine; nbr[nc] = theirs; nc++; }
+                    P->faceRestrict[i] = k;
+                }
+                P->nCoarse = nc;
+                free(nbr);
+            }
+        }
+        for (int d = 0; d < D; d++) {
+            const orc_domain *m = &S->dom[d];
+            gamg_level *L = &H->lev[d][l];
+            for (int p = 0; p < m->nIfaces; p++) {
+                gamg_patch *P = &H->patch[d][l][p];
+                free(pfc[d][p]);
+                pfc[d][p] = (label *)malloc(sizeof(label) * (size_t)(P->nCoarse ? P->nCoarse : 1));
+                memcpy(pfc[d][p], P->faceCells, sizeof(label) * (size_t)P->nCoarse);
+                pn[d][p] = P->nCoarse;
+            }
+            nFine[d] = L->nCoarse; nF[d] = L->nCoarseFaces; lo[d] = L->cLower; up[d] = L->cUpper;
+        }
+        H->nLevels++;
+    }
+    H->forwardOut = forward;
+    for (int d = 0; d < D; d++) {
+        free(w[d]);
+        for (int p = 0; p < S->dom[d].nIfaces; p++) free(pfc[d][p]);
+        free(pfc[d]); free(pn[d]);
+    }
+    free(w); free(lo); free(up); free(nFine); free(nF); free(pfc); free(pn);
+    return H;
+}
+
+int orc_gamg_sys_n_levels(const gamg_sys_hier *H) { return H->nLevels; }
+void orc_gamg_sys_level_sizes(const gamg_sys_hier *H, int d, int l, label *out4)
+{
+    out4[0] = H->lev[d][l].nFine; out4[1] = H->lev[d][l].nFineFaces; out4[2] = H->lev[d][l].nCoarse; out4[3] = H->lev[d][l].nCoarseFaces;
+}
+void orc_gamg_sys_level_maps(const gamg_sys_hier *H, int d, int l, label *restrictMap, label *cLower, label *cUpper)
+{
+    const gamg_level *L = &H->lev[d][l];
+    if (restrictMap) memcpy(restrictMap, L->restrictMap, sizeof(label) * (size_t)L->nFine);
+    if (cLower) memcpy(cLower, L->cLower, sizeof(label) * (size_t)L->nCoarseFaces);
+    if (cUpper) memcpy(cUpper, L->cUpper, sizeof(label) * (size_t)L->nCoarseFaces);
+}
+label orc_gamg_sys_patch(const gamg_sys_hier *H, int d, int l, int p, label *faceRestrict, label *faceCells)
+{
+    const gamg_patch *P = &H->patch[d][l][p];
+    if (faceRestrict) memcpy(faceRestrict, P->faceRestrict, sizeof(label) * (size_t)P->nFine);
+    if (faceCells) memcpy(faceCells, P->faceCells, sizeof(label) * (size_t)P->nCoarse);
+    return P->nCoarse;
+}
+void orc_gamg_sys_free(gamg_sys_hier *H)
+{
+    for (int d = 0; d < H->nDomains; d++) {
+        for (int l = 0; l < H->nLevels; l++) {
+            gamg_level *L = &H->lev[d][l];
+            free(L->restrictMap); free(L->faceRestrict); free(L->faceFlip); free(L->cLower); free(L->cUpper);
+            for (int p = 0; p < H->nPatches[d]; p++) { free(H->patch[d][l][p].faceRestrict); free(H->patch[d][l][p].faceCells); }
+            free(H->patch[d][l]);
+        }
+        free(H->lev[d]); free(H->patch[d]);
+    }
+    free(H->lev); free(H->patch); free(H->nPatches); free(H);
+}
+
+/* level l+1 system from level l (coefficients by summation, interfaces agglomerated) */
+static orc_system *coarse_system(const gamg_sys_hier *H, int l, const orc_system *F)
+{
+    const int D = H->nDomains;
+    orc_system *C = orc_sys_create(D);
+    for (int d = 0; d < D; d++) {
+        const gamg_level *L = &H->lev[d][l];
+        const orc_domain *fm = &F->dom[d];
+        const int asym = !fm->symmetric;
+        scalar *cd = (scalar *)malloc(sizeof(scalar) * (size_t)L->nCoarse);
+        scalar *cu = (scalar *)malloc(sizeof(scalar) * (size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1));
+        scalar *clw = asym ? (scalar *)malloc(sizeof(scalar) * (size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1)) : NULL;
+        agglomerate_matrix(L, asym, fm->diag, fm->upperC, asym ? fm->lowerC : NULL, cd, cu, clw);
+        orc_sys_set_domain(C, d, L->nCoarse, L->nCoarseFaces, L->cLower, L->cUpper, cd, clw, cu);
+        free(cd); free(cu); free(clw);
+    }
+    for (int d = 0; d < D; d++) {
+        const orc_domain *fm = &F->dom[d];
+        for (int p = 0; p < fm->nIfaces; p++) {
+            const gamg_patch *P = &H->patch[d][l][p];
+            scalar *cb = (scalar *)calloc((size_t)(P->nCoarse ? P->nCoarse : 1), sizeof(scalar));
+            scalar *ci = (scalar *)calloc((size_t)(P->nCoarse ? P->nCoarse : 1), sizeof(scalar));
+            for (label i = 0; i < P->nFine; i++) { cb[P->faceRestrict[i]] += fm->ifaces[p].bouCoeffs[i]; ci[P->faceRestrict[i]] += fm->ifaces[p].intCoeffs[i]; }
+            orc_sys_add_interface(C, d, fm->ifaces[p].nbrDomain, fm->ifaces[p].nbrPatch, P->nCoarse, P->faceCells, cb, ci);
+            free(cb); free(ci);
+        }
+    }
+    return C;
+}
+
+static void sys_restrict(const gamg_sys_hier *H, int l, const orc_system *F, const orc_system *C, const scalar *ff, scalar *cf)
+{
+    for (int d = 0; d < H->nDomains; d++) restrict_field(&H->lev[d][l], ff + F->dom[d].offset, cf + C->dom[d].offset);
+}
+static void sys_prolong(const gamg_sys_hier *H, int l, const orc_system *F, const orc_system *C, const scalar *cf, scalar *ff)
+{
+    for (int d = 0; d < H->nDomains; d++) prolong_field(&H->lev[d][l], cf + C->dom[d].offset, ff + F->dom[d].offset);
+}
+static void sys_scale(const orc_system *A, scalar *field, scalar *Acf, const scalar *source)
+{
+    orc_amul(A, field, Acf);
+    long double num = 0, den = 0;
+    for (int64_t i = 0; i < A->nTotal; i++) { num += (long double)source[i] * field[i]; den += (long double)Acf[i] * field[i]; }
+    scalar dd = (scalar)den;
+    scalar sf = (scalar)num / (dd >= 0 ? dd + G_VSMALL : dd - G_VSMALL);
+    for (int d = 0; d < A->nDomains; d++) {
+        const orc_domain *m = &A->dom[d];
+        for (label i = 0; i < m->nCells; i++) {
+            const int64_t g = m->offset + i;
+            field[g] = fma(sf, field[g], fma(-sf, Acf[g], source[g]) / m->diag[i]);
+        }
+    }
+}
+
+void orc_gamg_solve_sys(const gamg_sys_hier *H, const orc_system *S, scalar *psi, const scalar *source,
+                        const gamg_controls *ctl, gamg_perf *perf, scalar *hist, int histLen)
+{
+    const int nL = H->nLevels;
+    const int asym = !S->dom[0].symmetric;
+    const int doScale = ctl->scaleCorrection < 0 ? !asym : ctl->scaleCorrection;
+    memset(perf, 0, sizeof(*perf));
+    if (nL < 1) { perf->singular = 1; return; }
+    const orc_system **A = (const orc_system **)calloc((size_t)nL + 1, sizeof(*A));
+    A[0] = S;
+    for (int l = 0; l < nL; l++) A[l + 1] = coarse_system(H, l, A[l]);
+    /* coarsest level: the global matrix, dense LU */
+    const orc_system *Ac = A[nL];
+    const int nc = (int)Ac->nTotal;
+    scalar *dense = (scalar *)calloc((size_t)nc * (size_t)nc, sizeof(scalar));
+    int *piv = (int *)malloc(sizeof(int) * (size_t)(nc ? nc : 1));
+    for (int d = 0; d < Ac->nDomains; d++) {
+        const orc_domain *m = &Ac->dom[d];
+        const int64_t o = m->offset;
+        for (label i = 0; i < m->nCells; i++) dense[(size_t)(o + i) * nc + (size_t)(o + i)] = m->diag[i];
+        for (label f = 0; f < m->nFaces; f++) {
+            dense[(size_t)(o + m->lower[f]) * nc + (size_t)(o + m->upper[f])] = m->upperC[f];
+            dense[(size_t)(o + m->upper[f]) * nc + (size_t)(o + m->lower[f])] = m->lowerC[f];
+        }
+        for (int p = 0; p < m->nIfaces; p++) {
+            const orc_iface *me = &m->ifaces[p];
+            const orc_domain *nb = &Ac->dom[me->nbrDomain];
+            const orc_iface *ot = &nb->ifaces[me->nbrPatch];
+            for (label k = 0; k < me->nFaces; k++)
+                dense[(size_t)(o + me->faceCells[k]) * nc + (size_t)(nb->offset + ot->faceCells[k])] -= me->bouCoeffs[k];
+        }
+    }
+    lu_factor(nc, dense, piv);
+
+    const int64_t n0 = S->nTotal;
+    scalar **corr = (scalar **)calloc((size_t)nL, sizeof(*corr));
+    scalar **src = (scalar **)calloc((size_t)nL, sizeof(*src));
+    for (int l = 0; l < nL; l++) {
+        corr[l] = (scalar *)calloc((size_t)A[l + 1]->nTotal, sizeof(scalar));
+        src[l] = (scalar *)calloc((size_t)A[l + 1]->nTotal, sizeof(scalar));
+    }
+    scalar *Apsi = (scalar *)calloc((size_t)n0, sizeof(scalar));
+    scalar *fcorr = (scalar *)calloc((size_t)n0, sizeof(scalar));
+    scalar *fres = (scalar *)calloc((size_t)n0, sizeof(scalar));
+    scalar *scr1 = (scalar *)calloc((size_t)n0, sizeof(scalar));
+    scalar *scr2 = (scalar *)calloc((size_t)n0, sizeof(scalar));
+
+    orc_amul(S, psi, Apsi);
+    scalar normFactor = orc_norm_factor(S, psi, source, Apsi, fcorr);
+    perf->normFactor = normFactor;
+    for (int64_t i = 0; i < n0; i++) fres[i] = source[i] - Apsi[i];
+    perf->initialResidual = orc_gSumMag(S, fres) / normFactor;
+    perf->finalResidual = perf->initialResidual;
+    if (hist && histLen > 0) hist[0] = perf->initialResidual;
+
+    if (ctl->minIter > 0 || !conv_check(perf, ctl)) {
+        const int coarsest = nL - 1;
+        do {
+            sys_restrict(H, 0, A[0], A[1], fres, src[0]);
+            for (int l = 0; l < coarsest; l++) {
+                const int64_t nl = A[l + 1]->nTotal;
+                if (ctl->nPreSweeps) {
+                    memset(corr[l], 0, sizeof(scalar) * (size_t)nl);
+                    orc_jacobi_smooth(A[l + 1], ctl->omega, corr[l], src[l],
+                                      imin(ctl->nPreSweeps + ctl->preSweepsLevelMultiplier * l, ctl->maxPreSweeps));
+                    if (doScale && l < coarsest - 1) sys_scale(A[l + 1], corr[l], scr1, src[l]);
+                    orc_amul(A[l + 1], corr[l], scr1);
+                    for (int64_t i = 0; i < nl; i++) src[l][i] -= scr1[i];
+                }
+                sys_restrict(H, l + 1, A[l + 1], A[l + 2], src[l], src[l + 1]);
+            }
+            memcpy(corr[coarsest], src[coarsest], sizeof(scalar) * (size_t)nc);
+            lu_solve(nc, dense, piv, corr[coarsest]);
+            for (int l = coarsest - 1; l >= 0; l--) {
+                const int64_t nl = A[l + 1]->nTotal;
+                if (ctl->nPreSweeps) memcpy(scr2, corr[l], sizeof(scalar) * (size_t)nl);
+                sys_prolong(H, l + 1, A[l + 1], A[l + 2], corr[l + 1], corr[l]);
+                if (doScale && l < coarsest - 1) sys_scale(A[l + 1], corr[l], scr1, src[l]);
+                if (ctl->nPreSweeps) for (int64_t i = 0; i < nl; i++) corr[l][i] += scr2[i];
+                orc_jacobi_smooth(A[l + 1], ctl->omega, corr[l], src[l],
+                                  imin(ctl->nPostSweeps + ctl->postSweepsLevelMultiplier * l, ctl->maxPostSweeps));
+            }
+            sys_prolong(H, 0, A[0], A[1], corr[0], fcorr);
+            if (doScale) sys_scale(A[0], fcorr, Apsi, fres);
+            for (int64_t i = 0; i < n0; i++) psi[i] = psi[i] + fcorr[i];
+            orc_jacobi_smooth(S, ctl->omega, psi, source, ctl->nFinestSweeps);
+            orc_amul(S, psi, Apsi);
+            for (int64_t i = 0; i < n0; i++) fres[i] = source[i] - Apsi[i];
+            perf->finalResidual = orc_gSumMag(S, fres) / normFactor;
+            if (hist && perf->nIterations + 1 < histLen) hist[perf->nIterations + 1] = perf->finalResidual;
+        } while ((++perf->nIterations < ctl->maxIter && !conv_check(perf, ctl)) || perf->nIterations < ctl->minIter);
+    }
+    for (int l = 1; l <= nL; l++) orc_sys_destroy((orc_system *)A[l]);
+    for (int l = 0; l < nL; l++) { free(corr[l]); free(src[l]); }
+    free(A); free(corr); free(src); free(dense); free(piv);
+    free(Apsi); free(fcorr); free(fres); free(scr1); free(scr2);
 }

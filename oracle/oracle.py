@@ -279,6 +279,51 @@ class GamgHierarchy:
         return x, out
 
 
+class GamgSysHierarchy:
+    """GAMG over a System: coupled patches (cyclic) and decomposed cases (orc_gamg_build_sys / solve_sys)."""
+
+    def __init__(self, system, face_weights_per_domain, n_cells_in_coarsest_level=10, forward=True):
+        L = lib()
+        L.orc_gamg_build_sys.restype = C.c_void_p
+        self.system = system
+        w = _d(np.concatenate([np.asarray(x, dtype=np.float64) for x in face_weights_per_domain]))
+        self.h = C.c_void_p(L.orc_gamg_build_sys(system.h, _p(w, C.c_double), C.c_int32(n_cells_in_coarsest_level), int(forward)))
+        self.n_levels = int(L.orc_gamg_sys_n_levels(self.h))
+
+    def __del__(self):
+        try:
+            lib().orc_gamg_sys_free(self.h)
+        except Exception:
+            pass
+
+    def level(self, d, l):
+        s = (C.c_int32 * 4)()
+        lib().orc_gamg_sys_level_sizes(self.h, d, l, s)
+        nf, nff, nc, ncf = [int(v) for v in s]
+        rm, cl, cu = np.empty(nf, np.int32), np.empty(ncf, np.int32), np.empty(ncf, np.int32)
+        lib().orc_gamg_sys_level_maps(self.h, d, l, _p(rm, C.c_int32), _p(cl, C.c_int32), _p(cu, C.c_int32))
+        return dict(n_fine=nf, n_fine_faces=nff, n_coarse=nc, n_coarse_faces=ncf, restrict=rm, lower=cl, upper=cu)
+
+    def patch(self, d, l, p, n_fine_patch_faces):
+        fr = np.empty(n_fine_patch_faces, np.int32)
+        fc = np.empty(max(n_fine_patch_faces, 1), np.int32)
+        nc = int(lib().orc_gamg_sys_patch(self.h, d, l, p, _p(fr, C.c_int32), _p(fc, C.c_int32)))
+        return dict(face_restrict=fr, face_cells=fc[:nc].copy())
+
+    def solve(self, psi, source, **kw):
+        ctl = gamg_controls(**kw)
+        x = _d(psi).copy()
+        b = _d(source)
+        perf = Perf()
+        hist_len = ctl.maxIter + 2
+        hist = np.full(hist_len, np.nan)
+        lib().orc_gamg_solve_sys(self.h, self.system.h, _p(x, C.c_double), _p(b, C.c_double), C.byref(ctl), C.byref(perf),
+                                 _p(hist, C.c_double), hist_len)
+        out = {k: getattr(perf, k) for k, _ in Perf._fields_}
+        out["history"] = hist[~np.isnan(hist)].copy()
+        return x, out
+
+
 # ---------------------------------------------------------------------------------------------
 # fvMatrix assembly sweeps (fvm_oracle.c)
 # ---------------------------------------------------------------------------------------------

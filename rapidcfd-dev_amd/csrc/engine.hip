@@ -87,6 +87,7 @@ struct mi_addr_s {
     std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
     int32_t nInterior = 0, nBoundary = 0, nLocalPatches = 0;
     std::vector<char> patchIsLocal; // [nPatches] cyclic (local) coupled patch: no exchange
+    std::vector<std::vector<int32_t>> patchFaceCellsHost, patchNbrCellsHost; // caller order (GAMG interface agglomeration)
     int64_t nEntries = 0, nHaloTot = 0;
 };
 
@@ -251,6 +252,11 @@ extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
     a->nHaloTot = (int64_t)L.haloCell.size();
     a->lowerHost.assign(lower, lower + n_faces);
     a->upperHost.assign(upper, upper + n_faces);
+    a->patchFaceCellsHost.resize((size_t)n_patches); a->patchNbrCellsHost.resize((size_t)n_patches);
+    for (int32_t p = 0; p < n_patches; ++p) {
+        a->patchFaceCellsHost[(size_t)p].assign(patch_face_cells[p], patch_face_cells[p] + patch_sizes[p]);
+        if (a->patchIsLocal[(size_t)p]) a->patchNbrCellsHost[(size_t)p].assign(patch_nbr_cells[p], patch_nbr_cells[p] + patch_sizes[p]);
+    }
     // drop the big host tables that only the device needs
     std::vector<uint32_t>().swap(L.entries);
     std::vector<int32_t>().swap(L.slotFace);
@@ -1293,9 +1299,9 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
     return MI_OK;
 }
 
+#include "comm.inc"
 #include "gamg_engine.inc"
 #include "assembly.inc"
-#include "comm.inc"
 
 mi_matrix_s::~mi_matrix_s()
 {

@@ -102,7 +102,7 @@ void segment(int32_t nTargets, const std::vector<int32_t>& target, std::vector<i
 
 std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* lower, const int32_t* upper,
                                  const double* faceWeights, int32_t nCellsInCoarsestLevel, bool forwardInit,
-                                 GamgHierarchyHost& H)
+                                 GamgHierarchyHost& H, const GamgCoupling* cpl)
 {
     if (nCells <= 0 || !faceWeights) return "bad argument";
     H.levels.clear();
@@ -111,12 +111,17 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
     std::vector<double> w(faceWeights, faceWeights + nFaces);
     int32_t nFine = nCells, nF = nFaces;
     const int32_t *lo = lower, *up = upper;
+    const int32_t nPatches = cpl ? cpl->nPatches : 0;
+    std::vector<std::vector<int32_t>> pfc, pnb; // patch faceCells / local neighbour cells of the current fine level
+    if (cpl) { pfc = cpl->faceCells; pnb = cpl->nbrCells; }
     while ((int)H.levels.size() < maxLevels - 1) {
         GamgLevelHost L;
         L.nFine = nFine; L.nFineFaces = nF;
         L.nCoarse = match_pairs(nFine, nF, lo, up, w, forward, L.restrictMap);
         forward = !forward;
-        if (L.nCoarse < nCellsInCoarsestLevel || L.nCoarse == nFine) break; // continueAgglomerating
+        bool cont = !(L.nCoarse < nCellsInCoarsestLevel || L.nCoarse == nFine); // continueAgglomerating
+        if (cpl && cpl->allAnd) cont = cpl->allAnd(cpl->user, cont);              // ... on all processors
+        if (!cont) break;
         build_coarse_faces(L, lo, up);
         std::vector<double> cw((size_t)L.nCoarseFaces, 0.0); // restrictFaceField (host): plain summation
         for (int32_t f = 0; f < nF; ++f) if (L.faceRestrict[f] >= 0) cw[L.faceRestrict[f]] += w[f];
@@ -126,6 +131,48 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
         std::vector<int32_t> interior((size_t)nF);
         for (int32_t f = 0; f < nF; ++f) interior[f] = L.faceRestrict[f] < 0 ? -1 - L.faceRestrict[f] : -1;
         segment(L.nCoarse, interior, L.diagChildStart, L.diagChild);
+        if (nPatches > 0) {
+            // coarse-cell ids on both sides of every coupled patch face
+            std::vector<std::vector<int32_t>> mine((size_t)nPatches), theirs((size_t)nPatches), send((size_t)nPatches);
+            bool anyRemote = false;
+            for (int32_t p = 0; p < nPatches; ++p) {
+                mine[p].resize(pfc[p].size());
+                for (size_t i = 0; i < pfc[p].size(); ++i) mine[p][i] = L.restrictMap[pfc[p][i]];
+                if (cpl->isLocal[p]) {
+                    theirs[p].resize(pnb[p].size());
+                    for (size_t i = 0; i < pnb[p].size(); ++i) theirs[p][i] = L.restrictMap[pnb[p][i]];
+                } else { send[p] = mine[p]; anyRemote = true; }
+            }
+            if (anyRemote) {
+                if (!cpl->nbrRestrict) return "processor patches need the nbrRestrict callback";
+                std::vector<std::vector<int32_t>> recv((size_t)nPatches);
+                if (!cpl->nbrRestrict(cpl->user, (int)H.levels.size(), send, recv)) return "exchange of the restrict addressing failed";
+                for (int32_t p = 0; p < nPatches; ++p) if (!cpl->isLocal[p]) {
+                    if (recv[p].size() != mine[p].size()) return "exchange of the restrict addressing returned a wrong size";
+                    theirs[p].swap(recv[p]);
+                }
+            }
+            L.patches.resize((size_t)nPatches);
+            for (int32_t p = 0; p < nPatches; ++p) {
+                GamgPatchHost& P = L.patches[p];
+                std::unordered_map<uint64_t, int32_t> pairToFace;
+                pairToFace.reserve(mine[p].size() * 2);
+                P.faceRestrict.resize(mine[p].size());
+                for (size_t i = 0; i < mine[p].size(); ++i) {
+                    const uint64_t key = ((uint64_t)(uint32_t)mine[p][i] << 32) | (uint32_t)theirs[p][i];
+                    auto it = pairToFace.find(key);
+                    if (it == pairToFace.end()) {
+                        const int32_t k = (int32_t)P.faceCells.size();
+                        pairToFace.emplace(key, k);
+                        P.faceCells.push_back(mine[p][i]); P.nbrCells.push_back(theirs[p][i]);
+                        P.faceRestrict[i] = k;
+                    } else P.faceRestrict[i] = it->second;
+                }
+                segment((int32_t)P.faceCells.size(), P.faceRestrict, P.childStart, P.child);
+                pfc[p] = P.faceCells;
+                if (cpl->isLocal[p]) pnb[p] = P.nbrCells;
+            }
+        }
         H.levels.push_back(std::move(L));
         GamgLevelHost& B = H.levels.back();
         nFine = B.nCoarse; nF = B.nCoarseFaces; lo = B.cLower.data(); up = B.cUpper.data();

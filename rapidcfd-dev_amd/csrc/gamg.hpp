@@ -14,6 +14,16 @@
 
 namespace mi {
 
+// one coupled patch on one level (GAMGInterface, interfaces/GAMGInterface/GAMGInterface.H; processorGAMGInterface.C:54-128:
+// one coarse interface face per distinct (local coarse cell, neighbour coarse cell) pair, in order of first
+// appearance among the fine patch faces -- both sides visit matching faces in the same order, so they agree)
+struct GamgPatchHost {
+    std::vector<int32_t> faceCells;     // [nCoarseIfaceFaces] coarse cell on this side
+    std::vector<int32_t> nbrCells;      // [nCoarseIfaceFaces] coarse cell on the other side (its owner's numbering)
+    std::vector<int32_t> faceRestrict;  // [nFineIfaceFaces] -> coarse interface face
+    std::vector<int32_t> childStart, child; // fine patch faces of every coarse interface face, ascending
+};
+
 struct GamgLevelHost {
     int32_t nFine = 0, nFineFaces = 0, nCoarse = 0, nCoarseFaces = 0;
     std::vector<int32_t> restrictMap;    // [nFine] -> coarse cell
@@ -24,6 +34,23 @@ struct GamgLevelHost {
     std::vector<int32_t> cellChildStart, cellChild;   // children cells of every coarse cell
     std::vector<int32_t> faceChildStart, faceChild;   // fine faces mapped onto every coarse face
     std::vector<int32_t> diagChildStart, diagChild;   // fine faces interior to every coarse cell
+    std::vector<GamgPatchHost> patches;               // coupled patches of the COARSE side of this level
+};
+
+// The two places where the ranks of a decomposed case have to talk while the hierarchy is built:
+//   allAnd           continueAgglomerating (GAMGAgglomeration.C:72-81, reduce(andOp<bool>()))
+//   nbrRestrict      the neighbour's coarse-cell ids of the patch-internal cells, patch face order
+//                    (GAMGAgglomerateLduAddressing.C:464-520: initInternalFieldTransfer / internalFieldTransfer)
+// Local (cyclic) patches are resolved by the builder itself; processor patches go through the callbacks.
+struct GamgCoupling {
+    int32_t nPatches = 0;
+    std::vector<std::vector<int32_t>> faceCells;   // finest level, per patch
+    std::vector<std::vector<int32_t>> nbrCells;    // finest level, per patch; empty vector = processor patch
+    std::vector<char> isLocal;                     // per patch
+    bool (*allAnd)(void* user, bool v) = nullptr;
+    // in: send[p] = local coarse ids of patch p's cells (processor patches only); out: recv[p] same length
+    bool (*nbrRestrict)(void* user, int level, const std::vector<std::vector<int32_t>>& send, std::vector<std::vector<int32_t>>& recv) = nullptr;
+    void* user = nullptr;
 };
 
 struct GamgHierarchyHost {
@@ -34,7 +61,7 @@ struct GamgHierarchyHost {
 // faceWeights: [nFaces] (faceAreaPair: |Sf/sqrt|Sf| o (1,1.01,1.02)|; algebraicPair: |upper|)
 std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* lower, const int32_t* upper,
                                  const double* faceWeights, int32_t nCellsInCoarsestLevel, bool forwardInit,
-                                 GamgHierarchyHost& out);
+                                 GamgHierarchyHost& out, const GamgCoupling* coupling = nullptr);
 
 // dense inverse by Gauss-Jordan with partial pivoting (coarsest level); returns false if singular
 bool invert_dense(int n, std::vector<double>& A);

@@ -40,7 +40,7 @@ class SolverControls(C.Structure):
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
-    "mi_dpcg_comm_iterate", "mi_matrix_attach_comm", "mi_matrix_detach_comm",
+    "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
     "mi_addr_create", "mi_addr_create_coupled", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
     "mi_addr_n_ext", "mi_addr_cell_perm", "mi_addr_stats", "mi_addr_patch_offsets",
@@ -428,12 +428,20 @@ class Matrix:
 class Gamg:
     """GAMG hierarchy + solver (lduMatrix::solver 'GAMG', agglomerator faceAreaPair/algebraicPair)."""
 
-    def __init__(self, addr: Addressing, face_weights, n_cells_in_coarsest_level: int = 10, forward: bool = True):
+    def __init__(self, addr: Addressing, face_weights, n_cells_in_coarsest_level: int = 10, forward: bool = True,
+                 comms=None, patch_rank=None, patch_nbr_patch=None):
+        """comms = (reduce, halo) Comm pair of a decomposed case (the matrix must be attached to the same pair)"""
         self.addr = addr
         w = np.ascontiguousarray(face_weights, dtype=np.float64)
         self.h = C.c_void_p()
-        _chk(lib().mi_gamg_create(addr.h, w.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(n_cells_in_coarsest_level),
-                                  int(forward), C.byref(self.h)))
+        I32 = C.POINTER(C.c_int32)
+        pr = None if patch_rank is None else np.ascontiguousarray(patch_rank, dtype=np.int32)
+        pn = None if patch_nbr_patch is None else np.ascontiguousarray(patch_nbr_patch, dtype=np.int32)
+        _chk(lib().mi_gamg_create_coupled(addr.h, w.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(n_cells_in_coarsest_level),
+                                          int(forward), comms[0].h if comms else C.c_void_p(), comms[1].h if comms else C.c_void_p(),
+                                          pr.ctypes.data_as(I32) if pr is not None and pr.size else I32(),
+                                          pn.ctypes.data_as(I32) if pn is not None and pn.size else I32(), C.byref(self.h)))
+        self._keep = (comms, pr, pn)
         self.n_levels = int(lib().mi_gamg_n_levels(self.h))
         self.forward_out = bool(lib().mi_gamg_forward_out(self.h))
 

@@ -187,7 +187,7 @@ def decompose_box(case: LduCase, parts) -> List[LduCase]:
             upper=case.upper[fint].copy(),
             lower=None if case.lower is None else case.lower[fint].copy(),
             source=case.source[ids].copy(),
-            dims=(),
+            dims=(int(i[ids].max() - i[ids].min() + 1), int(j[ids].max() - j[ids].min() + 1), int(k[ids].max() - k[ids].min() + 1)),
             global_cells=ids.astype(np.int64),
         )
         for nb in sorted(pair_faces[d]):

@@ -154,3 +154,99 @@ def test_engine_gamg_history(pkg, orc, name, kw):
     psi2 = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf2 = G.solve(mat, psi2, dev(case.source), **args)
     assert np.array_equal(perf2["history"], perf["history"])
+
+
+# ---- coupled patches / decomposed cases -------------------------------------------------------------------
+def test_oracle_sys_gamg_equals_single_domain_path(pkg, orc):
+    # D = 1 without interfaces: the system restatement and the original single-domain one are the same arithmetic
+    case = pkg.synthetic.box_case(14, 11, 9)
+    w = orc.box_face_weights(case)
+    x1, p1 = orc.GamgHierarchy(case, w, 10).solve(np.zeros(case.n_cells), case.source, tolerance=1e-9, maxIter=60)
+    S = orc.System([case])
+    x2, p2 = orc.GamgSysHierarchy(S, [w], 10).solve(np.zeros(case.n_cells), case.source, tolerance=1e-9, maxIter=60)
+    assert np.array_equal(p1["history"], p2["history"]) and np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("parts", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
+def test_oracle_gamg_on_a_decomposed_case(pkg, orc, parts):
+    # every domain agglomerates on its own, interfaces are agglomerated from both sides' coarse ids, the coarsest
+    # level is the global system: the solve converges like the serial one and to the same solution
+    syn = pkg.synthetic
+    case = syn.box_case(16, 12, 12)
+    subs = syn.decompose_box(case, parts)
+    S = orc.System(subs)
+    H = orc.GamgSysHierarchy(S, [orc.box_face_weights(s) for s in subs], 10)
+    assert H.n_levels >= 3
+    # both sides of every processor patch built the same coarse interface faces
+    for d, sub in enumerate(subs):
+        for p, itf in enumerate(sub.interfaces):
+            a = H.patch(d, 0, p, len(itf.face_cells))
+            b = H.patch(itf.nbr_domain, 0, itf.nbr_patch, len(itf.face_cells))
+            assert np.array_equal(a["face_restrict"], b["face_restrict"]) and len(a["face_cells"]) == len(b["face_cells"])
+    src = np.concatenate([s.source for s in subs])
+    x, perf = H.solve(np.zeros(S.n), src, tolerance=1e-9, maxIter=100)
+    assert perf["converged"]
+    xs, ps = orc.GamgHierarchy(case, orc.box_face_weights(case), 10).solve(np.zeros(case.n_cells), case.source, tolerance=1e-9, maxIter=100)
+    assert abs(perf["nIterations"] - ps["nIterations"]) <= 4
+    glob = np.concatenate([s.global_cells for s in subs])
+    assert np.max(np.abs(x - xs[glob])) < 1e-6 * np.max(np.abs(xs))
+    assert abs(perf["normFactor"] - ps["normFactor"]) < 1e-10 * ps["normFactor"]
+
+
+def test_oracle_gamg_cyclic(pkg, orc):
+    syn = pkg.synthetic
+    case = syn.add_cyclic_y(syn.box_case(12, 12, 10))
+    S = orc.System([case])
+    H = orc.GamgSysHierarchy(S, [orc.box_face_weights(case)], 10)
+    x, perf = H.solve(np.zeros(case.n_cells), case.source, tolerance=1e-9, maxIter=100)
+    assert perf["converged"] and perf["nIterations"] < 40
+    xp, _ = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-12, maxIter=2000)
+    assert np.max(np.abs(x - xp)) < 1e-6 * np.max(np.abs(xp))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["cyclic", "processor_to_self"])
+@pytest.mark.parametrize("symmetric,kw", [(True, {}), (True, dict(nPreSweeps=1)), (False, {})])
+def test_engine_gamg_coupled_patches(pkg, orc, mode, symmetric, kw):
+    """GAMG on a matrix with coupled patches: 'cyclic' = local patches (cyclicGAMGInterface), 'processor_to_self' = the
+    same periodic box posed with processor patches whose neighbour rank is this rank, on a 1-rank RCCL communicator --
+    restrict-addressing exchange, per-level halo exchange, all-reduced scale factors and the global coarsest system all
+    run for real.  The oracle solves the same system with its own restatement of the interface agglomeration."""
+    import torch
+    syn, eng = pkg.synthetic, pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    case = syn.add_cyclic_y(syn.box_case(20, 16, 12, symmetric=symmetric), asym_shift=0.0 if symmetric else 0.2)
+    w = orc.box_face_weights(case)
+    S = orc.System([case])
+    args = dict(tolerance=1e-9, maxIter=100); args.update(kw)
+    H = orc.GamgSysHierarchy(S, [w], 10)
+    ref_psi, ref = H.solve(np.zeros(case.n_cells), case.source, **args)
+    fcs = [i.face_cells for i in case.interfaces]
+    comm = None
+    if mode == "cyclic":
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, fcs, [case.interfaces[i.nbr_patch].face_cells for i in case.interfaces])
+    else:
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, fcs)
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    for p, itf in enumerate(case.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if symmetric else dev(itf.int_coeffs))
+    if mode == "cyclic":
+        G = eng.Gamg(addr, w, 10)
+    else:
+        comm = eng.Comm(ctx, 1, 0, eng.Comm.unique_id())
+        mat.attach_comm(comm, comm, [0, 0], [1, 0], n_global=case.n_cells)
+        G = eng.Gamg(addr, w, 10, comms=(comm, comm), patch_rank=[0, 0], patch_nbr_patch=[1, 0])
+    assert G.n_levels == H.n_levels
+    for l in range(G.n_levels):
+        o, e = H.level(0, l), G.level_sizes(l)
+        assert (o["n_coarse"], o["n_coarse_faces"]) == (e["n_coarse"], e["n_coarse_faces"])
+    psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+    perf = G.solve(mat, psi, dev(case.source), **args)
+    assert perf["nIterations"] == ref["nIterations"] and perf["converged"] == ref["converged"]
+    h, hr = perf["history"], ref["history"]
+    assert h.shape == hr.shape
+    assert np.max(np.abs(h - hr)) < 1e-10 * hr[0]
+    torch.cuda.synchronize()
+    assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
