@@ -233,3 +233,61 @@ class DistributedPCG:
             self.iterate(batch)
             st = self.ops.status(0)
         return self.end()
+
+
+
+def make_comms(ctx, device=None):
+    """(reduce, halo) RCCL communicators of this rank: the unique ids come from rank 0 through torch.distributed."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    ids = [None]
+    if rank == 0:
+        ids = [[eng.Comm.unique_id(), eng.Comm.unique_id()]]
+    if world > 1:
+        dist.broadcast_object_list(ids, src=0)
+    reduce_c = eng.Comm(ctx, world, rank, ids[0][0])
+    halo_c = reduce_c if os.environ.get("MI_DPCG_ONE_COMM", "0") == "1" else eng.Comm(ctx, world, rank, ids[0][1])
+    return reduce_c, halo_c
+
+
+class DistributedMatrix:
+    """This rank's part of a decomposed lduMatrix with its communicators attached (mi_matrix_attach_comm): the object
+    the reference's solvers see on every MPI rank.  ``sub`` is an LduCase with processor interfaces; every solver entry
+    point of the engine then solves the global system (all ranks call together), vectors are this rank's cells in
+    caller order."""
+
+    def __init__(self, ctx, sub, device, n_global: Optional[int] = None, comms=None):
+        self.device = torch.device(device)
+        self.sub = sub
+        self.comms = comms if comms is not None else make_comms(ctx)
+        self.addr = eng.Addressing(ctx, sub.n_cells, sub.lower_addr, sub.upper_addr, [i.face_cells for i in sub.interfaces])
+        self.mat = eng.Matrix(self.addr)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.mat.set_coeffs(t(sub.diag), t(sub.upper), None if sub.lower is None else t(sub.lower))
+        for p, itf in enumerate(sub.interfaces):
+            self.mat.set_interface_coeffs(p, t(itf.bou_coeffs), None if sub.lower is None else t(itf.int_coeffs))
+        if n_global is None:
+            ng = torch.tensor([float(sub.n_cells)], dtype=torch.float64, device=self.device)
+            self.comms[0].allreduce_sum(ng)
+            torch.cuda.synchronize()
+            n_global = int(round(float(ng.item())))
+        self.n_global = n_global
+        self.patch_rank = [i.nbr_domain for i in sub.interfaces]
+        self.patch_nbr_patch = [i.nbr_patch for i in sub.interfaces]
+        self.mat.attach_comm(self.comms[0], self.comms[1], self.patch_rank, self.patch_nbr_patch, n_global)
+        self._gamg = None
+
+    def gamg(self, face_weights, n_cells_in_coarsest_level=10):
+        """GAMG hierarchy of the decomposed case (cached, like the reference's GAMGAgglomeration MeshObject)"""
+        if self._gamg is None:
+            self._gamg = eng.Gamg(self.addr, face_weights, n_cells_in_coarsest_level, comms=self.comms,
+                                  patch_rank=self.patch_rank, patch_nbr_patch=self.patch_nbr_patch)
+        return self._gamg
+
+    def solve(self, solver: str, psi, source, **kw):
+        """solver: PCG | PBiCG | PBiCGStab | smoothSolver | GAMG (GAMG needs face_weights=...)"""
+        if solver == "GAMG":
+            g = self.gamg(kw.pop("face_weights"), kw.pop("n_cells_in_coarsest_level", 10))
+            return g.solve(self.mat, psi, source, **kw)
+        fn = {"PCG": self.mat.pcg, "PBiCG": self.mat.pbicg, "PBiCGStab": self.mat.pbicgstab, "smoothSolver": self.mat.smooth_solve}[solver]
+        return fn(psi, source, **kw)

@@ -457,3 +457,25 @@ def test_attached_comm_operators_and_solvers(pkg, orc, ctx, symmetric):
     run(mat.smooth_solve, S.smooth_solve, n_sweeps=2, tolerance=1e-4, maxIter=400)
     mat.detach_comm()
     comm.close()
+
+
+def test_distributed_matrix_single_rank(pkg, orc, ctx):
+    """parallel.DistributedMatrix (the per-rank object of a decomposed case) on one rank: comm creation, attach, every solver."""
+    syn, par = pkg.synthetic, pkg.parallel
+    case = syn.add_cyclic_y(syn.box_case(16, 12, 10, symmetric=True))
+    S = orc.System([case])
+    dm = par.DistributedMatrix(ctx, case, "cuda:0")
+    assert dm.n_global == case.n_cells
+    n = case.n_cells
+    for solver, kw, ref_fn in [("PCG", dict(precond="diagonal", tolerance=1e-9, maxIter=400), S.pcg),
+                               ("smoothSolver", dict(n_sweeps=2, tolerance=1e-4, maxIter=300), S.smooth_solve)]:
+        psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        perf = dm.solve(solver, psi, dev(case.source), **kw)
+        ref_psi, ref = ref_fn(np.zeros(n), case.source, **kw)
+        _check_hist(perf, ref)
+    w = orc.box_face_weights(case)
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    perf = dm.solve("GAMG", psi, dev(case.source), face_weights=w, tolerance=1e-9, maxIter=60)
+    ref_psi, ref = orc.GamgSysHierarchy(S, [w], 10).solve(np.zeros(n), case.source, tolerance=1e-9, maxIter=60)
+    assert perf["nIterations"] == ref["nIterations"]
+    assert np.max(np.abs(perf["history"] - ref["history"])) < 1e-10 * ref["history"][0]
