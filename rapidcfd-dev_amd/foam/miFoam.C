@@ -6,6 +6,8 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <ctime>
 
 namespace Foam
 {
@@ -69,15 +71,32 @@ lduAddressing::lduAddressing(label nCells, const labelList& lower, const labelLi
 : size_(nCells), lower_(lower), upper_(upper), patchAddr_(patchAddr), addr_(nullptr), gamg_(nullptr), gamgCoarsest_(-1)
 {
     if (lower_.size() != upper_.size()) FatalErrorIn("lduAddressing::lduAddressing", "lowerAddr and upperAddr differ in size");
+    for (const labelList& fc : patchAddr_) { lduInterface i; i.faceCells = fc; interfaces_.push_back(i); }
+}
+lduAddressing::lduAddressing(label nCells, const labelList& lower, const labelList& upper, const std::vector<lduInterface>& interfaces)
+: size_(nCells), lower_(lower), upper_(upper), interfaces_(interfaces), addr_(nullptr), gamg_(nullptr), gamgCoarsest_(-1)
+{
+    if (lower_.size() != upper_.size()) FatalErrorIn("lduAddressing::lduAddressing", "lowerAddr and upperAddr differ in size");
+    for (const lduInterface& i : interfaces_) patchAddr_.push_back(i.faceCells);
+    for (std::size_t p = 0; p < interfaces_.size(); ++p) {
+        const lduInterface& i = interfaces_[p];
+        if (i.type == "cyclic" && (i.neighbPatchID < 0 || i.neighbPatchID >= (label)interfaces_.size() ||
+                                    interfaces_[i.neighbPatchID].faceCells.size() != i.faceCells.size()))
+            FatalErrorIn("lduAddressing::lduAddressing", "cyclic patch without a matching neighbour patch");
+        if (i.type != "cyclic" && i.type != "processor" && i.type != "coupled") FatalErrorIn("lduAddressing::lduAddressing", "Unknown interface type " + i.type);
+    }
 }
 lduAddressing::~lduAddressing() { if (gamg_) mi_gamg_destroy(gamg_); if (addr_) mi_addr_destroy(addr_); }
 mi_addr_t lduAddressing::handle() const
 {
     if (!addr_) {
-        std::vector<label> sizes; std::vector<const label*> ptrs;
-        for (const labelList& p : patchAddr_) { sizes.push_back((label)p.size()); ptrs.push_back(p.data()); }
-        miCheck(mi_addr_create(miEngine::New().ctx, size_, (label)lower_.size(), lower_.data(), upper_.data(), (label)sizes.size(),
-                               sizes.data(), ptrs.data(), &addr_), "lduAddressing::handle()");
+        std::vector<label> sizes; std::vector<const label*> ptrs, nbrs;
+        for (std::size_t p = 0; p < patchAddr_.size(); ++p) {
+            sizes.push_back((label)patchAddr_[p].size()); ptrs.push_back(patchAddr_[p].data());
+            nbrs.push_back(interfaces_[p].type == "cyclic" ? patchAddr_[(std::size_t)interfaces_[p].neighbPatchID].data() : nullptr);
+        }
+        miCheck(mi_addr_create_coupled(miEngine::New().ctx, size_, (label)lower_.size(), lower_.data(), upper_.data(), (label)sizes.size(),
+                                       sizes.data(), ptrs.data(), nbrs.data(), &addr_), "lduAddressing::handle()");
     }
     return addr_;
 }
@@ -86,6 +105,13 @@ mi_gamg_t lduAddressing::agglomeration(const scalarField& w, label nCoarsest) co
     if (gamg_ && gamgCoarsest_ != nCoarsest) { mi_gamg_destroy(gamg_); gamg_ = nullptr; }
     if (!gamg_) {
         if ((label)w.size() != (label)lower_.size()) FatalErrorIn("lduAddressing::agglomeration", "face weights do not match the number of faces");
+        if (hasProcessorPatches() || Pstream::parRun()) {
+            if (!Pstream::parRun()) FatalErrorIn("GAMGAgglomeration::New", "processor patches outside a parallel run (Pstream::init)");
+            std::vector<label> pr, pn;
+            for (const lduInterface& i : interfaces_) { pr.push_back(i.neighbProcNo); pn.push_back(i.neighbPatchID); }
+            miCheck(mi_gamg_create_coupled(handle(), w.data(), nCoarsest, 1, Pstream::reduceComm(), Pstream::haloComm(),
+                                           pr.data(), pn.data(), &gamg_), "GAMGAgglomeration::New");
+        } else
         miCheck(mi_gamg_create(handle(), w.data(), nCoarsest, 1, &gamg_), "GAMGAgglomeration::New");
         gamgCoarsest_ = nCoarsest;
     }
@@ -110,18 +136,33 @@ void lduMatrix::sync(const FieldFieldScalar* bou, const FieldFieldScalar* inte, 
         dirty_ = false;
     }
     const label nP = lduAddr_.nPatches();
+    if (nP == 0 && Pstream::parRun() && !attached_) {
+        miCheck(mi_matrix_attach_comm(mat_, Pstream::reduceComm(), Pstream::haloComm(), nullptr, nullptr,
+                                      Pstream::returnReduceSum(lduAddr_.size())), "lduMatrix::sync");
+        attached_ = true;
+    }
     if (nP == 0) return;
     if (!bou || (label)bou->size() != nP || !ifs || (label)ifs->size() != nP)
         FatalErrorIn("lduMatrix::sync", "interface coefficient lists do not match the coupled patches of the addressing");
-    scalargpuField ext(mi_addr_n_ext(lduAddr_.handle()));
+    const bool callerExt = !lduAddr_.engineCoupled();
+    scalargpuField ext(callerExt ? mi_addr_n_ext(lduAddr_.handle()) : 0);
     label off = 0;
     for (label p = 0; p < nP; ++p) {
         const label n = (label)lduAddr_.patchAddr(p).size();
         miCheck(mi_matrix_set_interface_coeffs(mat_, p, (*bou)[p].data(), inte && (label)inte->size() == nP ? (*inte)[p].data() : nullptr), "lduMatrix::sync");
-        if (n) miCopyD2D(ext.data() + off, (*ifs)[p]->patchNeighbourField.data(), sizeof(scalar) * n);
+        if (callerExt && n) miCopyD2D(ext.data() + off, (*ifs)[p]->patchNeighbourField.data(), sizeof(scalar) * n);
         off += n;
     }
-    miCheck(mi_matrix_set_ext(mat_, ext.data()), "lduMatrix::sync");
+    if (callerExt) miCheck(mi_matrix_set_ext(mat_, ext.data()), "lduMatrix::sync");
+    if (!attached_ && (lduAddr_.hasProcessorPatches() || Pstream::parRun())) {
+        // decomposed case: from here on the engine exchanges the processor-patch values and all-reduces the sums itself
+        if (!Pstream::parRun()) FatalErrorIn("lduMatrix::sync", "processor patches outside a parallel run (Pstream::init)");
+        std::vector<label> pr, pn;
+        for (label p = 0; p < nP; ++p) { pr.push_back(lduAddr_.interface(p).neighbProcNo); pn.push_back(lduAddr_.interface(p).neighbPatchID); }
+        miCheck(mi_matrix_attach_comm(mat_, Pstream::reduceComm(), Pstream::haloComm(), pr.data(), pn.data(),
+                                      Pstream::returnReduceSum(lduAddr_.size())), "lduMatrix::sync");
+        attached_ = true;
+    }
     mi_ctx_synchronize(miEngine::New().ctx);
 }
 void lduMatrix::Amul(scalargpuField& Apsi, const scalargpuField& psi, const FieldFieldScalar& b, const lduInterfaceFieldPtrsList& ifs, direction) const
@@ -196,9 +237,13 @@ solverPerformance perfOf(const word& solverName, const word& fieldName, const mi
 {
     return solverPerformance(solverName, fieldName, r.initialResidual, r.finalResidual, r.nIterations, r.converged != 0, r.singular != 0);
 }
+// whole-solver calls own the exchange: fine for cyclic / processor interfaces (the engine does it), not for interfaces
+// whose neighbour values the caller supplies once (they would go stale inside the iteration)
 void requireUncoupled(const lduInterfaceFieldPtrsList& ifs, const char* who)
 {
-    if (!ifs.empty()) FatalErrorIn(who, "coupled interfaces inside a whole-solver call need the distributed driver (mi_dpcg_phase / parallel.py)");
+    for (const lduInterfaceField* f : ifs)
+        if (f && f->type() == "coupled")
+            FatalErrorIn(who, "interfaces with caller-supplied neighbour values cannot be iterated on: use cyclicLduInterfaceField / processorLduInterfaceField");
 }
 } // namespace
 
@@ -454,6 +499,62 @@ void fvm::div(fvScalarMatrix& M, const scalargpuField& weights, const scalargpuF
 {
     scalargpuField& lower = M.lower();
     miCheck(mi_fvm_div(M.lduAddr().handle(), weights.data(), faceFlux.data(), lower.data(), M.upper().data(), M.diag().data()), "fvm::div");
+}
+
+// ---- Pstream: the parallel run as this path sees it -------------------------------------------------------------
+namespace {
+struct PstreamState { bool par = false; int rank = 0, n = 1; mi_comm_t red = nullptr, halo = nullptr; };
+PstreamState& pstream() { static PstreamState s; return s; }
+}
+bool Pstream::parRun() { return pstream().par; }
+int Pstream::myProcNo() { return pstream().rank; }
+int Pstream::nProcs() { return pstream().n; }
+mi_comm_t Pstream::reduceComm() { return pstream().red; }
+mi_comm_t Pstream::haloComm() { return pstream().halo; }
+void Pstream::init(int myProcNo, int nProcs, const std::string& idFile)
+{
+    PstreamState& P = pstream();
+    if (P.par) FatalErrorIn("Pstream::init", "already initialised");
+    if (nProcs < 1 || myProcNo < 0 || myProcNo >= nProcs) FatalErrorIn("Pstream::init", "bad rank / size");
+    unsigned char ids[256];
+    if (myProcNo == 0) {
+        miCheck(mi_comm_unique_id(ids, 128), "Pstream::init");
+        miCheck(mi_comm_unique_id(ids + 128, 128), "Pstream::init");
+        if (nProcs > 1) { // publish atomically: write beside, then rename
+            const std::string tmp = idFile + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(ids, 1, 256, f) != 256) FatalErrorIn("Pstream::init", "cannot write " + tmp);
+            fclose(f);
+            if (rename(tmp.c_str(), idFile.c_str()) != 0) FatalErrorIn("Pstream::init", "cannot publish " + idFile);
+        }
+    } else {
+        bool got = false;
+        for (int attempt = 0; attempt < 6000 && !got; ++attempt) { // up to ~10 min
+            FILE* f = fopen(idFile.c_str(), "rb");
+            if (f) { got = fread(ids, 1, 256, f) == 256; fclose(f); }
+            if (!got) { struct timespec ts = {0, 100 * 1000 * 1000}; nanosleep(&ts, nullptr); }
+        }
+        if (!got) FatalErrorIn("Pstream::init", "rank 0 never published the communicator ids in " + idFile);
+    }
+    mi_ctx_t ctx = miEngine::New().ctx;
+    miCheck(mi_comm_create(ctx, nProcs, myProcNo, ids, &P.red), "Pstream::init");
+    miCheck(mi_comm_create(ctx, nProcs, myProcNo, ids + 128, &P.halo), "Pstream::init");
+    P.par = true; P.rank = myProcNo; P.n = nProcs;
+}
+void Pstream::exit()
+{
+    PstreamState& P = pstream();
+    if (P.halo) mi_comm_destroy(P.halo);
+    if (P.red) mi_comm_destroy(P.red);
+    P = PstreamState();
+}
+label Pstream::returnReduceSum(label v)
+{
+    if (!parRun()) return v;
+    scalargpuField t(1);
+    t = scalarField(1, (scalar)v);
+    miCheck(mi_comm_allreduce_sum(reduceComm(), t.data(), 1), "returnReduce");
+    return (label)(t.asHost()[0] + 0.5);
 }
 
 } // namespace Foam

@@ -1,0 +1,130 @@
+// pEqnFoamPar.C -- the pressure step of a decomposed (or periodic) case, written against the OpenFOAM-style interface
+// of miFoam.H at the lduMatrix::solver level, the way fvMatrix<scalar>::solveSegregated calls it
+// (fvScalarMatrix.C:170-178): build lduAddressing with its coupled patches, fill the coefficients and the interface
+// coefficients, lduMatrix::solver::New(...)->solve(psi, source).
+//
+//   pEqnFoamPar nx ny nz cyclic       one process; the box is periodic in y through a cyclic patch pair
+//   pEqnFoamPar nx ny nz processor    one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment, as torchrun or
+//                                     mpirun wrappers set them; MI_COMM_ID_FILE = path all ranks can see): z-slab
+//                                     decomposition with processor patches between the slabs; the y-periodicity is posed
+//                                     with processor patches whose neighbour is the rank itself, so that even a 1-rank
+//                                     run sends its halo through RCCL.
+// Every rank prints nothing but rank 0's solverPerformance lines; tests/test_foam_mirror.py checks them against the oracle.
+#include "miFoam.H"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iomanip>
+#include <string>
+
+using namespace Foam;
+
+static double splitmixUniform(uint64_t seed, uint64_t i)
+{   // rapidcfd-dev_amd/synthetic.py::splitmix_uniform
+    uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+int main(int argc, char** argv)
+{
+    try {
+        const int nx = argc > 1 ? atoi(argv[1]) : 16, ny = argc > 2 ? atoi(argv[2]) : 16, nz = argc > 3 ? atoi(argv[3]) : 16;
+        const std::string mode = argc > 4 ? argv[4] : "cyclic";
+        const bool par = mode == "processor";
+        if (!par && mode != "cyclic") { fprintf(stderr, "usage: pEqnFoamPar nx ny nz cyclic|processor\n"); return 2; }
+        const int rank = par && getenv("RANK") ? atoi(getenv("RANK")) : 0;
+        const int world = par && getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
+        if (par) {
+            const char* f = getenv("MI_COMM_ID_FILE");
+            Pstream::init(rank, world, f ? f : "/tmp/mi_comm_id");
+        }
+        const scalar h = 1.0 / nx;
+        // z-slab of this rank: global k in [k0, k1)
+        const int k0 = (int)((long)nz * rank / world), k1 = (int)((long)nz * (rank + 1) / world), nzl = k1 - k0;
+        const label n = nx * ny * nzl;
+        auto gcell = [&](int i, int j, int kl) { return (uint64_t)i + (uint64_t)nx * ((uint64_t)j + (uint64_t)ny * (uint64_t)(kl + k0)); };
+        auto coef = [&](uint64_t globalOwner, int dir) { return h * (1.0 + 0.1 * splitmixUniform(12345, globalOwner * 3 + (uint64_t)dir)); };
+        labelList lower, upper; scalarField up; std::vector<int> dir;
+        for (int kl = 0; kl < nzl; ++kl) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const label c = i + nx * (j + ny * kl);
+            if (i < nx - 1) { lower.push_back(c); upper.push_back(c + 1); up.push_back(coef(gcell(i, j, kl), 0)); dir.push_back(0); }
+            if (j < ny - 1) { lower.push_back(c); upper.push_back(c + nx); up.push_back(coef(gcell(i, j, kl), 1)); dir.push_back(1); }
+            if (kl < nzl - 1) { lower.push_back(c); upper.push_back(c + nx * ny); up.push_back(coef(gcell(i, j, kl), 2)); dir.push_back(2); }
+        }
+        const label nf = (label)lower.size();
+        // coupled patches: 0 = y-min, 1 = y-max (periodic pair), then the slab cuts
+        std::vector<lduInterface> ifs(2);
+        std::vector<scalarField> bou(2);
+        for (int kl = 0; kl < nzl; ++kl) for (int i = 0; i < nx; ++i) {
+            ifs[0].faceCells.push_back(i + nx * (0 + ny * kl));
+            ifs[1].faceCells.push_back(i + nx * ((ny - 1) + ny * kl));
+        }
+        for (int p = 0; p < 2; ++p) {
+            ifs[p].type = par ? "processor" : "cyclic"; ifs[p].neighbPatchID = 1 - p; ifs[p].neighbProcNo = par ? rank : -1;
+            bou[p] = scalarField(ifs[p].faceCells.size(), -h);            // coupling kappa = h: boundaryCoeffs = -kappa
+        }
+        if (par && rank > 0) {          // cut below: the owner of a cut face is the cell of the lower slab
+            lduInterface I; I.type = "processor"; I.neighbProcNo = rank - 1; scalarField b;
+            for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) { I.faceCells.push_back(i + nx * j); b.push_back(-coef(gcell(i, j, -1), 2)); }
+            I.neighbPatchID = (rank - 1 > 0) ? 3 : 2;   // over there: its "cut above" patch comes after its "cut below" one
+            ifs.push_back(I); bou.push_back(b);
+        }
+        if (par && rank < world - 1) {
+            lduInterface I; I.type = "processor"; I.neighbProcNo = rank + 1; scalarField b;
+            for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) { I.faceCells.push_back(i + nx * (j + ny * (nzl - 1))); b.push_back(-coef(gcell(i, j, nzl - 1), 2)); }
+            I.neighbPatchID = 2;                         // the upper rank's "cut below" patch
+            ifs.push_back(I); bou.push_back(b);
+        }
+        lduAddressing addr(n, lower, upper, ifs);
+        scalarField faceAreaWeights(nf);
+        const double wdir[3] = {1.0, 1.01, 1.02};
+        for (label f = 0; f < nf; ++f) faceAreaWeights[f] = h * wdir[dir[f]];
+        setFaceAreaPairWeights(&faceAreaWeights);
+
+        // matrix: diag = -sum(offdiag incl. couplings) + fixedValue (-2h) on the x-min cells
+        scalarField diag(n, 0.0), src(n);
+        for (label f = 0; f < nf; ++f) { diag[lower[f]] -= up[f]; diag[upper[f]] -= up[f]; }
+        for (std::size_t p = 0; p < ifs.size(); ++p)
+            for (std::size_t q = 0; q < ifs[p].faceCells.size(); ++q) diag[ifs[p].faceCells[q]] += bou[p][q];  // -= kappa
+        for (int kl = 0; kl < nzl; ++kl) for (int j = 0; j < ny; ++j) diag[0 + nx * (j + ny * kl)] += -2.0 * h;
+        for (int kl = 0; kl < nzl; ++kl) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
+            src[i + nx * (j + ny * kl)] = (2.0 * splitmixUniform(777, gcell(i, j, kl)) - 1.0) * h * h * h;
+
+        lduMatrix A(addr);
+        A.diag() = diag; A.upper() = up;
+        FieldFieldScalar bouCoeffs, intCoeffs;
+        lduInterfaceFieldPtrsList interfaces;
+        for (std::size_t p = 0; p < ifs.size(); ++p) {
+            bouCoeffs.push_back(scalargpuField(bou[p])); intCoeffs.push_back(scalargpuField(bou[p]));
+            if (ifs[p].type == "cyclic") interfaces.push_back(new cyclicLduInterfaceField(ifs[p].faceCells, ifs[p].neighbPatchID));
+            else interfaces.push_back(new processorLduInterfaceField(ifs[p].faceCells, rank, ifs[p].neighbProcNo, ifs[p].neighbPatchID));
+        }
+        scalargpuField source(src);
+        const bool talk = !par || Pstream::master();
+        if (talk) {
+            Info << std::setprecision(17);
+            Info << "Create mesh: " << (long)nx * ny * nz << " cells on " << world << " processor(s), mode " << mode << std::endl;
+        }
+        const dictionary dicts[] = {
+            dictionary{{"solver", "PCG"}, {"preconditioner", "diagonal"}, {"tolerance", "1e-08"}, {"relTol", "0"}},
+            dictionary{{"solver", "PCG"}, {"preconditioner", "DIC"}, {"tolerance", "1e-08"}, {"relTol", "0"}},
+            dictionary{{"solver", "GAMG"}, {"smoother", "GaussSeidel"}, {"agglomerator", "faceAreaPair"}, {"nCellsInCoarsestLevel", "10"},
+                       {"mergeLevels", "1"}, {"tolerance", "1e-08"}, {"relTol", "0"}, {"cacheAgglomeration", "true"}},
+            dictionary{{"solver", "smoothSolver"}, {"smoother", "GaussSeidel"}, {"nSweeps", "2"}, {"tolerance", "1e-03"}, {"maxIter", "400"}},
+            dictionary{{"solver", "PBiCGStab"}, {"preconditioner", "diagonal"}, {"tolerance", "0"}, {"relTol", "0"}, {"maxIter", "12"}},
+        };
+        for (const dictionary& d : dicts) {
+            scalargpuField psi(n);
+            solverPerformance sp = lduMatrix::solver::New("p", A, bouCoeffs, intCoeffs, interfaces, d)->solve(psi, source);
+            if (talk) sp.print(Info);
+        }
+        for (auto* f : interfaces) delete f;
+        if (par) Pstream::exit();
+        if (talk) Info << "End" << std::endl;
+        return 0;
+    } catch (const Foam::error& e) { std::cerr << e.what() << std::endl; return 1; }
+}

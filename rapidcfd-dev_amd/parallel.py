@@ -128,15 +128,23 @@ class DistributedPCG:
         self._p2p = {}
         self.comms = None
         if self.driver == "native":
-            ids = [None]
-            if self.rank == 0:
-                ids = [[eng.Comm.unique_id(), eng.Comm.unique_id()]]
+            # both loops drive the same HIP phases over RCCL; if the C++ side cannot set its communicators up on ANY
+            # rank (e.g. librccl cannot be bound), all ranks agree to use the torch.distributed loop instead
+            ok = 1
+            try:
+                self.comms = make_comms(ctx)
+            except eng.MiError as e:  # pragma: no cover - needs a broken RCCL install
+                ok = 0
+                print(f"[parallel] native RCCL loop unavailable on rank {self.rank}: {e}", flush=True)
             if dist.is_initialized() and self.world > 1:
-                dist.broadcast_object_list(ids, src=0)
-            one = os.environ.get("MI_DPCG_ONE_COMM", "0") == "1"
-            reduce_c = eng.Comm(ctx, self.world, self.rank, ids[0][0])
-            halo_c = reduce_c if one else eng.Comm(ctx, self.world, self.rank, ids[0][1])
-            self.comms = (reduce_c, halo_c)
+                flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                self.comms = None
+                self.driver = "torch"
+                if len(set(self.nbrs)) != len(self.nbrs):
+                    raise ValueError("one processor patch per neighbour rank is supported by the torch.distributed loop")
 
     # -- collectives ----------------------------------------------------------
     def _allreduce(self, t):

@@ -87,3 +87,56 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     assert "Unknown symmetric matrix solver PCGG" in out.stdout and "Valid symmetric matrix solvers are" in out.stdout
     assert re.search(r"\(GAMG PBiCGStab PCG smoothSolver\)", out.stdout)
     assert out.stdout.strip().endswith("End")
+
+
+def _periodic_case(pkg, dims):
+    """the system pEqnFoamPar assembles (global numbering), as an oracle case with two interfaces that face each other"""
+    syn = pkg.synthetic
+    nx, ny, nz = dims
+    n, h = nx * ny * nz, 1.0 / nx
+    c = np.arange(n, dtype=np.int64)
+    i, j, k = c % nx, (c // nx) % ny, c // (nx * ny)
+    lo, up, key = [], [], []
+    for d, (mask, step) in enumerate(((i < nx - 1, 1), (j < ny - 1, nx), (k < nz - 1, nx * ny))):
+        lo.append(c[mask]); up.append(c[mask] + step); key.append(c[mask] * 3 + d)
+    lo, up, key = np.concatenate(lo), np.concatenate(up), np.concatenate(key)
+    order = np.lexsort((up, lo))                      # owner-sorted, upper-triangular: the application's face order
+    lo, up, key = lo[order], up[order], key[order]
+    upper = h * (1.0 + 0.1 * syn.splitmix_uniform(12345, int(key.max()) + 1)[key])
+    diag = np.zeros(n)
+    np.subtract.at(diag, lo, upper); np.subtract.at(diag, up, upper)
+    ymin, ymax = np.nonzero(j == 0)[0], np.nonzero(j == ny - 1)[0]
+    diag[ymin] -= h; diag[ymax] -= h
+    diag[i == 0] += -2.0 * h
+    src = (2.0 * syn.splitmix_uniform(777, n) - 1.0) * h ** 3
+    kap = np.full(ymin.shape[0], -h)
+    ifs = [syn.Interface(nbr_domain=0, nbr_patch=1, face_cells=ymin.astype(np.int32), bou_coeffs=kap, int_coeffs=kap),
+           syn.Interface(nbr_domain=0, nbr_patch=0, face_cells=ymax.astype(np.int32), bou_coeffs=kap, int_coeffs=kap)]
+    return syn.LduCase(n, lo.astype(np.int32), up.astype(np.int32), diag, upper, None, src, dims=dims, interfaces=ifs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["cyclic", "processor"])
+def test_pEqnFoamPar_matches_oracle(pkg, orc, mode, tmp_path):
+    """lduMatrix::solver::New(...)->solve on a matrix with cyclic patches / on a (1-rank) decomposed case whose halo goes
+    through RCCL (Pstream::init -> mi_matrix_attach_comm, mi_gamg_create_coupled), against the oracle's system."""
+    dims = (12, 10, 8)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MI_COMM_ID_FILE=str(tmp_path / "ids"))
+    out = subprocess.run([os.path.join(PKG, "pEqnFoamPar"), *map(str, dims), mode], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr
+    got = [(m.group(1), m.group(2), float(m.group(3)), float(m.group(4)), int(m.group(5))) for m in map(LINE.match, out.stdout.splitlines()) if m]
+    case = _periodic_case(pkg, dims)
+    S = orc.System([case])
+    z, src = np.zeros(case.n_cells), case.source
+    exp = []
+    _, p = S.pcg(z, src, "diagonal", tolerance=1e-8); exp.append(("diagonalPCG", p))
+    _, p = S.pcg(z, src, "AINV", tolerance=1e-8); exp.append(("AINVPCG", p))
+    _, p = orc.GamgSysHierarchy(S, [orc.box_face_weights(case)], 10).solve(z, src, tolerance=1e-8); exp.append(("GAMG", p))
+    _, p = S.smooth_solve(z, src, n_sweeps=2, tolerance=1e-3, maxIter=400); exp.append(("smoothSolver", p))
+    _, p = S.pbicgstab(z, src, "diagonal", tolerance=0.0, maxIter=12, replicate_quirk=True); exp.append(("diagonalPBiCGStab", p))
+    assert len(got) == len(exp), out.stdout + out.stderr
+    for (gname, gfield, gi, gf, gn), (ename, p) in zip(got, exp):
+        assert (gname, gfield) == (ename, "p")
+        assert gn == p["nIterations"], (gname, gn, p["nIterations"])
+        assert abs(gi - p["initialResidual"]) < 1e-12 and abs(gf - p["finalResidual"]) < 1e-10
+    assert out.stdout.strip().endswith("End")
