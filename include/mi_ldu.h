@@ -283,6 +283,28 @@ int mi_fvm_div(mi_addr_t addr, const double *weights_dev, const double *face_flu
                double *lower_out_dev, double *upper_out_dev, double *diag_out_dev);
 int mi_surface_integrate(mi_addr_t addr, const double *ssf_dev, const double *vol_dev_or_null, double *ivf_dev);
 int mi_face_interpolate(mi_addr_t addr, const double *lambda_dev, const double *phi_dev, double *sf_dev);
+/* ---- scheme front-end either side of the matrix ----
+ * mi_fvm_ddt_euler: EulerDdtScheme fvmDdt (src/finiteVolume/finiteVolume/ddtSchemes/EulerDdtScheme/EulerDdtScheme.C):
+ *   diag = rDeltaT*rho*V, source = rDeltaT*rho*psiOld*V (rho = 1 for the plain form).
+ * mi_upwind_weights: pos(faceFlux) (limitedSchemes/upwind, limitedSurfaceInterpolationScheme.C:177-187).
+ * mi_limited_linear_weights: limitedLinear(k) weights of a scalar field in one face pass -- r of
+ *   limitedSchemes/LimitedScheme/NVDTVD.H, limiter of limitedSchemes/limitedLinear/limitedLinear.H:79-97, weights of
+ *   limitedSurfaceInterpolationScheme.C:177-187; grad = cell gradient of phi (component arrays), c = cell centres;
+ *   limiter_out may be NULL.  The result feeds mi_fvm_div / mi_face_interpolate.
+ * mi_gauss_grad: fvc::grad with Gauss integration (finiteVolume/gradSchemes/gaussGrad/gaussGrad.C:27-90,143-250):
+ *   g = (sum_own Sf*ssf - sum_nei Sf*ssf)/V over the internal faces, component arrays; boundary faces are added with
+ *   mi_patch_add per component (vol = NULL here, then divide) exactly as the reference adds them per patch.
+ * mi_vec_axpby: out = a*x + b*y (fvMatrix operator+=, -=, *= on coefficient arrays; out may alias x or y).        */
+int mi_fvm_ddt_euler(mi_ctx_t ctx, int64_t n, double r_delta_t, double rho, const double *vol_dev,
+                     const double *psi_old_dev, double *diag_out_dev, double *source_out_dev);
+int mi_upwind_weights(mi_ctx_t ctx, int64_t n_faces, const double *face_flux_dev, double *weights_out_dev);
+int mi_limited_linear_weights(mi_addr_t addr, double k, const double *cd_weights_dev, const double *face_flux_dev,
+                              const double *phi_dev, const double *gradx_dev, const double *grady_dev,
+                              const double *gradz_dev, const double *cx_dev, const double *cy_dev,
+                              const double *cz_dev, double *weights_out_dev, double *limiter_out_dev_or_null);
+int mi_gauss_grad(mi_addr_t addr, const double *sfx_dev, const double *sfy_dev, const double *sfz_dev,
+                  const double *ssf_dev, const double *vol_dev_or_null, double *gx_dev, double *gy_dev, double *gz_dev);
+int mi_vec_axpby(mi_ctx_t ctx, int64_t n, double a, const double *x_dev, double b, const double *y_dev, double *out_dev);
 int mi_patch_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_patch_faces, const int32_t *face_cells_host, mi_patch_t *out);
 int mi_patch_destroy(mi_patch_t patch);
 int mi_patch_add(mi_patch_t patch, const double *pf_dev, double *intf_dev, int fn);

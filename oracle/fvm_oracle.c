@@ -129,3 +129,77 @@ void orc_face_interpolate(label nf, const label *lo, const label *up, const scal
 {
     for (label f = 0; f < nf; f++) sf[f] = fma(lambda[f], phi[lo[f]] - phi[up[f]], phi[up[f]]);
 }
+
+/* ---- fvm::ddt, Euler (finiteVolume/ddtSchemes/EulerDdtScheme/EulerDdtScheme.C fvmDdt(vf) / fvmDdt(rho, vf)):
+ *   diag = rDeltaT*rho*V ;  source = rDeltaT*rho*psi0*V   (left-to-right products, as written there)            */
+void orc_fvm_ddt_euler(label n, scalar rDeltaT, scalar rho, const scalar *vol, const scalar *psiOld, scalar *diag, scalar *source)
+{
+    for (label c = 0; c < n; c++) {
+        diag[c] = (rDeltaT * rho) * vol[c];
+        source[c] = ((rDeltaT * rho) * psiOld[c]) * vol[c];
+    }
+}
+
+/* ---- upwind weights: pos(faceFlux) (interpolation/surfaceInterpolation/limitedSchemes/upwind/upwind.H:limiter 0 =>
+ *      weights = pos(flux), limitedSurfaceInterpolationScheme.C:177-187)                                          */
+void orc_upwind_weights(label nf, const scalar *faceFlux, scalar *w)
+{
+    for (label f = 0; f < nf; f++) w[f] = faceFlux[f] >= 0 ? 1.0 : 0.0;
+}
+
+/* ---- limitedLinear(k) weights for a scalar field:
+ *   r        LimitedScheme/NVDTVD.H r(): gradf = phiN-phiP; gradcf = d & (flux>0 ? gradcP : gradcN), d = C[N]-C[P];
+ *            |gradcf| >= 1000|gradf| ? 2*1000*sign(gradcf)*sign(gradf)-1 : 2*(gradcf/gradf)-1
+ *   limiter  limitedLinear/limitedLinear.H:79-97  max(min(twoByk*r, 1), 0), twoByk = 2/max(k, SMALL)
+ *   weights  limitedSurfaceInterpolationScheme.C:177-187  lim*CDweight + (1-lim)*pos(flux)
+ * Products followed by an add are fused like nvcc contracts them (a*b + c -> fma).                                */
+static scalar sgn(scalar x) { return x >= 0 ? 1.0 : -1.0; }  /* Scalar.H sign() */
+void orc_limited_linear_weights(label nf, const label *lo, const label *up, scalar k, const scalar *cdWeights,
+                                const scalar *faceFlux, const scalar *phi, const scalar *gx, const scalar *gy,
+                                const scalar *gz, const scalar *Cx, const scalar *Cy, const scalar *Cz,
+                                scalar *w, scalar *limiterOut)
+{
+    const scalar twoByk = 2.0 / (k > 1e-15 ? k : 1e-15); /* SMALL = 1e-15 (doubleScalarSMALL) */
+    for (label f = 0; f < nf; f++) {
+        const label P = lo[f], N = up[f];
+        const scalar gradf = phi[N] - phi[P];
+        const scalar dx = Cx[N] - Cx[P], dy = Cy[N] - Cy[P], dz = Cz[N] - Cz[P];
+        const label c = faceFlux[f] > 0 ? P : N;
+        const scalar gradcf = fma(dz, gz[c], fma(dy, gy[c], dx * gx[c]));
+        scalar r;
+        if (fabs(gradcf) >= 1000 * fabs(gradf)) r = 2 * 1000 * sgn(gradcf) * sgn(gradf) - 1;
+        else r = fma(2.0, gradcf / gradf, -1.0);
+        scalar lim = twoByk * r;
+        lim = lim < 1 ? lim : 1;
+        lim = lim > 0 ? lim : 0;
+        if (limiterOut) limiterOut[f] = lim;
+        const scalar pos = faceFlux[f] >= 0 ? 1.0 : 0.0;
+        w[f] = fma(lim, cdWeights[f], (1.0 - lim) * pos);
+    }
+}
+
+/* ---- fvc::grad, Gauss (finiteVolume/gradSchemes/gaussGrad/gaussGrad.C:27-90 functor, :143-250 gradf):
+ *   grad[c] = ( sum_{own faces, ascending} Sf*ssf - sum_{neighbour faces, losort order} Sf*ssf ) / V
+ * internal-face part; the boundary faces are added per patch with orc_patch_add before the division when present
+ * (pass vol = NULL here, add, then divide).  Component arrays (Sfx, Sfy, Sfz; gx, gy, gz).                       */
+void orc_gauss_grad(label n, label nf, const label *lo, const label *up, const scalar *Sfx, const scalar *Sfy,
+                    const scalar *Sfz, const scalar *ssf, const scalar *vol, scalar *gx, scalar *gy, scalar *gz)
+{
+    tables t = mk(n, nf, lo, up);
+    for (label c = 0; c < n; c++) {
+        scalar ox = 0, oy = 0, oz = 0;
+        for (label j = t.os[c]; j < t.os[c + 1]; j++) { ox = fma(Sfx[j], ssf[j], ox); oy = fma(Sfy[j], ssf[j], oy); oz = fma(Sfz[j], ssf[j], oz); }
+        for (label j = t.ls[c]; j < t.ls[c + 1]; j++) {
+            const label f = t.losort[j];
+            ox = fma(-Sfx[f], ssf[f], ox); oy = fma(-Sfy[f], ssf[f], oy); oz = fma(-Sfz[f], ssf[f], oz);
+        }
+        gx[c] = vol ? ox / vol[c] : ox; gy[c] = vol ? oy / vol[c] : oy; gz[c] = vol ? oz / vol[c] : oz;
+    }
+    rel(t);
+}
+
+/* out = a*x + b*y : fvMatrix::operator+=, -=, *= on the coefficient arrays (fvMatrix.C:700-1000) */
+void orc_axpby(label n, scalar a, const scalar *x, scalar b, const scalar *y, scalar *out)
+{
+    for (label i = 0; i < n; i++) out[i] = fma(a, x[i], b * y[i]);
+}

@@ -395,3 +395,46 @@ def face_interpolate(lower_addr, upper_addr, lam, phi):
     lib().orc_face_interpolate(C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(_d(lam), C.c_double),
                                _p(_d(phi), C.c_double), _p(out, C.c_double))
     return out
+
+
+def fvm_ddt_euler(r_delta_t, rho, vol, psi_old):
+    v, p0 = _d(vol), _d(psi_old)
+    diag, src = np.empty_like(v), np.empty_like(v)
+    lib().orc_fvm_ddt_euler(C.c_int32(v.shape[0]), C.c_double(r_delta_t), C.c_double(rho), _p(v, C.c_double), _p(p0, C.c_double),
+                            _p(diag, C.c_double), _p(src, C.c_double))
+    return diag, src
+
+
+def upwind_weights(face_flux):
+    f = _d(face_flux)
+    w = np.empty_like(f)
+    lib().orc_upwind_weights(C.c_int32(f.shape[0]), _p(f, C.c_double), _p(w, C.c_double))
+    return w
+
+
+def limited_linear_weights(lower_addr, upper_addr, k, cd_weights, face_flux, phi, grad, centres):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    w, lim = np.empty(lo.shape[0]), np.empty(lo.shape[0])
+    g = [_d(x) for x in grad]; c = [_d(x) for x in centres]
+    lib().orc_limited_linear_weights(C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), C.c_double(k), _p(_d(cd_weights), C.c_double),
+                                     _p(_d(face_flux), C.c_double), _p(_d(phi), C.c_double), _p(g[0], C.c_double), _p(g[1], C.c_double),
+                                     _p(g[2], C.c_double), _p(c[0], C.c_double), _p(c[1], C.c_double), _p(c[2], C.c_double),
+                                     _p(w, C.c_double), _p(lim, C.c_double))
+    return w, lim
+
+
+def gauss_grad(n_cells, lower_addr, upper_addr, sf, ssf, vol=None):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    s = [_d(x) for x in sf]
+    g = [np.empty(n_cells) for _ in range(3)]
+    lib().orc_gauss_grad(C.c_int32(n_cells), C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(s[0], C.c_double),
+                         _p(s[1], C.c_double), _p(s[2], C.c_double), _p(_d(ssf), C.c_double),
+                         _p(_d(vol), C.c_double) if vol is not None else None, _p(g[0], C.c_double), _p(g[1], C.c_double), _p(g[2], C.c_double))
+    return g
+
+
+def axpby(a, x, b, y):
+    xx, yy = _d(x), _d(y)
+    out = np.empty_like(xx)
+    lib().orc_axpby(C.c_int32(xx.shape[0]), C.c_double(a), _p(xx, C.c_double), C.c_double(b), _p(yy, C.c_double), _p(out, C.c_double))
+    return out

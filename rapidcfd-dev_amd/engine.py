@@ -39,6 +39,7 @@ class SolverControls(C.Structure):
 
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
+    "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
     "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
@@ -543,6 +544,24 @@ class Assembly:
 
     def face_interpolate(self, lam, phi, sf):
         _chk(lib().mi_face_interpolate(self.addr.h, _ptr(lam), _ptr(phi), _ptr(sf)))
+
+    def fvm_ddt_euler(self, r_delta_t, rho, vol, psi_old, diag_out, source_out):
+        _chk(lib().mi_fvm_ddt_euler(self.addr.ctx.h, C.c_int64(vol.numel()), C.c_double(r_delta_t), C.c_double(rho), _ptr(vol), _ptr(psi_old),
+                                    _ptr(diag_out), _ptr(source_out)))
+
+    def upwind_weights(self, face_flux, w_out):
+        _chk(lib().mi_upwind_weights(self.addr.ctx.h, C.c_int64(face_flux.numel()), _ptr(face_flux), _ptr(w_out)))
+
+    def limited_linear_weights(self, k, cd_weights, face_flux, phi, grad, centres, w_out, limiter_out=None):
+        _chk(lib().mi_limited_linear_weights(self.addr.h, C.c_double(k), _ptr(cd_weights), _ptr(face_flux), _ptr(phi), _ptr(grad[0]), _ptr(grad[1]),
+                                             _ptr(grad[2]), _ptr(centres[0]), _ptr(centres[1]), _ptr(centres[2]), _ptr(w_out), _ptr(limiter_out)))
+
+    def gauss_grad(self, sf, ssf, vol, grad_out):
+        _chk(lib().mi_gauss_grad(self.addr.h, _ptr(sf[0]), _ptr(sf[1]), _ptr(sf[2]), _ptr(ssf), _ptr(vol), _ptr(grad_out[0]), _ptr(grad_out[1]),
+                                 _ptr(grad_out[2])))
+
+    def axpby(self, a, x, b, y, out):
+        _chk(lib().mi_vec_axpby(self.addr.ctx.h, C.c_int64(x.numel()), C.c_double(a), _ptr(x), C.c_double(b), _ptr(y), _ptr(out)))
 
     def relax(self, alpha, diag, lower, upper, source, psi, patches=(), internal_coeffs=(), boundary_coeffs=(), coupled=()):
         n = len(patches)

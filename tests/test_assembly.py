@@ -146,3 +146,107 @@ def test_assemble_then_solve_matches_oracle_end_to_end(pkg, orc):
     _, ref = orc.System([ref_case]).pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-8, maxIter=500)
     assert perf["nIterations"] == ref["nIterations"]
     assert np.max(np.abs(perf["history"] - ref["history"])) < 1e-10
+
+
+# ---- scheme front-end: ddt, upwind / limitedLinear weights, Gauss gradient ---------------------------------------
+def box_geometry(dims):
+    """cell centres, internal-face area vectors Sf and linear weights of the uniform lexicographic box"""
+    nx, ny, nz = dims
+    h = 1.0 / nx
+    c = np.arange(nx * ny * nz)
+    C = [(c % nx + 0.5) * h, ((c // nx) % ny + 0.5) * h, (c // (nx * ny) + 0.5) * h]
+    return h, C
+
+
+def face_dirs(case, dims):
+    d = case.upper_addr.astype(np.int64) - case.lower_addr
+    return np.where(d == 1, 0, np.where(d == dims[0], 1, 2))
+
+
+def test_gauss_grad_of_a_linear_field_is_exact_inside(pkg, orc):
+    dims = (9, 8, 7)
+    case = pkg.synthetic.box_case(*dims)
+    h, C = box_geometry(dims)
+    phi = 2.0 * C[0] - 3.0 * C[1] + 0.5 * C[2]
+    direction = face_dirs(case, dims)
+    Sf = [np.where(direction == k, h * h, 0.0) for k in range(3)]
+    ssf = orc.face_interpolate(case.lower_addr, case.upper_addr, np.full(case.n_faces, 0.5), phi)
+    g = orc.gauss_grad(case.n_cells, case.lower_addr, case.upper_addr, Sf, ssf, np.full(case.n_cells, h ** 3))
+    nx, ny, nz = dims
+    c = np.arange(case.n_cells); i, j, k = c % nx, (c // nx) % ny, c // (nx * ny)
+    inner = (i > 0) & (i < nx - 1) & (j > 0) & (j < ny - 1) & (k > 0) & (k < nz - 1)
+    for comp, exact in zip(g, (2.0, -3.0, 0.5)):
+        assert np.max(np.abs(comp[inner] - exact)) < 1e-11
+
+
+def test_limited_linear_reduces_to_its_limits(pkg, orc):
+    dims = (10, 6, 5)
+    case = pkg.synthetic.box_case(*dims)
+    h, C = box_geometry(dims)
+    syn = pkg.synthetic
+    flux = syn.splitmix_uniform(5, case.n_faces) - 0.4
+    cdw = np.full(case.n_faces, 0.5)
+    # smooth linear field with its exact gradient: r = 1 -> limiter 1 -> central weights
+    phi = 1.0 + C[0] + 2 * C[1]
+    g = [np.full(case.n_cells, 1.0), np.full(case.n_cells, 2.0), np.zeros(case.n_cells)]
+    w, lim = orc.limited_linear_weights(case.lower_addr, case.upper_addr, 1.0, cdw, flux, phi, g, C)
+    assert np.all(lim == 1.0) and np.all(w == 0.5)
+    # local extremum (gradient opposes the face difference): r < 0 -> limiter 0 -> upwind
+    g2 = [-x for x in g]
+    w2, lim2 = orc.limited_linear_weights(case.lower_addr, case.upper_addr, 1.0, cdw, flux, phi, g2, C)
+    xy = face_dirs(case, dims) != 2      # z faces: phi does not vary -> gradf = 0 -> the 1000-branch with sign(0) = +1 -> limiter 1
+    assert np.all(lim2[xy] == 0.0) and np.array_equal(w2[xy], orc.upwind_weights(flux)[xy]) and np.all(lim2[~xy] == 1.0)
+    # uniform field: gradf = 0 -> the 1000-branch, sign(0) = +1
+    w3, lim3 = orc.limited_linear_weights(case.lower_addr, case.upper_addr, 1.0, cdw, flux, np.ones(case.n_cells), g, C)
+    assert np.all((lim3 == 0.0) | (lim3 == 1.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(13, 11, 9), (3, 2, 2)])
+def test_engine_scheme_front_end_bit_exact(pkg, orc, dims):
+    import torch
+    syn, eng = pkg.synthetic, pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    host = lambda t: t.cpu().numpy()
+    case = syn.box_case(*dims)
+    n, nf = case.n_cells, case.n_faces
+    addr = eng.Addressing(ctx, n, case.lower_addr, case.upper_addr)
+    A = eng.Assembly(addr)
+    h, C = box_geometry(dims)
+    E = lambda m: torch.empty(m, dtype=torch.float64, device="cuda:0")
+    # ddt
+    vol = h ** 3 * (1.0 + 0.2 * syn.splitmix_uniform(1, n)); psi0 = syn.splitmix_uniform(2, n) - 0.5
+    d, s = E(n), E(n)
+    A.fvm_ddt_euler(1.0 / 2.5e-3, 1.2, dev(vol), dev(psi0), d, s)
+    rd, rs = orc.fvm_ddt_euler(1.0 / 2.5e-3, 1.2, vol, psi0)
+    assert np.array_equal(host(d), rd) and np.array_equal(host(s), rs)
+    # upwind / limitedLinear
+    flux = syn.splitmix_uniform(5, nf) - 0.4
+    w = E(nf); A.upwind_weights(dev(flux), w)
+    assert np.array_equal(host(w), orc.upwind_weights(flux))
+    phi = np.sin(3 * C[0]) * np.cos(2 * C[1]) + C[2] ** 2 + 0.05 * syn.splitmix_uniform(6, n)
+    direction = face_dirs(case, dims)
+    Sf = [np.where(direction == k, h * h * (1 + 0.1 * syn.splitmix_uniform(10 + k, nf)), 0.01 * h * h * (syn.splitmix_uniform(20 + k, nf) - 0.5)) for k in range(3)]
+    cdw = 0.4 + 0.2 * syn.splitmix_uniform(7, nf)
+    ssf = orc.face_interpolate(case.lower_addr, case.upper_addr, cdw, phi)
+    g = [E(n) for _ in range(3)]
+    A.gauss_grad([dev(x) for x in Sf], dev(ssf), dev(vol), g)
+    rg = orc.gauss_grad(n, case.lower_addr, case.upper_addr, Sf, ssf, vol)
+    for a, b in zip(g, rg):
+        assert np.array_equal(host(a), b)
+    gn = [E(n) for _ in range(3)]
+    A.gauss_grad([dev(x) for x in Sf], dev(ssf), None, gn)
+    for a, b in zip(gn, orc.gauss_grad(n, case.lower_addr, case.upper_addr, Sf, ssf, None)):
+        assert np.array_equal(host(a), b)
+    for k in (1.0, 0.33, 0.0):
+        wl, lim = E(nf), E(nf)
+        A.limited_linear_weights(k, dev(cdw), dev(flux), dev(phi), [dev(x) for x in rg], [dev(x) for x in C], wl, lim)
+        rw, rl = orc.limited_linear_weights(case.lower_addr, case.upper_addr, k, cdw, flux, phi, rg, C)
+        assert np.array_equal(host(lim), rl) and np.array_equal(host(wl), rw)
+    # operator+= / -= on coefficient arrays
+    x, y = syn.splitmix_uniform(8, nf) - 0.5, syn.splitmix_uniform(9, nf) - 0.5
+    out = E(nf); A.axpby(1.0, dev(x), -0.75, dev(y), out)
+    assert np.array_equal(host(out), orc.axpby(1.0, x, -0.75, y))
+    xd = dev(x); A.axpby(2.0, xd, 1.0, dev(y), xd)           # in place
+    assert np.array_equal(host(xd), orc.axpby(2.0, x, 1.0, y))
