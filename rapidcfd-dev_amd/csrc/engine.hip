@@ -150,8 +150,9 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
 {
     if (!out) return fail(MI_ERR_ARG, "out is NULL");
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-        return fail(MI_ERR_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+    const hipError_t e0 = hipGetDeviceCount(&n);
+    if (e0 != hipSuccess || n <= 0)
+        return fail(MI_ERR_DEVICE, std::string("no HIP device visible: the engine has no CPU fallback (hipGetDeviceCount: ") + hipGetErrorString(e0) + ", " + std::to_string(n) + " devices)");
     if (device < 0 || device >= n) return fail(MI_ERR_ARG, "device index out of range");
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;

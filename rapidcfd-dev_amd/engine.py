@@ -118,6 +118,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MiError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # PyTorch (the plumbing for device memory / streams here) preloads its bundled HIP runtime by path.  If the engine
+        # were loaded first it would bind /opt/rocm's copy, torch would then map a second runtime, and the second one
+        # cannot open the device ("no ROCm-capable device").  Loading torch first makes both share one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pure C-ABI use without PyTorch
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.mi_last_error.restype = C.c_char_p
     return _lib

@@ -501,6 +501,56 @@ void fvm::div(fvScalarMatrix& M, const scalargpuField& weights, const scalargpuF
     miCheck(mi_fvm_div(M.lduAddr().handle(), weights.data(), faceFlux.data(), lower.data(), M.upper().data(), M.diag().data()), "fvm::div");
 }
 
+// ---- fvMatrix operators and the scheme front-end ------------------------------------------------------------------
+void fvScalarMatrix::axpyFrom(const fvScalarMatrix& B, scalar b)
+{
+    if (&B.lduAddr() != &lduAddr()) FatalErrorIn("fvMatrix::operator+=", "incompatible matrices: different addressing");
+    mi_ctx_t ctx = miEngine::New().ctx;
+    auto ax = [&](scalargpuField& x, const scalargpuField& y) {
+        if (x.size() != y.size()) FatalErrorIn("fvMatrix::operator+=", "incompatible fields");
+        if (x.size()) miCheck(mi_vec_axpby(ctx, x.size(), 1.0, x.data(), b, y.data(), x.data()), "fvMatrix::operator+=");
+    };
+    if (B.asymmetric() && symmetric()) lower();                 // promote: lower becomes a copy of upper first
+    if (asymmetric()) ax(lower(), B.lower());                    // B.lower() aliases B.upper() when B is symmetric
+    ax(upper(), B.upper()); ax(diag(), B.diag()); ax(source_, B.source_);
+    for (std::size_t p = 0; p < internalCoeffs_.size(); ++p) { ax(internalCoeffs_[p], B.internalCoeffs_[p]); ax(boundaryCoeffs_[p], B.boundaryCoeffs_[p]); }
+}
+fvScalarMatrix& fvScalarMatrix::operator+=(const fvScalarMatrix& B) { axpyFrom(B, 1.0); return *this; }
+fvScalarMatrix& fvScalarMatrix::operator-=(const fvScalarMatrix& B) { axpyFrom(B, -1.0); return *this; }
+fvScalarMatrix& fvScalarMatrix::operator*=(scalar s)
+{
+    mi_ctx_t ctx = miEngine::New().ctx;
+    auto sc = [&](scalargpuField& x) { if (x.size()) miCheck(mi_vec_axpby(ctx, x.size(), s, x.data(), 0.0, x.data(), x.data()), "fvMatrix::operator*="); };
+    if (asymmetric()) sc(lower());
+    sc(upper()); sc(diag()); sc(source_);
+    for (std::size_t p = 0; p < internalCoeffs_.size(); ++p) { sc(internalCoeffs_[p]); sc(boundaryCoeffs_[p]); }
+    return *this;
+}
+void fvm::ddt(fvScalarMatrix& M, scalar rDeltaT, scalar rho, const scalargpuField& V, const scalargpuField& psiOld)
+{
+    miCheck(mi_fvm_ddt_euler(miEngine::New().ctx, V.size(), rDeltaT, rho, V.data(), psiOld.data(), M.diag().data(), M.source().data()), "fvm::ddt");
+}
+void fvc::grad(vectorgpuField& g, const lduAddressing& a, const vectorgpuField& Sf, const scalargpuField& ssf, const scalargpuField& V)
+{
+    miCheck(mi_gauss_grad(a.handle(), Sf.component(0).data(), Sf.component(1).data(), Sf.component(2).data(), ssf.data(), V.data(),
+                          g.component(0).data(), g.component(1).data(), g.component(2).data()), "fvc::grad");
+}
+void fvc::interpolate(scalargpuField& sf, const lduAddressing& a, const scalargpuField& weights, const scalargpuField& vf)
+{
+    miCheck(mi_face_interpolate(a.handle(), weights.data(), vf.data(), sf.data()), "fvc::interpolate");
+}
+void upwindWeights(scalargpuField& w, const scalargpuField& faceFlux)
+{
+    miCheck(mi_upwind_weights(miEngine::New().ctx, faceFlux.size(), faceFlux.data(), w.data()), "upwind::weights");
+}
+void limitedLinearWeights(scalargpuField& w, const lduAddressing& a, scalar k, const scalargpuField& cdWeights, const scalargpuField& faceFlux,
+                          const scalargpuField& vf, const vectorgpuField& gradVf, const vectorgpuField& C)
+{
+    miCheck(mi_limited_linear_weights(a.handle(), k, cdWeights.data(), faceFlux.data(), vf.data(), gradVf.component(0).data(),
+                                      gradVf.component(1).data(), gradVf.component(2).data(), C.component(0).data(), C.component(1).data(),
+                                      C.component(2).data(), w.data(), nullptr), "limitedLinear::weights");
+}
+
 // ---- Pstream: the parallel run as this path sees it -------------------------------------------------------------
 namespace {
 struct PstreamState { bool par = false; int rank = 0, n = 1; mi_comm_t red = nullptr, halo = nullptr; };

@@ -86,14 +86,12 @@ int main(int argc, char** argv)
             for (label f = 0; f < nf; ++f) { phi[f] = dir[f] == 0 ? 0.3 * h * h : 0.0; wts[f] = 1.0; } // upwind, flow in +x
             fvScalarMatrix conv("Ux", addr, patches, std::vector<bool>(6, false));
             fvm::div(conv, scalargpuField(wts), scalargpuField(phi));
-            // UEqn = ddt + conv - lap, assembled on the host side of the mirror (lduMatrix::operator+=/-= are whole-array axpys)
-            std::vector<scalar> cl = conv.lower().asHost(), cu = conv.upper().asHost(), cd = conv.diag().asHost();
-            std::vector<scalar> lu = pEqn.upper().asHost(), ld = pEqn.diag().asHost();
-            for (label f = 0; f < nf; ++f) { cl[f] -= lu[f]; cu[f] -= lu[f]; }
-            for (label c = 0; c < n; ++c) cd[c] = cd[c] - ld[c] + h * h * h / 1e-3;
+            // UEqn = fvm::ddt(U) + fvm::div(phi, U) - fvm::laplacian(nu, U), with the fvMatrix operators (fvMatrix.C:1693-1830)
             fvScalarMatrix UEqn("Ux", addr, patches, std::vector<bool>(6, false));
-            UEqn.lower() = cl; UEqn.upper() = cu; UEqn.diag() = cd; UEqn.source() = src;
-            UEqn.internalCoeffs()[0] = scalarField(patches[0].size(), 2.0 * h);
+            fvm::ddt(UEqn, 1.0 / 1e-3, 1.0, scalargpuField(scalarField(n, h * h * h)), scalargpuField(n));
+            UEqn += conv;
+            UEqn -= pEqn;                      // brings -(-2h) = 2h into internalCoeffs of the fixedValue patch as well
+            UEqn.source() = src;
             for (const char* s : {"PBiCG", "PBiCGStab"}) {
                 scalargpuField psi(n);
                 UEqn.solve(psi, dictionary{{"solver", s}, {"preconditioner", "DILU"}, {"tolerance", "1e-10"}, {"relTol", "0"}});
@@ -108,10 +106,11 @@ int main(int argc, char** argv)
             for (label f = 0; f < nf; ++f) phi[f] = dir[f] == 0 ? 0.3 * h * h : 0.0;
             fvScalarMatrix conv("U", addr, patches, std::vector<bool>(6, false));
             fvm::div(conv, scalargpuField(wts), scalargpuField(phi));
-            std::vector<scalar> cl = conv.lower().asHost(), cu = conv.upper().asHost(), cd = conv.diag().asHost();
-            std::vector<scalar> lu = pEqn.upper().asHost(), ld = pEqn.diag().asHost();
-            for (label f = 0; f < nf; ++f) { cl[f] -= lu[f]; cu[f] -= lu[f]; }
-            for (label c = 0; c < n; ++c) cd[c] = cd[c] - ld[c] + h * h * h / 1e-3;
+            fvScalarMatrix tmpEqn("U", addr, patches, std::vector<bool>(6, false));   // ddt + div - laplacian, shared by the components
+            fvm::ddt(tmpEqn, 1.0 / 1e-3, 1.0, scalargpuField(scalarField(n, h * h * h)), scalargpuField(n));
+            tmpEqn += conv;
+            tmpEqn -= pEqn;
+            std::vector<scalar> cl = tmpEqn.lower().asHost(), cu = tmpEqn.upper().asHost(), cd = tmpEqn.diag().asHost();
             fvVectorMatrix UEqn("U", addr, patches, std::vector<bool>(6, false));
             UEqn.lower() = cl; UEqn.upper() = cu; UEqn.diag() = cd;
             for (int d = 0; d < 3; ++d) {

@@ -55,7 +55,8 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     phi = np.where(direction == 0, 0.3 * h * h, 0.0)
     cl, cu, cd = orc.fvm_div(n, case.lower_addr, case.upper_addr, np.ones(nf), phi)
     ul, uu = cl - upper, cu - upper
-    ud = cd - diag + h ** 3 / 1e-3
+    ddt_d, _ = orc.fvm_ddt_euler(1.0 / 1e-3, 1.0, np.full(n, h * h * h), z)     # UEqn = ddt; += conv; -= lap (operator order)
+    ud = orc.axpby(1.0, orc.axpby(1.0, ddt_d, 1.0, cd), -1.0, diag)
     ud_solve = orc.patch_add(xmin, np.full(xmin.shape[0], 2.0 * h), ud, 0)
     U = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, ud_solve, uu, ul, src)])
     _, p = U.pbicg(z, src, "AINV", tolerance=1e-10); exp.append(("AINVPBiCG", "Ux", p))
