@@ -305,6 +305,8 @@ int mi_limited_linear_weights(mi_addr_t addr, double k, const double *cd_weights
 int mi_gauss_grad(mi_addr_t addr, const double *sfx_dev, const double *sfy_dev, const double *sfz_dev,
                   const double *ssf_dev, const double *vol_dev_or_null, double *gx_dev, double *gy_dev, double *gz_dev);
 int mi_vec_axpby(mi_ctx_t ctx, int64_t n, double a, const double *x_dev, double b, const double *y_dev, double *out_dev);
+/* out = x / y element-wise (fvMatrix::A = D/V, fvMatrix::H /= V; fvMatrix.C:1424-1506); out may alias x */
+int mi_vec_div(mi_ctx_t ctx, int64_t n, const double *x_dev, const double *y_dev, double *out_dev);
 int mi_patch_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_patch_faces, const int32_t *face_cells_host, mi_patch_t *out);
 int mi_patch_destroy(mi_patch_t patch);
 int mi_patch_add(mi_patch_t patch, const double *pf_dev, double *intf_dev, int fn);

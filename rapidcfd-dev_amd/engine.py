@@ -39,7 +39,7 @@ class SolverControls(C.Structure):
 
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
-    "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby",
+    "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
     "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",

@@ -515,6 +515,21 @@ void fvScalarMatrix::axpyFrom(const fvScalarMatrix& B, scalar b)
     ax(upper(), B.upper()); ax(diag(), B.diag()); ax(source_, B.source_);
     for (std::size_t p = 0; p < internalCoeffs_.size(); ++p) { ax(internalCoeffs_[p], B.internalCoeffs_[p]); ax(boundaryCoeffs_[p], B.boundaryCoeffs_[p]); }
 }
+void fvScalarMatrix::A(scalargpuField& Aphi, const scalargpuField& V) const
+{
+    Aphi = diag();
+    addBoundaryDiag(Aphi);
+    miCheck(mi_vec_div(miEngine::New().ctx, Aphi.size(), Aphi.data(), V.data(), Aphi.data()), "fvMatrix::A");
+}
+void fvScalarMatrix::H(scalargpuField& Hphi, const scalargpuField& psi, const scalargpuField& V) const
+{
+    static const FieldFieldScalar none; static const lduInterfaceFieldPtrsList noIfs;
+    miCheck(mi_H(handle(none, none, noIfs), psi.data(), Hphi.data()), "lduMatrix::H");
+    mi_ctx_t ctx = miEngine::New().ctx;
+    miCheck(mi_vec_axpby(ctx, Hphi.size(), 1.0, Hphi.data(), 1.0, source_.data(), Hphi.data()), "fvMatrix::H");
+    addBoundarySource(Hphi);
+    miCheck(mi_vec_div(ctx, Hphi.size(), Hphi.data(), V.data(), Hphi.data()), "fvMatrix::H");
+}
 fvScalarMatrix& fvScalarMatrix::operator+=(const fvScalarMatrix& B) { axpyFrom(B, 1.0); return *this; }
 fvScalarMatrix& fvScalarMatrix::operator-=(const fvScalarMatrix& B) { axpyFrom(B, -1.0); return *this; }
 fvScalarMatrix& fvScalarMatrix::operator*=(scalar s)

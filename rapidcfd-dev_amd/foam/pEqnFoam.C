@@ -96,6 +96,14 @@ int main(int argc, char** argv)
                 scalargpuField psi(n);
                 UEqn.solve(psi, dictionary{{"solver", s}, {"preconditioner", "DILU"}, {"tolerance", "1e-10"}, {"relTol", "0"}});
             }
+            {   // rAU / HbyA ingredients of the PISO-SIMPLE corrector: UEqn.A(), UEqn.H()
+                scalargpuField V(scalarField(n, h * h * h)), Aphi(n), Hphi(n), U0(src);
+                UEqn.A(Aphi, V); UEqn.H(Hphi, U0, V);
+                std::vector<scalar> a = Aphi.asHost(), hh = Hphi.asHost();
+                scalar sa = 0, sh = 0, ma = 0, mh = 0;
+                for (label c = 0; c < n; ++c) { sa += a[c]; sh += hh[c]; ma = std::max(ma, std::fabs(a[c])); mh = std::max(mh, std::fabs(hh[c])); }
+                Info << "A(Ux) sum max: " << sa << " " << ma << "  H(Ux) sum max: " << sh << " " << mh << std::endl;
+            }
             scalargpuField psi(n);
             UEqn.relax(0.7, psi);
             UEqn.solve(psi, dictionary{{"solver", "PBiCG"}, {"preconditioner", "diagonal"}, {"tolerance", "1e-10"}, {"relTol", "0"}});

@@ -61,6 +61,14 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     U = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, ud_solve, uu, ul, src)])
     _, p = U.pbicg(z, src, "AINV", tolerance=1e-10); exp.append(("AINVPBiCG", "Ux", p))
     _, p = U.pbicgstab(z, src, "AINV", tolerance=1e-10, replicate_quirk=True); exp.append(("AINVPBiCGStab", "Ux", p))
+    # fvMatrix::A / H of the assembled UEqn (before relax), psi = src
+    V = np.full(n, h * h * h)
+    a_ref = ud_solve / V
+    h_ref = (orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, ud, uu, ul, src)]).H(src) + src) / V
+    m = re.search(r"A\(Ux\) sum max: (\S+) (\S+)  H\(Ux\) sum max: (\S+) (\S+)", out.stdout)
+    assert m, out.stdout
+    assert abs(float(m.group(1)) - a_ref.sum()) < 1e-9 * abs(a_ref.sum()) and float(m.group(2)) == np.max(np.abs(a_ref))
+    assert abs(float(m.group(3)) - h_ref.sum()) < 1e-9 * np.abs(h_ref).sum() and float(m.group(4)) == np.max(np.abs(h_ref))
     rd, rs = orc.relax(n, case.lower_addr, case.upper_addr, 0.7, ud, ul, uu, src, z, [xmin], [np.full(xmin.shape[0], 2.0 * h)],
                        [np.zeros(xmin.shape[0])], [0])
     rd_solve = orc.patch_add(xmin, np.full(xmin.shape[0], 2.0 * h), rd, 0)
