@@ -1,4 +1,4 @@
-"""Regenerates tests/golden/golden_v1.npz from the CPU oracle.
+"""Regenerates tests/golden/golden_v2.npz (and, with --v1, golden_v1.npz) from the CPU oracle.
 
 The reference holds no golden vectors, so these fixtures are the oracle's own
 outputs on the synthetic cases, frozen so that any later change of the oracle or of the generators
@@ -46,9 +46,80 @@ def build(pkg, orc):
     return out
 
 
+def cyclic_case(pkg, symmetric):
+    return pkg.synthetic.add_cyclic_y(pkg.synthetic.box_case(12, 10, 8, symmetric=symmetric), asym_shift=0.0 if symmetric else 0.25)
+
+
+def front_end_inputs(pkg, case, dims):
+    """geometry + fields of the scheme front-end fixtures (uniform box, perturbed so that nothing is symmetric)"""
+    syn = pkg.synthetic
+    nx = dims[0]
+    h = 1.0 / nx
+    n, nf = case.n_cells, case.n_faces
+    c = np.arange(n)
+    C = [(c % nx + 0.5) * h, ((c // nx) % dims[1] + 0.5) * h, (c // (nx * dims[1]) + 0.5) * h]
+    d = case.upper_addr.astype(np.int64) - case.lower_addr
+    direction = np.where(d == 1, 0, np.where(d == nx, 1, 2))
+    Sf = [np.where(direction == k, h * h * (1 + 0.1 * syn.splitmix_uniform(10 + k, nf)), 0.01 * h * h * (syn.splitmix_uniform(20 + k, nf) - 0.5)) for k in range(3)]
+    vol = h ** 3 * (1.0 + 0.2 * syn.splitmix_uniform(1, n))
+    phi = np.sin(3 * C[0]) * np.cos(2 * C[1]) + C[2] ** 2 + 0.05 * syn.splitmix_uniform(6, n)
+    flux = syn.splitmix_uniform(5, nf) - 0.4
+    cdw = 0.4 + 0.2 * syn.splitmix_uniform(7, nf)
+    return dict(C=C, Sf=Sf, vol=vol, phi=phi, flux=flux, cdw=cdw)
+
+
+def build_v2(pkg, orc):
+    """second fixture set: coupled patches, GAMG (single domain, cyclic, decomposed), scheme front-end"""
+    syn = pkg.synthetic
+    out = {}
+    for sym in (True, False):
+        case = cyclic_case(pkg, sym)
+        S = orc.System([case])
+        tag = "cyclic_sym" if sym else "cyclic_asym"
+        x = syn.splitmix_uniform(2024, case.n_cells) - 0.5
+        step = max(1, case.n_cells // 257)
+        out[f"{tag}/amul"] = S.amul(x)[::step]
+        out[f"{tag}/tmul"] = S.tmul(x)[::step]
+        out[f"{tag}/jacobi2"] = S.jacobi_smooth(x, case.source, 2)[::step]
+        z = np.zeros(case.n_cells)
+        if sym:
+            out[f"{tag}/pcg_diagonal"] = S.pcg(z, case.source, "diagonal", tolerance=1e-8, maxIter=1000)[1]["history"]
+        else:
+            out[f"{tag}/pbicg_AINV"] = S.pbicg(z, case.source, "AINV", tolerance=1e-10, maxIter=300)[1]["history"]
+        out[f"{tag}/gamg"] = orc.GamgSysHierarchy(S, [orc.box_face_weights(case)], 10).solve(z, case.source, tolerance=1e-9, maxIter=100)[1]["history"]
+    case = syn.box_case(16, 12, 12)
+    out["box_16x12x12/gamg"] = orc.GamgHierarchy(case, orc.box_face_weights(case), 10).solve(np.zeros(case.n_cells), case.source, tolerance=1e-9, maxIter=100)[1]["history"]
+    subs = syn.decompose_box(case, (2, 2, 1))
+    S = orc.System(subs)
+    H = orc.GamgSysHierarchy(S, [orc.box_face_weights(s) for s in subs], 10)
+    out["box_16x12x12_2x2x1/gamg"] = H.solve(np.zeros(S.n), np.concatenate([s.source for s in subs]), tolerance=1e-9, maxIter=100)[1]["history"]
+    out["box_16x12x12_2x2x1/level0_coarse_cells"] = np.array([H.level(d, 0)["n_coarse"] for d in range(4)])
+    # scheme front-end
+    dims = (13, 11, 9)
+    case = syn.box_case(*dims)
+    f = front_end_inputs(pkg, case, dims)
+    ssf = orc.face_interpolate(case.lower_addr, case.upper_addr, f["cdw"], f["phi"])
+    g = orc.gauss_grad(case.n_cells, case.lower_addr, case.upper_addr, f["Sf"], ssf, f["vol"])
+    stepc, stepf = max(1, case.n_cells // 257), max(1, case.n_faces // 257)
+    for k in range(3):
+        out[f"front_end/grad{k}"] = g[k][::stepc]
+    for kk in (1.0, 0.33):
+        w, lim = orc.limited_linear_weights(case.lower_addr, case.upper_addr, kk, f["cdw"], f["flux"], f["phi"], g, f["C"])
+        out[f"front_end/limitedLinear_{kk}_w"] = w[::stepf]
+        out[f"front_end/limitedLinear_{kk}_limiter"] = lim[::stepf]
+    d, s = orc.fvm_ddt_euler(400.0, 1.2, f["vol"], f["phi"])
+    out["front_end/ddt_diag"] = d[::stepc]; out["front_end/ddt_source"] = s[::stepc]
+    lo, up, dg = orc.fvm_div(case.n_cells, case.lower_addr, case.upper_addr, orc.upwind_weights(f["flux"]), f["flux"])
+    out["front_end/div_upwind_lower"] = lo[::stepf]; out["front_end/div_upwind_upper"] = up[::stepf]; out["front_end/div_upwind_diag"] = dg[::stepc]
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
     from oracle import oracle as orc
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.npz"), **build(pkg, orc))
+    here = os.path.dirname(os.path.abspath(__file__))
+    if "--v1" in sys.argv:   # v1 is frozen; regenerate only on purpose
+        np.savez_compressed(os.path.join(here, "golden_v1.npz"), **build(pkg, orc))
+    np.savez_compressed(os.path.join(here, "golden_v2.npz"), **build_v2(pkg, orc))
     print("written")
