@@ -90,6 +90,12 @@ class System:
         except Exception:
             pass
 
+    def baseline_pcg(self, source, n_iter):
+        """timing kernel of bench.py's cpu_baseline: one OpenMP thread per domain = one MPI rank per core (baseline_oracle.c)"""
+        sec, res = C.c_double(), C.c_double()
+        n = lib().orc_baseline_pcg(self.h, _p(_d(source), C.c_double), C.c_int(n_iter), C.byref(sec), C.byref(res))
+        return int(n), float(sec.value), float(res.value)
+
     def set_accurate(self, on: bool):
         lib().orc_sys_set_accurate(self.h, int(on))
 

@@ -137,3 +137,18 @@ def test_jacobi_fixed_point(pkg, orc):
     assert np.max(np.abs(S.jacobi_smooth(exact, case.source, 3) - exact)) < 1e-12 * np.max(np.abs(exact))
     x = S.jacobi_smooth(np.zeros(case.n_cells), case.source, 400)
     assert np.max(np.abs(x - exact)) < 1e-3 * np.max(np.abs(exact))
+
+
+def test_cpu_baseline_kernel_is_the_same_pcg(pkg, orc):
+    # bench.py's cpu_baseline leg (one OpenMP thread per domain, face-loop Amul) runs the same diagonal PCG:
+    # its sum|rA| after k iterations equals the parity oracle's residual, serial and decomposed
+    syn = pkg.synthetic
+    case = syn.box_case(20, 16, 12)
+    _, p = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=0.0, maxIter=29)
+    ref = p["finalResidual"] * p["normFactor"]
+    for parts in ((1, 1, 1), (1, 1, 3), (1, 1, 4)):
+        subs = syn.decompose_box(case, parts) if parts != (1, 1, 1) else [case]
+        S = orc.System(subs)
+        n, sec, res = S.baseline_pcg(np.concatenate([s.source for s in subs]), 30)
+        assert n == 30 and sec > 0
+        assert abs(res - ref) < 1e-9 * ref
