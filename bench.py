@@ -109,8 +109,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     nx, ny, nz = args.dims
     t0 = time.perf_counter()
-    case = syn.box_case(nx, ny, nz)
-    N, F = case.n_cells, case.n_faces
+    N, F = nx * ny * nz, 3 * nx * ny * nz - (ny * nz + nx * nz + nx * ny)
+    force_dist = bool(os.environ.get("MI_BENCH_FORCE_DIST"))  # exercise the N>1 code path on one GPU
+    single = world == 1 and not force_dist
+    # N = 1: the whole case (the CPU baseline needs it too); N > 1: every rank builds only its own sub-domain
+    case = syn.box_case(nx, ny, nz) if (single or (rank == 0 and not args.no_cpu and world == 1)) else None
     if rank == 0:
         log(f"[bench] case {nx}x{ny}x{nz}: N={N} F={F} built in {time.perf_counter() - t0:.1f}s")
 
@@ -128,8 +131,8 @@ def main():
     amul_ms = None
     host_enqueue_us = None
     host_loop = "single-GPU device-resident pipeline (mi_pcg_iterate)"
-    force_dist = bool(os.environ.get("MI_BENCH_FORCE_DIST"))  # exercise the N>1 code path on one GPU
-    if world == 1 and not force_dist:
+    weak = None
+    if single:
         t0 = time.perf_counter()
         addr = eng.Addressing(ctx, N, case.lower_addr, case.upper_addr)
         mat = eng.Matrix(addr)
@@ -152,7 +155,7 @@ def main():
     else:
         from importlib import import_module
         par = import_module(graft.PKG_NAME + ".parallel")
-        sub = syn.decompose_box(case, parts_for(world))[rank]
+        sub = syn.box_subdomain((nx, ny, nz), parts_for(world), rank)   # == decompose_box(box_case(...))[rank], built directly
         solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
         host_loop = {"native": "C++ loop over RCCL (mi_dpcg_comm_iterate)", "torch": "torch.distributed loop (parallel.py)"}[solver.driver]
         solver.begin(tolerance=0.0, max_iter=W + K + 8)
@@ -162,7 +165,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        amul_ms = solver.iterate(K, time_amul=True)
+        amul_ms = solver.iterate(K, time_amul=True, event_stride=8)   # sampled: event records cost ~3 us each in this latency-bound loop
         host_enqueue_us = 1e6 * solver.last_enqueue_s / K   # host time to enqueue one iteration (incl. collectives)
         torch.cuda.synchronize()
         if world > 1:
@@ -175,6 +178,33 @@ def main():
         perf = solver.end()
         assert perf["nIterations"] == W + K, perf
         n_amul_cells, n_amul_faces = sub.n_cells, sub.n_faces + sum(len(i.face_cells) for i in sub.interfaces)
+        # supplement (not `value`): the same solver with the per-GPU work held at the N = 1 size (weak scaling;
+        # at 8 GPUs this is the 80 M-cell box of BASELINE config 5), so that the latency-bound strong-scaling number
+        # above can be read beside the regime the halo/all-reduce overlap is designed for
+        if world > 1 or os.environ.get("MI_BENCH_WEAK"):
+            px, py, pz = parts_for(world)
+            del solver
+            wsub = syn.box_subdomain((nx * px, ny * py, nz * pz), (px, py, pz), rank)
+            ws = par.DistributedPCG(ctx, wsub, dev, precond=args.precond)
+            ws.begin(tolerance=0.0, max_iter=W + K + 8)
+            ws.iterate(W)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            ws.iterate(K)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            wel = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([wel], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                wel = float(tmax.item())
+            wperf = ws.end()
+            assert wperf["nIterations"] == W + K, wperf
+            weak = {"cells_per_gpu": wsub.n_cells, "global_cells": nx * px * ny * py * nz * pz, "iterations_per_s": K / wel,
+                    "ms_per_step": 1e3 * wel / K, "cell_iterations_per_s": nx * px * ny * py * nz * pz * K / wel}
 
     its = K / elapsed
     amul_avg_s = (amul_ms / 1e3) / K
@@ -199,6 +229,7 @@ def main():
             "cells": N, "faces": F, "parallelism": f"domain-decomposition {parts_for(world)}" if world > 1 else "single GPU",
             "pcg_algorithmic_GBps": (160 * N + 16 * F) * its / 1e9,
             "host_enqueue_us_per_step": host_enqueue_us, "host_loop": host_loop,
+            "weak_scaling_supplement": weak,
         },
         "roofline": {
             "kernel": "tile_kernel<OP_AMUL> (lduMatrix::Amul)",
@@ -210,7 +241,9 @@ def main():
         },
     }
     if rank == 0:
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
+            if case is None:
+                case = syn.box_case(nx, ny, nz)
             v, n_it, dt, cores = cpu_baseline(case, syn, args.cpu_iters)
             out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": cores, "kind": "port",
                                    "sample": f"{n_it} diagonal-PCG iterations of the same {nx}x{ny}x{nz} matrix in {dt:.1f}s: upstream OpenFOAM "

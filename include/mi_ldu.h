@@ -362,8 +362,8 @@ int mi_dpcg_status(mi_matrix_t m, mi_solver_perf *perf_out, int32_t *done_out,
  *     and the scalar all-reduces progress independently.  patch_rank[p] = rank on the other side of
  *     processor patch p; patch_nbr_patch[p] = index of the matching patch on that rank (NULL = same index).
  *   mi_dpcg_comm_iterate: enqueue n_iters iterations without host synchronisation; poll with
- *     mi_dpcg_status.  record_amul_events != 0 brackets the Amul phases of the k-th enqueued iteration
- *     with the events 2k, 2k+1 of the matrix (mi_event_elapsed_ms).                                   */
+ *     mi_dpcg_status.  record_amul_events = s > 0 brackets the Amul phases of every s-th enqueued iteration
+ *     (k = 0, s, 2s, ...) with the events 2(k/s), 2(k/s)+1 of the matrix (mi_event_elapsed_ms).       */
 int mi_comm_unique_id(void *id_out, int32_t len);
 int mi_comm_create(mi_ctx_t ctx, int32_t n_ranks, int32_t rank, const void *id, mi_comm_t *out);
 int mi_comm_destroy(mi_comm_t comm);

@@ -406,8 +406,8 @@ class Matrix:
         _chk(lib().mi_dpcg_comm_begin(self.h, reduce.h, halo.h, pr.ctypes.data_as(I32) if pr.size else I32(),
                                       pn.ctypes.data_as(I32) if pn is not None and pn.size else I32(), C.c_int64(n_global)))
 
-    def dpcg_comm_iterate(self, n_iters: int, time_amul: bool = False):
-        _chk(lib().mi_dpcg_comm_iterate(self.h, C.c_int32(n_iters), C.c_int32(1 if time_amul else 0)))
+    def dpcg_comm_iterate(self, n_iters: int, event_stride: int = 0):
+        _chk(lib().mi_dpcg_comm_iterate(self.h, C.c_int32(n_iters), C.c_int32(event_stride)))
 
     def event_record(self, idx: int):
         _chk(lib().mi_event_record(self.h, C.c_int32(idx)))

@@ -197,29 +197,32 @@ class DistributedPCG:
         self.it = 0
         self.max_iter, self.min_iter = max_iter, min_iter
 
-    def iterate(self, n_iters: int, time_amul: bool = False):
-        """enqueue n_iters iterations (device no-ops once converged); no host synchronisation."""
+    def iterate(self, n_iters: int, time_amul: bool = False, event_stride: int = 1):
+        """enqueue n_iters iterations (device no-ops once converged); no host synchronisation.  time_amul: HIP events
+        around the Amul phases of every event_stride-th iteration; returns their mean duration x n_iters (ms)."""
         o = self.ops
         import time
         t0 = time.perf_counter()
         if self.driver == "native":
-            o.mat.dpcg_comm_iterate(n_iters, time_amul)
+            o.mat.dpcg_comm_iterate(n_iters, event_stride if time_amul else 0)
             self.it += n_iters
             self.last_enqueue_s = time.perf_counter() - t0   # host time to enqueue (no synchronisation inside)
             if time_amul:
-                return sum(o.event_elapsed_ms(2 * k, 2 * k + 1) for k in range(n_iters))
+                ns = (n_iters + event_stride - 1) // event_stride
+                return sum(o.event_elapsed_ms(2 * k, 2 * k + 1) for k in range(ns)) * (n_iters / ns)
             return None
         for k in range(n_iters):
             it = self.it
             o.phase(10, it)
             wait = self._start_exchange(o.pA)
-            if time_amul:
-                o.event_record(2 * k)
+            rec = time_amul and k % event_stride == 0
+            if rec:
+                o.event_record(2 * (k // event_stride))
             o.phase(11, it)      # interior tiles overlap the exchange
             wait()
             o.phase(12, it)      # boundary tiles
-            if time_amul:
-                o.event_record(2 * k + 1)
+            if rec:
+                o.event_record(2 * (k // event_stride) + 1)
             self._allreduce(self._s2)
             o.phase(13, it)
             self._allreduce(self._s01)
@@ -228,7 +231,8 @@ class DistributedPCG:
             o.phase(14, self.it - 1)
         self.last_enqueue_s = time.perf_counter() - t0
         if time_amul:
-            return sum(o.event_elapsed_ms(2 * k, 2 * k + 1) for k in range(n_iters))
+            ns = (n_iters + event_stride - 1) // event_stride
+            return sum(o.event_elapsed_ms(2 * k, 2 * k + 1) for k in range(ns)) * (n_iters / ns)
         return None
 
     def end(self):

@@ -39,6 +39,17 @@ def splitmix_uniform(seed: int, n: int, start: int = 0) -> np.ndarray:
     return (z >> _U64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
+def splitmix_at(seed: int, idx: np.ndarray) -> np.ndarray:
+    """splitmix_uniform(seed, .)[idx] without generating the whole sequence"""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(idx).astype(np.uint64) + _U64(1)) * _U64(0x9E3779B97F4A7C15)
+        z = z + _U64(seed & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
+        z = z ^ (z >> _U64(31))
+    return (z >> _U64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
 @dataclass
 class Interface:
     """One processor patch of a sub-domain (processorLduInterface + coeffs)."""
@@ -236,3 +247,79 @@ def add_cyclic_y(case: LduCase, kappa_scale: float = 1.0, asym_shift: float = 0.
         Interface(nbr_domain=0, nbr_patch=0, face_cells=ymax, bou_coeffs=-(kappa - sign * asym_shift * h), int_coeffs=-kappa),
     ]
     return out
+
+
+def _chunks(nd: int, p: int) -> np.ndarray:
+    return (np.arange(p + 1) * nd) // p
+
+
+def _global_face_index(c, i, j, k, direction, dims):
+    """index of the internal face (owner c, +direction) in box_addressing's order, in closed form"""
+    nx, ny, nz = dims
+    before = 3 * c - c // nx - (k * nx + np.where(j == ny - 1, i, 0)) - np.where(k == nz - 1, c - (nz - 1) * nx * ny, 0)
+    has_x, has_y = (i < nx - 1).astype(np.int64), (j < ny - 1).astype(np.int64)
+    return before + np.where(direction == 0, 0, np.where(direction == 1, has_x, has_x + has_y))
+
+
+def box_subdomain(global_dims, parts, rank: int, *, vary: float = 0.1, seed: int = 12345, rhs_seed: int = 777) -> LduCase:
+    """Sub-domain ``rank`` of decompose_box(box_case(*global_dims), parts) built DIRECTLY (symmetric case): the global
+    case is never formed, so an 8 x 216^3 weak-scaling run costs every rank only its own 10 M cells.  Identical, array
+    for array, to the decomposed global case (tests/test_distributed.py)."""
+    nx, ny, nz = global_dims
+    px, py, pz = parts
+    bx, by, bz = _chunks(nx, px), _chunks(ny, py), _chunks(nz, pz)
+    rx, ry, rz = rank % px, (rank // px) % py, rank // (px * py)
+    i0, i1, j0, j1, k0, k1 = bx[rx], bx[rx + 1], by[ry], by[ry + 1], bz[rz], bz[rz + 1]
+    lx, ly, lz = int(i1 - i0), int(j1 - j0), int(k1 - k0)
+    n = lx * ly * lz
+    h = 1.0 / nx
+    lo, up, direction = box_addressing(lx, ly, lz)
+    c = np.arange(n, dtype=np.int64)
+    gi, gj, gk = c % lx + i0, (c // lx) % ly + j0, c // (lx * ly) + k0
+    gc = gi + nx * (gj + ny * gk)
+
+    def coef(owner_local, d):   # coefficient of the global face (owner, +d)
+        o = owner_local
+        f = _global_face_index(gc[o], gi[o], gj[o], gk[o], d, (nx, ny, nz))
+        return h * (1.0 + vary * splitmix_at(seed, f))
+
+    upper = coef(lo.astype(np.int64), direction.astype(np.int64))
+    diag = -(np.bincount(lo, weights=upper, minlength=n) + np.bincount(up, weights=upper, minlength=n)).astype(np.float64)
+    diag[gi == 0] += -2.0 * h
+    source = (2.0 * splitmix_at(rhs_seed, gc) - 1.0) * h ** 3
+    sub = LduCase(n, lo, up, diag, upper, None, source, dims=(lx, ly, lz), global_cells=gc)
+    # processor patches, ordered by neighbour rank (as decompose_box orders them); faces by global face id
+    def nbr_list(qx, qy, qz):
+        out = []
+        for dz, dy, dx in ((-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 1), (0, 1, 0), (1, 0, 0)):
+            ax, ay, az = qx + dx, qy + dy, qz + dz
+            if 0 <= ax < px and 0 <= ay < py and 0 <= az < pz:
+                out.append(ax + px * (ay + py * az))
+        return sorted(out)
+    mine = nbr_list(rx, ry, rz)
+    for nb in mine:
+        ax, ay, az = nb % px, (nb // px) % py, nb // (px * py)
+        d = 0 if ax != rx else (1 if ay != ry else 2)
+        plus = (ax > rx) if d == 0 else ((ay > ry) if d == 1 else (az > rz))   # neighbour on the + side of this block
+        if d == 0:
+            cells = c[(gi == (i1 - 1 if plus else i0))]
+        elif d == 1:
+            cells = c[(gj == (j1 - 1 if plus else j0))]
+        else:
+            cells = c[(gk == (k1 - 1 if plus else k0))]
+        # the owner of a cut face is the cell on the lower side; its global face index orders the patch
+        if plus:
+            fidx = _global_face_index(gc[cells], gi[cells], gj[cells], gk[cells], d, (nx, ny, nz))
+        else:
+            step = (1, nx, nx * ny)[d]
+            oc = gc[cells] - step
+            oi, oj, ok = gi[cells] - (d == 0), gj[cells] - (d == 1), gk[cells] - (d == 2)
+            fidx = _global_face_index(oc, oi, oj, ok, d, (nx, ny, nz))
+        order = np.argsort(fidx, kind="stable")
+        cells, fidx = cells[order], fidx[order]
+        cf = h * (1.0 + vary * splitmix_at(seed, fidx))
+        np.subtract.at(sub.diag, cells, cf)
+        theirs = nbr_list(ax, ay, az)
+        sub.interfaces.append(Interface(nbr_domain=nb, nbr_patch=theirs.index(rank), face_cells=cells.astype(np.int32),
+                                        bou_coeffs=-cf, int_coeffs=-cf))
+    return sub
