@@ -250,3 +250,34 @@ def test_engine_gamg_coupled_patches(pkg, orc, mode, symmetric, kw):
     assert np.max(np.abs(h - hr)) < 1e-10 * hr[0]
     torch.cuda.synchronize()
     assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+@pytest.mark.gpu
+def test_full_size_gamg_properties(pkg, orc):
+    """BASELINE config 3 size (216^3, GAMG pressure solve): size-independent properties -- the reported residual is the true
+    residual of the returned psi, the cycle count is mesh independent (same as at 24^3 +- 4), PCG agrees on the solution."""
+    import torch
+    syn, eng = pkg.synthetic, pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    small = syn.box_case(24, 24, 24)
+    _, ps = orc.GamgHierarchy(small, orc.box_face_weights(small), 10).solve(np.zeros(small.n_cells), small.source, tolerance=1e-6, maxIter=100)
+    case = syn.box_case(216, 216, 216)
+    n = case.n_cells
+    addr = eng.Addressing(ctx, n, case.lower_addr, case.upper_addr)
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None)
+    G = eng.Gamg(addr, orc.box_face_weights(case), 100)
+    assert G.n_levels >= 12 and G.level_sizes(0)["n_coarse"] == n // 2
+    b = dev(case.source)
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    perf = G.solve(mat, psi, b, tolerance=1e-6, maxIter=100)
+    assert perf["converged"] and abs(perf["nIterations"] - ps["nIterations"]) <= 4
+    h = perf["history"]
+    assert np.all(np.diff(h) < 0)                                  # every V-cycle reduces the residual
+    r = torch.empty_like(psi); mat.residual(psi, b, r)
+    assert abs(ctx.sum_mag(r) / perf["normFactor"] - perf["finalResidual"]) < 1e-8 * perf["finalResidual"]
+    psi2 = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    p2 = mat.pcg(psi2, b, "diagonal", tolerance=1e-8, maxIter=5000)
+    assert p2["converged"]
+    assert float(torch.max(torch.abs(psi - psi2))) < 1e-3 * float(torch.max(torch.abs(psi2)))
