@@ -145,7 +145,8 @@ def main():
         mat.pcg_iterate(W)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        amul_ms = mat.pcg_iterate(K, time_amul=True)  # HIP events around every Amul launch
+        ev_stride = int(os.environ.get("MI_BENCH_EVENT_STRIDE", "4"))
+        amul_ms = mat.pcg_iterate(K, time_amul=True, event_stride=ev_stride)  # HIP events around every 4th Amul launch of the timed region
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         perf = mat.pcg_end(None, history_len=W + K + 2)
@@ -235,7 +236,7 @@ def main():
             "kernel": "tile_kernel<OP_AMUL> (lduMatrix::Amul)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": amul_bytes, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_g_rocprof_summary_final.md)",
+            "algorithmic_bytes_per_launch": amul_bytes, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_h_rocprof_summary.md)",
             "avg_launch_us": amul_avg_s * 1e6,
             "traffic": traffic_from_profile(nx, ny, nz, n_gpus),
         },

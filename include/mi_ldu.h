@@ -207,6 +207,8 @@ int mi_pcg_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
 int mi_pcg_begin(mi_matrix_t m, const double *psi0_dev, const double *source_dev,
                  const mi_solver_controls *controls, int precond, int32_t history_len);
 int mi_pcg_iterate(mi_matrix_t m, int32_t n_iters, float *amul_ms_sum);
+/* same, events around every event_stride-th Amul only; *amul_ms_sum = mean sampled duration x n_iters */
+int mi_pcg_iterate_sampled(mi_matrix_t m, int32_t n_iters, int32_t event_stride, float *amul_ms_sum);
 int mi_pcg_end(mi_matrix_t m, double *psi_out_dev, mi_solver_perf *perf_out,
                double *residual_history_host, int32_t history_len);
 

@@ -758,7 +758,7 @@ int copy_hist(mi_matrix_s* m, double* hist_host, int len, int nIter)
 // diagonal / none: 5 launches per iteration -- update_p (precondition fused), Amul (+ fused
 // gSumProd partials), fold, update_psi_r (+ next iteration's wArA partials), final.
 // AINV: the preconditioner is itself a tile pass, so wA is materialised.
-int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool timeAmul)
+int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) // evStride > 0: HIP events around every evStride-th Amul
 {
     mi_addr_s* a = m->addr;
     mi_ctx_s* c = a->ctx;
@@ -780,12 +780,14 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool timeAmul)
         } else {
             k_pcg_update_p<2><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, nullptr, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen);
         }
-        if (timeAmul) {
-            while (m->evPool.size() < (size_t)(2 * (it - it0 + 1))) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); m->evPool.push_back(e); }
-            HIPCHK(hipEventRecord(m->evPool[(size_t)2 * (it - it0)], s));
+        const bool rec = evStride > 0 && ((it - it0) % evStride) == 0;
+        const size_t ev = rec ? (size_t)2 * (size_t)((it - it0) / evStride) : 0;
+        if (rec) {
+            while (m->evPool.size() < ev + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); m->evPool.push_back(e); }
+            HIPCHK(hipEventRecord(m->evPool[ev], s));
         }
         MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0, m->tilePartial.p));
-        if (timeAmul) HIPCHK(hipEventRecord(m->evPool[(size_t)2 * (it - it0) + 1], s));
+        if (rec) HIPCHK(hipEventRecord(m->evPool[ev + 1], s));
         k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P2);
         if (precond == MI_PRECOND_AINV)
             k_pcg_update_psi_r<0><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
@@ -831,17 +833,29 @@ extern "C" int mi_pcg_begin(mi_matrix_t m, const double* psi0, const double* sou
     return MI_OK;
 }
 
+extern "C" int mi_pcg_iterate_sampled(mi_matrix_t m, int32_t n_iters, int32_t event_stride, float* amul_ms_sum);
 extern "C" int mi_pcg_iterate(mi_matrix_t m, int32_t n_iters, float* amul_ms_sum)
 {
     if (!m || !m->pcgActive || n_iters < 0) return fail(MI_ERR_STATE, "mi_pcg_iterate: no active PCG session");
     HIPCHK(hipSetDevice(m->addr->ctx->device));
-    MICHK(pcg_enqueue(m, m->pcgIt, n_iters, m->pcgPrecond, amul_ms_sum != nullptr));
+    return mi_pcg_iterate_sampled(m, n_iters, amul_ms_sum ? 1 : 0, amul_ms_sum);
+}
+
+// the same, with HIP events around every event_stride-th Amul only (an event record costs a few us on the stream, which
+// matters to a caller timing the whole loop); *amul_ms_sum = mean sampled duration x n_iters
+extern "C" int mi_pcg_iterate_sampled(mi_matrix_t m, int32_t n_iters, int32_t event_stride, float* amul_ms_sum)
+{
+    if (!m || !m->pcgActive || n_iters < 0 || event_stride < 0) return fail(MI_ERR_STATE, "mi_pcg_iterate: no active PCG session");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    const int stride = amul_ms_sum ? (event_stride > 0 ? event_stride : 1) : 0;
+    MICHK(pcg_enqueue(m, m->pcgIt, n_iters, m->pcgPrecond, stride));
     m->pcgIt += n_iters;
     if (amul_ms_sum) {
         HIPCHK(hipStreamSynchronize(m->addr->ctx->stream));
+        const int ns = (n_iters + stride - 1) / stride;
         float tot = 0;
-        for (int i = 0; i < n_iters; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, m->evPool[(size_t)2 * i], m->evPool[(size_t)2 * i + 1])); tot += ms; }
-        *amul_ms_sum = tot;
+        for (int i = 0; i < ns; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, m->evPool[(size_t)2 * i], m->evPool[(size_t)2 * i + 1])); tot += ms; }
+        *amul_ms_sum = ns > 0 ? tot * ((float)n_iters / (float)ns) : 0.f;
     }
     return MI_OK;
 }
@@ -1239,7 +1253,7 @@ extern "C" int mi_bench_pcg_iters(mi_matrix_t m, const double* source, int32_t i
     // psi0 = 0 in caller order == 0 in engine order
     MICHK(mi_pcg_begin(m, zero, source, &ctl, precond, 1));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    MICHK(pcg_enqueue(m, 0, iters, precond, false));
+    MICHK(pcg_enqueue(m, 0, iters, precond, 0));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));

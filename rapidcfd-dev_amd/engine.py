@@ -39,6 +39,7 @@ class SolverControls(C.Structure):
 
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
+    "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
     "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm",
@@ -347,10 +348,10 @@ class Matrix:
         _chk(lib().mi_pcg_begin(self.h, _ptr(psi0), _ptr(source), C.byref(ctl), C.c_int(PRECOND[precond]),
                                 C.c_int32(history_len)))
 
-    def pcg_iterate(self, n_iters: int, time_amul: bool = False) -> Optional[float]:
+    def pcg_iterate(self, n_iters: int, time_amul: bool = False, event_stride: int = 1) -> Optional[float]:
         if time_amul:
             ms = C.c_float()
-            _chk(lib().mi_pcg_iterate(self.h, C.c_int32(n_iters), C.byref(ms)))
+            _chk(lib().mi_pcg_iterate_sampled(self.h, C.c_int32(n_iters), C.c_int32(event_stride), C.byref(ms)))
             return ms.value
         _chk(lib().mi_pcg_iterate(self.h, C.c_int32(n_iters), None))
         return None
