@@ -2,6 +2,7 @@
 // Host-side orchestration only; all arithmetic is in kernels.hip.hpp.
 // There is no CPU fallback: without a gfx950 device every compute entry point
 // returns MI_ERR_DEVICE.
+#include <hip/hip_ext.h>
 #include "../../include/mi_ldu.h"
 #include "kernels.hip.hpp"
 #include "tiling.hpp"
@@ -73,6 +74,7 @@ struct mi_ctx_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int amulBS = 0;
     int tileFlags = 0;
+    int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
 };
 
@@ -105,6 +107,7 @@ struct mi_matrix_s {
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
     bool pcgActive = false;
     std::vector<hipEvent_t> evPool;
+    hipEvent_t kevStart = nullptr, kevStop = nullptr; // when set: attached to the next tile-kernel launch (hipExtLaunchKernel)
     struct mi_dpcg_comm_s* dpc = nullptr; // attached RCCL communicators + exchange plan (comm.inc)
     DevBuf<double> sendBuf, dscal;         // halo send buffer / scalar block of engine-driven distributed solves
     ~mi_matrix_s();
@@ -173,6 +176,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
         delete c; return fail(MI_ERR_DEVICE, "pinned host / event allocation failed");
     }
     c->tileFlags = env_int("MI_TILE_FLAGS", 0);
+    c->attachEvents = env_int("MI_EVENT_ATTACH", 1);
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
     if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 0;
@@ -387,6 +391,9 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
             HIPCHK(hipFuncSetAttribute((const void*)tile_kernel<OP, ASYM, TRANS, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); \
             attr##BS = true;                                                                                            \
         }                                                                                                               \
+        if (m->kevStart) /* start/stop events stamped by the kernel's own begin/end: the profiler's clock */           \
+            hipExtLaunchKernelGGL((tile_kernel<OP, ASYM, TRANS, BS>), dim3(nTiles), dim3(BS), (uint32_t)lds, s, m->kevStart, m->kevStop, 0, args); \
+        else                                                                                                            \
         tile_kernel<OP, ASYM, TRANS, BS><<<nTiles, BS, lds, s>>>(args);                                                 \
     }
     if (bs == 1024) MI_LAUNCH(1024)
@@ -782,12 +789,15 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
         }
         const bool rec = evStride > 0 && ((it - it0) % evStride) == 0;
         const size_t ev = rec ? (size_t)2 * (size_t)((it - it0) / evStride) : 0;
-        if (rec) {
+        if (rec) { // the event pair rides on the Amul launch itself: it brackets the kernel, not the launch gap before it
             while (m->evPool.size() < ev + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); m->evPool.push_back(e); }
-            HIPCHK(hipEventRecord(m->evPool[ev], s));
+            if (c->attachEvents) { m->kevStart = m->evPool[ev]; m->kevStop = m->evPool[ev + 1]; }
+            else HIPCHK(hipEventRecord(m->evPool[ev], s));
         }
-        MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0, m->tilePartial.p));
-        if (rec) HIPCHK(hipEventRecord(m->evPool[ev + 1], s));
+        const int rcA = launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0, m->tilePartial.p);
+        m->kevStart = nullptr; m->kevStop = nullptr;
+        MICHK(rcA);
+        if (rec && !c->attachEvents) HIPCHK(hipEventRecord(m->evPool[ev + 1], s));
         k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P2);
         if (precond == MI_PRECOND_AINV)
             k_pcg_update_psi_r<0><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
