@@ -74,6 +74,8 @@ struct mi_ctx_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int amulBS = 0;
     int tileFlags = 0;
+    int persist = 0;      // MI_TILE_PERSIST: persistent tile launches (workgroups = resident slots, each walks a run of tiles)
+    int nCU = 0;
     int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
 };
@@ -177,6 +179,8 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     }
     c->tileFlags = env_int("MI_TILE_FLAGS", 0);
     c->attachEvents = env_int("MI_EVENT_ATTACH", 1);
+    c->persist = env_int("MI_TILE_PERSIST", 0);
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
     if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 0;
@@ -391,10 +395,21 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
             HIPCHK(hipFuncSetAttribute((const void*)tile_kernel<OP, ASYM, TRANS, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); \
             attr##BS = true;                                                                                            \
         }                                                                                                               \
+        int grid = nTiles;                                                                                              \
+        if (m->addr->ctx->persist) {                                                                                    \
+            static int occ##BS = 0; static size_t occLds##BS = 0;                                                       \
+            if (occ##BS == 0 || occLds##BS != lds) {                                                                    \
+                int nb = 0;                                                                                             \
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP, ASYM, TRANS, BS>, BS, lds)); \
+                occ##BS = nb > 0 ? nb : 1; occLds##BS = lds;                                                            \
+            }                                                                                                           \
+            const int slots = ((occ##BS * m->addr->ctx->nCU * m->addr->ctx->persist) / 8) * 8;                          \
+            if (slots >= 8 && nTiles > 2 * slots) grid = slots;                                                         \
+        }                                                                                                               \
         if (m->kevStart) /* start/stop events stamped by the kernel's own begin/end: the profiler's clock */           \
-            hipExtLaunchKernelGGL((tile_kernel<OP, ASYM, TRANS, BS>), dim3(nTiles), dim3(BS), (uint32_t)lds, s, m->kevStart, m->kevStop, 0, args); \
+            hipExtLaunchKernelGGL((tile_kernel<OP, ASYM, TRANS, BS>), dim3(grid), dim3(BS), (uint32_t)lds, s, m->kevStart, m->kevStop, 0, args); \
         else                                                                                                            \
-        tile_kernel<OP, ASYM, TRANS, BS><<<nTiles, BS, lds, s>>>(args);                                                 \
+        tile_kernel<OP, ASYM, TRANS, BS><<<grid, BS, lds, s>>>(args);                                                   \
     }
     if (bs == 1024) MI_LAUNCH(1024)
     else if (bs == 512) MI_LAUNCH(512)
@@ -423,6 +438,7 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     t.tileList = nullptr;
     if (which == 1) { t.tileList = a->interiorTiles.p; nTiles = a->nInterior; }
     else if (which == 2) { t.tileList = a->boundaryTiles.p; nTiles = a->nBoundary; }
+    t.nPos = nTiles;
     if (m->asym) {
         if (trans) return launch_tile_bs<OP, true, true>(m, t, nTiles, lds);
         return launch_tile_bs<OP, true, false>(m, t, nTiles, lds);

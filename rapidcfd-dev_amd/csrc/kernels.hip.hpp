@@ -92,6 +92,7 @@ struct TileArgs {
     const int32_t* sliceEntryStart;
     const uint32_t* entries;
     const int32_t* tileList; // nullptr => identity
+    int32_t nPos;            // number of tile positions of this launch (== gridDim.x unless the launch is persistent)
     const double* diag;
     const double* up;
     const double* low;
@@ -150,24 +151,15 @@ __device__ __forceinline__ void stage_gather(const double* __restrict__ x, const
     for (; k < n; k += BS) dst[k] = x[idx[k]];
 }
 
+// one tile: position p of the launch (p indexes tileList / dotPartial)
 template <int OP, bool ASYM, bool TRANS, int BS>
-__global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
+__device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double* __restrict__ smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     double* cU = smem;
     double* cL = smem + a.offLow;
     double* xs = smem + a.offX;
     double* rDs = smem + a.offRD;
-
-    // XCD-aware mapping: hardware places block b on XCD b%8; give each XCD a
-    // contiguous run of tiles so that neighbouring tiles (which share halo
-    // cells) hit the same L2.  Speed only, never correctness.
-    int t;
-    {
-        const int b = blockIdx.x, per = gridDim.x >> 3;
-        t = (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;
-    }
-    if (a.tileList) t = a.tileList[t];
+    const int t = a.tileList ? a.tileList[p] : p;
 
     const int tid = threadIdx.x;
     const int c0 = a.tileCellStart[t], nc = a.tileCellStart[t + 1] - c0;
@@ -273,7 +265,31 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
     if (OP == OP_AMUL && a.dotPartial) { // fused gSumProd(wA, pA), PCG.C:166
         __shared__ double red[BS / 64];
         const double tsum = block_sum<BS>(dot, red);
-        if (tid == 0) a.dotPartial[blockIdx.x] = tsum;
+        if (tid == 0) a.dotPartial[p] = tsum;
+    }
+}
+
+// XCD-aware mapping: hardware places block b on XCD b%8; every XCD gets a contiguous run of tile positions so that
+// neighbouring tiles (which share halo cells) hit the same L2.  Speed only, never correctness.
+//   gridDim.x == nPos : one workgroup per tile.
+//   gridDim.x <  nPos : PERSISTENT launch -- as many workgroups as the chip holds at once (a multiple of 8), each walks
+//                       a contiguous run of its XCD's tiles; saves the dispatch/teardown of ~10 short workgroups per slot.
+template <int OP, bool ASYM, bool TRANS, int BS>
+__global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, G = gridDim.x, nT = a.nPos;
+    if (G >= nT) {
+        const int per = G >> 3;
+        tile_body<OP, ASYM, TRANS, BS>(a, (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b, smem);
+        return;
+    }
+    const int per = G >> 3, x = b & 7, j = b >> 3;
+    const int x0 = (int)((long long)x * nT / 8), x1 = (int)((long long)(x + 1) * nT / 8);
+    const int p0 = x0 + (int)((long long)j * (x1 - x0) / per), p1 = x0 + (int)((long long)(j + 1) * (x1 - x0) / per);
+    for (int p = p0; p < p1; ++p) {
+        tile_body<OP, ASYM, TRANS, BS>(a, p, smem);
+        __syncthreads(); // every wave is done with the LDS image before the next tile is staged
     }
 }
 
