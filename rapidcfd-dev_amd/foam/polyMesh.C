@@ -1,0 +1,281 @@
+// polyMesh.C -- see polyMesh.H
+#include "polyMesh.H"
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+
+namespace Foam
+{
+namespace
+{
+// a whole OpenFOAM file in memory with a cursor: comments skipped, tokens = words, numbers, punctuation ( ) { } ;
+struct IFstream
+{
+    std::string buf, name;
+    std::size_t pos = 0;
+    bool binary = false;
+    explicit IFstream(const std::string& file) : name(file)
+    {
+        std::ifstream f(file, std::ios::binary);
+        if (!f) FatalErrorIn("IFstream::IFstream", "cannot open file " + file);
+        buf.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    }
+    void skipSpace()
+    {
+        for (;;) {
+            while (pos < buf.size() && std::isspace((unsigned char)buf[pos])) ++pos;
+            if (pos + 1 < buf.size() && buf[pos] == '/' && buf[pos + 1] == '/') { while (pos < buf.size() && buf[pos] != '\n') ++pos; continue; }
+            if (pos + 1 < buf.size() && buf[pos] == '/' && buf[pos + 1] == '*') {
+                const std::size_t e = buf.find("*/", pos + 2);
+                pos = e == std::string::npos ? buf.size() : e + 2; continue;
+            }
+            return;
+        }
+    }
+    bool eof() { skipSpace(); return pos >= buf.size(); }
+    char peek() { skipSpace(); return pos < buf.size() ? buf[pos] : '\0'; }
+    std::string token()
+    {
+        skipSpace();
+        if (pos >= buf.size()) FatalErrorIn("IFstream::token", "unexpected end of file " + name);
+        const char c = buf[pos];
+        if (c == '(' || c == ')' || c == '{' || c == '}' || c == ';') { ++pos; return std::string(1, c); }
+        if (c == '"') { const std::size_t e = buf.find('"', pos + 1); std::string s = buf.substr(pos + 1, e - pos - 1); pos = e + 1; return s; }
+        const std::size_t b = pos;
+        while (pos < buf.size() && !std::isspace((unsigned char)buf[pos]) && !strchr("(){};", buf[pos])) ++pos;
+        return buf.substr(b, pos - b);
+    }
+    void expect(const char* t) { const std::string g = token(); if (g != t) FatalErrorIn("IFstream::expect", "expected '" + std::string(t) + "' but found '" + g + "' in " + name); }
+    label readLabel() { return (label)std::strtol(token().c_str(), nullptr, 10); }
+    scalar readScalar() { return std::strtod(token().c_str(), nullptr); }
+    // FoamFile { ... }: picks up "format"
+    void header()
+    {
+        if (token() != "FoamFile") FatalErrorIn("IFstream::header", name + " does not start with a FoamFile header");
+        expect("{");
+        for (;;) {
+            const std::string k = token();
+            if (k == "}") break;
+            std::string v = token();
+            if (k == "format") binary = (v == "binary");
+            while (v != ";") v = token();
+        }
+    }
+    // raw bytes of a binary list: the cursor stands right after "N("
+    void raw(void* dst, std::size_t bytes)
+    {
+        if (pos + bytes > buf.size()) FatalErrorIn("IFstream::raw", "binary list truncated in " + name);
+        std::memcpy(dst, buf.data() + pos, bytes); pos += bytes;
+    }
+};
+
+template <class T, class ReadOne>
+std::vector<T> readList(IFstream& is, ReadOne one)
+{
+    const label n = is.readLabel();
+    std::vector<T> out((std::size_t)n);
+    if (is.binary && n > 0) {                // "N(<bytes>)": no white space between '(' and the data
+        is.skipSpace();
+        if (is.buf[is.pos] != '(') FatalErrorIn("readList", "expected '(' in " + is.name);
+        ++is.pos;
+        is.raw(out.data(), sizeof(T) * (std::size_t)n);
+        is.expect(")");
+    } else {
+        is.expect("(");
+        for (label i = 0; i < n; ++i) out[(std::size_t)i] = one(is);
+        is.expect(")");
+    }
+    return out;
+}
+labelList readLabels(IFstream& is) { return readList<label>(is, [](IFstream& s) { return s.readLabel(); }); }
+vector readVec(IFstream& s) { s.expect("("); vector v{s.readScalar(), s.readScalar(), s.readScalar()}; s.expect(")"); return v; }
+
+vector operator-(const vector& a, const vector& b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+vector operator+(const vector& a, const vector& b) { return {a[0] + b[0], a[1] + b[1], a[2] + b[2]}; }
+vector operator*(scalar s, const vector& a) { return {s * a[0], s * a[1], s * a[2]}; }
+scalar dot(const vector& a, const vector& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+vector cross(const vector& a, const vector& b) { return {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}; }
+scalar mag(const vector& a) { return std::sqrt(dot(a, a)); }
+} // namespace
+
+labelList readLabelList(const std::string& file) { IFstream is(file); is.header(); return readLabels(is); }
+vectorField readVectorField(const std::string& file) { IFstream is(file); is.header(); return readList<vector>(is, readVec); }
+
+polyMesh::polyMesh(const std::string& caseDir)
+{
+    const std::string dir = caseDir + "/constant/polyMesh/";
+    points = readVectorField(dir + "points");
+    owner = readLabelList(dir + "owner");
+    neighbour = readLabelList(dir + "neighbour");
+    {
+        IFstream is(dir + "faces");
+        is.header();
+        if (is.binary) {                       // faceCompactList: offsets then labels
+            const labelList start = readLabels(is), lab = readLabels(is);
+            faces.resize(start.size() - 1);
+            for (std::size_t f = 0; f + 1 < start.size(); ++f) faces[f].assign(lab.begin() + start[f], lab.begin() + start[f + 1]);
+        } else {
+            const label n = is.readLabel();
+            is.expect("(");
+            faces.resize((std::size_t)n);
+            for (label f = 0; f < n; ++f) {
+                const label np = is.readLabel();
+                is.expect("(");
+                faces[(std::size_t)f].resize((std::size_t)np);
+                for (label k = 0; k < np; ++k) faces[(std::size_t)f][(std::size_t)k] = is.readLabel();
+                is.expect(")");
+            }
+            is.expect(")");
+        }
+    }
+    {
+        IFstream is(dir + "boundary");
+        is.header();
+        const label n = is.readLabel();
+        is.expect("(");
+        for (label p = 0; p < n; ++p) {
+            polyPatch P;
+            P.name = is.token();
+            is.expect("{");
+            for (;;) {
+                const std::string k = is.token();
+                if (k == "}") break;
+                std::vector<std::string> v;
+                for (std::string t = is.token(); t != ";"; t = is.token()) v.push_back(t);
+                if (v.empty()) continue;
+                if (k == "type") P.type = v[0];
+                else if (k == "nFaces") P.nFaces = (label)std::atol(v[0].c_str());
+                else if (k == "startFace") P.startFace = (label)std::atol(v[0].c_str());
+                else if (k == "myProcNo") P.myProcNo = std::atoi(v[0].c_str());
+                else if (k == "neighbProcNo") P.neighbProcNo = std::atoi(v[0].c_str());
+            }
+            boundary.push_back(P);
+        }
+        is.expect(")");
+    }
+    if (owner.size() != faces.size()) FatalErrorIn("polyMesh::polyMesh", "owner and faces differ in size");
+    if (neighbour.size() > owner.size()) FatalErrorIn("polyMesh::polyMesh", "more neighbours than faces");
+    nCells = 0;
+    for (label c : owner) nCells = std::max(nCells, c + 1);
+    for (std::size_t f = 0; f < neighbour.size(); ++f)
+        if (!(owner[f] < neighbour[f])) FatalErrorIn("polyMesh::polyMesh", "internal faces are not in upper-triangular order");
+    label next = nInternalFaces();
+    for (const polyPatch& P : boundary) {
+        if (P.startFace != next) FatalErrorIn("polyMesh::polyMesh", "patch " + P.name + " does not start where the previous one ends");
+        next += P.nFaces;
+    }
+    if (next != nFaces()) FatalErrorIn("polyMesh::polyMesh", "boundary patches do not cover the boundary faces");
+    calcGeometry();
+}
+
+labelList polyMesh::patchFaceCells(label p) const
+{
+    const polyPatch& P = boundary[(std::size_t)p];
+    return labelList(owner.begin() + P.startFace, owner.begin() + P.startFace + P.nFaces);
+}
+
+void polyMesh::calcGeometry()
+{
+    const std::size_t nF = faces.size(), nI = neighbour.size();
+    Cf.resize(nF); Sf.resize(nF); magSf.resize(nF);
+    for (std::size_t fi = 0; fi < nF; ++fi) {               // primitiveMeshFaceCentresAndAreas.C:60-130
+        const labelList& f = faces[fi];
+        const std::size_t nP = f.size();
+        if (nP == 3) {
+            Cf[fi] = (1.0 / 3.0) * (points[f[0]] + points[f[1]] + points[f[2]]);
+            Sf[fi] = 0.5 * cross(points[f[1]] - points[f[0]], points[f[2]] - points[f[0]]);
+        } else {
+            vector sumN{0, 0, 0}, sumAc{0, 0, 0};
+            scalar sumA = 0;
+            vector fc = points[f[0]];
+            for (std::size_t pi = 1; pi < nP; ++pi) fc = fc + points[f[pi]];
+            fc = (1.0 / (scalar)nP) * fc;
+            for (std::size_t pi = 0; pi < nP; ++pi) {
+                const vector& p0 = points[f[pi]];
+                const vector& p1 = points[f[(pi + 1) % nP]];
+                const vector c = p0 + p1 + fc;
+                const vector n = cross(p1 - p0, fc - p0);
+                const scalar a = mag(n);
+                sumN = sumN + n; sumA += a; sumAc = sumAc + a * c;
+            }
+            if (sumA < 1e-150) { Cf[fi] = fc; Sf[fi] = {0, 0, 0}; }
+            else { Cf[fi] = ((1.0 / 3.0) / sumA) * sumAc; Sf[fi] = 0.5 * sumN; }
+        }
+        magSf[fi] = mag(Sf[fi]);
+    }
+    C.assign((std::size_t)nCells, vector{0, 0, 0}); V.assign((std::size_t)nCells, 0.0);   // primitiveMeshCellCentresAndVols.C:60-170
+    vectorField cEst((std::size_t)nCells, vector{0, 0, 0});
+    std::vector<label> nCellFaces((std::size_t)nCells, 0);
+    for (std::size_t f = 0; f < nF; ++f) { cEst[owner[f]] = cEst[owner[f]] + Cf[f]; ++nCellFaces[owner[f]]; }
+    for (std::size_t f = 0; f < nI; ++f) { cEst[neighbour[f]] = cEst[neighbour[f]] + Cf[f]; ++nCellFaces[neighbour[f]]; }
+    for (label c = 0; c < nCells; ++c) cEst[c] = (1.0 / (scalar)nCellFaces[c]) * cEst[c];
+    for (std::size_t f = 0; f < nF; ++f) {
+        const label c = owner[f];
+        const scalar pyr3 = dot(Sf[f], Cf[f] - cEst[c]);
+        C[c] = C[c] + pyr3 * (0.75 * Cf[f] + 0.25 * cEst[c]); V[c] += pyr3;
+    }
+    for (std::size_t f = 0; f < nI; ++f) {
+        const label c = neighbour[f];
+        const scalar pyr3 = dot(Sf[f], cEst[c] - Cf[f]);
+        C[c] = C[c] + pyr3 * (0.75 * Cf[f] + 0.25 * cEst[c]); V[c] += pyr3;
+    }
+    for (label c = 0; c < nCells; ++c) {
+        if (std::fabs(V[c]) > 1e-300) C[c] = (1.0 / V[c]) * C[c]; else C[c] = cEst[c];
+        V[c] *= 1.0 / 3.0;
+    }
+    weights.resize(nI); nonOrthDeltaCoeffs.resize(nI);               // surfaceInterpolation.C:151-260,368-460
+    for (std::size_t f = 0; f < nI; ++f) {
+        const scalar sOwn = std::fabs(dot(Sf[f], Cf[f] - C[owner[f]])), sNei = std::fabs(dot(Sf[f], C[neighbour[f]] - Cf[f]));
+        weights[f] = sNei / (sOwn + sNei);
+        const vector d = C[neighbour[f]] - C[owner[f]];
+        const vector n = (1.0 / magSf[f]) * Sf[f];
+        nonOrthDeltaCoeffs[f] = 1.0 / std::max(dot(n, d), 0.05 * mag(d));
+    }
+    patchDeltaCoeffs.clear(); patchMagSf.clear();
+    for (const polyPatch& P : boundary) {
+        scalarField dc((std::size_t)P.nFaces), ms((std::size_t)P.nFaces);
+        for (label i = 0; i < P.nFaces; ++i) {
+            const std::size_t f = (std::size_t)(P.startFace + i);
+            const vector d = Cf[f] - C[owner[f]];                    // fvPatch::delta()
+            const vector n = (1.0 / magSf[f]) * Sf[f];
+            dc[(std::size_t)i] = 1.0 / std::max(dot(n, d), 0.05 * mag(d));
+            ms[(std::size_t)i] = magSf[f];
+        }
+        patchDeltaCoeffs.push_back(dc); patchMagSf.push_back(ms);
+    }
+}
+
+scalarField polyMesh::faceAreaPairWeights() const
+{
+    // |Sf/sqrt|Sf| o (1, 1.01, 1.02)|  (faceAreaPairGAMGAgglomeration.C:54-81)
+    scalarField w(neighbour.size());
+    for (std::size_t f = 0; f < neighbour.size(); ++f) {
+        const scalar r = 1.0 / std::sqrt(magSf[f]);
+        const vector s{Sf[f][0] * r * 1.0, Sf[f][1] * r * 1.01, Sf[f][2] * r * 1.02};
+        w[f] = mag(s);
+    }
+    return w;
+}
+
+scalarField readVolScalarInternalField(const std::string& file, label nCells)
+{
+    IFstream is(file);
+    is.header();
+    for (;;) {
+        if (is.eof()) FatalErrorIn("readVolScalarInternalField", "no internalField in " + file);
+        const std::string k = is.token();
+        if (k == "internalField") break;
+        if (k == "{") { int depth = 1; while (depth) { const std::string t = is.token(); if (t == "{") ++depth; else if (t == "}") --depth; } continue; }
+        if (k == "dimensions") { while (is.token() != ";") {} continue; }
+    }
+    const std::string kind = is.token();
+    if (kind == "uniform") return scalarField((std::size_t)nCells, is.readScalar());
+    if (kind != "nonuniform") FatalErrorIn("readVolScalarInternalField", "internalField must be uniform or nonuniform in " + file);
+    const std::string cls = is.token();
+    if (cls != "List<scalar>") FatalErrorIn("readVolScalarInternalField", "expected List<scalar> but found " + cls + " in " + file);
+    scalarField v = readList<scalar>(is, [](IFstream& s) { return s.readScalar(); });
+    if ((label)v.size() != nCells) FatalErrorIn("readVolScalarInternalField", "field size does not match the mesh in " + file);
+    return v;
+}
+} // namespace Foam
