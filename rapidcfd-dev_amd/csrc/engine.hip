@@ -109,6 +109,7 @@ struct mi_matrix_s {
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
     bool pcgActive = false;
     std::vector<hipEvent_t> evPool;
+    bool gateDone = false; // tile launches of a device-resident solver loop read PcgState::done and exit past convergence
     hipEvent_t kevStart = nullptr, kevStop = nullptr; // when set: attached to the next tile-kernel launch (hipExtLaunchKernel)
     struct mi_dpcg_comm_s* dpc = nullptr; // attached RCCL communicators + exchange plan (comm.inc)
     DevBuf<double> sendBuf, dscal;         // halo send buffer / scalar block of engine-driven distributed solves
@@ -439,6 +440,7 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     if (which == 1) { t.tileList = a->interiorTiles.p; nTiles = a->nInterior; }
     else if (which == 2) { t.tileList = a->boundaryTiles.p; nTiles = a->nBoundary; }
     t.nPos = nTiles;
+    t.done = m->gateDone ? &a->ctx->state.p->done : nullptr;
     if (m->asym) {
         if (trans) return launch_tile_bs<OP, true, true>(m, t, nTiles, lds);
         return launch_tile_bs<OP, true, false>(m, t, nTiles, lds);
@@ -793,6 +795,7 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
     if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
     if (m->tilePartial.n < (size_t)a->L.nTiles) MICHK(m->tilePartial.alloc((size_t)a->L.nTiles));
     const bool fuse = c->fuseFinal && precond != MI_PRECOND_AINV;
+    struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
     for (int it = it0; it < it0 + count; ++it) {
         if (precond == MI_PRECOND_AINV) {
             MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0));
@@ -1073,6 +1076,72 @@ int host_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* p
 }
 } // namespace
 
+namespace {
+// enqueue PBiCG iteration bodies it0 .. it0+count-1 (no host sync): precondition both residuals (+ fused sum wA.rT),
+// update pA/pT, Amul, Tmul, sum wA.pT, update psi/rA/rT (+ sum|rA|), convergence test
+int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, double* pA, double* wA, double* rA,
+                 double* pT, double* wT, double* rT)
+{
+    mi_addr_s* a = m->addr;
+    mi_ctx_s* c = a->ctx;
+    hipStream_t s = c->stream;
+    const int64_t n = a->L.nCells;
+    double* P1 = c->partial.p; double* P2 = c->partial.p + RG; double* P3 = c->partial.p + 2 * RG;
+    if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
+    struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
+    for (int it = it0; it < it0 + count; ++it) {
+        if (precond == MI_PRECOND_AINV) {
+            MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0));
+            MICHK(launch_tile<OP_AINV>(m, true, rT, nullptr, m->rD.p, wT, 0.0, 0));
+            k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rT, n, P1);
+        } else if (precond == MI_PRECOND_DIAGONAL) k_bicg_precond_dot<true><<<RG, RB, 0, s>>>(c->state.p, m->rD.p, rA, rT, wA, wT, n, P1);
+        else k_bicg_precond_dot<false><<<RG, RB, 0, s>>>(c->state.p, nullptr, rA, rT, wA, wT, n, P1);
+        k_bicg_update_p<<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, wT, pA, pT, n);
+        MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0));
+        MICHK(launch_tile<OP_AMUL>(m, true, pT, nullptr, nullptr, wT, 0.0, 0));
+        k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, pT, n, P2);
+        k_bicg_update_psi_r<<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, wT, psi, rA, rT, n, P3);
+        k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
+    }
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+// PBiCG with every scalar on the device (single GPU; a communicator-attached matrix keeps the host-stepped loop below,
+// whose sums are all-reduced)
+int pbicg_solve_device(mi_matrix_s* m, double* psi_io, const double* source, const mi_solver_controls* ctl, int precond,
+                       mi_solver_perf* perf, double* hist_host, int32_t hist_len)
+{
+    mi_addr_s* a = m->addr;
+    mi_ctx_s* c = a->ctx;
+    hipStream_t s = c->stream;
+    const int64_t n = a->L.nCells;
+    double *psi, *src, *pA, *wA, *rA, *pT, *wT, *rT;
+    MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
+    MICHK(m->vec(8, &pT)); MICHK(m->vec(9, &wT)); MICHK(m->vec(10, &rT));
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    const int histLen = ctl->maxIter + 2;
+    MICHK(solve_prologue(m, ctl, psi, src, wA, rA, pA, histLen));     // wA = A psi, rA = src - wA, normFactor, first test
+    MICHK(launch_tile<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0, 0));
+    k_sub<<<RG, RB, 0, s>>>(rT, src, wT, n);
+    MICHK(fetch_state(c));
+    const int batch = env_int("MI_PCG_BATCH", 16);
+    int it = 0;
+    while (!c->hostState->done && it <= ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0)) {
+        MICHK(bicg_enqueue(m, it, batch, precond, psi, pA, wA, rA, pT, wT, rT));
+        it += batch;
+        MICHK(fetch_state(c));
+    }
+    k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, psi_io, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    if (perf) fill_perf(*c->hostState, perf);
+    MICHK(copy_hist(m, hist_host, hist_len, c->hostState->nIterations));
+    HIPCHK(hipStreamSynchronize(s));
+    return MI_OK;
+}
+} // namespace
+
 extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* source, const mi_solver_controls* ctl,
                               int precond, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
 {
@@ -1080,6 +1149,8 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
+    if (!comm_attached(m) && env_int("MI_PBICG_HOST_STEPPED", 0) == 0)
+        return pbicg_solve_device(m, psi_io, source, ctl, precond, perf, hist_host, hist_len);
     hipStream_t s = a->ctx->stream;
     const int64_t n = a->L.nCells;
     double *psi, *src, *pA, *wA, *rA, *pT, *wT, *rT;

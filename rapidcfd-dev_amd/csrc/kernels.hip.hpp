@@ -93,6 +93,7 @@ struct TileArgs {
     const uint32_t* entries;
     const int32_t* tileList; // nullptr => identity
     int32_t nPos;            // number of tile positions of this launch (== gridDim.x unless the launch is persistent)
+    const int32_t* done;     // device-resident solver loops: &PcgState::done, launches past convergence exit at once (else nullptr)
     const double* diag;
     const double* up;
     const double* low;
@@ -278,6 +279,7 @@ template <int OP, bool ASYM, bool TRANS, int BS>
 __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (a.done && *a.done) return;
     const int b = blockIdx.x, G = gridDim.x, nT = a.nPos;
     if (G >= nT) {
         const int per = G >> 3;
@@ -604,6 +606,76 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
         if (threadIdx.x == 0) partial1[blockIdx.x] = u;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->alpha = alpha; st->wApA = wApA; }
+}
+
+// ---------------------------------------------------------------------------
+// Device-resident PBiCG (PBiCG.C:67-246): same scheme as PCG -- scalars in PcgState (wArA[] holds wArT),
+// per-block partials re-reduced by the consumers, kernels past convergence exit at once.
+// ---------------------------------------------------------------------------
+// wA = rD*rA, wT = rD*rT (or copies), partial1 = sum wA*rT          [PBiCG.C:149-155, diagonal / no preconditioner]
+template <bool HAVE_RD>
+__global__ __launch_bounds__(RB) void k_bicg_precond_dot(const PcgState* __restrict__ st, const double* __restrict__ rD,
+                                                         const double* __restrict__ rA, const double* __restrict__ rT,
+                                                         double* __restrict__ wA, double* __restrict__ wT, int64_t n,
+                                                         double* __restrict__ partial)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) {
+            const double2 a = ld2(rA, i), t = ld2(rT, i); double2 w = a, v = t;
+            if (HAVE_RD) { const double2 d = ld2(rD, i); w.x = d.x * a.x; w.y = d.y * a.y; v.x = d.x * t.x; v.y = d.y * t.y; }
+            st2(wA, i, w); st2(wT, i, v); acc0 = fma(w.x, t.x, acc0); acc1 = fma(w.y, t.y, acc1); },
+        [&](int64_t i) { const double a = rA[i], t = rT[i]; const double w = HAVE_RD ? rD[i] * a : a, v = HAVE_RD ? rD[i] * t : t;
+            wA[i] = w; wT[i] = v; acc0 = fma(w, t, acc0); });
+    const double s = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// wArT = sum(partial1); beta; pA = wA + beta pA; pT = wT + beta pT       [PBiCG.C:157-175]
+__global__ __launch_bounds__(RB) void k_bicg_update_p(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
+                                                      const double* __restrict__ wA, const double* __restrict__ wT,
+                                                      double* __restrict__ pA, double* __restrict__ pT, int64_t n)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double wArT = sum_partials(partial1, red);
+    const bool first = (it == 0);
+    const double beta = first ? 0.0 : wArT / st->wArA[(it & 1) ^ 1];
+    chunk_loop(n, [&](int64_t i) {
+            const double2 w = ld2(wA, i), v = ld2(wT, i);
+            if (first) { st2(pA, i, w); st2(pT, i, v); }
+            else { const double2 p = ld2(pA, i), q = ld2(pT, i);
+                   st2(pA, i, make_double2(fma(beta, p.x, w.x), fma(beta, p.y, w.y))); st2(pT, i, make_double2(fma(beta, q.x, v.x), fma(beta, q.y, v.y))); } },
+        [&](int64_t i) { pA[i] = first ? wA[i] : fma(beta, pA[i], wA[i]); pT[i] = first ? wT[i] : fma(beta, pT[i], wT[i]); });
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->wArA[it & 1] = wArT;
+}
+// wApT = sum(partial2); singular?; alpha; psi += alpha pA; rA -= alpha wA; rT -= alpha wT; partial3 = sum|rA|  [PBiCG.C:177-215]
+__global__ __launch_bounds__(RB) void k_bicg_update_psi_r(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
+                                                          const double* __restrict__ pA, const double* __restrict__ wA,
+                                                          const double* __restrict__ wT, double* __restrict__ psi,
+                                                          double* __restrict__ rA, double* __restrict__ rT, int64_t n,
+                                                          double* __restrict__ partial3)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double wApT = sum_partials(partial2, red);
+    if (fabs(wApT) / st->normFactor < SP_VSMALL) {
+        if (threadIdx.x == 0) partial3[blockIdx.x] = -1.0; // "singular" marker for k_pcg_final
+        return;
+    }
+    const double alpha = st->wArA[it & 1] / wApT;
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) {
+            const double2 p = ld2(pA, i), w = ld2(wA, i), v = ld2(wT, i); double2 x = ld2(psi, i), r = ld2(rA, i), t = ld2(rT, i);
+            x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y);
+            r.x = fma(-alpha, w.x, r.x); r.y = fma(-alpha, w.y, r.y);
+            t.x = fma(-alpha, v.x, t.x); t.y = fma(-alpha, v.y, t.y);
+            st2(psi, i, x); st2(rA, i, r); st2(rT, i, t); acc0 += fabs(r.x); acc1 += fabs(r.y); },
+        [&](int64_t i) { psi[i] = fma(alpha, pA[i], psi[i]); const double r = fma(-alpha, wA[i], rA[i]); rA[i] = r;
+            rT[i] = fma(-alpha, wT[i], rT[i]); acc0 += fabs(r); });
+    const double s = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial3[blockIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->alpha = alpha; st->wApA = wApT; }
 }
 
 // residual, history, do-while condition                                  [PCG.C:195-204]
