@@ -23,6 +23,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / cross-process buffers); already exported on the boxes
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
