@@ -1195,6 +1195,70 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
     return finish_host(m, hp, hist, psi, psi_io, perf, hist_host, hist_len);
 }
 
+namespace {
+int stab_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool quirk, double* psi, double* pA, double* yA, double* rA,
+                 double* AyA, double* sA, double* zA, double* tA, double* rA0)
+{
+    mi_addr_s* a = m->addr;
+    mi_ctx_s* c = a->ctx;
+    hipStream_t s = c->stream;
+    const int64_t n = a->L.nCells;
+    double* P1 = c->partial.p; double* P2 = c->partial.p + RG; double* P3 = c->partial.p + 2 * RG; double* P4 = c->partial.p + 3 * RG;
+    struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
+    for (int it = it0; it < it0 + count; ++it) {
+        k_reduce<RED_PROD><<<RG, RB, 0, s>>>(rA0, rA, n, P1);
+        k_stab_update_p<<<RG, RB, 0, s>>>(c->state.p, it, P1, rA, AyA, pA, n);
+        MICHK(precond_engine(m, precond, false, pA, yA));
+        MICHK(launch_tile<OP_AMUL>(m, false, yA, nullptr, nullptr, AyA, 0.0, 0));
+        k_reduce<RED_PROD><<<RG, RB, 0, s>>>(rA0, AyA, n, P2);
+        k_stab_s<<<RG, RB, 0, s>>>(c->state.p, it, P2, rA, AyA, sA, n, P3);
+        k_stab_mid<<<RG, RB, 0, s>>>(c->state.p, P3, yA, psi, n);
+        k_stab_mid_final<<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
+        MICHK(precond_engine(m, precond, false, sA, zA));
+        MICHK(launch_tile<OP_AMUL>(m, false, zA, nullptr, nullptr, tA, 0.0, 0));
+        k_reduce_two<<<RG, RB, 0, s>>>(tA, sA, n, P1, P2);
+        k_stab_update<<<RG, RB, 0, s>>>(c->state.p, P1, P2, yA, quirk ? yA : zA, sA, tA, psi, rA, n, P4);
+        k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P4, m->hist.p, m->histLen);
+    }
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+// PBiCGStab with every scalar on the device (single GPU; communicator-attached matrices keep the host-stepped loop)
+int pbicgstab_solve_device(mi_matrix_s* m, double* psi_io, const double* source, const mi_solver_controls* ctl, int precond,
+                           int replicate_quirk, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
+{
+    mi_addr_s* a = m->addr;
+    mi_ctx_s* c = a->ctx;
+    hipStream_t s = c->stream;
+    const int64_t n = a->L.nCells;
+    if (c->partial.n < (size_t)4 * RG) return fail(MI_ERR_STATE, "partial buffer too small");
+    double *psi, *src, *pA, *yA, *rA, *AyA, *sA, *zA, *tA, *rA0;
+    MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &yA)); MICHK(m->vec(7, &rA));
+    MICHK(m->vec(8, &AyA)); MICHK(m->vec(9, &sA)); MICHK(m->vec(10, &zA)); MICHK(m->vec(11, &tA)); MICHK(m->vec(12, &rA0));
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
+    const int histLen = ctl->maxIter + 2;
+    MICHK(solve_prologue(m, ctl, psi, src, yA, rA, pA, histLen));
+    HIPCHK(hipMemcpyAsync(rA0, rA, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    MICHK(fetch_state(c));
+    const int batch = env_int("MI_PCG_BATCH", 16);
+    int it = 0;
+    while (!c->hostState->done && it <= ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0)) {
+        MICHK(stab_enqueue(m, it, batch, precond, replicate_quirk != 0, psi, pA, yA, rA, AyA, sA, zA, tA, rA0));
+        it += batch;
+        MICHK(fetch_state(c));
+    }
+    k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, psi_io, a->L.nCells);
+    HIPCHK(hipGetLastError());
+    if (perf) fill_perf(*c->hostState, perf);
+    MICHK(copy_hist(m, hist_host, hist_len, c->hostState->nIterations));
+    HIPCHK(hipStreamSynchronize(s));
+    return MI_OK;
+}
+} // namespace
+
 extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* source, const mi_solver_controls* ctl,
                                   int precond, int replicate_quirk, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
 {
@@ -1202,6 +1266,8 @@ extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* s
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
+    if (!comm_attached(m) && env_int("MI_PBICG_HOST_STEPPED", 0) == 0)
+        return pbicgstab_solve_device(m, psi_io, source, ctl, precond, replicate_quirk, perf, hist_host, hist_len);
     hipStream_t s = a->ctx->stream;
     const int64_t n = a->L.nCells;
     double *psi, *src, *pA, *yA, *rA, *AyA, *sA, *zA, *tA, *rA0, *res1;

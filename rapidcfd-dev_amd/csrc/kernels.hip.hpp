@@ -678,6 +678,112 @@ __global__ __launch_bounds__(RB) void k_bicg_update_psi_r(PcgState* __restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->alpha = alpha; st->wApA = wApT; }
 }
 
+// ---------------------------------------------------------------------------
+// Device-resident PBiCGStab (PBiCGStab.C:67-300).  PcgState: wArA[] = rA0rA (by iteration parity), alpha, wApA = omega.
+// A kernel that decides something from data every workgroup recomputes the decision itself (same partials => same bits);
+// `done` is only ever written by single-workgroup kernels or by workgroups that all take the same early exit.
+// ---------------------------------------------------------------------------
+// rA0rA = sum(P1); singular tests; beta = (rA0rA/rA0rAold)*(alpha/omega); pA = rA + beta*(pA - omega*AyA)   [:150-190]
+__global__ __launch_bounds__(RB) void k_stab_update_p(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
+                                                      const double* __restrict__ rA, const double* __restrict__ AyA,
+                                                      double* __restrict__ pA, int64_t n)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double rA0rA = sum_partials(partial1, red);
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (fabs(rA0rA) < SP_VSMALL) { if (lead) { st->singular = 1; st->done = 1; } return; }       // checkSingularity, break
+    if (it == 0) {
+        chunk_loop(n, [&](int64_t i) { st2(pA, i, ld2(rA, i)); }, [&](int64_t i) { pA[i] = rA[i]; });
+    } else {
+        const double omega = st->wApA, alpha = st->alpha;
+        if (fabs(omega) < SP_VSMALL) { if (lead) { st->singular = 1; st->done = 1; } return; }
+        const double beta = (rA0rA / st->wArA[(it & 1) ^ 1]) * (alpha / omega);
+        chunk_loop(n, [&](int64_t i) {
+                const double2 r = ld2(rA, i), y = ld2(AyA, i), p = ld2(pA, i);
+                st2(pA, i, make_double2(fma(beta, fma(-omega, y.x, p.x), r.x), fma(beta, fma(-omega, y.y, p.y), r.y))); },
+            [&](int64_t i) { pA[i] = fma(beta, fma(-omega, AyA[i], pA[i]), rA[i]); });
+    }
+    if (lead) st->wArA[it & 1] = rA0rA;
+}
+// alpha = rA0rA / sum(P2); sA = rA - alpha*AyA; P3 = sum|sA|                                   [:200-215]
+__global__ __launch_bounds__(RB) void k_stab_s(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
+                                               const double* __restrict__ rA, const double* __restrict__ AyA,
+                                               double* __restrict__ sA, int64_t n, double* __restrict__ partial3)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double alpha = st->wArA[it & 1] / sum_partials(partial2, red);
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 r = ld2(rA, i), y = ld2(AyA, i);
+            const double2 sv = make_double2(fma(-alpha, y.x, r.x), fma(-alpha, y.y, r.y)); st2(sA, i, sv); acc0 += fabs(sv.x); acc1 += fabs(sv.y); },
+        [&](int64_t i) { const double sv = fma(-alpha, AyA[i], rA[i]); sA[i] = sv; acc0 += fabs(sv); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial3[blockIdx.x] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
+}
+// mid-iteration exit: if sum|sA|/normFactor has converged, psi += alpha*yA                       [:217-232]
+__global__ __launch_bounds__(RB) void k_stab_mid(const PcgState* __restrict__ st, const double* __restrict__ partial3,
+                                                 const double* __restrict__ yA, double* __restrict__ psi, int64_t n)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double res = sum_partials(partial3, red) / st->normFactor;
+    if (!sp_converged(st, res)) return;
+    const double alpha = st->alpha;
+    chunk_loop(n, [&](int64_t i) { const double2 y = ld2(yA, i); double2 x = ld2(psi, i); x.x = fma(alpha, y.x, x.x); x.y = fma(alpha, y.y, x.y); st2(psi, i, x); },
+        [&](int64_t i) { psi[i] = fma(alpha, yA[i], psi[i]); });
+}
+__global__ __launch_bounds__(RB) void k_stab_mid_final(PcgState* __restrict__ st, int it, const double* __restrict__ partial3,
+                                                       double* __restrict__ hist, int histLen)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double res = sum_partials(partial3, red) / st->normFactor;
+    if (threadIdx.x != 0) return;
+    st->finalResidual = res;
+    if (sp_converged(st, res)) { // nIterations++; return (the residual of this half step is the last history entry)
+        st->converged = 1; st->nIterations = it + 1; st->done = 1;
+        if (it + 1 < histLen) hist[it + 1] = res;
+    }
+}
+// two inner products of one vector in one pass: P4 = sum a*a, P5 = sum a*b                        [:240-247]
+__global__ __launch_bounds__(RB) void k_reduce_two(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                                   double* __restrict__ partialAA, double* __restrict__ partialAB)
+{
+    __shared__ double red[RB / 64];
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 x = ld2(a, i), y = ld2(b, i);
+            a0 = fma(x.x, x.x, a0); a1 = fma(x.y, x.y, a1); b0 = fma(x.x, y.x, b0); b1 = fma(x.y, y.y, b1); },
+        [&](int64_t i) { const double x = a[i]; a0 = fma(x, x, a0); b0 = fma(x, b[i], b0); });
+    const double t = block_sum<RB>(a0 + a1, red);
+    const double u = block_sum<RB>(b0 + b1, red);
+    if (threadIdx.x == 0) { partialAA[blockIdx.x] = t; partialAB[blockIdx.x] = u; }
+}
+// omega = tAsA/tAtA; psi += alpha*yA; psi += omega*q; rA = sA - omega*tA; P3 = sum|rA|            [:249-285]
+__global__ __launch_bounds__(RB) void k_stab_update(PcgState* __restrict__ st, const double* __restrict__ partialTT,
+                                                    const double* __restrict__ partialTS, const double* __restrict__ yA,
+                                                    const double* __restrict__ q, const double* __restrict__ sA,
+                                                    const double* __restrict__ tA, double* __restrict__ psi,
+                                                    double* __restrict__ rA, int64_t n, double* __restrict__ partial3)
+{
+    if (st->done) return;
+    __shared__ double red[RB / 64];
+    const double tAtA = sum_partials(partialTT, red);
+    const double tAsA = sum_partials(partialTS, red);
+    const double omega = tAsA / tAtA, alpha = st->alpha;
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) {
+            const double2 y = ld2(yA, i), z = ld2(q, i), sv = ld2(sA, i), t = ld2(tA, i); double2 x = ld2(psi, i);
+            x.x = fma(omega, z.x, fma(alpha, y.x, x.x)); x.y = fma(omega, z.y, fma(alpha, y.y, x.y));
+            const double2 r = make_double2(fma(-omega, t.x, sv.x), fma(-omega, t.y, sv.y));
+            st2(psi, i, x); st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y); },
+        [&](int64_t i) { psi[i] = fma(omega, q[i], fma(alpha, yA[i], psi[i])); const double r = fma(-omega, tA[i], sA[i]); rA[i] = r; acc0 += fabs(r); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial3[blockIdx.x] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->wApA = omega;
+}
+
 // residual, history, do-while condition                                  [PCG.C:195-204]
 template <bool DIST = false>
 __global__ __launch_bounds__(RB) void k_pcg_final(PcgState* __restrict__ st, int it, const double* __restrict__ partial3,

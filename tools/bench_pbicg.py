@@ -21,5 +21,10 @@ for dims in ((108, 108, 108), (216, 216, 216)):
             psi.zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()
             p = mat.pbicg(psi, b, pre, tolerance=0.0, maxIter=63)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
-            out.setdefault(f"{dims[0]}^3 {pre}", {}).setdefault("host_stepped" if mode == "1" else "device_resident", []).append(round(1e6 * dt / p["nIterations"], 1))
+            out.setdefault(f"PBiCG {dims[0]}^3 {pre}", {}).setdefault("host_stepped" if mode == "1" else "device_resident", []).append(round(1e6 * dt / p["nIterations"], 1))
+            psi.zero_(); mat.pbicgstab(psi, b, pre, tolerance=0.0, maxIter=3)
+            psi.zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            p = mat.pbicgstab(psi, b, pre, tolerance=0.0, maxIter=63)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            out.setdefault(f"PBiCGStab {dims[0]}^3 {pre}", {}).setdefault("host_stepped" if mode == "1" else "device_resident", []).append(round(1e6 * dt / max(p["nIterations"], 1), 1))
 print(json.dumps(out, indent=1))
