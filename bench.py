@@ -106,6 +106,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if world > 1:          # one rank compiles (if anything is stale), the others wait: no concurrent writers of the .so files
+        if rank == 0:
+            graft.build()
+        dist.barrier()
     graft.build()
     pkg = graft.load_package()
     syn, eng = pkg.synthetic, pkg.engine
