@@ -798,8 +798,9 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
     struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
     for (int it = it0; it < it0 + count; ++it) {
         if (precond == MI_PRECOND_AINV) {
-            MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0));
-            k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rA, n, P1); // not gated by done: harmless
+            // AINV apply with sum wA.rA fused into the tile pass (per-tile partials folded into P1): no separate reduction pass
+            MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0, m->tilePartial.p));
+            k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P1);
             k_pcg_update_p<0><<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, nullptr, nullptr, pA, n); // AINV path keeps k_pcg_final (P1 is rewritten before it)
         } else if (precond == MI_PRECOND_DIAGONAL) {
             k_pcg_update_p<1><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, m->rD.p, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen);

@@ -250,7 +250,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
             for (int j = PRE; j < wcur; ++j) accumulate(ent[j * 64]);
         }
         if (live) {
-            if (OP == OP_AINV) a.y[gi] = rDs[i] * (xi - acc);
+            if (OP == OP_AINV) { const double w = rDs[i] * (xi - acc); a.y[gi] = w; dot = fma(w, xi, dot); } // + fused gSumProd(wA, rA), PCG.C:139-142
             else if (OP == OP_JACOBI) {
                 const double rD = 1.0 / a.diag[gi];
                 const double extra = (1 - a.omega) * xi + a.omega * rD * accI;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
         for (int j = 0; j < PRE; ++j) ecur[j] = enext[j];
         wcur = wnext; e0cur = e0next;
     }
-    if (OP == OP_AMUL && a.dotPartial) { // fused gSumProd(wA, pA), PCG.C:166
+    if ((OP == OP_AMUL || OP == OP_AINV) && a.dotPartial) { // fused gSumProd(wA, pA), PCG.C:166 / gSumProd(wA, rA), PCG.C:142
         __shared__ double red[BS / 64];
         const double tsum = block_sum<BS>(dot, red);
         if (tid == 0) a.dotPartial[p] = tsum;
