@@ -185,3 +185,42 @@ def test_cyclic_patches_are_local_couplings(pkg, orc):
         bou = np.concatenate([i.bou_coeffs for i in case.interfaces])
         got = interpret_amul(L, case, x, ext=np.zeros(len(bou)), bou=bou)
         assert np.max(np.abs(got - S.amul(x))) < 1e-15
+
+
+def test_layout_property_random_coupled_patches(pkg, orc):
+    """property test: random graphs with a random cyclic patch pair AND a random processor patch (ext values supplied) ->
+    the interpreted tables reproduce the oracle's Amul with interfaces; partners may fall in the same or another tile."""
+    from hypothesis import given, settings, strategies as st
+    syn = pkg.synthetic
+
+    @settings(max_examples=20, deadline=None)
+    @given(n=st.integers(8, 300), extra=st.floats(0.5, 3.0), seed=st.integers(0, 10_000), tile=st.sampled_from([5, 33, 128, 1024]),
+           npair=st.integers(1, 12), nproc=st.integers(0, 9))
+    def run(n, extra, seed, tile, npair, nproc):
+        case = random_graph_case(pkg, n, extra=extra, seed=seed)
+        u = syn.splitmix_uniform(seed + 11, 2 * npair + nproc)
+        a = (u[:npair] * n).astype(np.int32); b = (u[npair:2 * npair] * n).astype(np.int32)
+        pc = (u[2 * npair:] * n).astype(np.int32)
+        kap = -(0.1 + syn.splitmix_uniform(seed + 12, npair))
+        pb = -(0.1 + syn.splitmix_uniform(seed + 13, nproc))
+        ext_vals = syn.splitmix_uniform(seed + 14, nproc) - 0.5
+        import copy
+        cs = copy.copy(case)
+        cs.interfaces = [syn.Interface(0, 1, a, kap, kap), syn.Interface(0, 0, b, kap, kap)]
+        # the oracle sees the processor patch as a second domain of `nproc` cells that holds the ext values
+        S = None
+        L = pkg.engine.host_layout(n, case.lower_addr, case.upper_addr, [a, b, pc], tile_cells=tile, patch_nbr_cells=[b, a, None])
+        assert np.all(L["haloCell"] < n + 2 * npair + nproc)
+        x = syn.splitmix_uniform(seed + 7, n) - 0.5
+        ref = orc.System([cs]).amul(x)
+        np.subtract.at(ref, pc, pb * ext_vals)           # result[faceCells] -= bouCoeffs * psi_neighbour
+        ext = np.concatenate([np.zeros(2 * npair), ext_vals])
+        got = interpret_amul(L, case, x, ext=ext, bou=np.concatenate([kap, kap, pb]))
+        assert np.max(np.abs(got - ref)) <= 1e-13 * max(np.max(np.abs(ref)), 1e-300)
+        # tiles that read the ext region are exactly the boundary tiles
+        bt = set(L["boundaryTiles"].tolist())
+        for t in range(len(L["tileCellStart"]) - 1):
+            h = L["haloCell"][L["tileHaloStart"][t]:L["tileHaloStart"][t + 1]]
+            assert (np.any(h >= n)) == (t in bt)
+
+    run()
