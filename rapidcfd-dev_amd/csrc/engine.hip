@@ -109,6 +109,9 @@ struct mi_matrix_s {
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
     bool pcgActive = false;
     std::vector<hipEvent_t> evPool;
+    // hipGraph of one batch of device-resident PCG iterations (launch-bound regime: small meshes, coarse ranks)
+    hipGraphExec_t pcgGraph = nullptr;
+    struct { int precond = -1, batch = 0, histLen = 0; const void* hist = nullptr; const void* psi = nullptr; } pcgGraphKey;
     bool gateDone = false; // tile launches of a device-resident solver loop read PcgState::done and exit past convergence
     hipEvent_t kevStart = nullptr, kevStop = nullptr; // when set: attached to the next tile-kernel launch (hipExtLaunchKernel)
     struct mi_dpcg_comm_s* dpc = nullptr; // attached RCCL communicators + exchange plan (comm.inc)
@@ -796,7 +799,8 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
     if (m->tilePartial.n < (size_t)a->L.nTiles) MICHK(m->tilePartial.alloc((size_t)a->L.nTiles));
     const bool fuse = c->fuseFinal && precond != MI_PRECOND_AINV;
     struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
-    for (int it = it0; it < it0 + count; ++it) {
+    for (int k = 0; k < count; ++k) {
+        const int it = it0 < 0 ? -1 : it0 + k; // it0 < 0: the iteration counter lives on the device (graph replay)
         if (precond == MI_PRECOND_AINV) {
             // AINV apply with sum wA.rA fused into the tile pass (per-tile partials folded into P1): no separate reduction pass
             MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0, m->tilePartial.p));
@@ -807,8 +811,8 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
         } else {
             k_pcg_update_p<2><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, nullptr, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen);
         }
-        const bool rec = evStride > 0 && ((it - it0) % evStride) == 0;
-        const size_t ev = rec ? (size_t)2 * (size_t)((it - it0) / evStride) : 0;
+        const bool rec = evStride > 0 && (k % evStride) == 0;
+        const size_t ev = rec ? (size_t)2 * (size_t)(k / evStride) : 0;
         if (rec) { // the event pair rides on the Amul launch itself: it brackets the kernel, not the launch gap before it
             while (m->evPool.size() < ev + 2) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); m->evPool.push_back(e); }
             if (c->attachEvents) { m->kevStart = m->evPool[ev]; m->kevStop = m->evPool[ev + 1]; }
@@ -829,7 +833,7 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
         if (!fuse) k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
     }
     // test of the last enqueued iteration (idempotent: the next batch's first kernel repeats it)
-    if (count > 0 && fuse) k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it0 + count - 1, P3, m->hist.p, m->histLen);
+    if (count > 0 && fuse) k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it0 < 0 ? -1 : it0 + count - 1, P3, m->hist.p, m->histLen);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -917,8 +921,40 @@ extern "C" int mi_pcg_solve(mi_matrix_t m, double* psi, const double* source, co
     mi_ctx_s* c = m->addr->ctx;
     MICHK(fetch_state(c));
     const int batch = env_int("MI_PCG_BATCH", 16);
+    const int limit = ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0);
+    // Launch-bound regime (small meshes: a 32^3 cavity iteration is five ~5 us launches): one batch of iterations is
+    // captured ONCE into a hipGraph -- the iteration counter lives in PcgState, so the kernel arguments never change --
+    // and replayed until the device reports done.  Same kernels, same order: results are bit-identical.
+    const int wantGraph = env_int("MI_PCG_GRAPH", -1);
+    const bool useGraph = (precond == MI_PRECOND_DIAGONAL || precond == MI_PRECOND_NONE) && !c->fuseFinal &&
+                          (wantGraph == 1 || (wantGraph < 0 && m->addr->L.nCells <= 4000000));
+    if (useGraph && !c->hostState->done) {
+        double* psiE; MICHK(m->vec(3, &psiE));
+        auto& K = m->pcgGraphKey;
+        if (!m->pcgGraph || K.precond != precond || K.batch != batch || K.histLen != m->histLen || K.hist != m->hist.p || K.psi != psiE) {
+            if (m->pcgGraph) { (void)hipGraphExecDestroy(m->pcgGraph); m->pcgGraph = nullptr; }
+            if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));                                  // no allocation inside a capture
+            if (m->tilePartial.n < (size_t)m->addr->L.nTiles) MICHK(m->tilePartial.alloc((size_t)m->addr->L.nTiles));
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int rcE = pcg_enqueue(m, -1, batch, precond, 0);
+            const hipError_t eE = hipStreamEndCapture(c->stream, &g);
+            MICHK(rcE);
+            HIPCHK(eE);
+            const hipError_t eI = hipGraphInstantiate(&m->pcgGraph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            HIPCHK(eI);
+            K.precond = precond; K.batch = batch; K.histLen = m->histLen; K.hist = m->hist.p; K.psi = psiE;
+        }
+        while (!c->hostState->done && m->pcgIt <= limit) {
+            HIPCHK(hipGraphLaunch(m->pcgGraph, c->stream));
+            m->pcgIt += batch;
+            MICHK(fetch_state(c));
+        }
+        return mi_pcg_end(m, psi, perf, hist_host, hist_len);
+    }
     // bodies run for it = 0 .. maxIter inclusive at most (nIterations++ < maxIter, PCG.C:197-204)
-    while (!c->hostState->done && m->pcgIt <= ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0)) {
+    while (!c->hostState->done && m->pcgIt <= limit) {
         MICHK(mi_pcg_iterate(m, batch, nullptr));
         MICHK(fetch_state(c));
     }
@@ -1484,6 +1520,7 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
 
 mi_matrix_s::~mi_matrix_s()
 {
+    if (pcgGraph) (void)hipGraphExecDestroy(pcgGraph);
     for (auto* w : work) delete w;
     for (auto e : evPool) (void)hipEventDestroy(e);
     if (dpc) {

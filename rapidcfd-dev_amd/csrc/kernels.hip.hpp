@@ -485,6 +485,7 @@ struct PcgState {
     double tolerance, relTol;
     int32_t maxIter, minIter;
     int32_t nIterations, done, converged, singular;
+    int32_t it, pad_;  // device-side iteration counter: kernels launched with it < 0 (graph replays) read it here
 };
 
 constexpr double SP_SMALL = 1e-20, SP_VSMALL = 1e-300, SP_GREAT = 1e20; // SolverPerformance.H:269-275
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
                                                      int histLen = 0)
 {
     if (st->done) return;
+    if (it < 0) it = st->it; // graph replay: the counter lives on the device (advanced by k_pcg_final)
     __shared__ double red[RB / 64];
     if (partial3 && it > 0 && !pcg_test_previous<DIST>(st, it - 1, partial3, hist, histLen, red)) return;
     const double wArA = DIST ? partial1[0] : sum_partials(partial1, red); // DIST: global sum from the allreduce
@@ -578,6 +580,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
                                                          double* __restrict__ partial3, double* __restrict__ partial1)
 {
     if (st->done) return;
+    if (it < 0) it = st->it;
     __shared__ double red[RB / 64];
     const double wApA = DIST ? partial2[0] : sum_partials(partial2, red);
     if (fabs(wApA) / st->normFactor < SP_VSMALL) { // checkSingularity, SolverPerformance.C:32-44
@@ -790,6 +793,7 @@ __global__ __launch_bounds__(RB) void k_pcg_final(PcgState* __restrict__ st, int
                                                   double* __restrict__ hist, int histLen)
 {
     if (st->done) return;
+    if (it < 0) it = st->it;
     __shared__ double red[RB / 64];
     const bool sing = partial3[0] < 0.0; // sum|r| partials are never negative
     const double s = DIST ? partial3[0] : sum_partials(partial3, red);
@@ -799,6 +803,7 @@ __global__ __launch_bounds__(RB) void k_pcg_final(PcgState* __restrict__ st, int
     st->finalResidual = res;
     if (it + 1 < histLen) hist[it + 1] = res;
     st->nIterations = it + 1;
+    st->it = it + 1;
     const bool conv = sp_converged(st, res);
     st->converged = conv;
     const bool cont = (it < st->maxIter && !conv) || (it + 1 < st->minIter);
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(RB) void k_solve_init(PcgState* __restrict__ st, co
     const double res = sr / nf;
     st->initialResidual = res; st->finalResidual = res;
     if (histLen > 0) hist[0] = res;
-    st->nIterations = 0; st->singular = 0;
+    st->nIterations = 0; st->singular = 0; st->it = 0;
     st->wArA[0] = SP_GREAT; st->wArA[1] = SP_GREAT;
     const bool conv = sp_converged(st, res);
     st->converged = conv;
