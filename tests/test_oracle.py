@@ -152,3 +152,86 @@ def test_cpu_baseline_kernel_is_the_same_pcg(pkg, orc):
         n, sec, res = S.baseline_pcg(np.concatenate([s.source for s in subs]), 30)
         assert n == 30 and sec > 0
         assert abs(res - ref) < 1e-9 * ref
+
+
+# ---- independent restatement of the Krylov loops (dense numpy, long double): pins the C oracle's arithmetic ------------
+def _np_solver_history(case, solver, precond, n_iter, quirk=True):
+    """PCG.C:68-208 / PBiCG.C:67-246 / PBiCGStab.C:67-300 written again from the reference text, on a dense long-double
+    matrix: shares no code with oracle/ldu_oracle.c"""
+    ld = np.longdouble
+    A = dense(case).astype(ld)
+    b = case.source.astype(ld)
+    D = np.diag(A).copy()
+    rD = 1 / D
+    LU = A - np.diag(D)
+
+    def M(r, transpose=False):
+        if precond == "none":
+            return r.copy()
+        if precond == "diagonal":
+            return rD * r
+        return rD * (r - (LU.T if transpose else LU) @ (rD * r))      # AINVPreconditionerF.H:41-99
+    psi = np.zeros_like(b)
+    Apsi = A @ psi
+    sumA = A.sum(axis=1)
+    xref = psi.mean()
+    nf = (np.abs(Apsi - xref * sumA) + np.abs(b - xref * sumA)).sum() + ld(1e-20)   # lduMatrixSolver.C:182-236
+    r = b - Apsi
+    hist = [float(np.abs(r).sum() / nf)]
+    if solver == "pcg":
+        p = np.zeros_like(b); wr_old = None
+        for it in range(n_iter):
+            w = M(r); wr = w @ r
+            p = w if it == 0 else w + (wr / wr_old) * p
+            w = A @ p
+            alpha = wr / (w @ p)
+            psi = psi + alpha * p; r = r - alpha * w; wr_old = wr
+            hist.append(float(np.abs(r).sum() / nf))
+    elif solver == "pbicg":
+        rT = b - A.T @ psi
+        p = pT = None; wr_old = None
+        for it in range(n_iter):
+            w, wT = M(r), M(rT, True); wr = w @ rT
+            if it == 0:
+                p, pT = w, wT
+            else:
+                beta = wr / wr_old; p, pT = w + beta * p, wT + beta * pT
+            w, wT = A @ p, A.T @ pT
+            alpha = wr / (w @ pT)
+            psi = psi + alpha * p; r = r - alpha * w; rT = rT - alpha * wT; wr_old = wr
+            hist.append(float(np.abs(r).sum() / nf))
+    else:
+        r0 = r.copy(); p = None; rr_old = alpha = omega = None; Ay = None
+        for it in range(n_iter):
+            rr = r0 @ r
+            p = r.copy() if it == 0 else r + (rr / rr_old) * (alpha / omega) * (p - omega * Ay)
+            y = M(p); Ay = A @ y
+            alpha = rr / (r0 @ Ay)
+            s = r - alpha * Ay
+            z = M(s); t = A @ z
+            omega = (t @ s) / (t @ t)
+            psi = psi + alpha * y + omega * (y if quirk else z)
+            r = s - omega * t; rr_old = rr
+            hist.append(float(np.abs(r).sum() / nf))
+    return np.array(hist), float(nf)
+
+
+@pytest.mark.parametrize("solver,symmetric,precond", [("pcg", True, "diagonal"), ("pcg", True, "AINV"), ("pcg", True, "none"),
+                                                      ("pbicg", False, "diagonal"), ("pbicg", False, "AINV"),
+                                                      ("pbicgstab", False, "diagonal"), ("pbicgstab", False, "AINV")])
+def test_krylov_histories_against_an_independent_restatement(pkg, orc, solver, symmetric, precond):
+    case = pkg.synthetic.box_case(7, 6, 5, symmetric=symmetric)
+    n_iter = 12
+    S = orc.System([case])
+    z = np.zeros(case.n_cells)
+    kw = dict(tolerance=0.0, maxIter=n_iter - 1)
+    for quirk in ((True, False) if solver == "pbicgstab" else (True,)):
+        if solver == "pbicgstab":
+            _, perf = S.pbicgstab(z, case.source, precond, replicate_quirk=quirk, **kw)
+        else:
+            _, perf = getattr(S, solver)(z, case.source, precond, **kw)
+        ref, nf = _np_solver_history(case, solver, precond, n_iter, quirk)
+        assert abs(perf["normFactor"] - nf) < 1e-14 * nf
+        h = perf["history"]
+        assert h.shape == ref.shape
+        assert np.max(np.abs(h - ref) / ref) < 1e-9, (solver, precond, quirk)
