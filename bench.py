@@ -243,7 +243,7 @@ def main():
             "kernel": "tile_kernel<OP_AMUL> (lduMatrix::Amul)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": amul_bytes, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_h_rocprof_summary.md)",
+            "algorithmic_bytes_per_launch": amul_bytes, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_m_rocprof_summary.md)",
             "avg_launch_us": amul_avg_s * 1e6,
             "traffic": traffic_from_profile(nx, ny, nz, n_gpus),
         },
