@@ -1,6 +1,9 @@
 /*
  * gamg_oracle.c -- CPU ORACLE for the GAMG solver (test infrastructure, NOT product code;
- * see the header of ldu_oracle.c: PARITY UNPINNED, the reference ships no tests).
+ * see the header of ldu_oracle.c: PARITY UNPINNED for the device arithmetic, the reference ships no tests).
+ * PINNED BY THE REFERENCE'S OWN CODE: pair_agglomerate() below is checked, level by level, against
+ * pairGAMGAgglomeration::agglomerate compiled from /root/reference (oracle/ref_shim, Makefile target `ref`,
+ * tests/golden/golden_ref_pair.npz, tests/test_gamg.py::test_pair_agglomeration_equals_the_reference_code).
  *
  * Restates (single domain: orc_gamg_build/solve; coupled patches and decomposed cases: orc_gamg_build_sys/solve_sys
  * at the end of the file), paths relative to

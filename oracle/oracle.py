@@ -36,6 +36,10 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith("_oracle.c")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    # oracle/_ref: the reference's own host code compiled where it lies; only where /root/reference exists (the GPU box
+    # uses the prebuilt file that travelled with the snapshot)
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -444,3 +448,25 @@ def axpby(a, x, b, y):
     out = np.empty_like(xx)
     lib().orc_axpby(C.c_int32(xx.shape[0]), C.c_double(a), _p(xx, C.c_double), C.c_double(b), _p(yy, C.c_double), _p(out, C.c_double))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle/_ref: the REFERENCE's own pairGAMGAgglomeration::agglomerate, compiled from /root/reference against a shim
+# (oracle/ref_shim, oracle/Makefile target `ref`).  Present where the reference tree was available at build time.
+# ---------------------------------------------------------------------------------------------
+REF_PAIR_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_pair.so")
+
+
+def ref_pair_available() -> bool:
+    return os.path.exists(REF_PAIR_LIB)
+
+
+def ref_pair_agglomerate(n_cells, lower_addr, upper_addr, face_weights, forward=True):
+    """returns (coarseCellMap, nCoarseCells, forward_after) computed by the reference's code"""
+    L = C.CDLL(REF_PAIR_LIB)
+    lo, up, w = _i(lower_addr), _i(upper_addr), _d(face_weights)
+    out = np.empty(n_cells, np.int32)
+    fwd = C.c_int()
+    nc = L.ref_pair_agglomerate(C.c_int(n_cells), C.c_int(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(w, C.c_double),
+                                C.c_int(int(forward)), _p(out, C.c_int32), C.byref(fwd))
+    return out, int(nc), bool(fwd.value)

@@ -1,0 +1,63 @@
+"""Golden vectors produced by the REFERENCE's own code: pairGAMGAgglomeration::agglomerate compiled from
+/root/reference (oracle/_ref/libref_pair.so, oracle/Makefile target `ref`) is run level by level on a few meshes; its
+coarse-cell maps are frozen in tests/golden/golden_ref_pair.npz.  Needs the reference tree:
+    python tests/golden/make_golden_ref.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as graft  # noqa: E402
+
+
+def cases(pkg, orc):
+    from conftest import random_graph_case
+    syn = pkg.synthetic
+    out = {}
+    for name, dims in (("box_14x11x9", (14, 11, 9)), ("box_7x5x3", (7, 5, 3)), ("box_24x1x1", (24, 1, 1))):
+        c = syn.box_case(*dims)
+        out[name] = (c, orc.box_face_weights(c))
+    g = random_graph_case(pkg, 800)
+    out["graph_800"] = (g, 0.5 + syn.splitmix_uniform(77, g.n_faces))
+    g = random_graph_case(pkg, 300, extra=4.0, seed=9)
+    out["graph_300_ties"] = (g, np.ones(g.n_faces))          # all weights equal: pure tie-breaking
+    return out
+
+
+def reference_levels(orc, case, w, n_coarsest, forward):
+    """drive the reference's agglomerate() through the levels the way its level loop does (pairGAMGAgglomerate.C:46-120),
+    taking the coarse addressing / restricted weights of each level from the oracle's hierarchy"""
+    H = orc.GamgHierarchy(case, w, n_coarsest, forward)
+    lo, up, ww, n, fwd = case.lower_addr, case.upper_addr, np.asarray(w, dtype=np.float64), case.n_cells, forward
+    maps = []
+    for l in range(H.n_levels):
+        m, nc, fwd = orc.ref_pair_agglomerate(n, lo, up, ww, fwd)
+        maps.append(m)
+        lv = H.level(l)
+        cw = np.zeros(lv["n_coarse_faces"])
+        keep = lv["face_restrict"] >= 0
+        np.add.at(cw, lv["face_restrict"][keep], ww[keep])
+        lo, up, ww, n = lv["lower"], lv["upper"], cw, lv["n_coarse"]
+    return maps
+
+
+def build(pkg, orc):
+    out = {}
+    for name, (case, w) in cases(pkg, orc).items():
+        for forward in (True, False):
+            for l, m in enumerate(reference_levels(orc, case, w, 4, forward)):
+                out[f"{name}/fwd{int(forward)}/level{l}"] = m
+    return out
+
+
+if __name__ == "__main__":
+    graft.build()
+    pkg = graft.load_package()
+    from oracle import oracle as orc
+    assert orc.ref_pair_available(), "oracle/_ref/libref_pair.so missing: needs /root/reference (make -C oracle ref)"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_pair.npz"), **build(pkg, orc))
+    print("written")

@@ -281,3 +281,48 @@ def test_full_size_gamg_properties(pkg, orc):
     p2 = mat.pcg(psi2, b, "diagonal", tolerance=1e-8, maxIter=5000)
     assert p2["converged"]
     assert float(torch.max(torch.abs(psi - psi2))) < 1e-3 * float(torch.max(torch.abs(psi2)))
+
+
+# ---- pinned against the REFERENCE's own code -----------------------------------------------------------------------
+def _ref_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_pair.npz"))
+
+
+def test_pair_agglomeration_equals_the_reference_code(pkg, orc):
+    """tests/golden/golden_ref_pair.npz holds the coarse-cell maps computed by pairGAMGAgglomeration::agglomerate COMPILED
+    FROM /root/reference (oracle/ref_shim + oracle/Makefile `ref`; generator tests/golden/make_golden_ref.py).  Both
+    restatements -- the oracle's C and the engine's C++ -- must reproduce them on every level, both sweep directions,
+    boxes, ragged graphs and an all-ties case."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = _ref_golden()
+    n_checked = 0
+    for name, (case, w) in make_golden_ref.cases(pkg, orc).items():
+        for forward in (True, False):
+            H = orc.GamgHierarchy(case, w, 4, forward)
+            E = pkg.engine.gamg_host_hierarchy(case.n_cells, case.lower_addr, case.upper_addr, w, 4, forward)
+            keys = sorted(k for k in G.files if k.startswith(f"{name}/fwd{int(forward)}/"))
+            assert len(keys) == H.n_levels == len(E) >= 1, name
+            for l in range(H.n_levels):
+                ref = G[f"{name}/fwd{int(forward)}/level{l}"]
+                assert np.array_equal(H.level(l)["restrict"], ref), (name, forward, l, "oracle")
+                assert np.array_equal(E[l]["restrictMap"], ref), (name, forward, l, "engine")
+                n_checked += 1
+    assert n_checked >= 40
+
+
+def test_reference_code_live_when_its_build_is_present(pkg, orc):
+    # where oracle/_ref/libref_pair.so exists (this container; it also travels to the GPU box) the goldens are regenerated
+    # from the reference's code on the spot
+    if not orc.ref_pair_available():
+        pytest.skip("oracle/_ref/libref_pair.so not built (needs /root/reference)")
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    now = make_golden_ref.build(pkg, orc)
+    G = _ref_golden()
+    assert sorted(now) == sorted(G.files)
+    for k in G.files:
+        assert np.array_equal(now[k], G[k]), k
