@@ -470,3 +470,23 @@ def ref_pair_agglomerate(n_cells, lower_addr, upper_addr, face_weights, forward=
     nc = L.ref_pair_agglomerate(C.c_int(n_cells), C.c_int(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(w, C.c_double),
                                 C.c_int(int(forward)), _p(out, C.c_int32), C.byref(fwd))
     return out, int(nc), bool(fwd.value)
+
+
+REF_SOLVERS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_solvers.so")
+
+
+def ref_solvers_available() -> bool:
+    return os.path.exists(REF_SOLVERS_LIB)
+
+
+def ref_krylov_solve(kind: str, system: "System", psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):
+    """the REFERENCE's own PCG::solve / PBiCG::solve / PBiCGStab::solve (compiled from /root/reference against
+    oracle/ref_shim/foam_solver_shim.H) driving this oracle's primitives; returns (psi, perf)"""
+    lib()                                     # liboracle.so must be in the process before the dependent library
+    L = C.CDLL(REF_SOLVERS_LIB)
+    x = _d(psi).copy()
+    b = _d(source)
+    out = (C.c_double * 5)()
+    L.ref_krylov_solve(C.c_int({"pcg": 0, "pbicg": 1, "pbicgstab": 2}[kind]), system.h, _p(x, C.c_double), _p(b, C.c_double),
+                       C.c_int(PRECOND[precond]), C.c_double(tolerance), C.c_double(relTol), C.c_int(maxIter), C.c_int(minIter), out)
+    return x, dict(initialResidual=out[0], finalResidual=out[1], nIterations=int(out[2]), converged=bool(out[3]), singular=bool(out[4]))

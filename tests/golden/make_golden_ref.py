@@ -1,6 +1,8 @@
 """Golden vectors produced by the REFERENCE's own code: pairGAMGAgglomeration::agglomerate compiled from
 /root/reference (oracle/_ref/libref_pair.so, oracle/Makefile target `ref`) is run level by level on a few meshes; its
-coarse-cell maps are frozen in tests/golden/golden_ref_pair.npz.  Needs the reference tree:
+coarse-cell maps are frozen in tests/golden/golden_ref_pair.npz; its PCG::solve / PBiCG::solve / PBiCGStab::solve (PCG.C,
+PBiCG.C, PBiCGStab.C + the functor headers, oracle/_ref/libref_solvers.so) run on the oracle's primitives and their psi and
+solverPerformance are frozen in tests/golden/golden_ref_solvers.npz.  Needs the reference tree:
     python tests/golden/make_golden_ref.py
 """
 import os
@@ -54,10 +56,37 @@ def build(pkg, orc):
     return out
 
 
+SOLVER_RUNS = [(True, "pcg", ("none", "diagonal", "AINV")), (False, "pbicg", ("diagonal", "AINV")), (False, "pbicgstab", ("diagonal", "AINV"))]
+SOLVER_CONTROLS = [dict(tolerance=0.0, maxIter=7), dict(tolerance=1e-9, maxIter=500), dict(tolerance=1e30, maxIter=50, minIter=3),
+                   dict(tolerance=1e-3, relTol=0.1, maxIter=40)]
+
+
+def solver_runs(pkg):
+    for sym, kind, pres in SOLVER_RUNS:
+        case = pkg.synthetic.box_case(9, 8, 7, symmetric=sym)
+        for pre in pres:
+            for k, kw in enumerate(SOLVER_CONTROLS):
+                yield f"{kind}/{pre}/{k}", case, kind, pre, kw
+
+
+def build_solvers(pkg, orc):
+    """psi and solverPerformance of the REFERENCE's PCG::solve / PBiCG::solve / PBiCGStab::solve (compiled from /root/reference,
+    oracle/_ref/libref_solvers.so) on the oracle's primitives"""
+    out = {}
+    for key, case, kind, pre, kw in solver_runs(pkg):
+        S = orc.System([case])
+        x, p = orc.ref_krylov_solve(kind, S, np.zeros(case.n_cells), case.source, pre, **kw)
+        out[key + "/psi"] = x
+        out[key + "/perf"] = np.array([p["initialResidual"], p["finalResidual"], p["nIterations"], p["converged"], p["singular"]], dtype=np.float64)
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
     from oracle import oracle as orc
     assert orc.ref_pair_available(), "oracle/_ref/libref_pair.so missing: needs /root/reference (make -C oracle ref)"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_pair.npz"), **build(pkg, orc))
+    assert orc.ref_solvers_available(), "oracle/_ref/libref_solvers.so missing"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_solvers.npz"), **build_solvers(pkg, orc))
     print("written")

@@ -235,3 +235,44 @@ def test_krylov_histories_against_an_independent_restatement(pkg, orc, solver, s
         h = perf["history"]
         assert h.shape == ref.shape
         assert np.max(np.abs(h - ref) / ref) < 1e-9, (solver, precond, quirk)
+
+
+# ---- pinned against the REFERENCE's own solver sources -------------------------------------------------------------
+def _ref_solver_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_solvers.npz"))
+
+
+def test_krylov_loops_equal_the_reference_sources(pkg, orc):
+    """tests/golden/golden_ref_solvers.npz was produced by the reference's PCG::solve, PBiCG::solve and PBiCGStab::solve
+    COMPILED FROM /root/reference (PCG.C, PBiCG.C, PBiCGStab.C and their functor headers, against oracle/ref_shim/
+    foam_solver_shim.H) running on this oracle's Amul/precondition/gSum primitives.  The oracle's own restatement of those
+    loops must give the same bits: psi, residuals, iteration counts, converged/singular -- fixed iteration counts,
+    converged runs, the minIter rule (incl. PBiCGStab's mid-iteration exit) and relTol."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = _ref_solver_golden()
+    n = 0
+    for key, case, kind, pre, kw in make_golden_ref.solver_runs(pkg):
+        S = orc.System([case])
+        x, p = getattr(S, kind)(np.zeros(case.n_cells), case.source, pre, **kw)
+        ref = G[key + "/perf"]
+        assert np.array_equal(x, G[key + "/psi"]), key
+        assert p["initialResidual"] == ref[0] and p["finalResidual"] == ref[1] and p["nIterations"] == int(ref[2]), key
+        assert bool(p["converged"]) == bool(ref[3]) and bool(p["singular"]) == bool(ref[4]), key
+        n += 1
+    assert n == 28
+
+
+def test_reference_solver_sources_live_when_built(pkg, orc):
+    if not orc.ref_solvers_available():
+        pytest.skip("oracle/_ref/libref_solvers.so not built (needs /root/reference)")
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    now = make_golden_ref.build_solvers(pkg, orc)
+    G = _ref_solver_golden()
+    assert sorted(now) == sorted(G.files)
+    for k in G.files:
+        assert np.array_equal(now[k], G[k]), k
