@@ -9,10 +9,18 @@
  * PARITY UNPINNED: the reference tree holds no tests, tutorials, golden
  * vectors or benchmarks and cannot be compiled in
  * this container (needs nvcc + Thrust + a CUDA device).  The oracle is
- * therefore pinned only by (i) algebraic identities checked in
+ * therefore pinned by (i) algebraic identities checked in
  * tests/test_oracle.py (dense recomputation in long double, x'Ay == y'Ax,
- * Tmul(A) == Amul(A'), face-loop order vs row-gather order) and (ii) the
- * golden fixtures it generated itself (tests/golden/).
+ * Tmul(A) == Amul(A'), face-loop order vs row-gather order), (ii) the
+ * golden fixtures it generated itself (tests/golden/golden_v1/v2.npz), and
+ * (iii) THE REFERENCE'S OWN SOURCES wherever they are host code: PCG.C,
+ * PBiCG.C, PBiCGStab.C (+ their functor headers) and
+ * pairGAMGAgglomerate.C are compiled from /root/reference against
+ * oracle/ref_shim/ into oracle/_ref/ (Makefile target `ref`); the solver
+ * loops below reproduce the reference's solve() functions bit for bit
+ * (tests/golden/golden_ref_*.npz, make_golden_ref.py).  Still an
+ * assumption: the rounding inside the device row functors (see
+ * orc_amul_functor_literal).
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference/src/OpenFOAM/matrices/lduMatrix/ unless noted).
@@ -225,6 +233,39 @@ void orc_tmul(const orc_system *s, const scalar *psi, scalar *Tpsi)
         const orc_domain *m = &s->dom[d];
         dom_mul_rows(m, m->upperC, m->lowerC, psi + m->offset, Tpsi + m->offset);
         update_interfaces(s, d, 1, 1.0, psi, Tpsi + m->offset, 0);
+    }
+}
+
+/* The reference functor read LITERALLY (lduMatrixATmul.C:42-138, matrixMultiplyFunctor<fast,3>): the products of the first
+ * three own-side and the first three neighbour-side faces are staged in tmpSum[] behind `if (i < size)` guards and then
+ * added to out = diag*psi one by one; further own-side faces are folded as out += upper*psi; further neighbour-side faces
+ * go to a separate accumulator nExtra that is added last.  Which of these adds nvcc fuses with their multiplies cannot be
+ * established without the CUDA binary: a product that reaches its add through a guarded array element (the staged six)
+ * most likely stays separately rounded, the `+= a*b` statements of the extras most likely become fma.  orc_amul above uses
+ * ONE fma per term in row order (own faces ascending, then neighbour faces in losort order) -- the same order for rows
+ * with at most 3+3 faces (every hex mesh), a different association for longer rows.  This literal variant exists so the
+ * difference is measured instead of assumed (tests/test_oracle.py::test_functor_literal_variant_is_within_rounding).   */
+void orc_amul_functor_literal(const orc_system *s, const scalar *psiAll, scalar *ApsiAll)
+{
+    int d;
+    for (d = 0; d < s->nDomains; d++) {
+        const orc_domain *m = &s->dom[d];
+        const scalar *psi = psiAll + m->offset; scalar *Apsi = ApsiAll + m->offset;
+        label c, i;
+        for (c = 0; c < m->nCells; c++) {
+            const label oStart = m->ownerStart[c], oSize = m->ownerStart[c + 1] - oStart;
+            const label nStart = m->losortStart[c], nSize = m->losortStart[c + 1] - nStart;
+            scalar tmpSum[6] = {0, 0, 0, 0, 0, 0}, nExtra = 0;
+            volatile scalar prod;                      /* keeps the staged products separately rounded under any compiler flags */
+            scalar out = m->diag[c] * psi[c];
+            for (i = 0; i < 3; i++) if (i < oSize) { prod = m->upperC[oStart + i] * psi[m->upper[oStart + i]]; tmpSum[i] = prod; }
+            for (i = 0; i < 3; i++) if (i < nSize) { const label f = m->losort[nStart + i]; prod = m->lowerC[f] * psi[m->lower[f]]; tmpSum[i + 3] = prod; }
+            for (i = 0; i < 6; i++) out += tmpSum[i];
+            for (i = 3; i < oSize; i++) out = fma(m->upperC[oStart + i], psi[m->upper[oStart + i]], out);
+            for (i = 3; i < nSize; i++) { const label f = m->losort[nStart + i]; nExtra = fma(m->lowerC[f], psi[m->lower[f]], nExtra); }
+            Apsi[c] = out + nExtra;
+        }
+        update_interfaces(s, d, 0, 1.0, psiAll, Apsi, 0);
     }
 }
 

@@ -113,6 +113,9 @@ class System:
     def amul(self, psi):
         return self._unary("orc_amul", psi)
 
+    def amul_functor_literal(self, psi):
+        return self._unary("orc_amul_functor_literal", psi)
+
     def tmul(self, psi):
         return self._unary("orc_tmul", psi)
 

@@ -276,3 +276,20 @@ def test_reference_solver_sources_live_when_built(pkg, orc):
     assert sorted(now) == sorted(G.files)
     for k in G.files:
         assert np.array_equal(now[k], G[k]), k
+
+
+def test_functor_literal_variant_is_within_rounding(pkg, orc):
+    """The reference's Amul functor stages the first 3+3 products in tmpSum[] (lduMatrixATmul.C:42-138); whether nvcc fuses
+    those adds is not knowable here.  The oracle's one-fma-per-term row sum and the literal reading agree to a few ulp of
+    the row's magnitude on boxes AND on ragged rows (where the literal reading also changes the association), far inside
+    the 1e-10 bar set for residual histories."""
+    syn = pkg.synthetic
+    for case in (syn.box_case(12, 10, 8), syn.box_case(9, 8, 7, symmetric=False), random_graph_case(pkg, 500, extra=4.0)):
+        S = orc.System([case])
+        x = syn.splitmix_uniform(4, case.n_cells) - 0.5
+        a, b = S.amul(x), S.amul_functor_literal(x)
+        lower = case.upper if case.lower is None else case.lower
+        row_mag = np.abs(case.diag * x)
+        np.add.at(row_mag, case.lower_addr, np.abs(case.upper * x[case.upper_addr])); np.add.at(row_mag, case.upper_addr, np.abs(lower * x[case.lower_addr]))
+        assert np.max(np.abs(a - b) / row_mag) < 8 * np.finfo(float).eps
+        assert np.max(np.abs(a - b)) > 0          # they ARE different roundings: the question is real
