@@ -3,7 +3,10 @@
  * see the header of ldu_oracle.c: PARITY UNPINNED for the device arithmetic, the reference ships no tests).
  * PINNED BY THE REFERENCE'S OWN CODE: pair_agglomerate() below is checked, level by level, against
  * pairGAMGAgglomeration::agglomerate compiled from /root/reference (oracle/ref_shim, Makefile target `ref`,
- * tests/golden/golden_ref_pair.npz, tests/test_gamg.py::test_pair_agglomeration_equals_the_reference_code).
+ * tests/golden/golden_ref_pair.npz, tests/test_gamg.py::test_pair_agglomeration_equals_the_reference_code), and
+ * orc_gamg_solve_sys() against the reference's GAMGSolverSolve.C (solve/Vcycle/initVcycle/solveCoarsestLevel compiled
+ * the same way and run on the primitives below: tests/golden/golden_ref_gamg.npz,
+ * tests/test_gamg.py::test_vcycle_equals_the_reference_source).
  *
  * Restates (single domain: orc_gamg_build/solve; coupled patches and decomposed cases: orc_gamg_build_sys/solve_sys
  * at the end of the file), paths relative to
@@ -628,6 +631,10 @@ static void sys_scale(const orc_system *A, scalar *field, scalar *Acf, const sca
     }
 }
 
+typedef struct { int n; scalar *dense; int *piv; } orc_lu;
+orc_lu *orc_gamg_sys_coarsest_lu(const orc_system *Ac);
+void orc_lu_free(orc_lu *L);
+
 void orc_gamg_solve_sys(const gamg_sys_hier *H, const orc_system *S, scalar *psi, const scalar *source,
                         const gamg_controls *ctl, gamg_perf *perf, scalar *hist, int histLen)
 {
@@ -642,25 +649,8 @@ void orc_gamg_solve_sys(const gamg_sys_hier *H, const orc_system *S, scalar *psi
     /* coarsest level: the global matrix, dense LU */
     const orc_system *Ac = A[nL];
     const int nc = (int)Ac->nTotal;
-    scalar *dense = (scalar *)calloc((size_t)nc * (size_t)nc, sizeof(scalar));
-    int *piv = (int *)malloc(sizeof(int) * (size_t)(nc ? nc : 1));
-    for (int d = 0; d < Ac->nDomains; d++) {
-        const orc_domain *m = &Ac->dom[d];
-        const int64_t o = m->offset;
-        for (label i = 0; i < m->nCells; i++) dense[(size_t)(o + i) * nc + (size_t)(o + i)] = m->diag[i];
-        for (label f = 0; f < m->nFaces; f++) {
-            dense[(size_t)(o + m->lower[f]) * nc + (size_t)(o + m->upper[f])] = m->upperC[f];
-            dense[(size_t)(o + m->upper[f]) * nc + (size_t)(o + m->lower[f])] = m->lowerC[f];
-        }
-        for (int p = 0; p < m->nIfaces; p++) {
-            const orc_iface *me = &m->ifaces[p];
-            const orc_domain *nb = &Ac->dom[me->nbrDomain];
-            const orc_iface *ot = &nb->ifaces[me->nbrPatch];
-            for (label k = 0; k < me->nFaces; k++)
-                dense[(size_t)(o + me->faceCells[k]) * nc + (size_t)(nb->offset + ot->faceCells[k])] -= me->bouCoeffs[k];
-        }
-    }
-    lu_factor(nc, dense, piv);
+    orc_lu *LU = orc_gamg_sys_coarsest_lu(Ac);
+    scalar *dense = LU->dense; int *piv = LU->piv;
 
     const int64_t n0 = S->nTotal;
     scalar **corr = (scalar **)calloc((size_t)nL, sizeof(*corr));
@@ -722,6 +712,41 @@ void orc_gamg_solve_sys(const gamg_sys_hier *H, const orc_system *S, scalar *psi
     }
     for (int l = 1; l <= nL; l++) orc_sys_destroy((orc_system *)A[l]);
     for (int l = 0; l < nL; l++) { free(corr[l]); free(src[l]); }
-    free(A); free(corr); free(src); free(dense); free(piv);
+    free(A); free(corr); free(src); orc_lu_free(LU);
     free(Apsi); free(fcorr); free(fres); free(scr1); free(scr2);
 }
+
+/* ---- primitives of the multi-domain GAMG exposed one by one: oracle/ref_shim drives them from the REFERENCE's own
+ *      GAMGSolverSolve.C (solve / Vcycle / initVcycle / solveCoarsestLevel compiled from /root/reference) ------------- */
+orc_system *orc_gamg_sys_coarse_system(const gamg_sys_hier *H, int l, const orc_system *F) { return coarse_system(H, l, F); }
+void orc_gamg_sys_restrict(const gamg_sys_hier *H, int l, const orc_system *F, const orc_system *C, const scalar *ff, scalar *cf) { sys_restrict(H, l, F, C, ff, cf); }
+void orc_gamg_sys_prolong(const gamg_sys_hier *H, int l, const orc_system *F, const orc_system *C, const scalar *cf, scalar *ff) { sys_prolong(H, l, F, C, cf, ff); }
+void orc_gamg_sys_scale(const orc_system *A, scalar *field, scalar *Acf, const scalar *source) { sys_scale(A, field, Acf, source); }
+orc_lu *orc_gamg_sys_coarsest_lu(const orc_system *Ac)
+{
+    orc_lu *L = (orc_lu *)calloc(1, sizeof(*L));
+    const int nc = (int)Ac->nTotal;
+    L->n = nc;
+    L->dense = (scalar *)calloc((size_t)nc * (size_t)nc, sizeof(scalar));
+    L->piv = (int *)malloc(sizeof(int) * (size_t)(nc ? nc : 1));
+    for (int d = 0; d < Ac->nDomains; d++) {
+        const orc_domain *m = &Ac->dom[d];
+        const int64_t o = m->offset;
+        for (label i = 0; i < m->nCells; i++) L->dense[(size_t)(o + i) * nc + (size_t)(o + i)] = m->diag[i];
+        for (label f = 0; f < m->nFaces; f++) {
+            L->dense[(size_t)(o + m->lower[f]) * nc + (size_t)(o + m->upper[f])] = m->upperC[f];
+            L->dense[(size_t)(o + m->upper[f]) * nc + (size_t)(o + m->lower[f])] = m->lowerC[f];
+        }
+        for (int p = 0; p < m->nIfaces; p++) {
+            const orc_iface *me = &m->ifaces[p];
+            const orc_domain *nb = &Ac->dom[me->nbrDomain];
+            const orc_iface *ot = &nb->ifaces[me->nbrPatch];
+            for (label k = 0; k < me->nFaces; k++)
+                L->dense[(size_t)(o + me->faceCells[k]) * nc + (size_t)(nb->offset + ot->faceCells[k])] -= me->bouCoeffs[k];
+        }
+    }
+    lu_factor(nc, L->dense, L->piv);
+    return L;
+}
+void orc_lu_solve(const orc_lu *L, scalar *b) { lu_solve(L->n, L->dense, L->piv, b); }
+void orc_lu_free(orc_lu *L) { free(L->dense); free(L->piv); free(L); }

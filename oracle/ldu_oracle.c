@@ -14,10 +14,11 @@
  * Tmul(A) == Amul(A'), face-loop order vs row-gather order), (ii) the
  * golden fixtures it generated itself (tests/golden/golden_v1/v2.npz), and
  * (iii) THE REFERENCE'S OWN SOURCES wherever they are host code: PCG.C,
- * PBiCG.C, PBiCGStab.C (+ their functor headers) and
+ * PBiCG.C, PBiCGStab.C (+ their functor headers), GAMGSolverSolve.C and
  * pairGAMGAgglomerate.C are compiled from /root/reference against
  * oracle/ref_shim/ into oracle/_ref/ (Makefile target `ref`); the solver
- * loops below reproduce the reference's solve() functions bit for bit
+ * loops here and the V-cycle in gamg_oracle.c reproduce the reference's
+ * solve()/Vcycle() functions bit for bit
  * (tests/golden/golden_ref_*.npz, make_golden_ref.py).  Still an
  * assumption: the rounding inside the device row functors (see
  * orc_amul_functor_literal).

@@ -493,3 +493,23 @@ def ref_krylov_solve(kind: str, system: "System", psi, source, precond="diagonal
     L.ref_krylov_solve(C.c_int({"pcg": 0, "pbicg": 1, "pbicgstab": 2}[kind]), system.h, _p(x, C.c_double), _p(b, C.c_double),
                        C.c_int(PRECOND[precond]), C.c_double(tolerance), C.c_double(relTol), C.c_int(maxIter), C.c_int(minIter), out)
     return x, dict(initialResidual=out[0], finalResidual=out[1], nIterations=int(out[2]), converged=bool(out[3]), singular=bool(out[4]))
+
+
+REF_GAMG_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_gamg.so")
+
+
+def ref_gamg_available() -> bool:
+    return os.path.exists(REF_GAMG_LIB)
+
+
+def ref_gamg_solve(hier: "GamgSysHierarchy", psi, source, **kw):
+    """the REFERENCE's own GAMGSolver::solve / Vcycle / initVcycle / solveCoarsestLevel (GAMGSolverSolve.C compiled from
+    /root/reference against oracle/ref_shim/foam_gamg_shim.H) on this oracle's hierarchy and primitives; returns (psi, perf)"""
+    lib()
+    L = C.CDLL(REF_GAMG_LIB)
+    ctl = gamg_controls(**kw)
+    x = _d(psi).copy()
+    b = _d(source)
+    out = (C.c_double * 5)()
+    L.ref_gamg_solve(hier.h, hier.system.h, _p(x, C.c_double), _p(b, C.c_double), C.byref(ctl), out)
+    return x, dict(initialResidual=out[0], finalResidual=out[1], nIterations=int(out[2]), converged=bool(out[3]), singular=bool(out[4]))

@@ -2,7 +2,9 @@
 /root/reference (oracle/_ref/libref_pair.so, oracle/Makefile target `ref`) is run level by level on a few meshes; its
 coarse-cell maps are frozen in tests/golden/golden_ref_pair.npz; its PCG::solve / PBiCG::solve / PBiCGStab::solve (PCG.C,
 PBiCG.C, PBiCGStab.C + the functor headers, oracle/_ref/libref_solvers.so) run on the oracle's primitives and their psi and
-solverPerformance are frozen in tests/golden/golden_ref_solvers.npz.  Needs the reference tree:
+solverPerformance are frozen in tests/golden/golden_ref_solvers.npz; its GAMGSolver::solve / Vcycle / initVcycle /
+solveCoarsestLevel (GAMGSolverSolve.C, oracle/_ref/libref_gamg.so) run on the oracle's hierarchy and primitives ->
+tests/golden/golden_ref_gamg.npz.  Needs the reference tree:
     python tests/golden/make_golden_ref.py
 """
 import os
@@ -81,6 +83,36 @@ def build_solvers(pkg, orc):
     return out
 
 
+def gamg_runs(pkg, orc):
+    syn = pkg.synthetic
+    case = syn.box_case(16, 12, 12)
+    asym = syn.box_case(16, 12, 12, symmetric=False)
+    runs = [("sym/0", [case], dict(tolerance=1e-9, maxIter=100)), ("sym/1", [case], dict(tolerance=0.0, maxIter=4)),
+            ("sym/2", [case], dict(tolerance=1e-9, maxIter=100, nPreSweeps=1)),
+            ("sym/3", [case], dict(tolerance=1e-9, maxIter=100, nPreSweeps=2, preSweepsLevelMultiplier=2, scaleCorrection=0)),
+            ("sym/4", [case], dict(tolerance=1e30, maxIter=20, minIter=2)),
+            ("sym/5", [case], dict(tolerance=1e-9, maxIter=100, nPostSweeps=1, postSweepsLevelMultiplier=2, maxPostSweeps=3, nFinestSweeps=1)),
+            ("asym/0", [asym], dict(tolerance=1e-9, maxIter=100)), ("asym/1", [asym], dict(tolerance=1e-9, maxIter=100, scaleCorrection=1, nPreSweeps=1)),
+            ("decomposed_2x2x1/0", syn.decompose_box(case, (2, 2, 1)), dict(tolerance=1e-9, maxIter=100)),
+            ("decomposed_1x1x3/0", syn.decompose_box(case, (1, 1, 3)), dict(tolerance=1e-9, maxIter=100, nPreSweeps=1)),
+            ("cyclic/0", [syn.add_cyclic_y(syn.box_case(12, 12, 10))], dict(tolerance=1e-9, maxIter=100, nPreSweeps=1))]
+    for key, subs, kw in runs:
+        S = orc.System(subs)
+        H = orc.GamgSysHierarchy(S, [orc.box_face_weights(s) for s in subs], 10)
+        yield key, S, H, np.concatenate([s.source for s in subs]), kw
+
+
+def build_gamg(pkg, orc):
+    """psi and solverPerformance of the REFERENCE's GAMGSolver::solve (GAMGSolverSolve.C compiled from /root/reference,
+    oracle/_ref/libref_gamg.so) on the oracle's hierarchy and primitives"""
+    out = {}
+    for key, S, H, src, kw in gamg_runs(pkg, orc):
+        x, p = orc.ref_gamg_solve(H, np.zeros(S.n), src, **kw)
+        out[key + "/psi"] = x
+        out[key + "/perf"] = np.array([p["initialResidual"], p["finalResidual"], p["nIterations"], p["converged"], p["singular"]], dtype=np.float64)
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
@@ -89,4 +121,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_pair.npz"), **build(pkg, orc))
     assert orc.ref_solvers_available(), "oracle/_ref/libref_solvers.so missing"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_solvers.npz"), **build_solvers(pkg, orc))
+    assert orc.ref_gamg_available(), "oracle/_ref/libref_gamg.so missing"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg.npz"), **build_gamg(pkg, orc))
     print("written")

@@ -326,3 +326,27 @@ def test_reference_code_live_when_its_build_is_present(pkg, orc):
     assert sorted(now) == sorted(G.files)
     for k in G.files:
         assert np.array_equal(now[k], G[k]), k
+
+
+def test_vcycle_equals_the_reference_source(pkg, orc):
+    """tests/golden/golden_ref_gamg.npz was produced by the reference's GAMGSolver::solve, ::Vcycle, ::initVcycle and
+    ::solveCoarsestLevel COMPILED FROM /root/reference (solvers/GAMG/GAMGSolverSolve.C against oracle/ref_shim/
+    foam_gamg_shim.H) running on this oracle's hierarchy, level matrices, smoother, restrict/prolong, scale and coarsest LU.
+    The oracle's own V-cycle (orc_gamg_solve_sys) must give the same bits: pre/post/finest sweep schedules, level
+    multipliers, scaling on and off, symmetric and asymmetric, decomposed and cyclic systems, the minIter rule."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_gamg.npz"))
+    n = 0
+    for key, S, H, src, kw in make_golden_ref.gamg_runs(pkg, orc):
+        x, p = H.solve(np.zeros(S.n), src, **kw)
+        ref = G[key + "/perf"]
+        assert np.array_equal(x, G[key + "/psi"]), key
+        assert p["initialResidual"] == ref[0] and p["finalResidual"] == ref[1] and p["nIterations"] == int(ref[2]) and bool(p["converged"]) == bool(ref[3]), key
+        n += 1
+    assert n == 11
+    if orc.ref_gamg_available():      # and live, where the reference build is present
+        now = make_golden_ref.build_gamg(pkg, orc)
+        for k in G.files:
+            assert np.array_equal(now[k], G[k]), k
