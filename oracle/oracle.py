@@ -482,7 +482,8 @@ def ref_solvers_available() -> bool:
     return os.path.exists(REF_SOLVERS_LIB)
 
 
-def ref_krylov_solve(kind: str, system: "System", psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):
+def ref_krylov_solve(kind: str, system: "System", psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0,
+                     n_sweeps=1, omega=0.9):
     """the REFERENCE's own PCG::solve / PBiCG::solve / PBiCGStab::solve (compiled from /root/reference against
     oracle/ref_shim/foam_solver_shim.H) driving this oracle's primitives; returns (psi, perf)"""
     lib()                                     # liboracle.so must be in the process before the dependent library
@@ -490,8 +491,9 @@ def ref_krylov_solve(kind: str, system: "System", psi, source, precond="diagonal
     x = _d(psi).copy()
     b = _d(source)
     out = (C.c_double * 5)()
-    L.ref_krylov_solve(C.c_int({"pcg": 0, "pbicg": 1, "pbicgstab": 2}[kind]), system.h, _p(x, C.c_double), _p(b, C.c_double),
-                       C.c_int(PRECOND[precond]), C.c_double(tolerance), C.c_double(relTol), C.c_int(maxIter), C.c_int(minIter), out)
+    L.ref_krylov_solve(C.c_int({"pcg": 0, "pbicg": 1, "pbicgstab": 2, "smooth": 3}[kind]), system.h, _p(x, C.c_double), _p(b, C.c_double),
+                       C.c_int(PRECOND[precond]), C.c_double(tolerance), C.c_double(relTol), C.c_int(maxIter), C.c_int(minIter),
+                       C.c_int(n_sweeps), C.c_double(omega), out)
     return x, dict(initialResidual=out[0], finalResidual=out[1], nIterations=int(out[2]), converged=bool(out[3]), singular=bool(out[4]))
 
 

@@ -5,6 +5,7 @@
 #define PBiCG_H
 #define PBiCGStab_H
 #define PCGCache_H
+#define smoothSolver_H
 #define lduMatrix_H
 #define REF_STR2(x) #x
 #define REF_STR(x) REF_STR2(x)
@@ -16,19 +17,21 @@ const scalar solverPerformance::great_ = 1e20; const scalar solverPerformance::s
 #include REF_FILE(solvers/PCG/PCG.C)
 #include REF_FILE(solvers/PBiCG/PBiCG.C)
 #include REF_FILE(solvers/PBiCGStab/PBiCGStab.C)
+#include REF_FILE(solvers/smoothSolver/smoothSolver.C)
 
-// C entry point: kind 0 PCG, 1 PBiCG, 2 PBiCGStab; out5 = {initialResidual, finalResidual, nIterations, converged, singular}
+// C entry point: kind 0 PCG, 1 PBiCG, 2 PBiCGStab, 3 smoothSolver (n_sweeps, omega); out5 = {initialResidual, finalResidual, nIterations, converged, singular}
 extern "C" void ref_krylov_solve(int kind, const orc_system* sys, double* psi, const double* source, int precond, double tolerance,
-                                 double relTol, int maxIter, int minIter, double* out5)
+                                 double relTol, int maxIter, int minIter, int n_sweeps, double omega, double* out5)
 {
     using namespace Foam;
-    ctx.sys = sys; ctx.precond = precond;
+    ctx.sys = sys; ctx.precond = precond; ctx.omega = omega;
     const label n = (label)sys->nTotal;
     lduMatrix A; FieldField<gpuField, scalar> b, i; lduInterfaceFieldPtrsList ifs; dictionary d;
     scalargpuField x(psi, n), s(const_cast<double*>(source), n);
     solverPerformance* sp = 0;
     if (kind == 0) { PCG S("p", A, b, i, ifs, d); S.maxIter_ = maxIter; S.minIter_ = minIter; S.tolerance_ = tolerance; S.relTol_ = relTol; sp = new solverPerformance(S.solve(x, s)); }
     else if (kind == 1) { PBiCG S("U", A, b, i, ifs, d); S.maxIter_ = maxIter; S.minIter_ = minIter; S.tolerance_ = tolerance; S.relTol_ = relTol; sp = new solverPerformance(S.solve(x, s)); }
+    else if (kind == 3) { smoothSolver S("p", A, b, i, ifs, d); S.nSweeps_ = n_sweeps; S.maxIter_ = maxIter; S.minIter_ = minIter; S.tolerance_ = tolerance; S.relTol_ = relTol; sp = new solverPerformance(S.solve(x, s)); }
     else { PBiCGStab S("U", A, b, i, ifs, d); S.maxIter_ = maxIter; S.minIter_ = minIter; S.tolerance_ = tolerance; S.relTol_ = relTol; sp = new solverPerformance(S.solve(x, s)); }
     out5[0] = sp->initialResidual(); out5[1] = sp->finalResidual(); out5[2] = sp->nIterations(); out5[3] = sp->converged(); out5[4] = sp->singular();
     delete sp;

@@ -1,7 +1,7 @@
 """Golden vectors produced by the REFERENCE's own code: pairGAMGAgglomeration::agglomerate compiled from
 /root/reference (oracle/_ref/libref_pair.so, oracle/Makefile target `ref`) is run level by level on a few meshes; its
-coarse-cell maps are frozen in tests/golden/golden_ref_pair.npz; its PCG::solve / PBiCG::solve / PBiCGStab::solve (PCG.C,
-PBiCG.C, PBiCGStab.C + the functor headers, oracle/_ref/libref_solvers.so) run on the oracle's primitives and their psi and
+coarse-cell maps are frozen in tests/golden/golden_ref_pair.npz; its PCG::solve / PBiCG::solve / PBiCGStab::solve / smoothSolver::solve (PCG.C,
+PBiCG.C, PBiCGStab.C, smoothSolver.C + the functor headers, oracle/_ref/libref_solvers.so) run on the oracle's primitives and their psi and
 solverPerformance are frozen in tests/golden/golden_ref_solvers.npz; its GAMGSolver::solve / Vcycle / initVcycle /
 solveCoarsestLevel (GAMGSolverSolve.C, oracle/_ref/libref_gamg.so) run on the oracle's hierarchy and primitives ->
 tests/golden/golden_ref_gamg.npz.  Needs the reference tree:
@@ -63,12 +63,27 @@ SOLVER_CONTROLS = [dict(tolerance=0.0, maxIter=7), dict(tolerance=1e-9, maxIter=
                    dict(tolerance=1e-3, relTol=0.1, maxIter=40)]
 
 
+SMOOTH_CONTROLS = [dict(n_sweeps=2, tolerance=1e-4, maxIter=400), dict(n_sweeps=3, tolerance=0.0, maxIter=10), dict(n_sweeps=-4),
+                   dict(n_sweeps=1, tolerance=1e30, maxIter=50, minIter=5)]
+
+
 def solver_runs(pkg):
     for sym, kind, pres in SOLVER_RUNS:
         case = pkg.synthetic.box_case(9, 8, 7, symmetric=sym)
         for pre in pres:
             for k, kw in enumerate(SOLVER_CONTROLS):
                 yield f"{kind}/{pre}/{k}", case, kind, pre, kw
+    for sym in (True, False):      # smoothSolver.C (smoother = the reference's Jacobi "GaussSeidel")
+        case = pkg.synthetic.box_case(9, 8, 7, symmetric=sym)
+        for k, kw in enumerate(SMOOTH_CONTROLS):
+            yield f"smooth/{'sym' if sym else 'asym'}/{k}", case, "smooth", None, kw
+
+
+def oracle_solve(orc, S, case, kind, pre, kw):
+    z = np.zeros(case.n_cells)
+    if kind == "smooth":
+        return S.smooth_solve(z, case.source, **kw)
+    return getattr(S, kind)(z, case.source, pre, **kw)
 
 
 def build_solvers(pkg, orc):
@@ -77,7 +92,7 @@ def build_solvers(pkg, orc):
     out = {}
     for key, case, kind, pre, kw in solver_runs(pkg):
         S = orc.System([case])
-        x, p = orc.ref_krylov_solve(kind, S, np.zeros(case.n_cells), case.source, pre, **kw)
+        x, p = orc.ref_krylov_solve(kind, S, np.zeros(case.n_cells), case.source, pre or "diagonal", **kw)
         out[key + "/psi"] = x
         out[key + "/perf"] = np.array([p["initialResidual"], p["finalResidual"], p["nIterations"], p["converged"], p["singular"]], dtype=np.float64)
     return out

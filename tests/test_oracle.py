@@ -244,8 +244,8 @@ def _ref_solver_golden():
 
 
 def test_krylov_loops_equal_the_reference_sources(pkg, orc):
-    """tests/golden/golden_ref_solvers.npz was produced by the reference's PCG::solve, PBiCG::solve and PBiCGStab::solve
-    COMPILED FROM /root/reference (PCG.C, PBiCG.C, PBiCGStab.C and their functor headers, against oracle/ref_shim/
+    """tests/golden/golden_ref_solvers.npz was produced by the reference's PCG::solve, PBiCG::solve, PBiCGStab::solve and
+    smoothSolver::solve COMPILED FROM /root/reference (PCG.C, PBiCG.C, PBiCGStab.C, smoothSolver.C and their functor headers, against oracle/ref_shim/
     foam_solver_shim.H) running on this oracle's Amul/precondition/gSum primitives.  The oracle's own restatement of those
     loops must give the same bits: psi, residuals, iteration counts, converged/singular -- fixed iteration counts,
     converged runs, the minIter rule (incl. PBiCGStab's mid-iteration exit) and relTol."""
@@ -256,13 +256,13 @@ def test_krylov_loops_equal_the_reference_sources(pkg, orc):
     n = 0
     for key, case, kind, pre, kw in make_golden_ref.solver_runs(pkg):
         S = orc.System([case])
-        x, p = getattr(S, kind)(np.zeros(case.n_cells), case.source, pre, **kw)
+        x, p = make_golden_ref.oracle_solve(orc, S, case, kind, pre, kw)
         ref = G[key + "/perf"]
         assert np.array_equal(x, G[key + "/psi"]), key
         assert p["initialResidual"] == ref[0] and p["finalResidual"] == ref[1] and p["nIterations"] == int(ref[2]), key
         assert bool(p["converged"]) == bool(ref[3]) and bool(p["singular"]) == bool(ref[4]), key
         n += 1
-    assert n == 28
+    assert n == 36
 
 
 def test_reference_solver_sources_live_when_built(pkg, orc):
