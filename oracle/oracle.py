@@ -515,3 +515,46 @@ def ref_gamg_solve(hier: "GamgSysHierarchy", psi, source, **kw):
     out = (C.c_double * 5)()
     L.ref_gamg_solve(hier.h, hier.system.h, _p(x, C.c_double), _p(b, C.c_double), C.byref(ctl), out)
     return x, dict(initialResidual=out[0], finalResidual=out[1], nIterations=int(out[2]), converged=bool(out[3]), singular=bool(out[4]))
+
+
+REF_FUNCTORS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_functors.so")
+
+
+def ref_functors_available() -> bool:
+    return os.path.exists(REF_FUNCTORS_LIB)
+
+
+def _row_tables(case):
+    n = case.n_cells
+    lo, up = _i(case.lower_addr), _i(case.upper_addr)
+    own_start = np.zeros(n + 1, np.int32); np.add.at(own_start, lo.astype(np.int64) + 1, 1); own_start = np.cumsum(own_start).astype(np.int32)
+    los_start = np.zeros(n + 1, np.int32); np.add.at(los_start, up.astype(np.int64) + 1, 1); los_start = np.cumsum(los_start).astype(np.int32)
+    losort = np.argsort(up, kind="stable").astype(np.int32)
+    return lo, up, own_start, los_start, losort
+
+
+def ref_jacobi_rows(case, omega, psi, b):
+    """one Jacobi sweep computed row by row by the REFERENCE's JacobiSmootherFunctor<false,3> (JacobiSmootherF.H, host-compiled)"""
+    L = C.CDLL(REF_FUNCTORS_LIB)
+    lo, up, os_, ls_, losort = _row_tables(case)
+    lower = _d(case.upper if case.lower is None else case.lower)
+    out = np.empty(case.n_cells)
+    L.ref_jacobi_rows(C.c_int(case.n_cells), C.c_double(omega), _p(_d(psi), C.c_double), _p(_d(case.diag), C.c_double), _p(_d(b), C.c_double),
+                      _p(lower, C.c_double), _p(_d(case.upper), C.c_double), _p(lo, C.c_int32), _p(up, C.c_int32), _p(os_, C.c_int32),
+                      _p(ls_, C.c_int32), _p(losort, C.c_int32), _p(out, C.c_double))
+    return out
+
+
+def ref_ainv_rows(case, r, transpose=False):
+    """AINV preconditioner applied by the REFERENCE's AINVPreconditionerFunctor<false,3> (AINVPreconditionerF.H, host-compiled)"""
+    L = C.CDLL(REF_FUNCTORS_LIB)
+    lo, up, os_, ls_, losort = _row_tables(case)
+    lower = _d(case.upper if case.lower is None else case.lower)
+    upper = _d(case.upper)
+    if transpose:       # preconditionT swaps the roles of the coefficient arrays (AINVPreconditioner.C:87-120)
+        lower, upper = upper, lower
+    rD = 1.0 / _d(case.diag)
+    out = np.empty(case.n_cells)
+    L.ref_ainv_rows(C.c_int(case.n_cells), _p(_d(r), C.c_double), _p(rD, C.c_double), _p(lower, C.c_double), _p(upper, C.c_double),
+                    _p(lo, C.c_int32), _p(up, C.c_int32), _p(os_, C.c_int32), _p(ls_, C.c_int32), _p(losort, C.c_int32), _p(out, C.c_double))
+    return out

@@ -128,6 +128,25 @@ def build_gamg(pkg, orc):
     return out
 
 
+def functor_cases(pkg):
+    from conftest import random_graph_case
+    syn = pkg.synthetic
+    return {"box_sym": syn.box_case(10, 9, 8), "box_asym": syn.box_case(9, 8, 7, symmetric=False),
+            "graph_sym": random_graph_case(pkg, 400, extra=4.0), "graph_asym": random_graph_case(pkg, 300, extra=3.0, symmetric=False)}
+
+
+def build_functors(pkg, orc):
+    """row results of the REFERENCE's JacobiSmootherFunctor / AINVPreconditionerFunctor (F.H headers host-compiled,
+    oracle/_ref/libref_functors.so)"""
+    out = {}
+    for name, case in functor_cases(pkg).items():
+        x = pkg.synthetic.splitmix_uniform(4, case.n_cells) - 0.5
+        out[name + "/jacobi"] = orc.ref_jacobi_rows(case, 0.9, x, case.source)
+        out[name + "/ainv"] = orc.ref_ainv_rows(case, x)
+        out[name + "/ainvT"] = orc.ref_ainv_rows(case, x, True)
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
@@ -136,6 +155,8 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_pair.npz"), **build(pkg, orc))
     assert orc.ref_solvers_available(), "oracle/_ref/libref_solvers.so missing"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_solvers.npz"), **build_solvers(pkg, orc))
+    assert orc.ref_functors_available(), "oracle/_ref/libref_functors.so missing"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_functors.npz"), **build_functors(pkg, orc))
     assert orc.ref_gamg_available(), "oracle/_ref/libref_gamg.so missing"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg.npz"), **build_gamg(pkg, orc))
     print("written")

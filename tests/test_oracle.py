@@ -293,3 +293,24 @@ def test_functor_literal_variant_is_within_rounding(pkg, orc):
         np.add.at(row_mag, case.lower_addr, np.abs(case.upper * x[case.upper_addr])); np.add.at(row_mag, case.upper_addr, np.abs(lower * x[case.lower_addr]))
         assert np.max(np.abs(a - b) / row_mag) < 8 * np.finfo(float).eps
         assert np.max(np.abs(a - b)) > 0          # they ARE different roundings: the question is real
+
+
+def test_row_functors_match_the_reference_headers(pkg, orc):
+    """JacobiSmootherF.H and AINVPreconditionerF.H of the reference, compiled as host code (oracle/_ref/libref_functors.so),
+    produced tests/golden/golden_ref_functors.npz.  The oracle's Jacobi sweep and AINV apply (plain and transposed) agree to
+    a few ulp: the structure of the row arithmetic (sides, signs, transposition, rD placement) is the reference's; which
+    mul/add pairs are fused is a compiler's choice (gcc there, explicit fma here, nvcc in the real thing), hence no bitwise bar."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_functors.npz"))
+    for name, case in make_golden_ref.functor_cases(pkg).items():
+        S = orc.System([case])
+        x = pkg.synthetic.splitmix_uniform(4, case.n_cells) - 0.5
+        for key, got in (("jacobi", S.jacobi_smooth(x, case.source, 1)), ("ainv", S.precondition("AINV", x)), ("ainvT", S.precondition("AINV", x, transpose=True))):
+            ref = G[f"{name}/{key}"]
+            assert np.max(np.abs(got - ref)) < 4e-15 * np.max(np.abs(ref)), (name, key)
+    if orc.ref_functors_available():
+        now = make_golden_ref.build_functors(pkg, orc)
+        for k in G.files:
+            assert np.array_equal(now[k], G[k]), k
