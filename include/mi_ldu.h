@@ -188,6 +188,11 @@ int mi_jacobi_smooth(mi_matrix_t m, double omega, double *psi_dev, const double 
 int mi_sum(mi_ctx_t ctx, const double *a_dev, int64_t n, double *out_host);
 int mi_sum_prod(mi_ctx_t ctx, const double *a_dev, const double *b_dev, int64_t n, double *out_host);
 int mi_sum_mag(mi_ctx_t ctx, const double *a_dev, int64_t n, double *out_host);
+/* lduMatrix::solver::normFactor (lduMatrixSolver.C:182-236):
+ *   sum(|Apsi - avg(psi)*sumA| + |source - avg(psi)*sumA|) + small_ ; caller order; the same
+ * bits as perf.normFactor of the whole solvers; global when a communicator is attached.  */
+int mi_norm_factor(mi_matrix_t m, const double *psi_dev, const double *source_dev,
+                   const double *Apsi_dev, double *out_host);
 
 /* ---- whole solvers (lduMatrix::solver::solve; PCG.C:68-208, PBiCG.C:67-246,
  *      PBiCGStab.C:67-300, smoothSolver.C:77-196).  psi in/out, caller order.

@@ -693,6 +693,41 @@ extern "C" int mi_sum_mag(mi_ctx_t c, const double* a, int64_t n, double* out) {
 // solvers
 // ---------------------------------------------------------------------------
 namespace {
+int reduce_sync_fwd(mi_matrix_s* m, const double* a, double* out);
+}
+
+// lduMatrix::solver::normFactor (lduMatrixSolver.C:182-236) for caller-order psi/source/Apsi. The
+// vectors are gathered into engine order first, so the value is bit-identical to the normFactor
+// the solvers' own prologue computes (and global when a communicator is attached).
+extern "C" int mi_norm_factor(mi_matrix_t m, const double* psi, const double* source, const double* Apsi, double* out)
+{
+    if (!m || !psi || !source || !Apsi || !out) return fail(MI_ERR_ARG, "mi_norm_factor: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_addr_s* a = m->addr;
+    mi_ctx_s* c = a->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t n = a->L.nCells;
+    double *v0, *v1, *v2, *v3;
+    MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1)); MICHK(m->vec(2, &v2)); MICHK(m->vec(3, &v3));
+    k_gather_perm<<<RG, RB, 0, s>>>(Apsi, a->e2c.p, v0, n);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, v2, n);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, v3, n);
+    MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, v1, 0.0, 0));
+    double sumPsi = 0;
+    MICHK(reduce_sync_fwd(m, v3, &sumPsi));
+    const double avg = sumPsi / (double)(comm_attached(m) ? comm_n_global(m) : n);
+    k_normfactor<<<RG, RB, 0, s>>>(v0, v2, v1, avg, n, c->partial.p);
+    k_reduce_final<<<1, RB, 0, s>>>(c->partial.p, c->scalars.p);
+    HIPCHK(hipGetLastError());
+    if (comm_attached(m)) MICHK(comm_allreduce(m, c->scalars.p, 1));
+    HIPCHK(hipMemcpyAsync(c->hostScal, c->scalars.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *out = c->hostScal[0] + SP_SMALL; // + matrix.small_ (lduMatrixSolver.C:228)
+    return MI_OK;
+}
+
+namespace {
 
 // engine-order preconditioner application
 int precond_engine(mi_matrix_s* m, int kind, bool transpose, const double* r, double* w)
@@ -721,6 +756,8 @@ int reduce_sync(mi_matrix_s* m, const double* a, const double* b, double* out)
     *out = c->hostScal[0];
     return MI_OK;
 }
+
+int reduce_sync_fwd(mi_matrix_s* m, const double* a, double* out) { return reduce_sync<RED_SUM>(m, a, nullptr, out); }
 
 // common start of every solver (PCG.C:91-121 and siblings): given psi_e, src_e:
 //   wA = A psi ; rA = src - wA ; normFactor ; initial residual ; convergence test.

@@ -50,7 +50,7 @@ SYMBOLS = [
     "mi_matrix_set_ext", "mi_halo_pack_engine", "mi_vec_to_engine", "mi_vec_from_engine",
     "mi_amul", "mi_tmul", "mi_sumA", "mi_residual", "mi_H", "mi_H1", "mi_faceH",
     "mi_amul_engine", "mi_tmul_engine", "mi_precondition", "mi_jacobi_smooth",
-    "mi_sum", "mi_sum_prod", "mi_sum_mag",
+    "mi_sum", "mi_sum_prod", "mi_sum_mag", "mi_norm_factor",
     "mi_pcg_solve", "mi_pcg_begin", "mi_pcg_iterate", "mi_pcg_end",
     "mi_pbicg_solve", "mi_pbicgstab_solve", "mi_smooth_solve",
     "mi_bench_amul", "mi_bench_pcg_iters", "mi_debug_occupancy",
@@ -297,6 +297,11 @@ class Matrix:
 
     def H1(self, out):
         _chk(lib().mi_H1(self.h, _ptr(out)))
+
+    def norm_factor(self, psi, source, Apsi):
+        out = C.c_double(0.0)
+        _chk(lib().mi_norm_factor(self.h, _ptr(psi), _ptr(source), _ptr(Apsi), C.byref(out)))
+        return out.value
 
     def faceH(self, psi, out):
         _chk(lib().mi_faceH(self.h, _ptr(psi), _ptr(out)))
