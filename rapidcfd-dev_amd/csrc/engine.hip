@@ -84,7 +84,10 @@ struct mi_addr_s {
     mi_ctx_s* ctx = nullptr;
     TileLayout L; // host copy (big vectors are dropped after upload except the permutations)
     DevBuf<int32_t> e2c, c2e, tileCellStart, tileSlotStart, tileIfaceSlot0, tileHaloStart, haloCell, tileSliceStart, sliceEntryStart;
-    DevBuf<uint32_t> entries;
+    DevBuf<uint32_t> entries, entries16;
+    DevBuf<int32_t> sliceEntryStart16, tileSbStart;
+    DevBuf<uint16_t> slotBase;
+    bool compact = false; // 16-bit row entries in use (MI_ENTRY16=1)
     DevBuf<int32_t> slotFace, extSlot, interiorTiles, boundaryTiles, patchFaceCellsE, faceSlot, lowerAddr, upperAddr;
     DevBuf<int32_t> ownerStartC, losortStartC, losortC; // caller-order row tables for the assembly sweeps (lazy)
     DevBuf<double> relaxD0, relaxSumOff;
@@ -242,6 +245,7 @@ extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
     TileParams prm;
     prm.tileCells = env_int("MI_TILE_CELLS", 1024);
     prm.slotCap = env_int("MI_TILE_SLOTS", 4094);
+    prm.compact = env_int("MI_ENTRY16", 0) != 0; // opt-in: half the entry bytes, measured 2-4 % slower (profiles/r01_n_compact_entries_ab.md)
     const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L, patch_nbr_cells);
     if (!err.empty()) { delete a; return fail(MI_ERR_LIMIT, "mi_addr_create: " + err); }
     a->nLocalPatches = 0;
@@ -253,7 +257,10 @@ extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
 #define UP(buf, vec) if (r == MI_OK) r = a->buf.upload(vec, s)
     UP(e2c, L.e2c); UP(c2e, L.c2e); UP(tileCellStart, L.tileCellStart); UP(tileSlotStart, L.tileSlotStart); UP(tileIfaceSlot0, L.tileIfaceSlot0);
     UP(tileHaloStart, L.tileHaloStart); UP(haloCell, L.haloCell); UP(tileSliceStart, L.tileSliceStart);
-    UP(sliceEntryStart, L.sliceEntryStart); UP(entries, L.entries); UP(slotFace, L.slotFace);
+    a->compact = L.compact;
+    if (L.compact) { UP(sliceEntryStart16, L.sliceEntryStart16); UP(entries16, L.entries16); UP(slotBase, L.slotBase); UP(tileSbStart, L.tileSbStart); }
+    else { UP(sliceEntryStart, L.sliceEntryStart); UP(entries, L.entries); }
+    UP(slotFace, L.slotFace);
     UP(extSlot, L.extSlot); UP(interiorTiles, L.interiorTiles); UP(boundaryTiles, L.boundaryTiles);
     UP(patchFaceCellsE, L.patchFaceCellsE); UP(faceSlot, L.faceSlot);
 #undef UP
@@ -261,7 +268,7 @@ extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
     if (hipStreamSynchronize(s) != hipSuccess) { delete a; return fail(MI_ERR_DEVICE, "upload failed"); }
     a->nInterior = (int32_t)L.interiorTiles.size();
     a->nBoundary = (int32_t)L.boundaryTiles.size();
-    a->nEntries = (int64_t)L.entries.size();
+    a->nEntries = (int64_t)(L.compact ? L.entries16.size() : L.entries.size()); // 32-bit words of row entries on the device
     a->nHaloTot = (int64_t)L.haloCell.size();
     a->lowerHost.assign(lower, lower + n_faces);
     a->upperHost.assign(upper, upper + n_faces);
@@ -272,6 +279,9 @@ extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
     }
     // drop the big host tables that only the device needs
     std::vector<uint32_t>().swap(L.entries);
+    std::vector<uint32_t>().swap(L.entries16);
+    std::vector<int32_t>().swap(L.sliceEntryStart16);
+    std::vector<uint16_t>().swap(L.slotBase);
     std::vector<int32_t>().swap(L.slotFace);
     std::vector<int32_t>().swap(L.haloCell);
     std::vector<int32_t>().swap(L.sliceEntryStart);
@@ -300,7 +310,7 @@ extern "C" int mi_addr_patch_offsets(mi_addr_t a, int32_t* off)
     return MI_OK;
 }
 
-static size_t lds_bytes(const TileLayout& L, bool asym, bool ainv, int32_t* offLow, int32_t* offX, int32_t* offRD)
+static size_t lds_bytes(const TileLayout& L, bool asym, bool ainv, int32_t* offLow, int32_t* offX, int32_t* offRD, int32_t* offSB = nullptr)
 {
     const int32_t slots = (L.maxSlots + 3) & ~1; // even
     const int32_t xlen = ((L.maxCells + 63) & ~63) + L.maxHalo + 2;
@@ -308,6 +318,7 @@ static size_t lds_bytes(const TileLayout& L, bool asym, bool ainv, int32_t* offL
     *offLow = off; if (asym) off += slots;
     *offX = off; off += (xlen + 1) & ~1;
     *offRD = off; if (ainv) off += (xlen + 1) & ~1;
+    if (offSB) { *offSB = off; if (L.compact) off += (L.maxCells + L.maxHalo + 1 + 3) / 4 + 1; } // uint16 slot bases
     return (size_t)off * sizeof(double);
 }
 
@@ -317,7 +328,8 @@ extern "C" int mi_addr_stats(mi_addr_t a, int64_t st[8])
     int32_t o1, o2, o3;
     st[0] = a->L.nTiles; st[1] = a->L.totalSlots; st[2] = a->nEntries; st[3] = a->nHaloTot;
     st[4] = a->L.maxCells; st[5] = a->L.maxSlots; st[6] = a->L.maxHalo;
-    st[7] = (int64_t)lds_bytes(a->L, false, false, &o1, &o2, &o3);
+    int32_t o4;
+    st[7] = (int64_t)lds_bytes(a->L, false, false, &o1, &o2, &o3, &o4);
     return MI_OK;
 }
 
@@ -382,7 +394,7 @@ extern "C" int mi_matrix_set_interface_coeffs(mi_matrix_t m, int32_t patch, cons
 // ---------------------------------------------------------------------------
 namespace {
 
-template <int OP, bool ASYM, bool TRANS>
+template <int OP, bool ASYM, bool TRANS, bool C16>
 int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
 {
     hipStream_t s = m->addr->ctx->stream;
@@ -396,7 +408,7 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
     {                                                                                                                   \
         static bool attr##BS = false;                                                                                   \
         if (!attr##BS) {                                                                                                \
-            HIPCHK(hipFuncSetAttribute((const void*)tile_kernel<OP, ASYM, TRANS, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); \
+            HIPCHK(hipFuncSetAttribute((const void*)tile_kernel<OP, ASYM, TRANS, BS, C16>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); \
             attr##BS = true;                                                                                            \
         }                                                                                                               \
         int grid = nTiles;                                                                                              \
@@ -404,16 +416,16 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
             static int occ##BS = 0; static size_t occLds##BS = 0;                                                       \
             if (occ##BS == 0 || occLds##BS != lds) {                                                                    \
                 int nb = 0;                                                                                             \
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP, ASYM, TRANS, BS>, BS, lds)); \
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP, ASYM, TRANS, BS, C16>, BS, lds)); \
                 occ##BS = nb > 0 ? nb : 1; occLds##BS = lds;                                                            \
             }                                                                                                           \
             const int slots = ((occ##BS * m->addr->ctx->nCU * m->addr->ctx->persist) / 8) * 8;                          \
             if (slots >= 8 && nTiles > 2 * slots) grid = slots;                                                         \
         }                                                                                                               \
         if (m->kevStart) /* start/stop events stamped by the kernel's own begin/end: the profiler's clock */           \
-            hipExtLaunchKernelGGL((tile_kernel<OP, ASYM, TRANS, BS>), dim3(grid), dim3(BS), (uint32_t)lds, s, m->kevStart, m->kevStop, 0, args); \
+            hipExtLaunchKernelGGL((tile_kernel<OP, ASYM, TRANS, BS, C16>), dim3(grid), dim3(BS), (uint32_t)lds, s, m->kevStart, m->kevStop, 0, args); \
         else                                                                                                            \
-        tile_kernel<OP, ASYM, TRANS, BS><<<grid, BS, lds, s>>>(args);                                                   \
+        tile_kernel<OP, ASYM, TRANS, BS, C16><<<grid, BS, lds, s>>>(args);                                                   \
     }
     if (bs == 1024) MI_LAUNCH(1024)
     else if (bs == 512) MI_LAUNCH(512)
@@ -433,10 +445,10 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     TileArgs t;
     t.tileCellStart = a->tileCellStart.p; t.tileSlotStart = a->tileSlotStart.p; t.tileIfaceSlot0 = a->tileIfaceSlot0.p; t.tileHaloStart = a->tileHaloStart.p;
     t.haloCell = a->haloCell.p; t.tileSliceStart = a->tileSliceStart.p; t.sliceEntryStart = a->sliceEntryStart.p;
-    t.entries = a->entries.p;
+    t.entries = a->entries.p; t.entries16 = a->entries16.p; t.sliceEntryStart16 = a->sliceEntryStart16.p; t.slotBase = reinterpret_cast<const uint32_t*>(a->slotBase.p); t.tileSbStart = a->tileSbStart.p;
     t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
     t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega; t.dotPartial = dotPartial; t.flags = a->ctx->tileFlags;
-    const size_t lds = lds_bytes(a->L, m->asym, OP == OP_AINV, &t.offLow, &t.offX, &t.offRD);
+    const size_t lds = lds_bytes(a->L, m->asym, OP == OP_AINV, &t.offLow, &t.offX, &t.offRD, &t.offSB);
     if (lds > 159 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 159 KiB of LDS");
     int nTiles = a->L.nTiles;
     t.tileList = nullptr;
@@ -444,11 +456,18 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     else if (which == 2) { t.tileList = a->boundaryTiles.p; nTiles = a->nBoundary; }
     t.nPos = nTiles;
     t.done = m->gateDone ? &a->ctx->state.p->done : nullptr;
-    if (m->asym) {
-        if (trans) return launch_tile_bs<OP, true, true>(m, t, nTiles, lds);
-        return launch_tile_bs<OP, true, false>(m, t, nTiles, lds);
+    if (a->compact) {
+        if (m->asym) {
+            if (trans) return launch_tile_bs<OP, true, true, true>(m, t, nTiles, lds);
+            return launch_tile_bs<OP, true, false, true>(m, t, nTiles, lds);
+        }
+        return launch_tile_bs<OP, false, false, true>(m, t, nTiles, lds);
     }
-    return launch_tile_bs<OP, false, false>(m, t, nTiles, lds);
+    if (m->asym) {
+        if (trans) return launch_tile_bs<OP, true, true, false>(m, t, nTiles, lds);
+        return launch_tile_bs<OP, true, false, false>(m, t, nTiles, lds);
+    }
+    return launch_tile_bs<OP, false, false, false>(m, t, nTiles, lds);
 }
 
 int ensure_rD(mi_matrix_s* m)
@@ -1451,13 +1470,14 @@ extern "C" int mi_debug_occupancy(mi_matrix_t m, int32_t* blocks_per_cu, int32_t
     if (!m || !blocks_per_cu) return fail(MI_ERR_ARG, "mi_debug_occupancy: bad argument");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
-    int32_t o1, o2, o3;
-    const size_t lds = lds_bytes(a->L, m->asym, false, &o1, &o2, &o3);
+    int32_t o1, o2, o3, o4;
+    const size_t lds = lds_bytes(a->L, m->asym, false, &o1, &o2, &o3, &o4);
     const int bs = a->ctx->amulBS ? a->ctx->amulBS : ((lds > 53 * 1024) ? 1024 : 512);
     int nb = 0;
-    if (bs == 1024) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, 1024>, 1024, lds));
-    else if (bs == 512) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, 512>, 512, lds));
-    else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, 256>, 256, lds));
+#define MI_OCC(BS) { if (a->compact) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, BS, true>, BS, lds)); \
+                     else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, BS, false>, BS, lds)); }
+    if (bs == 1024) MI_OCC(1024) else if (bs == 512) MI_OCC(512) else MI_OCC(256)
+#undef MI_OCC
     *blocks_per_cu = nb;
     if (lds_bytes_out) *lds_bytes_out = (int32_t)lds;
     if (block_size) *block_size = bs;
@@ -1525,7 +1545,7 @@ extern "C" int mi_layout_array(void* handle, const char* name, const void** data
     const std::string n(name);
 #define ARR(field) if (n == #field) { *data = L->field.data(); *len = (int64_t)L->field.size(); return MI_OK; }
     ARR(e2c) ARR(c2e) ARR(tileCellStart) ARR(tileSlotStart) ARR(tileIfaceSlot0) ARR(tileHaloStart) ARR(haloCell) ARR(tileSliceStart)
-    ARR(sliceEntryStart) ARR(entries) ARR(slotFace) ARR(extSlot) ARR(interiorTiles) ARR(boundaryTiles)
+    ARR(sliceEntryStart) ARR(entries) ARR(sliceEntryStart16) ARR(entries16) ARR(slotBase) ARR(tileSbStart) ARR(slotFace) ARR(extSlot) ARR(interiorTiles) ARR(boundaryTiles)
     ARR(patchOffset) ARR(patchFaceCellsE) ARR(faceSlot)
 #undef ARR
     return fail(MI_ERR_ARG, "mi_layout_array: unknown array " + n);

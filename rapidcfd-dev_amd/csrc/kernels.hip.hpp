@@ -91,6 +91,10 @@ struct TileArgs {
     const int32_t* tileSliceStart;
     const int32_t* sliceEntryStart;
     const uint32_t* entries;
+    const uint32_t* entries16;         // compact form (C16 kernels): two 16-bit entries per word
+    const int32_t* sliceEntryStart16;
+    const uint32_t* slotBase;          // per tile nc + nh + 1 16-bit slot bases, two per word
+    const int32_t* tileSbStart;        // [nTiles+1] in words
     const int32_t* tileList; // nullptr => identity
     int32_t nPos;            // number of tile positions of this launch (== gridDim.x unless the launch is persistent)
     const int32_t* done;     // device-resident solver loops: &PcgState::done, launches past convergence exit at once (else nullptr)
@@ -103,7 +107,7 @@ struct TileArgs {
     double* y;
     double* dotPartial; // Amul only: per-workgroup partial of sum(y*x) (fused gSumProd), or nullptr
     double omega;
-    int32_t offLow, offX, offRD; // LDS offsets in doubles
+    int32_t offLow, offX, offRD, offSB; // LDS offsets in doubles
     int32_t flags;               // bit0: non-temporal coefficient loads, bit1: non-temporal entry loads, bit2: nt result stores
 };
 
@@ -153,7 +157,7 @@ __device__ __forceinline__ void stage_gather(const double* __restrict__ x, const
 }
 
 // one tile: position p of the launch (p indexes tileList / dotPartial)
-template <int OP, bool ASYM, bool TRANS, int BS>
+template <int OP, bool ASYM, bool TRANS, int BS, bool C16>
 __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double* __restrict__ smem)
 {
     double* cU = smem;
@@ -166,7 +170,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     const int c0 = a.tileCellStart[t], nc = a.tileCellStart[t + 1] - c0;
     const int s0 = a.tileSlotStart[t], ns = a.tileSlotStart[t + 1] - s0; // even
     const int h0 = a.tileHaloStart[t], nh = a.tileHaloStart[t + 1] - h0;
-    const int ifs0 = (OP == OP_JACOBI || OP == OP_AINV) ? a.tileIfaceSlot0[t] : 0; // first interface slot of the tile
+    const int ifs0 = (OP == OP_JACOBI || OP == OP_AINV || OP == OP_H || OP == OP_H1 || (C16 && ASYM)) ? a.tileIfaceSlot0[t] : 0; // first interface slot of the tile
+    uint16_t* sb = reinterpret_cast<uint16_t*>(smem + a.offSB);
     constexpr bool NEEDX = (OP != OP_SUMA && OP != OP_H1);
 
     // ---- stage: coefficients (16-byte coalesced), psi, halo -------------------
@@ -183,6 +188,12 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
             stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
         }
     }
+    if (C16) { // slot bases of the tile's cells, halo cells and the pad cell (whose x is 0 and whose slot is the zero slot)
+        const int w0 = a.tileSbStart[t], nw = a.tileSbStart[t + 1] - w0;
+#pragma unroll 2
+        for (int k = tid; k < nw; k += BS) reinterpret_cast<uint32_t*>(sb)[k] = a.slotBase[w0 + k];
+        if (tid == 0 && NEEDX) { xs[nc + nh] = 0.0; if (OP == OP_AINV) rDs[nc + nh] = 0.0; }
+    }
 
     // ---- rows: one wavefront per 64-row slice, uniform trip count -------------
     // The {slot, other} entries of a slice are fetched into registers one slice
@@ -191,15 +202,18 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     const int sl0 = a.tileSliceStart[t], nsl = a.tileSliceStart[t + 1] - sl0;
     const int wave = tid >> 6, lane = tid & 63;
     constexpr int NW = BS / 64;
-    constexpr int PRE = 8;
-    const uint32_t padEnt = (uint32_t)(ns - 1) << 16; // last slot of the segment is always 0.0
+    constexpr int PRE = C16 ? 4 : 8; // words held in registers: 8 entries either way
+    const uint32_t pad16 = (uint32_t)(nc + nh) | 0x8000u;
+    const uint32_t padEnt = C16 ? (pad16 | (pad16 << 16)) : (uint32_t)(ns - 1) << 16; // last slot of the segment is always 0.0
+    const uint32_t* const entBase = C16 ? a.entries16 : a.entries;
+    const int32_t* const sesBase = C16 ? a.sliceEntryStart16 : a.sliceEntryStart;
     uint32_t ecur[PRE];
     int wcur = 0, e0cur = 0;
     auto fetch = [&](int s, uint32_t (&e)[PRE], int& e0, int& width) {
-        e0 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s]);
-        const int e1 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s + 1]);
+        e0 = __builtin_amdgcn_readfirstlane(sesBase[sl0 + s]);
+        const int e1 = __builtin_amdgcn_readfirstlane(sesBase[sl0 + s + 1]);
         width = (e1 - e0) >> 6;
-        const uint32_t* ent = a.entries + e0 + lane;
+        const uint32_t* ent = entBase + e0 + lane;
 #pragma unroll
         for (int j = 0; j < PRE; ++j) e[j] = (j < width) ? ((a.flags & 2) ? __builtin_nontemporal_load(ent + j * 64) : ent[j * 64]) : padEnt;
     };
@@ -229,25 +243,43 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
         else if (OP == OP_SUMA) acc = a.diag[gi];
         else if (OP == OP_RESIDUAL) acc = a.b[gi] - a.diag[gi] * xi;
         else acc = 0.0;
-        auto accumulate = [&](uint32_t en) {
-            const int o = en & 0xFFFFu;
-            const int sl = (en >> 16) & 0x7FFFu;
+        auto apply = [&](const int o, const int sl, const bool lowerSide) {
             double c;
-            if (ASYM) c = (((en >> 31) != 0u) != TRANS) ? cL[sl] : cU[sl];
+            if (ASYM) c = (lowerSide != TRANS) ? cL[sl] : cU[sl];
             else c = cU[sl];
             if (OP == OP_JACOBI) { // coupled patches go to bPrime, faces to the row sum (JacobiSmoother.C:75-93, JacobiSmootherF.H)
                 if (sl >= ifs0) accI = fma(-c, xs[o], accI); else acc = fma(c, xs[o], acc);
             } else if (OP == OP_AMUL) acc = fma(c, xs[o], acc);
             else if (OP == OP_SUMA) acc += c;
-            else if (OP == OP_RESIDUAL || OP == OP_H) acc = fma(-c, xs[o], acc);
-            else if (OP == OP_H1) acc -= c;
+            else if (OP == OP_RESIDUAL) acc = fma(-c, xs[o], acc);
+            else if (OP == OP_H) { if (sl < ifs0) acc = fma(-c, xs[o], acc); }   // lduMatrix::H / H1 are face sums only
+            else if (OP == OP_H1) { if (sl < ifs0) acc -= c; }                     // (lduMatrixOperations.C:130-154, lduMatrixATmul.C:533-554)
             else if (OP == OP_AINV) { if (sl < ifs0) acc = fma(c * rDs[o], xs[o], acc); } // faces only (AINVPreconditioner.C)
         };
+        auto accumulate = [&](uint32_t en) { apply(en & 0xFFFFu, (en >> 16) & 0x7FFFu, (en >> 31) != 0u); };
+        // compact entry j of the row: rule 0 -> the row's own run of slots, rule 1 -> the other cell's run (+k); the
+        // coefficient is the lower one for rule-1 faces (interfaces, slot >= ifs0, always take the upper array)
+        const int sbi = C16 ? (int)sb[live ? i : 0] : 0;
+        auto accumulate16 = [&](uint32_t e16, int j) {
+            const int o = e16 & 0xFFFu;
+            const bool rule = (e16 & 0x8000u) != 0u;
+            const int sl = rule ? (int)sb[o] + (int)((e16 >> 12) & 7u) : sbi + j;
+            apply(o, sl, ASYM ? (rule && sl < ifs0) : false);
+        };
+        if (C16) {
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) if (j < wcur) { accumulate16(ecur[j] & 0xFFFFu, 2 * j); accumulate16(ecur[j] >> 16, 2 * j + 1); }
+            if (wcur > PRE) {
+                const uint32_t* ent = entBase + e0cur + lane;
+                for (int j = PRE; j < wcur; ++j) { const uint32_t w = ent[j * 64]; accumulate16(w & 0xFFFFu, 2 * j); accumulate16(w >> 16, 2 * j + 1); }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < PRE; ++j) if (j < wcur) accumulate(ecur[j]);
         if (wcur > PRE) {
             const uint32_t* ent = a.entries + e0cur + lane;
             for (int j = PRE; j < wcur; ++j) accumulate(ent[j * 64]);
+        }
         }
         if (live) {
             if (OP == OP_AINV) { const double w = rDs[i] * (xi - acc); a.y[gi] = w; dot = fma(w, xi, dot); } // + fused gSumProd(wA, rA), PCG.C:139-142
@@ -275,7 +307,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
 //   gridDim.x == nPos : one workgroup per tile.
 //   gridDim.x <  nPos : PERSISTENT launch -- as many workgroups as the chip holds at once (a multiple of 8), each walks
 //                       a contiguous run of its XCD's tiles; saves the dispatch/teardown of ~10 short workgroups per slot.
-template <int OP, bool ASYM, bool TRANS, int BS>
+template <int OP, bool ASYM, bool TRANS, int BS, bool C16>
 __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -283,14 +315,14 @@ __global__ __launch_bounds__(BS) void tile_kernel(const TileArgs a)
     const int b = blockIdx.x, G = gridDim.x, nT = a.nPos;
     if (G >= nT) {
         const int per = G >> 3;
-        tile_body<OP, ASYM, TRANS, BS>(a, (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b, smem);
+        tile_body<OP, ASYM, TRANS, BS, C16>(a, (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b, smem);
         return;
     }
     const int per = G >> 3, x = b & 7, j = b >> 3;
     const int x0 = (int)((long long)x * nT / 8), x1 = (int)((long long)(x + 1) * nT / 8);
     const int p0 = x0 + (int)((long long)j * (x1 - x0) / per), p1 = x0 + (int)((long long)(j + 1) * (x1 - x0) / per);
     for (int p = p0; p < p1; ++p) {
-        tile_body<OP, ASYM, TRANS, BS>(a, p, smem);
+        tile_body<OP, ASYM, TRANS, BS, C16>(a, p, smem);
         __syncthreads(); // every wave is done with the LDS image before the next tile is staged
     }
 }

@@ -112,10 +112,13 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     std::vector<int32_t> ownStart((size_t)nCells + 1, 0), neiStart((size_t)nCells + 1, 0);
     for (int32_t f = 0; f < nFaces; ++f) { ownStart[(size_t)lower[f] + 1]++; neiStart[(size_t)upper[f] + 1]++; }
     for (int32_t c = 0; c < nCells; ++c) { ownStart[(size_t)c + 1] += ownStart[c]; neiStart[(size_t)c + 1] += neiStart[c]; }
-    std::vector<int32_t> ownFaces((size_t)nFaces), neiFaces((size_t)nFaces);
+    std::vector<int32_t> ownFaces((size_t)nFaces), neiFaces((size_t)nFaces), ownPos((size_t)nFaces); // ownPos: rank of f among its owner's faces
     {
         std::vector<int32_t> co(ownStart.begin(), ownStart.end() - 1), cn(neiStart.begin(), neiStart.end() - 1);
-        for (int32_t f = 0; f < nFaces; ++f) { ownFaces[(size_t)co[lower[f]]++] = f; neiFaces[(size_t)cn[upper[f]]++] = f; }
+        for (int32_t f = 0; f < nFaces; ++f) {
+            ownPos[f] = co[lower[f]] - ownStart[lower[f]];
+            ownFaces[(size_t)co[lower[f]]++] = f; neiFaces[(size_t)cn[upper[f]]++] = f;
+        }
     }
     // patch faces per cell (patch order, then face order)
     std::vector<int32_t> pfStart((size_t)nCells + 1, 0), pfList((size_t)L.nExt);
@@ -199,15 +202,21 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     }
 
     // ---- slots, halos, row entries --------------------------------------------
+    // Slot order of a tile: for every local row its owner faces (ascending face id) as one run, then for every halo
+    // cell the faces it owns whose neighbour is a local row, then the interface slots, then the zero slot.  Every
+    // interface face has a halo entry of its own (remote: its ext cell; cyclic: a private reference to the partner
+    // cell), so that slotBase[other] names its slot.
     L.tileSlotStart.assign((size_t)nT + 1, 0);
     L.tileIfaceSlot0.assign((size_t)nT, 0);
-    std::vector<int32_t> ifaceEnt, ifaceX;
     L.tileHaloStart.assign((size_t)nT + 1, 0);
     L.tileSliceStart.assign((size_t)nT + 1, 0);
     L.sliceEntryStart.clear(); L.sliceEntryStart.push_back(0);
-    L.slotFace.clear(); L.haloCell.clear(); L.entries.clear();
+    L.sliceEntryStart16.clear(); L.sliceEntryStart16.push_back(0);
+    L.tileSbStart.assign(1, 0);
+    L.slotFace.clear(); L.haloCell.clear(); L.entries.clear(); L.entries16.clear(); L.slotBase.clear();
     L.slotFace.reserve((size_t)nFaces + nFaces / 4 + 16);
     L.entries.reserve((size_t)2 * nFaces + nCells);
+    L.compact = prm.compact;
     L.extSlot.assign((size_t)L.nExt, -1);
     L.faceSlot.assign((size_t)nFaces, -1);
     L.patchFaceCellsE.resize((size_t)L.nExt);
@@ -215,74 +224,107 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         for (int32_t i = 0; i < patchSizes[p]; ++i)
             L.patchFaceCellsE[(size_t)L.patchOffset[p] + i] = L.c2e[patchFaceCells[p][i]];
 
-    std::vector<int32_t> faceLocalSlot((size_t)nFaces, -1); // slot (tile-local) of internal face, valid within current tile
+    struct RowEnt { int32_t other, slot, k; bool rule, lowerSide; };
+    struct Pending { int32_t ent, halo, id; };
     std::vector<int32_t> haloStamp((size_t)nCells + L.nExt, -1), haloIdx((size_t)nCells + L.nExt, 0);
-    std::vector<uint32_t> rowEnt;        // entries of the rows of the current tile, row-major
-    std::vector<int32_t> rowEntStart;
+    std::vector<RowEnt> rowEnt;          // entries of the rows of the current tile, row-major
+    std::vector<int32_t> rowEntStart, sbLocal, haloCnt, sbHalo;
+    std::vector<Pending> cutList, ifaceList;
 
     for (int32_t t = 0; t < nT; ++t) {
         const int32_t cs = L.tileCellStart[t], ce = L.tileCellStart[(size_t)t + 1], nc = ce - cs;
         const int64_t slotBase = (int64_t)L.slotFace.size();
-        const int32_t haloBase = (int32_t)L.haloCell.size();
-        int32_t nSlots = 0, nHalo = 0;
-        bool boundary = false;
+        int32_t nHalo = 0;
+        bool boundary = false, fits16 = true;
         rowEnt.clear(); rowEntStart.assign(1, 0);
-        ifaceEnt.clear(); ifaceX.clear();
+        cutList.clear(); ifaceList.clear(); haloCnt.clear();
 
+        sbLocal.assign((size_t)nc + 1, 0);
+        for (int32_t e = cs; e < ce; ++e) { const int32_t c = L.e2c[e]; sbLocal[(size_t)(e - cs) + 1] = sbLocal[e - cs] + (ownStart[(size_t)c + 1] - ownStart[c]); }
+        const int32_t nLocal = sbLocal[nc];
         auto halo_of = [&](int32_t engineCell) -> int32_t {
-            if (haloStamp[engineCell] != t) { haloStamp[engineCell] = t; haloIdx[engineCell] = nHalo++; L.haloCell.push_back(engineCell); }
+            if (haloStamp[engineCell] != t) { haloStamp[engineCell] = t; haloIdx[engineCell] = nHalo++; L.haloCell.push_back(engineCell); haloCnt.push_back(0); }
             return nc + haloIdx[engineCell];
         };
+        auto place = [&](int32_t slot, int32_t what) {
+            const size_t at = (size_t)slotBase + (size_t)slot;
+            if (L.slotFace.size() <= at) L.slotFace.resize(at + 1, -1);
+            L.slotFace[at] = what;
+        };
         for (int32_t e = cs; e < ce; ++e) {
-            const int32_t c = L.e2c[e];
+            const int32_t c = L.e2c[e], i = e - cs;
             // owner side, ascending face id: row uses upper[f], other = upper cell
             for (int32_t j = ownStart[c]; j < ownStart[(size_t)c + 1]; ++j) {
                 const int32_t f = ownFaces[j], o = upper[f];
-                int32_t slot, other;
-                if (part[o] == t) { slot = nSlots++; faceLocalSlot[f] = slot; L.slotFace.push_back(f); other = L.c2e[o] - cs; L.faceSlot[f] = (int32_t)(slotBase + slot); }
-                else { slot = nSlots++; L.slotFace.push_back(f); other = halo_of(L.c2e[o]); if (L.faceSlot[f] < 0) L.faceSlot[f] = (int32_t)(slotBase + slot); }
-                rowEnt.push_back((uint32_t)other | ((uint32_t)slot << 16));
+                const int32_t slot = sbLocal[i] + (j - ownStart[c]);
+                place(slot, f);
+                int32_t other;
+                if (part[o] == t) { other = L.c2e[o] - cs; L.faceSlot[f] = (int32_t)(slotBase + slot); }
+                else { other = halo_of(L.c2e[o]); if (L.faceSlot[f] < 0) L.faceSlot[f] = (int32_t)(slotBase + slot); }
+                rowEnt.push_back({other, slot, 0, false, false});
             }
-            // neighbour side, losort order: row uses lower[f], other = lower cell
+            // neighbour side, losort order: row uses lower[f], other = lower cell (the owner of the face)
             for (int32_t j = neiStart[c]; j < neiStart[(size_t)c + 1]; ++j) {
                 const int32_t f = neiFaces[j], o = lower[f];
-                int32_t slot, other;
-                if (part[o] == t) { slot = faceLocalSlot[f]; other = L.c2e[o] - cs; } // owner (smaller id) was visited first
-                else { slot = nSlots++; L.slotFace.push_back(f); other = halo_of(L.c2e[o]); if (L.faceSlot[f] < 0) L.faceSlot[f] = (int32_t)(slotBase + slot); }
-                rowEnt.push_back((uint32_t)other | ((uint32_t)slot << 16) | 0x80000000u);
+                if (part[o] == t) {
+                    const int32_t ol = L.c2e[o] - cs, k = ownPos[f];
+                    rowEnt.push_back({ol, sbLocal[ol] + k, k, true, true});
+                } else {
+                    const int32_t h = halo_of(L.c2e[o]) - nc, k = haloCnt[h]++;
+                    cutList.push_back({(int32_t)rowEnt.size(), h, f});
+                    rowEnt.push_back({nc + h, -1, k, true, true});
+                }
             }
-            // coupled interfaces in patch order
+            // coupled interfaces in patch order; their slots follow all face slots of the tile so that a kernel
+            // can tell them apart with one compare: slot >= tileIfaceSlot0[t]
             for (int32_t j = pfStart[c]; j < pfStart[(size_t)c + 1]; ++j) {
-                // interface slots are numbered after all face slots of the tile (second pass below) so that
-                // a kernel can tell them apart with one compare: slot >= tileIfaceSlot0[t]
                 const int32_t x = pfList[j];
-                const int32_t slot = 0;
-                ifaceEnt.push_back((int32_t)rowEnt.size()); ifaceX.push_back(x);
-                int32_t other;
                 const int32_t nb = ifaceLocalNbr[x];
-                if (nb < 0) { other = halo_of(nCells + x); boundary = true; }      // remote: value arrives in the ext region
-                else if (part[nb] == t) other = L.c2e[nb] - cs;                      // cyclic partner inside this tile
-                else other = halo_of(L.c2e[nb]);                                     // cyclic partner in another tile
-                rowEnt.push_back((uint32_t)other | ((uint32_t)slot << 16));
+                int32_t h;
+                if (nb < 0) { h = halo_of(nCells + x) - nc; boundary = true; }          // remote: value arrives in the ext region
+                else { h = nHalo++; L.haloCell.push_back(L.c2e[nb]); haloCnt.push_back(0); } // cyclic partner (any tile): private halo entry
+                ifaceList.push_back({(int32_t)rowEnt.size(), h, x});
+                rowEnt.push_back({nc + h, -1, 0, true, false});
             }
             rowEntStart.push_back((int32_t)rowEnt.size());
         }
-        L.tileIfaceSlot0[t] = nSlots;
-        for (size_t k = 0; k < ifaceEnt.size(); ++k) {
+        sbHalo.assign((size_t)nHalo + 1, 0);
+        for (int32_t h = 0; h < nHalo; ++h) sbHalo[(size_t)h + 1] = sbHalo[h] + haloCnt[h];
+        const int32_t nFaceSlots = nLocal + sbHalo[nHalo];
+        for (int32_t h = 0; h <= nHalo; ++h) sbHalo[h] += nLocal;
+        for (const Pending& q : cutList) {
+            RowEnt& re = rowEnt[(size_t)q.ent];
+            re.slot = sbHalo[q.halo] + re.k;
+            place(re.slot, q.id);
+            if (L.faceSlot[q.id] < 0) L.faceSlot[q.id] = (int32_t)(slotBase + re.slot);
+        }
+        L.tileIfaceSlot0[t] = nFaceSlots;
+        int32_t nSlots = nFaceSlots;
+        for (const Pending& q : ifaceList) {
             const int32_t slot = nSlots++;
-            L.slotFace.push_back(-(2 + ifaceX[k]));
-            L.extSlot[ifaceX[k]] = (int32_t)(slotBase + slot);
-            rowEnt[(size_t)ifaceEnt[k]] |= ((uint32_t)slot << 16);
+            rowEnt[(size_t)q.ent].slot = slot;
+            place(slot, -(2 + q.id));
+            L.extSlot[q.id] = (int32_t)(slotBase + slot);
+            sbHalo[q.halo] = slot;
         }
         if (nSlots > 32766 || nc + nHalo > 65535) return "tile exceeds the entry field widths";
+        if (nc + nHalo + 1 > 4096) fits16 = false;
+        for (const RowEnt& re : rowEnt) if (re.rule && re.k > 7) { fits16 = false; break; }
+        if (!fits16) L.compact = false;
         // zero slot + pad the segment to an even length (16-byte aligned double2 loads)
-        L.slotFace.push_back(-1); // the zero slot, local index nSlots
+        place(nSlots, -1); // the zero slot, local index nSlots
         if ((L.slotFace.size() & 1u) != 0) L.slotFace.push_back(-1);
         L.tileSlotStart[(size_t)t + 1] = (int32_t)L.slotFace.size();
         L.tileHaloStart[(size_t)t + 1] = (int32_t)L.haloCell.size();
-        (void)haloBase;
-        // slices of 64 rows, column-major, padded with {zero slot, other 0}
+        // slot bases: local rows, halo cells, the pad cell (-> zero slot)
+        for (int32_t i = 0; i < nc; ++i) L.slotBase.push_back((uint16_t)sbLocal[i]);
+        for (int32_t h = 0; h < nHalo; ++h) L.slotBase.push_back((uint16_t)sbHalo[h]);
+        L.slotBase.push_back((uint16_t)nSlots);
+        if ((L.slotBase.size() & 1u) != 0) L.slotBase.push_back(0);
+        L.tileSbStart.push_back((int32_t)(L.slotBase.size() / 2));
+        // slices of 64 rows, column-major, padded with {zero slot, other 0} / {pad cell}
         const uint32_t padEnt = ((uint32_t)nSlots << 16);
+        const uint32_t pad16 = (uint32_t)((nc + nHalo) & 0xFFF) | 0x8000u;
         const int32_t nSl = (nc + 63) / 64;
         for (int32_t s = 0; s < nSl; ++s) {
             const int32_t r0 = s * 64, r1 = std::min(nc, r0 + 64);
@@ -290,11 +332,23 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
             for (int32_t r = r0; r < r1; ++r) width = std::max(width, rowEntStart[(size_t)r + 1] - rowEntStart[r]);
             const size_t base = L.entries.size();
             L.entries.resize(base + (size_t)width * 64, padEnt);
+            const int32_t width2 = (width + 1) / 2;
+            const size_t base16 = L.entries16.size();
+            if (L.compact) L.entries16.resize(base16 + (size_t)width2 * 64, pad16 | (pad16 << 16));
             for (int32_t r = r0; r < r1; ++r) {
                 const int32_t len = rowEntStart[(size_t)r + 1] - rowEntStart[r];
-                for (int32_t j = 0; j < len; ++j) L.entries[base + (size_t)j * 64 + (r - r0)] = rowEnt[(size_t)rowEntStart[r] + j];
+                for (int32_t j = 0; j < len; ++j) {
+                    const RowEnt& re = rowEnt[(size_t)rowEntStart[r] + j];
+                    L.entries[base + (size_t)j * 64 + (r - r0)] = (uint32_t)re.other | ((uint32_t)re.slot << 16) | (re.lowerSide ? 0x80000000u : 0u);
+                    if (L.compact) {
+                        const uint32_t e16 = (uint32_t)(re.other & 0xFFF) | ((uint32_t)(re.k & 7) << 12) | (re.rule ? 0x8000u : 0u);
+                        uint32_t& w = L.entries16[base16 + (size_t)(j >> 1) * 64 + (r - r0)];
+                        w = (j & 1) ? ((w & 0x0000FFFFu) | (e16 << 16)) : ((w & 0xFFFF0000u) | e16);
+                    }
+                }
             }
             L.sliceEntryStart.push_back((int32_t)L.entries.size());
+            L.sliceEntryStart16.push_back((int32_t)L.entries16.size());
         }
         L.tileSliceStart[(size_t)t + 1] = L.tileSliceStart[t] + nSl;
         L.maxCells = std::max(L.maxCells, nc);
@@ -304,6 +358,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         if (L.entries.size() > (size_t)INT32_MAX - 4096 || L.slotFace.size() > (size_t)INT32_MAX - 4096)
             return "mesh too large for 32-bit layout offsets";
     }
+    if (!L.compact) { std::vector<uint32_t>().swap(L.entries16); std::vector<int32_t>().swap(L.sliceEntryStart16); }
     L.nSlices = L.tileSliceStart[nT];
     L.totalSlots = (int64_t)L.slotFace.size();
     return std::string();

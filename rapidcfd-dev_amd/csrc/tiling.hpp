@@ -11,7 +11,8 @@
 //     coalesced loads,
 //   * a halo list (cells of other tiles / other ranks it reads),
 //   * per-row entry lists {slot, other cell, side} stored in 64-row slices
-//     column-major so a wavefront reads them coalesced and loops uniformly.
+//     column-major so a wavefront reads them coalesced and loops uniformly
+//     (32-bit explicit form, and a 16-bit form with implied slots).
 // Entries of a row are ordered exactly like the reference's row gather
 // (lduMatrixATmul.C:90-136: upper faces ascending, then lower faces in losort
 // order, then the coupled interfaces in patch order) so the floating-point
@@ -35,6 +36,15 @@ struct TileLayout {
     std::vector<int32_t> tileSliceStart;  // [nTiles+1]
     std::vector<int32_t> sliceEntryStart; // [nSlices+1]
     std::vector<uint32_t> entries;        // other | slot<<16 | isLower<<31
+    // compact form (half the bytes), usable when every tile has <= 4095 cells+halo and no cell owns more than 8 faces
+    // of one tile: 16-bit entries {other:12 | k:3 | rule:1}, two per word.  The slot is implied by the slot ORDER of a
+    // tile: rule 0 (the row owns the face; always the leading entries of a row) slot = slotBase[row] + position in row;
+    // rule 1 (the other cell owns the face, or an interface) slot = slotBase[other] + k.
+    bool compact = false;
+    std::vector<uint32_t> entries16;        // [pair][lane] per slice
+    std::vector<int32_t> sliceEntryStart16; // [nSlices+1], in words
+    std::vector<uint16_t> slotBase;         // per tile: nc + nh + 1 values (the last one is the zero slot), padded to an even count
+    std::vector<int32_t> tileSbStart;       // [nTiles+1] start of a tile's slotBase segment, in 32-bit words
     std::vector<int32_t> slotFace;        // caller face id; -1 = padding; <= -2 : interface slot -(2+ext)
     std::vector<int32_t> extSlot;         // [nExt] slot of each interface face
     std::vector<int32_t> interiorTiles, boundaryTiles;
@@ -48,6 +58,7 @@ struct TileLayout {
 struct TileParams {
     int32_t tileCells = 1024; // max cells per tile
     int32_t slotCap = 4094;   // max coefficient slots per tile
+    bool compact = true;      // also build the 16-bit entry form when the mesh allows it
 };
 
 // returns empty string on success, else an error message

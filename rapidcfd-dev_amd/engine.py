@@ -99,12 +99,12 @@ def host_layout(n_cells, lower_addr, upper_addr, patch_face_cells=(), tile_cells
     try:
         for name in ("e2c", "c2e", "tileCellStart", "tileSlotStart", "tileIfaceSlot0", "tileHaloStart", "haloCell",
                      "tileSliceStart", "sliceEntryStart", "entries", "slotFace", "extSlot", "interiorTiles", "boundaryTiles",
-                     "patchOffset", "patchFaceCellsE", "faceSlot"):
+                     "patchOffset", "patchFaceCellsE", "faceSlot", "sliceEntryStart16", "entries16", "slotBase", "tileSbStart"):
             data, ln = C.c_void_p(), C.c_int64()
             _chk(lib().mi_layout_array(h, name.encode(), C.byref(data), C.byref(ln)))
-            dt = np.uint32 if name == "entries" else np.int32
+            dt = np.uint32 if name in ("entries", "entries16") else (np.uint16 if name == "slotBase" else np.int32)
             if ln.value:
-                buf = (C.c_char * (ln.value * 4)).from_address(data.value)
+                buf = (C.c_char * (ln.value * np.dtype(dt).itemsize)).from_address(data.value)
                 out[name] = np.frombuffer(buf, dtype=dt).copy()
             else:
                 out[name] = np.zeros(0, dtype=dt)

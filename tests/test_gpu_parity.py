@@ -382,6 +382,8 @@ def test_cyclic_interfaces(pkg, orc, ctx, symmetric):
     mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
     mat.sumA(out); assert np.array_equal(host(out), S.sumA())
     mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
+    mat.H(dev(x), out); assert np.array_equal(host(out), S.H(x))           # H and H1 are face sums: no interface terms
+    mat.H1(out); assert np.array_equal(host(out), S.H1())
     psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 2)
     assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 2))   # interface terms enter bPrime, like the reference
     psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
@@ -392,6 +394,47 @@ def test_cyclic_interfaces(pkg, orc, ctx, symmetric):
         mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
         perf = mat.pbicg(psi, dev(case.source), "DILU", tolerance=1e-10, maxIter=300)
         ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV", tolerance=1e-10, maxIter=300)
+    _check_hist(perf, ref)
+    assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_compact_row_entries_opt_in(pkg, orc, ctx, symmetric, monkeypatch):
+    """MI_ENTRY16=1: 16-bit row entries with implied slots (half the addressing bytes) -- the same bits as the
+    explicit form for every operator, with face and interface (cyclic) terms, AINV and Jacobi included."""
+    syn, eng = pkg.synthetic, pkg.engine
+    monkeypatch.setenv("MI_ENTRY16", "1")
+    case = syn.add_cyclic_y(syn.box_case(18, 12, 10, symmetric=symmetric), asym_shift=0.0 if symmetric else 0.25)
+    fcs = [i.face_cells for i in case.interfaces]
+    nbrs = [case.interfaces[i.nbr_patch].face_cells for i in case.interfaces]
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, fcs, nbrs)
+    monkeypatch.delenv("MI_ENTRY16")
+    ref_addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, fcs, nbrs)
+    assert addr.stats()["entries"] < 0.6 * ref_addr.stats()["entries"]      # the compact form is in use
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    for p, itf in enumerate(case.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if symmetric else dev(itf.int_coeffs))
+    S = orc.System([case])
+    n = case.n_cells
+    x = syn.splitmix_uniform(3, n) - 0.5
+    out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+    mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
+    mat.sumA(out); assert np.array_equal(host(out), S.sumA())
+    mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
+    mat.H(dev(x), out); assert np.array_equal(host(out), S.H(x))
+    mat.H1(out); assert np.array_equal(host(out), S.H1())
+    mat.precondition("AINV", dev(x), out); assert np.array_equal(host(out), S.precondition("AINV", x))
+    psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 2)
+    assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 2))
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    if symmetric:
+        perf = mat.pcg(psi, dev(case.source), "AINV", tolerance=1e-9, maxIter=500)
+        ref_psi, ref = S.pcg(np.zeros(n), case.source, "AINV", tolerance=1e-9, maxIter=500)
+    else:
+        perf = mat.pbicgstab(psi, dev(case.source), "AINV", tolerance=1e-10, maxIter=300)
+        ref_psi, ref = S.pbicgstab(np.zeros(n), case.source, "AINV", tolerance=1e-10, maxIter=300)
     _check_hist(perf, ref)
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
 

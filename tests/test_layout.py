@@ -6,8 +6,11 @@ import pytest
 from conftest import random_graph_case
 
 
-def interpret_amul(L, case, x, ext=None, bou=None, transpose=False):
-    """numpy re-enactment of tile_kernel<OP_AMUL> over the layout tables."""
+def _interpret(L, case, x, ext=None, bou=None, transpose=False, compact=False):
+    """numpy re-enactment of tile_kernel<OP_AMUL> over the layout tables (explicit 32-bit entries, or the
+    compact 16-bit entries whose slots are implied by the slot order)."""
+    if compact:
+        assert L["entries16"].shape[0] > 0 or case.n_faces == 0, "layout has no compact form"
     n = case.n_cells
     e2c = L["e2c"]
     xe = np.concatenate([x[e2c], ext if ext is not None else np.zeros(0)])
@@ -28,23 +31,54 @@ def interpret_amul(L, case, x, ext=None, bou=None, transpose=False):
         h0, h1 = L["tileHaloStart"][t], L["tileHaloStart"][t + 1]
         xs = np.concatenate([xe[c0:c1], xe[L["haloCell"][h0:h1]]])
         nc = c1 - c0
+        nh = h1 - h0
+        if compact:  # slot bases of cells, halo cells and the pad cell; the pad cell reads x = 0
+            w0 = 2 * L["tileSbStart"][t]
+            sb = L["slotBase"][w0: w0 + nc + nh + 1].astype(np.int64)
+            xs = np.concatenate([xs, np.zeros(1)])
+            ifs0 = L["tileIfaceSlot0"][t]
         for s in range(L["tileSliceStart"][t], L["tileSliceStart"][t + 1]):
-            e0, e1 = L["sliceEntryStart"][s], L["sliceEntryStart"][s + 1]
-            ent = L["entries"][e0:e1].reshape(-1, 64)
             r0 = (s - L["tileSliceStart"][t]) * 64
             rows = np.arange(r0, min(r0 + 64, nc))
             acc = case.diag[e2c[c0 + rows]] * xs[rows]
-            for j in range(ent.shape[0]):
-                en = ent[j, : rows.shape[0]]
-                o = (en & 0xFFFF).astype(np.int64)
-                sl = ((en >> 16) & 0x7FFF).astype(np.int64)
-                is_low = (en >> 31).astype(bool)
-                coef = np.where(is_low != transpose, lo[s0 + sl], up[s0 + sl])
-                acc = acc + coef * xs[o]
+            if compact:
+                e0, e1 = L["sliceEntryStart16"][s], L["sliceEntryStart16"][s + 1]
+                words = L["entries16"][e0:e1].reshape(-1, 64)
+                for j in range(2 * words.shape[0]):
+                    w = words[j // 2, : rows.shape[0]]
+                    en = ((w >> 16) if (j & 1) else (w & 0xFFFF)).astype(np.int64)
+                    o = en & 0xFFF
+                    rule = (en >> 15).astype(bool)
+                    sl = np.where(rule, sb[o] + ((en >> 12) & 7), sb[rows] + j)
+                    is_low = rule & (sl < ifs0)
+                    coef = np.where(is_low != transpose, lo[s0 + sl], up[s0 + sl])
+                    acc = acc + coef * xs[o]
+            else:
+                e0, e1 = L["sliceEntryStart"][s], L["sliceEntryStart"][s + 1]
+                ent = L["entries"][e0:e1].reshape(-1, 64)
+                for j in range(ent.shape[0]):
+                    en = ent[j, : rows.shape[0]]
+                    o = (en & 0xFFFF).astype(np.int64)
+                    sl = ((en >> 16) & 0x7FFF).astype(np.int64)
+                    is_low = (en >> 31).astype(bool)
+                    coef = np.where(is_low != transpose, lo[s0 + sl], up[s0 + sl])
+                    acc = acc + coef * xs[o]
             ye[c0 + rows] = acc
     y = np.empty(n)
     y[e2c] = ye
     return y
+
+
+def interpret_amul(L, case, x, **kw):
+    """explicit form; when the layout also carries the compact form, that one must give the same bits"""
+    y = _interpret(L, case, x, compact=False, **kw)
+    if L["entries16"].shape[0] > 0:
+        COMPACT_SEEN.append(1)
+        assert np.array_equal(_interpret(L, case, x, compact=True, **kw), y)
+    return y
+
+
+COMPACT_SEEN = []
 
 
 @pytest.mark.parametrize("tile_cells", [64, 1024])
@@ -224,3 +258,35 @@ def test_layout_property_random_coupled_patches(pkg, orc):
             assert (np.any(h >= n)) == (t in bt)
 
     run()
+
+
+def test_compact_entries_are_built_for_boxes_and_not_for_hubs(pkg):
+    """the 16-bit form exists for mesh-like graphs; a hub cell (more than 8 owned faces towards one tile) or a
+    tile with more than 4095 cells+halo falls back to the explicit form"""
+    syn, eng = pkg.synthetic, pkg.engine
+    case = syn.box_case(13, 9, 7)
+    L = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr)
+    assert L["entries16"].shape[0] > 0 and L["slotBase"].shape[0] >= case.n_cells + L["haloCell"].shape[0] + (L["tileCellStart"].shape[0] - 1)
+    assert 2 * L["entries16"].shape[0] <= L["entries"].shape[0] + 64 * (L["tileSliceStart"][-1])
+    n = 40
+    lower = np.zeros(n - 1, dtype=np.int32); upper = np.arange(1, n, dtype=np.int32)   # cell 0 owns 39 faces
+    L = eng.host_layout(n, lower, upper)
+    assert L["entries16"].shape[0] == 0 and L["entries"].shape[0] > 0
+
+
+def test_compact_form_was_exercised_with_patches(pkg, orc):
+    """cyclic + processor-like patches on a box: the compact form must exist and reproduce Amul (private halo
+    entries name the interface slots)"""
+    syn, eng = pkg.synthetic, pkg.engine
+    case = syn.add_cyclic_y(syn.box_case(9, 8, 7, symmetric=False), asym_shift=0.05)
+    fcs = [i.face_cells for i in case.interfaces]
+    nbrs = [case.interfaces[i.nbr_patch].face_cells for i in case.interfaces]
+    L = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr, fcs, tile_cells=128, patch_nbr_cells=nbrs)
+    assert L["entries16"].shape[0] > 0
+    x = syn.splitmix_uniform(4, case.n_cells) - 0.5
+    bou = np.concatenate([i.bou_coeffs for i in case.interfaces])
+    before = len(COMPACT_SEEN)
+    got = interpret_amul(L, case, x, ext=np.zeros(len(bou)), bou=bou)
+    assert len(COMPACT_SEEN) == before + 1
+    ref = orc.System([case]).amul(x)
+    assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref))
