@@ -27,6 +27,8 @@ int main(int argc, char** argv)
     }
     const int F = (int)lower.size();
     TileLayout L; TileParams prm;
+    if (getenv("TILE_CELLS")) prm.tileCells = atoi(getenv("TILE_CELLS"));
+    if (getenv("TILE_SLOTS")) prm.slotCap = atoi(getenv("TILE_SLOTS"));
     const std::string err = build_tile_layout(N, F, lower.data(), upper.data(), 0, nullptr, nullptr, prm, L);
     if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     printf("N=%d F=%d tiles=%d slots=%lld maxSlots=%d maxHalo=%d compact=%d\n", N, F, L.nTiles, (long long)L.totalSlots, L.maxSlots, L.maxHalo, (int)L.compact);
@@ -44,7 +46,8 @@ int main(int argc, char** argv)
     const int slots = (L.maxSlots + 3) & ~1, xlen = ((L.maxCells + 63) & ~63) + L.maxHalo + 2;
     a.offLow = slots; a.offX = slots; a.offRD = slots + ((xlen + 1) & ~1); a.offSB = a.offRD;
     const size_t lds = (size_t)(a.offSB + (L.maxCells + L.maxHalo + 8) / 4 + 1) * 8;
-    printf("lds per tile image %zu bytes\n", lds);
+    const size_t ldsX = (size_t)a.offRD * 8; // explicit entries: no slotBase table
+    printf("lds per tile image %zu bytes (explicit entries %zu)\n", lds, ldsX);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double algBytes = 24.0 * N + 16.0 * F;
     auto run = [&](const char* name, auto launch, double* y) {
@@ -66,7 +69,12 @@ int main(int argc, char** argv)
         printf("   %s vs baseline: %zu of %d values differ\n", name, bad, N);
     };
     CK(hipFuncSetAttribute((const void*)tile_kernel<OP_AMUL, false, false, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    CK(hipFuncSetAttribute((const void*)tile_kernel<OP_AMUL, false, false, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    CK(hipFuncSetAttribute((const void*)tile_kernel<OP_AMUL, false, false, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     for (int pass = 0; pass < 2; ++pass) {
+        run("explicit BS512 (own LDS)", [&] { tile_kernel<OP_AMUL, false, false, 512, false><<<L.nTiles, 512, ldsX, 0>>>(a); }, y0);
+        run("explicit BS256 (own LDS)", [&] { tile_kernel<OP_AMUL, false, false, 256, false><<<L.nTiles, 256, ldsX, 0>>>(a); }, y1);
+        run("explicit BS1024 (own LDS)", [&] { tile_kernel<OP_AMUL, false, false, 1024, false><<<L.nTiles, 1024, ldsX, 0>>>(a); }, y1);
         run("baseline 512 explicit", [&] { tile_kernel<OP_AMUL, false, false, 512, false><<<L.nTiles, 512, lds, 0>>>(a); }, y0);
         exp_variants(a, L, lds, run, check, y1);
     }
