@@ -317,6 +317,11 @@ int mi_vec_div(mi_ctx_t ctx, int64_t n, const double *x_dev, const double *y_dev
 int mi_patch_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_patch_faces, const int32_t *face_cells_host, mi_patch_t *out);
 int mi_patch_destroy(mi_patch_t patch);
 int mi_patch_add(mi_patch_t patch, const double *pf_dev, double *intf_dev, int fn);
+/* boundary part of fvMatrix::flux (fvMatrix.C:1621-1653): flux[i] = internalCoeffs[i]*psi[faceCells[i]] -
+ * boundaryCoeffs[i] * patchNeighbourField[i]  (coupled patch) | - boundaryCoeffs[i]  (NULL neighbour field: not coupled).
+ * The internal-face part of flux() is mi_faceH.                                                                      */
+int mi_patch_flux(mi_patch_t patch, const double *internal_coeffs_dev, const double *boundary_coeffs_dev,
+                  const double *psi_dev, const double *patch_neighbour_field_dev_or_null, double *flux_dev);
 /* fvMatrix<scalar>::relax(alpha): coupled[p] != 0 marks processor-like patches */
 int mi_relax(mi_addr_t addr, double alpha, double *diag_dev, const double *lower_dev, const double *upper_dev,
              double *source_dev, const double *psi_dev, int32_t n_patches, const mi_patch_t *patches,

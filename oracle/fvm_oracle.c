@@ -82,6 +82,20 @@ void orc_patch_add(label nPatchFaces, const label *faceCells, const scalar *pf, 
 }
 
 /* relax, scalar Type.  coupled[p] != 0: processor-like patch. */
+/* boundary part of fvMatrix::flux (fvMatrix.C:1621-1653): InternalContrib = internalCoeffs*patchInternalField,
+ * NeighbourContrib = boundaryCoeffs (*patchNeighbourField when coupled), flux = InternalContrib - NeighbourContrib.
+ * Three separate field operations in the reference, hence three roundings (no fma).                                */
+void orc_patch_flux(label nPatchFaces, const label *faceCells, const scalar *ic, const scalar *bc, const scalar *psi,
+                    const scalar *psiNbr, scalar *out)
+{
+    label i;
+    for (i = 0; i < nPatchFaces; i++) {
+        volatile scalar inContrib = ic[i] * psi[faceCells[i]];
+        volatile scalar nbContrib = psiNbr ? bc[i] * psiNbr[i] : bc[i];
+        out[i] = inContrib - nbContrib;
+    }
+}
+
 void orc_relax(label n, label nf, const label *lo, const label *up, scalar alpha, scalar *diag,
                const scalar *lowerC, const scalar *upperC, scalar *source, const scalar *psi, int nPatches,
                const label *patchSizes, const label *const *faceCells, const scalar *const *iCoeffs,

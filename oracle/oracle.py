@@ -374,6 +374,16 @@ def patch_add(face_cells, pf, intf, fn=0):
     return out
 
 
+def patch_flux(face_cells, internal_coeffs, boundary_coeffs, psi, patch_neighbour_field=None):
+    """boundary part of fvMatrix::flux (fvMatrix.C:1621-1653)"""
+    fc = _i(face_cells)
+    out = np.empty(fc.shape[0])
+    nb = None if patch_neighbour_field is None else _d(patch_neighbour_field)
+    lib().orc_patch_flux(C.c_int32(fc.shape[0]), _p(fc, C.c_int32), _p(_d(internal_coeffs), C.c_double), _p(_d(boundary_coeffs), C.c_double),
+                         _p(_d(psi), C.c_double), _p(nb, C.c_double) if nb is not None else None, _p(out, C.c_double))
+    return out
+
+
 def relax(n_cells, lower_addr, upper_addr, alpha, diag, lower, upper, source, psi, face_cells=(), icoeffs=(), bcoeffs=(), coupled=()):
     lo, up = _i(lower_addr), _i(upper_addr)
     d, s = _d(diag).copy(), _d(source).copy()

@@ -530,6 +530,20 @@ void fvScalarMatrix::H(scalargpuField& Hphi, const scalargpuField& psi, const sc
     addBoundarySource(Hphi);
     miCheck(mi_vec_div(ctx, Hphi.size(), Hphi.data(), V.data(), Hphi.data()), "fvMatrix::H");
 }
+void fvScalarMatrix::flux(scalargpuField& internalFlux, FieldFieldScalar& boundaryFlux, const scalargpuField& psi,
+                          const std::vector<const scalargpuField*>& patchNeighbourField) const
+{
+    static const FieldFieldScalar none; static const lduInterfaceFieldPtrsList noIfs;
+    miCheck(mi_faceH(handle(none, none, noIfs), psi.data(), internalFlux.data()), "lduMatrix::faceH");
+    if (boundaryFlux.size() != patchFaceCells_.size()) boundaryFlux.resize(patchFaceCells_.size());
+    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p) {
+        if (boundaryFlux[p].size() != (label)patchFaceCells_[p].size()) boundaryFlux[p] = scalargpuField((label)patchFaceCells_[p].size());
+        const scalargpuField* nbr = (patchCoupled_[p] && p < patchNeighbourField.size()) ? patchNeighbourField[p] : nullptr;
+        if (patchCoupled_[p] && !nbr) throw error("fvMatrix::flux: coupled patch without patchNeighbourField");
+        miCheck(mi_patch_flux(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]), internalCoeffs_[p].data(), boundaryCoeffs_[p].data(),
+                              psi.data(), nbr ? nbr->data() : nullptr, boundaryFlux[p].data()), "fvMatrix::flux");
+    }
+}
 fvScalarMatrix& fvScalarMatrix::operator+=(const fvScalarMatrix& B) { axpyFrom(B, 1.0); return *this; }
 fvScalarMatrix& fvScalarMatrix::operator-=(const fvScalarMatrix& B) { axpyFrom(B, -1.0); return *this; }
 fvScalarMatrix& fvScalarMatrix::operator*=(scalar s)

@@ -104,6 +104,15 @@ int main(int argc, char** argv)
                 for (label c = 0; c < n; ++c) { sa += a[c]; sh += hh[c]; ma = std::max(ma, std::fabs(a[c])); mh = std::max(mh, std::fabs(hh[c])); }
                 Info << "A(Ux) sum max: " << sa << " " << ma << "  H(Ux) sum max: " << sh << " " << mh << std::endl;
             }
+            {   // fvMatrix::flux of the assembled UEqn for psi = src: internal faces + every boundary patch
+                scalargpuField fl(nf), U0(src); FieldFieldScalar bfl;
+                UEqn.flux(fl, bfl, U0);
+                std::vector<scalar> f = fl.asHost();
+                scalar sf = 0, mf = 0, sb = 0;
+                for (label k = 0; k < nf; ++k) { sf += std::fabs(f[k]); mf = std::max(mf, std::fabs(f[k])); }
+                for (const scalargpuField& b : bfl) for (scalar v : b.asHost()) sb += v;
+                Info << "flux(Ux) sumMag max boundarySum: " << sf << " " << mf << " " << sb << std::endl;
+            }
             scalargpuField psi(n);
             UEqn.relax(0.7, psi);
             UEqn.solve(psi, dictionary{{"solver", "PBiCG"}, {"preconditioner", "diagonal"}, {"tolerance", "1e-10"}, {"relTol", "0"}});

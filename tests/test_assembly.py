@@ -116,6 +116,12 @@ def test_engine_assembly_bit_exact(pkg, orc, dims):
     asm.relax(0.7, d, dev(case.lower), dev(case.upper), s, dev(psi), ph, [dev(a) for a in ic], [dev(a) for a in bc], coupled)
     rd, rs = orc.relax(n, lo, up, 0.7, case.diag, case.lower, case.upper, case.source, psi, patches, ic, bc, coupled)
     assert np.array_equal(host(d), rd) and np.array_equal(host(s), rs)
+    # boundary part of fvMatrix::flux: coupled patches multiply boundaryCoeffs by the neighbour field, the others do not
+    for k, (p, h) in enumerate(zip(patches, ph)):
+        nbr = syn.splitmix_uniform(60 + k, p.shape[0]) if coupled[k] else None
+        out = E(p.shape[0])
+        h.flux(dev(ic[k]), dev(bc[k]), dev(psi), out, None if nbr is None else dev(nbr))
+        assert np.array_equal(host(out), orc.patch_flux(p, ic[k], bc[k], psi, nbr))
 
 
 @pytest.mark.gpu

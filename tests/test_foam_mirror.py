@@ -69,6 +69,13 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     assert m, out.stdout
     assert abs(float(m.group(1)) - a_ref.sum()) < 1e-9 * abs(a_ref.sum()) and float(m.group(2)) == np.max(np.abs(a_ref))
     assert abs(float(m.group(3)) - h_ref.sum()) < 1e-9 * np.abs(h_ref).sum() and float(m.group(4)) == np.max(np.abs(h_ref))
+    # fvMatrix::flux of UEqn for psi = src: faceH on the internal faces, internalCoeffs*psi - boundaryCoeffs on the patches
+    fh = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, ud, uu, ul, src)]).faceH(src)
+    bsum = orc.patch_flux(xmin, np.full(xmin.shape[0], 2.0 * h), np.zeros(xmin.shape[0]), src).sum()
+    m = re.search(r"flux\(Ux\) sumMag max boundarySum: (\S+) (\S+) (\S+)", out.stdout)
+    assert m, out.stdout
+    assert abs(float(m.group(1)) - np.abs(fh).sum()) < 1e-11 * np.abs(fh).sum() and abs(float(m.group(2)) - np.max(np.abs(fh))) < 1e-14 * np.max(np.abs(fh))
+    assert abs(float(m.group(3)) - bsum) < 1e-11 * np.abs(src[xmin]).sum() * 2.0 * h
     rd, rs = orc.relax(n, case.lower_addr, case.upper_addr, 0.7, ud, ul, uu, src, z, [xmin], [np.full(xmin.shape[0], 2.0 * h)],
                        [np.zeros(xmin.shape[0])], [0])
     rd_solve = orc.patch_add(xmin, np.full(xmin.shape[0], 2.0 * h), rd, 0)
