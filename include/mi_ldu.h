@@ -225,7 +225,9 @@ int mi_pcg_end(mi_matrix_t m, double *psi_out_dev, mi_solver_perf *perf_out,
  *   face_weights_host: [n_faces] agglomeration weights -- faceAreaPair passes
  *     |Sf/sqrt|Sf| o (1,1.01,1.02)| (src/finiteVolume/.../faceAreaPairGAMGAgglomeration.C:54-81),
  *     algebraicPair passes |upper|.
- *   n_cells_in_coarsest_level: the mandatory fvSolution key (GAMGAgglomeration.C:96-99); mergeLevels 1.
+ *   n_cells_in_coarsest_level: the mandatory fvSolution key (GAMGAgglomeration.C:96-99).
+ *   merge_levels: fvSolution's mergeLevels (pairGAMGAgglomerate.C:110-117): every level folds that many pair steps
+ *     (GAMGAgglomeration::combineLevels, GAMGAgglomerateLduAddressing.C:606-760); 1 = one pair step per level.
  *   forward_init: the reference's process-wide static sweep direction (pairGAMGAgglomeration.C:33),
  *     true in a fresh process; mi_gamg_forward_out returns its value after the build.
  * mi_gamg_solve agglomerates the level matrices from the matrix's current coefficients (the
@@ -242,7 +244,7 @@ typedef struct {
     double omega;                                                   /* 0.9     */
 } mi_gamg_controls;
 int mi_gamg_create(mi_addr_t fine_addr, const double *face_weights_host, int32_t n_cells_in_coarsest_level,
-                   int forward_init, mi_gamg_t *out);
+                   int32_t merge_levels, int forward_init, mi_gamg_t *out);
 /* Same for a matrix with coupled patches.  Cyclic (local) patches need no communicator (pass NULLs; mi_gamg_create
  * does that).  Processor patches (processorGAMGInterface, solvers/GAMG/interfaces/processorGAMGInterface/
  * processorGAMGInterface.C:54-245; GAMGAgglomerateLduAddressing.C:464-520) need the communicators the matrix is
@@ -251,7 +253,7 @@ int mi_gamg_create(mi_addr_t fine_addr, const double *face_weights_host, int32_t
  * (GAMGSolverScale.C:104-107) and the coarsest level is the GLOBAL system (LUscalarMatrix.C:57-150) whose dense
  * inverse every rank holds the rows of.  All ranks call create/solve together.                                  */
 int mi_gamg_create_coupled(mi_addr_t fine_addr, const double *face_weights_host,
-                           int32_t n_cells_in_coarsest_level, int forward_init, mi_comm_t reduce_or_null,
+                           int32_t n_cells_in_coarsest_level, int32_t merge_levels, int forward_init, mi_comm_t reduce_or_null,
                            mi_comm_t halo_or_null, const int32_t *patch_rank,
                            const int32_t *patch_nbr_patch_or_null, mi_gamg_t *out);
 int mi_gamg_destroy(mi_gamg_t g);
@@ -333,7 +335,7 @@ int mi_relax(mi_addr_t addr, double alpha, double *diag_dev, const double *lower
  * cUpper, cellChildStart, cellChild, faceChildStart, faceChild, diagChildStart, diagChild.     */
 int mi_gamg_host_build(int32_t n_cells, int32_t n_faces, const int32_t *lower_addr_host,
                        const int32_t *upper_addr_host, const double *face_weights_host,
-                       int32_t n_cells_in_coarsest_level, int forward_init, void **hierarchy_out);
+                       int32_t n_cells_in_coarsest_level, int32_t merge_levels, int forward_init, void **hierarchy_out);
 int32_t mi_gamg_host_n_levels(void *hierarchy);
 int mi_gamg_host_array(void *hierarchy, int32_t level, const char *name, const void **data,
                        int64_t *len, int32_t *elem_size);

@@ -14,7 +14,7 @@
  *   - pair agglomeration        GAMGAgglomerations/pairGAMGAgglomeration/pairGAMGAgglomerate.C:31-313
  *   - coarse addressing         GAMGAgglomerations/GAMGAgglomeration/GAMGAgglomerateLduAddressing.C:245-461
  *   - face-weight restriction   GAMGAgglomerations/GAMGAgglomeration/GAMGAgglomerationTemplates.C:236-270
- *   - level loop / stop rule    pairGAMGAgglomerate.C:46-120, GAMGAgglomeration.C:72-81 (mergeLevels 1 only)
+ *   - level loop / stop rule    pairGAMGAgglomerate.C:46-120, GAMGAgglomeration.C:72-81 (mergeLevels: combineLevels, GAMGAgglomerateLduAddressing.C:606-760)
  *   - coarse matrices           GAMGSolverAgglomerateMatrix.C:37-321 + GAMGSolverAgglomerateMatrixF.H:9-159
  *   - restrict / prolong        GAMGAgglomerationTemplates.C:35-153,273-308, GAMGAgglomerationF.H:9-38
  *   - scale                     GAMGSolverScale.C:40-171
@@ -143,8 +143,36 @@ static void coarse_addressing(gamg_level *L, const label *lower, const label *up
     free(ccn); free(ccf); free(initNei); free(cmap);
 }
 
+/* GAMGAgglomeration::combineLevels (GAMGAgglomerateLduAddressing.C:606-760): fold pair step C into the previous level P
+ * (mergeLevels > 1, pairGAMGAgglomerate.C:110-117).  Restrict maps are composed; a face that was a coarse face of P
+ * takes C's target AND C's flip -- the flip P recorded is dropped (:624-629), exactly as the reference does; a face
+ * already inside a coarse cell of P follows that cell (:631-636; its flip is never read).  P takes C's coarse mesh. */
+static void combine_levels(gamg_level *P, gamg_level *C)
+{
+    label i;
+    for (i = 0; i < P->nFineFaces; i++) {
+        const label t = P->faceRestrict[i];
+        if (t >= 0) { P->faceRestrict[i] = C->faceRestrict[t]; P->faceFlip[i] = C->faceFlip[t]; }
+        else { P->faceRestrict[i] = -C->restrictMap[-t - 1] - 1; P->faceFlip[i] = 0; }
+    }
+    for (i = 0; i < P->nFine; i++) P->restrictMap[i] = C->restrictMap[P->restrictMap[i]];
+    P->nCoarse = C->nCoarse; P->nCoarseFaces = C->nCoarseFaces;
+    free(P->cLower); free(P->cUpper);
+    P->cLower = C->cLower; P->cUpper = C->cUpper;
+    free(C->restrictMap); free(C->faceRestrict); free(C->faceFlip);
+    memset(C, 0, sizeof(*C));
+}
+
+gamg_hier *orc_gamg_build_merged(label nCells, label nFaces, const label *lower, const label *upper,
+                                 const scalar *faceWeights, label nCellsInCoarsestLevel, int forwardInit, int mergeLevels);
 gamg_hier *orc_gamg_build(label nCells, label nFaces, const label *lower, const label *upper,
                           const scalar *faceWeights, label nCellsInCoarsestLevel, int forwardInit)
+{
+    return orc_gamg_build_merged(nCells, nFaces, lower, upper, faceWeights, nCellsInCoarsestLevel, forwardInit, 1);
+}
+
+gamg_hier *orc_gamg_build_merged(label nCells, label nFaces, const label *lower, const label *upper,
+                                 const scalar *faceWeights, label nCellsInCoarsestLevel, int forwardInit, int mergeLevels)
 {
     const int maxLevels = 50; /* GAMGAgglomeration.C:94 */
     gamg_hier *H = (gamg_hier *)calloc(1, sizeof(gamg_hier));
@@ -154,6 +182,7 @@ gamg_hier *orc_gamg_build(label nCells, label nFaces, const label *lower, const 
     const label *lo = lower, *up = upper;
     scalar *w = (scalar *)malloc(sizeof(scalar) * (size_t)(nF ? nF : 1));
     memcpy(w, faceWeights, sizeof(scalar) * (size_t)nF);
+    int nPairLevels = 0;
     while (H->nLevels < maxLevels - 1) {
         gamg_level *L = &H->lev[H->nLevels];
         L->nFine = nFine; L->nFineFaces = nF;
@@ -165,8 +194,10 @@ gamg_hier *orc_gamg_build(label nCells, label nFaces, const label *lower, const 
         scalar *cw = (scalar *)calloc((size_t)(L->nCoarseFaces ? L->nCoarseFaces : 1), sizeof(scalar));
         for (label f = 0; f < nF; f++) if (L->faceRestrict[f] >= 0) cw[L->faceRestrict[f]] += w[f];
         free(w); w = cw;
+        if (nPairLevels % mergeLevels) { combine_levels(&H->lev[H->nLevels - 1], L); L = &H->lev[H->nLevels - 1]; }
+        else H->nLevels++;
+        nPairLevels++;
         nFine = L->nCoarse; nF = L->nCoarseFaces; lo = L->cLower; up = L->cUpper;
-        H->nLevels++;
     }
     free(w);
     H->forwardOut = forward;
@@ -443,8 +474,14 @@ typedef struct {
     int *nPatches;             /* [d] */
 } gamg_sys_hier;
 
+gamg_sys_hier *orc_gamg_build_sys_merged(const orc_system *S, const scalar *faceWeights, label nCellsInCoarsestLevel, int forwardInit, int mergeLevels);
 gamg_sys_hier *orc_gamg_build_sys(const orc_system *S, const scalar *faceWeights /* per domain, concatenated */,
                                   label nCellsInCoarsestLevel, int forwardInit)
+{
+    return orc_gamg_build_sys_merged(S, faceWeights, nCellsInCoarsestLevel, forwardInit, 1);
+}
+gamg_sys_hier *orc_gamg_build_sys_merged(const orc_system *S, const scalar *faceWeights /* per domain, concatenated */,
+                                         label nCellsInCoarsestLevel, int forwardInit, int mergeLevels)
 {
     const int maxLevels = 50, D = S->nDomains;
     gamg_sys_hier *H = (gamg_sys_hier *)calloc(1, sizeof(*H));
@@ -474,7 +511,7 @@ gamg_sys_hier *orc_gamg_build_sys(const orc_system *S, const scalar *faceWeights
             memcpy(pfc[d][p], m->ifaces[p].faceCells, sizeof(label) * (size_t)pn[d][p]);
         }
     }
-    int forward = forwardInit;
+    int forward = forwardInit, nPairLevels = 0;
     while (H->nLevels < maxLevels - 1) {
         const int l = H->nLevels;
         int cont = 1;
@@ -532,7 +569,19 @@ gamg_sys_hier *orc_gamg_build_sys(const orc_system *S, const scalar *faceWeights
             }
             nFine[d] = L->nCoarse; nF[d] = L->nCoarseFaces; lo[d] = L->cLower; up[d] = L->cUpper;
         }
-        H->nLevels++;
+        if (nPairLevels % mergeLevels) { /* combineLevels, per processor; patch maps: GAMGAgglomerateLduAddressing.C:700-760 */
+            for (int d = 0; d < D; d++) {
+                combine_levels(&H->lev[d][l - 1], &H->lev[d][l]);
+                for (int p = 0; p < S->dom[d].nIfaces; p++) {
+                    gamg_patch *P = &H->patch[d][l - 1][p], *C = &H->patch[d][l][p];
+                    for (label i = 0; i < P->nFine; i++) P->faceRestrict[i] = C->faceRestrict[P->faceRestrict[i]];
+                    free(P->faceCells); P->faceCells = C->faceCells; P->nCoarse = C->nCoarse;
+                    free(C->faceRestrict);
+                }
+                free(H->patch[d][l]); H->patch[d][l] = NULL;
+            }
+        } else H->nLevels++;
+        nPairLevels++;
     }
     H->forwardOut = forward;
     for (int d = 0; d < D; d++) {

@@ -236,15 +236,15 @@ def box_face_weights(case):
 
 
 class GamgHierarchy:
-    def __init__(self, case, face_weights, n_cells_in_coarsest_level=10, forward=True):
+    def __init__(self, case, face_weights, n_cells_in_coarsest_level=10, forward=True, merge_levels=1):
         L = lib()
-        L.orc_gamg_build.restype = C.c_void_p
+        L.orc_gamg_build_merged.restype = C.c_void_p
         self.case = case
         lo, up, w = _i(case.lower_addr), _i(case.upper_addr), _d(face_weights)
         self._keep = (lo, up)
-        self.h = C.c_void_p(L.orc_gamg_build(C.c_int32(case.n_cells), C.c_int32(case.n_faces), _p(lo, C.c_int32),
-                                             _p(up, C.c_int32), _p(w, C.c_double), C.c_int32(n_cells_in_coarsest_level),
-                                             int(forward)))
+        self.h = C.c_void_p(L.orc_gamg_build_merged(C.c_int32(case.n_cells), C.c_int32(case.n_faces), _p(lo, C.c_int32),
+                                                    _p(up, C.c_int32), _p(w, C.c_double), C.c_int32(n_cells_in_coarsest_level),
+                                                    int(forward), int(merge_levels)))
         self.n_levels = int(L.orc_gamg_n_levels(self.h))
         self.forward_out = bool(L.orc_gamg_forward_out(self.h))
 
@@ -295,12 +295,13 @@ class GamgHierarchy:
 class GamgSysHierarchy:
     """GAMG over a System: coupled patches (cyclic) and decomposed cases (orc_gamg_build_sys / solve_sys)."""
 
-    def __init__(self, system, face_weights_per_domain, n_cells_in_coarsest_level=10, forward=True):
+    def __init__(self, system, face_weights_per_domain, n_cells_in_coarsest_level=10, forward=True, merge_levels=1):
         L = lib()
-        L.orc_gamg_build_sys.restype = C.c_void_p
+        L.orc_gamg_build_sys_merged.restype = C.c_void_p
         self.system = system
         w = _d(np.concatenate([np.asarray(x, dtype=np.float64) for x in face_weights_per_domain]))
-        self.h = C.c_void_p(L.orc_gamg_build_sys(system.h, _p(w, C.c_double), C.c_int32(n_cells_in_coarsest_level), int(forward)))
+        self.h = C.c_void_p(L.orc_gamg_build_sys_merged(system.h, _p(w, C.c_double), C.c_int32(n_cells_in_coarsest_level), int(forward),
+                                                        int(merge_levels)))
         self.n_levels = int(L.orc_gamg_sys_n_levels(self.h))
 
     def __del__(self):

@@ -102,9 +102,9 @@ void segment(int32_t nTargets, const std::vector<int32_t>& target, std::vector<i
 
 std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* lower, const int32_t* upper,
                                  const double* faceWeights, int32_t nCellsInCoarsestLevel, bool forwardInit,
-                                 GamgHierarchyHost& H, const GamgCoupling* cpl)
+                                 GamgHierarchyHost& H, const GamgCoupling* cpl, int32_t mergeLevels)
 {
-    if (nCells <= 0 || !faceWeights) return "bad argument";
+    if (nCells <= 0 || !faceWeights || mergeLevels < 1) return "bad argument";
     H.levels.clear();
     bool forward = forwardInit;
     const int maxLevels = 50;
@@ -114,6 +114,7 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
     const int32_t nPatches = cpl ? cpl->nPatches : 0;
     std::vector<std::vector<int32_t>> pfc, pnb; // patch faceCells / local neighbour cells of the current fine level
     if (cpl) { pfc = cpl->faceCells; pnb = cpl->nbrCells; }
+    int nPairLevels = 0;
     while ((int)H.levels.size() < maxLevels - 1) {
         GamgLevelHost L;
         L.nFine = nFine; L.nFineFaces = nF;
@@ -126,11 +127,6 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
         std::vector<double> cw((size_t)L.nCoarseFaces, 0.0); // restrictFaceField (host): plain summation
         for (int32_t f = 0; f < nF; ++f) if (L.faceRestrict[f] >= 0) cw[L.faceRestrict[f]] += w[f];
         w.swap(cw);
-        segment(L.nCoarse, L.restrictMap, L.cellChildStart, L.cellChild);
-        segment(L.nCoarseFaces, L.faceRestrict, L.faceChildStart, L.faceChild);
-        std::vector<int32_t> interior((size_t)nF);
-        for (int32_t f = 0; f < nF; ++f) interior[f] = L.faceRestrict[f] < 0 ? -1 - L.faceRestrict[f] : -1;
-        segment(L.nCoarse, interior, L.diagChildStart, L.diagChild);
         if (nPatches > 0) {
             // coarse-cell ids on both sides of every coupled patch face
             std::vector<std::vector<int32_t>> mine((size_t)nPatches), theirs((size_t)nPatches), send((size_t)nPatches);
@@ -173,9 +169,36 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                 if (cpl->isLocal[p]) pnb[p] = P.nbrCells;
             }
         }
-        H.levels.push_back(std::move(L));
+        if (nPairLevels % mergeLevels) {
+            // GAMGAgglomeration::combineLevels (GAMGAgglomerateLduAddressing.C:606-760): fold this pair step into the
+            // previous level.  Face flips: the reference keeps the flip of this step only (:624-637).
+            GamgLevelHost& P = H.levels.back();
+            for (int32_t i = 0; i < P.nFineFaces; ++i) {
+                const int32_t t = P.faceRestrict[i];
+                if (t >= 0) { P.faceRestrict[i] = L.faceRestrict[t]; P.faceFlip[i] = L.faceFlip[t]; }
+                else { P.faceRestrict[i] = -L.restrictMap[-t - 1] - 1; P.faceFlip[i] = 0; }
+            }
+            for (int32_t i = 0; i < P.nFine; ++i) P.restrictMap[i] = L.restrictMap[P.restrictMap[i]];
+            P.nCoarse = L.nCoarse; P.nCoarseFaces = L.nCoarseFaces;
+            P.cLower.swap(L.cLower); P.cUpper.swap(L.cUpper);
+            for (int32_t p = 0; p < nPatches; ++p) {
+                GamgPatchHost& PP = P.patches[p];
+                const GamgPatchHost& LP = L.patches[p];
+                for (size_t i = 0; i < PP.faceRestrict.size(); ++i) PP.faceRestrict[i] = LP.faceRestrict[PP.faceRestrict[i]];
+                PP.faceCells = LP.faceCells; PP.nbrCells = LP.nbrCells;
+                segment((int32_t)PP.faceCells.size(), PP.faceRestrict, PP.childStart, PP.child);
+            }
+        } else H.levels.push_back(std::move(L));
+        ++nPairLevels;
         GamgLevelHost& B = H.levels.back();
         nFine = B.nCoarse; nF = B.nCoarseFaces; lo = B.cLower.data(); up = B.cUpper.data();
+    }
+    for (GamgLevelHost& B : H.levels) { // device tables from the final (possibly combined) maps
+        segment(B.nCoarse, B.restrictMap, B.cellChildStart, B.cellChild);
+        segment(B.nCoarseFaces, B.faceRestrict, B.faceChildStart, B.faceChild);
+        std::vector<int32_t> interior((size_t)B.nFineFaces);
+        for (int32_t f = 0; f < B.nFineFaces; ++f) interior[f] = B.faceRestrict[f] < 0 ? -1 - B.faceRestrict[f] : -1;
+        segment(B.nCoarse, interior, B.diagChildStart, B.diagChild);
     }
     H.forwardOut = forward;
     return std::string();

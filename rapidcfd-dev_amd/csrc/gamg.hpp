@@ -4,7 +4,7 @@
 // Implements the reference's *algorithm* so that the same cells are agglomerated:
 //   pair matching          pairGAMGAgglomerate.C:135-313 (greedy, max face weight, alternating sweep direction)
 //   coarse addressing      GAMGAgglomerateLduAddressing.C:245-461 (coarse faces grouped by owner in creation order)
-//   level loop / stop      pairGAMGAgglomerate.C:46-120 (mergeLevels 1), GAMGAgglomeration.C:72-81
+//   level loop / stop      pairGAMGAgglomerate.C:46-120 (mergeLevels: combineLevels), GAMGAgglomeration.C:72-81
 // and derives the device tables the MI355X kernels need (segmented children lists instead of
 // the reference's sort/target/targetStart triplets, GAMGAgglomerateLduAddressing.C:37-120).
 #pragma once
@@ -61,7 +61,10 @@ struct GamgHierarchyHost {
 // faceWeights: [nFaces] (faceAreaPair: |Sf/sqrt|Sf| o (1,1.01,1.02)|; algebraicPair: |upper|)
 std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* lower, const int32_t* upper,
                                  const double* faceWeights, int32_t nCellsInCoarsestLevel, bool forwardInit,
-                                 GamgHierarchyHost& out, const GamgCoupling* coupling = nullptr);
+                                 GamgHierarchyHost& out, const GamgCoupling* coupling = nullptr, int32_t mergeLevels = 1);
+// mergeLevels m > 1: every created level is m consecutive pair steps folded into one by
+// GAMGAgglomeration::combineLevels (GAMGAgglomerateLduAddressing.C:606-760), including its face-flip rule (the flip
+// of the LAST pair step is kept, the earlier ones are dropped -- the reference's behaviour, reproduced as is).
 
 // dense inverse by Gauss-Jordan with partial pivoting (coarsest level); returns false if singular
 bool invert_dense(int n, std::vector<double>& A);

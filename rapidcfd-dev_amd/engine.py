@@ -443,7 +443,7 @@ class Gamg:
     """GAMG hierarchy + solver (lduMatrix::solver 'GAMG', agglomerator faceAreaPair/algebraicPair)."""
 
     def __init__(self, addr: Addressing, face_weights, n_cells_in_coarsest_level: int = 10, forward: bool = True,
-                 comms=None, patch_rank=None, patch_nbr_patch=None):
+                 comms=None, patch_rank=None, patch_nbr_patch=None, merge_levels: int = 1):
         """comms = (reduce, halo) Comm pair of a decomposed case (the matrix must be attached to the same pair)"""
         self.addr = addr
         w = np.ascontiguousarray(face_weights, dtype=np.float64)
@@ -452,7 +452,7 @@ class Gamg:
         pr = None if patch_rank is None else np.ascontiguousarray(patch_rank, dtype=np.int32)
         pn = None if patch_nbr_patch is None else np.ascontiguousarray(patch_nbr_patch, dtype=np.int32)
         _chk(lib().mi_gamg_create_coupled(addr.h, w.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(n_cells_in_coarsest_level),
-                                          int(forward), comms[0].h if comms else C.c_void_p(), comms[1].h if comms else C.c_void_p(),
+                                          C.c_int32(merge_levels), int(forward), comms[0].h if comms else C.c_void_p(), comms[1].h if comms else C.c_void_p(),
                                           pr.ctypes.data_as(I32) if pr is not None and pr.size else I32(),
                                           pn.ctypes.data_as(I32) if pn is not None and pn.size else I32(), C.byref(self.h)))
         self._keep = (comms, pr, pn)
@@ -490,7 +490,7 @@ class Gamg:
             self.h = C.c_void_p()
 
 
-def gamg_host_hierarchy(n_cells, lower_addr, upper_addr, face_weights, n_cells_in_coarsest_level=10, forward=True):
+def gamg_host_hierarchy(n_cells, lower_addr, upper_addr, face_weights, n_cells_in_coarsest_level=10, forward=True, merge_levels=1):
     """Host-only build of the GAMG hierarchy; returns a list of per-level dicts of numpy arrays (tests)."""
     lo = np.ascontiguousarray(lower_addr, dtype=np.int32)
     up = np.ascontiguousarray(upper_addr, dtype=np.int32)
@@ -498,7 +498,7 @@ def gamg_host_hierarchy(n_cells, lower_addr, upper_addr, face_weights, n_cells_i
     h = C.c_void_p()
     _chk(lib().mi_gamg_host_build(C.c_int32(n_cells), C.c_int32(lo.shape[0]), lo.ctypes.data_as(C.POINTER(C.c_int32)),
                                   up.ctypes.data_as(C.POINTER(C.c_int32)), w.ctypes.data_as(C.POINTER(C.c_double)),
-                                  C.c_int32(n_cells_in_coarsest_level), int(forward), C.byref(h)))
+                                  C.c_int32(n_cells_in_coarsest_level), C.c_int32(merge_levels), int(forward), C.byref(h)))
     out = []
     try:
         for lvl in range(int(lib().mi_gamg_host_n_levels(h))):

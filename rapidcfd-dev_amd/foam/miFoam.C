@@ -100,20 +100,20 @@ mi_addr_t lduAddressing::handle() const
     }
     return addr_;
 }
-mi_gamg_t lduAddressing::agglomeration(const scalarField& w, label nCoarsest) const
+mi_gamg_t lduAddressing::agglomeration(const scalarField& w, label nCoarsest, label mergeLevels) const
 {
-    if (gamg_ && gamgCoarsest_ != nCoarsest) { mi_gamg_destroy(gamg_); gamg_ = nullptr; }
+    if (gamg_ && (gamgCoarsest_ != nCoarsest || gamgMerge_ != mergeLevels)) { mi_gamg_destroy(gamg_); gamg_ = nullptr; }
     if (!gamg_) {
         if ((label)w.size() != (label)lower_.size()) FatalErrorIn("lduAddressing::agglomeration", "face weights do not match the number of faces");
         if (hasProcessorPatches() || Pstream::parRun()) {
             if (!Pstream::parRun()) FatalErrorIn("GAMGAgglomeration::New", "processor patches outside a parallel run (Pstream::init)");
             std::vector<label> pr, pn;
             for (const lduInterface& i : interfaces_) { pr.push_back(i.neighbProcNo); pn.push_back(i.neighbPatchID); }
-            miCheck(mi_gamg_create_coupled(handle(), w.data(), nCoarsest, 1, Pstream::reduceComm(), Pstream::haloComm(),
+            miCheck(mi_gamg_create_coupled(handle(), w.data(), nCoarsest, mergeLevels, 1, Pstream::reduceComm(), Pstream::haloComm(),
                                            pr.data(), pn.data(), &gamg_), "GAMGAgglomeration::New");
         } else
-        miCheck(mi_gamg_create(handle(), w.data(), nCoarsest, 1, &gamg_), "GAMGAgglomeration::New");
-        gamgCoarsest_ = nCoarsest;
+        miCheck(mi_gamg_create(handle(), w.data(), nCoarsest, mergeLevels, 1, &gamg_), "GAMGAgglomeration::New");
+        gamgCoarsest_ = nCoarsest; gamgMerge_ = mergeLevels;
     }
     return gamg_;
 }
@@ -352,7 +352,8 @@ public:
         const label nCoarsest = controlDict_.lookupOrDefault<label>("nCellsInCoarsestLevel", -1);
         if (nCoarsest < 0) FatalErrorIn("GAMGAgglomeration::GAMGAgglomeration", "keyword nCellsInCoarsestLevel is undefined in dictionary"); // GAMGAgglomeration.C:96-99
         if (!controlDict_.found("mergeLevels")) FatalErrorIn("pairGAMGAgglomeration::pairGAMGAgglomeration", "keyword mergeLevels is undefined in dictionary");
-        if (controlDict_.lookupOrDefault<label>("mergeLevels", 1) != 1) FatalErrorIn("GAMGSolver", "mergeLevels != 1 is not supported yet");
+        const label mergeLevels = controlDict_.lookupOrDefault<label>("mergeLevels", 1);
+        if (mergeLevels < 1) FatalErrorIn("pairGAMGAgglomeration::pairGAMGAgglomeration", "mergeLevels must be positive");
         const word sm = controlDict_.lookupOrDefault<word>("smoother", "GaussSeidel");
         if (sm != "GaussSeidel" && sm != "Jacobi") FatalErrorIn("lduMatrix::smoother::New", "Unknown smoother " + sm);
         scalarField w;
@@ -362,7 +363,7 @@ public:
             if (!faceWeights_) FatalErrorIn("faceAreaPairGAMGAgglomeration", "no face-area weights registered for this mesh (" + key + ")");
             w = *faceWeights_;
         } else FatalErrorIn("GAMGAgglomeration::New", "Unknown GAMGAgglomeration type " + agg);
-        mi_gamg_t g = matrix_.lduAddr().agglomeration(w, nCoarsest);
+        mi_gamg_t g = matrix_.lduAddr().agglomeration(w, nCoarsest, mergeLevels);
         mi_gamg_controls c;
         c.tolerance = tolerance_; c.relTol = relTol_; c.maxIter = maxIter_; c.minIter = minIter_;
         c.nPreSweeps = controlDict_.lookupOrDefault<label>("nPreSweeps", 0);

@@ -36,6 +36,51 @@ def test_engine_hierarchy_equals_oracle(pkg, orc, kind, ncoarsest, forward):
     assert H.level(H.n_levels - 1)["n_coarse"] >= ncoarsest
 
 
+@pytest.mark.parametrize("kind", ["box", "graph"])
+@pytest.mark.parametrize("merge", [2, 3])
+def test_merge_levels_folds_consecutive_pair_steps(pkg, orc, kind, merge):
+    """mergeLevels m (pairGAMGAgglomerate.C:110-117 -> GAMGAgglomeration::combineLevels): the pair steps are the same as
+    with mergeLevels 1; created level k is steps m*k .. m*k+m-1 composed; the face map follows the composition and its
+    flip is the LAST step's flip (the reference drops the earlier ones, GAMGAgglomerateLduAddressing.C:624-629).
+    Oracle and engine builders (independent restatements) must agree exactly."""
+    if kind == "box":
+        case = pkg.synthetic.box_case(14, 11, 9); w = orc.box_face_weights(case)
+    else:
+        case = random_graph_case(pkg, 800); w = graph_weights(pkg, case)
+    H1 = orc.GamgHierarchy(case, w, 6, True)
+    Hm = orc.GamgHierarchy(case, w, 6, True, merge_levels=merge)
+    E = pkg.engine.gamg_host_hierarchy(case.n_cells, case.lower_addr, case.upper_addr, w, 6, True, merge_levels=merge)
+    assert Hm.n_levels == len(E) == -(-H1.n_levels // merge) and Hm.forward_out == H1.forward_out
+    for k in range(Hm.n_levels):
+        steps = [H1.level(l) for l in range(merge * k, min(merge * k + merge, H1.n_levels))]
+        rm = steps[0]["restrict"].copy(); fr = steps[0]["face_restrict"].copy(); flip = steps[0]["face_flip"].copy()
+        for st in steps[1:]:
+            pos = fr >= 0
+            cell_of_interior = -fr[~pos] - 1
+            new_fr = np.empty_like(fr); new_flip = np.zeros_like(flip)
+            new_fr[pos] = st["face_restrict"][fr[pos]]; new_flip[pos] = st["face_flip"][fr[pos]]
+            new_fr[~pos] = -st["restrict"][cell_of_interior] - 1
+            fr, flip, rm = new_fr, new_flip, st["restrict"][rm]
+        o, e = Hm.level(k), E[k]
+        assert np.array_equal(o["restrict"], rm) and np.array_equal(o["face_restrict"], fr)
+        used = fr >= 0
+        assert np.array_equal(o["face_flip"][used], flip[used])
+        assert np.array_equal(o["lower"], steps[-1]["lower"]) and np.array_equal(o["upper"], steps[-1]["upper"])
+        assert np.array_equal(e["restrictMap"], o["restrict"]) and np.array_equal(e["faceRestrict"], o["face_restrict"])
+        assert np.array_equal(e["faceFlip"].astype(bool)[used], o["face_flip"][used])
+        assert np.array_equal(e["cLower"], o["lower"]) and np.array_equal(e["cUpper"], o["upper"])
+        cnt = np.bincount(o["restrict"], minlength=o["n_coarse"])
+        assert np.array_equal(np.diff(e["cellChildStart"]), cnt) and cnt.min() >= 1
+
+
+def test_merge_levels_oracle_solves(pkg, orc):
+    case = pkg.synthetic.box_case(16, 12, 10)
+    w = orc.box_face_weights(case)
+    _, p1 = orc.GamgHierarchy(case, w, 10).solve(np.zeros(case.n_cells), case.source, tolerance=1e-9, maxIter=100)
+    _, p2 = orc.GamgHierarchy(case, w, 10, merge_levels=2).solve(np.zeros(case.n_cells), case.source, tolerance=1e-9, maxIter=100)
+    assert p1["converged"] and p2["converged"] and p2["nIterations"] <= 3 * p1["nIterations"]
+
+
 def test_coarse_matrix_is_galerkin_by_summation(pkg, orc):
     # piecewise-constant restriction R: coarse A = R A R^T (GAMGSolverAgglomerateMatrix.C)
     case = pkg.synthetic.box_case(8, 7, 6, symmetric=False)
@@ -125,7 +170,8 @@ def test_engine_gamg_operators_bit_exact(pkg, orc, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,kw", [("box_sym", {}), ("box_sym", dict(nPreSweeps=1)), ("box_sym", dict(scaleCorrection=0)),
                                      ("box_asym", {}), ("graph_sym", {}), ("box_sym", dict(tolerance=0.0, maxIter=4)),
-                                     ("box_sym", dict(tolerance=1e30, minIter=2))])
+                                     ("box_sym", dict(tolerance=1e30, minIter=2)), ("box_sym", dict(merge_levels=2)),
+                                     ("box_asym", dict(merge_levels=2)), ("graph_sym", dict(merge_levels=3, nPreSweeps=1))])
 def test_engine_gamg_history(pkg, orc, name, kw):
     import torch
     eng = pkg.engine
@@ -136,12 +182,14 @@ def test_engine_gamg_history(pkg, orc, name, kw):
     else:
         case = pkg.synthetic.box_case(24, 20, 16, symmetric=(name == "box_sym")); w = orc.box_face_weights(case)
     args = dict(tolerance=1e-9, maxIter=100); args.update(kw)
-    H = orc.GamgHierarchy(case, w, 10)
+    merge = args.pop("merge_levels", 1)
+    H = orc.GamgHierarchy(case, w, 10, merge_levels=merge)
     ref_psi, ref = H.solve(np.zeros(case.n_cells), case.source, **args)
     addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
     mat = eng.Matrix(addr)
     mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
-    G = eng.Gamg(addr, w, 10)
+    G = eng.Gamg(addr, w, 10, merge_levels=merge)
+    assert G.n_levels == H.n_levels
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = G.solve(mat, psi, dev(case.source), **args)
     assert perf["nIterations"] == ref["nIterations"] and perf["converged"] == ref["converged"]
@@ -206,7 +254,7 @@ def test_oracle_gamg_cyclic(pkg, orc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["cyclic", "processor_to_self"])
-@pytest.mark.parametrize("symmetric,kw", [(True, {}), (True, dict(nPreSweeps=1)), (False, {})])
+@pytest.mark.parametrize("symmetric,kw", [(True, {}), (True, dict(nPreSweeps=1)), (False, {}), (True, dict(merge_levels=2)), (False, dict(merge_levels=2))])
 def test_engine_gamg_coupled_patches(pkg, orc, mode, symmetric, kw):
     """GAMG on a matrix with coupled patches: 'cyclic' = local patches (cyclicGAMGInterface), 'processor_to_self' = the
     same periodic box posed with processor patches whose neighbour rank is this rank, on a 1-rank RCCL communicator --
@@ -220,7 +268,8 @@ def test_engine_gamg_coupled_patches(pkg, orc, mode, symmetric, kw):
     w = orc.box_face_weights(case)
     S = orc.System([case])
     args = dict(tolerance=1e-9, maxIter=100); args.update(kw)
-    H = orc.GamgSysHierarchy(S, [w], 10)
+    merge = args.pop("merge_levels", 1)
+    H = orc.GamgSysHierarchy(S, [w], 10, merge_levels=merge)
     ref_psi, ref = H.solve(np.zeros(case.n_cells), case.source, **args)
     fcs = [i.face_cells for i in case.interfaces]
     comm = None
@@ -233,11 +282,11 @@ def test_engine_gamg_coupled_patches(pkg, orc, mode, symmetric, kw):
     for p, itf in enumerate(case.interfaces):
         mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if symmetric else dev(itf.int_coeffs))
     if mode == "cyclic":
-        G = eng.Gamg(addr, w, 10)
+        G = eng.Gamg(addr, w, 10, merge_levels=merge)
     else:
         comm = eng.Comm(ctx, 1, 0, eng.Comm.unique_id())
         mat.attach_comm(comm, comm, [0, 0], [1, 0], n_global=case.n_cells)
-        G = eng.Gamg(addr, w, 10, comms=(comm, comm), patch_rank=[0, 0], patch_nbr_patch=[1, 0])
+        G = eng.Gamg(addr, w, 10, comms=(comm, comm), patch_rank=[0, 0], patch_nbr_patch=[1, 0], merge_levels=merge)
     assert G.n_levels == H.n_levels
     for l in range(G.n_levels):
         o, e = H.level(0, l), G.level_sizes(l)
