@@ -319,6 +319,9 @@ int mi_vec_div(mi_ctx_t ctx, int64_t n, const double *x_dev, const double *y_dev
 int mi_patch_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_patch_faces, const int32_t *face_cells_host, mi_patch_t *out);
 int mi_patch_destroy(mi_patch_t patch);
 int mi_patch_add(mi_patch_t patch, const double *pf_dev, double *intf_dev, int fn);
+/* coupled part of fvMatrix::addBoundarySource (fvMatrix.C:318-346; used by fvMatrix::H, :1458-1506):
+ * intf[faceCells[i]] +=(fn 0) / -=(fn 1) pf[i]*q[i], e.g. boundaryCoeffs * patchNeighbourField.            */
+int mi_patch_add_product(mi_patch_t patch, const double *pf_dev, const double *q_dev, double *intf_dev, int fn);
 /* boundary part of fvMatrix::flux (fvMatrix.C:1621-1653): flux[i] = internalCoeffs[i]*psi[faceCells[i]] -
  * boundaryCoeffs[i] * patchNeighbourField[i]  (coupled patch) | - boundaryCoeffs[i]  (NULL neighbour field: not coupled).
  * The internal-face part of flux() is mi_faceH.                                                                      */

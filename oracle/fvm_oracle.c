@@ -82,6 +82,16 @@ void orc_patch_add(label nPatchFaces, const label *faceCells, const scalar *pf, 
 }
 
 /* relax, scalar Type.  coupled[p] != 0: processor-like patch. */
+/* coupled part of fvMatrix::addBoundarySource (fvMatrix.C:318-346): cmptMultiply(pbc, pnf) is a rounded temporary field,
+ * then addToInternalField adds it face by face */
+void orc_patch_add_product(label nPatchFaces, const label *faceCells, const scalar *pf, const scalar *q, int fn, scalar *intf)
+{
+    for (label i = 0; i < nPatchFaces; i++) {
+        volatile scalar v = pf[i] * q[i];
+        intf[faceCells[i]] += fn == 0 ? v : -v;
+    }
+}
+
 /* boundary part of fvMatrix::flux (fvMatrix.C:1621-1653): InternalContrib = internalCoeffs*patchInternalField,
  * NeighbourContrib = boundaryCoeffs (*patchNeighbourField when coupled), flux = InternalContrib - NeighbourContrib.
  * Three separate field operations in the reference, hence three roundings (no fma).                                */

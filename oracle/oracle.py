@@ -375,6 +375,13 @@ def patch_add(face_cells, pf, intf, fn=0):
     return out
 
 
+def patch_add_product(face_cells, pf, q, intf, fn=0):
+    fc = _i(face_cells)
+    out = _d(intf).copy()
+    lib().orc_patch_add_product(C.c_int32(fc.shape[0]), _p(fc, C.c_int32), _p(_d(pf), C.c_double), _p(_d(q), C.c_double), int(fn), _p(out, C.c_double))
+    return out
+
+
 def patch_flux(face_cells, internal_coeffs, boundary_coeffs, psi, patch_neighbour_field=None):
     """boundary part of fvMatrix::flux (fvMatrix.C:1621-1653)"""
     fc = _i(face_cells)

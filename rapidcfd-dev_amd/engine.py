@@ -60,7 +60,7 @@ SYMBOLS = [
     "mi_gamg_solve", "mi_gamg_restrict", "mi_gamg_prolong", "mi_gamg_level_coeffs",
     "mi_gamg_host_build", "mi_gamg_host_n_levels", "mi_gamg_host_array", "mi_gamg_host_free",
     "mi_row_face_op", "mi_fvm_laplacian", "mi_fvm_div", "mi_surface_integrate", "mi_face_interpolate",
-    "mi_patch_create", "mi_patch_destroy", "mi_patch_add", "mi_patch_flux", "mi_relax",
+    "mi_patch_create", "mi_patch_destroy", "mi_patch_add", "mi_patch_add_product", "mi_patch_flux", "mi_relax",
 ]
 
 
@@ -530,6 +530,10 @@ class Patch:
 
     def add(self, pf, intf, fn: int = 0):
         _chk(lib().mi_patch_add(self.h, _ptr(pf), _ptr(intf), int(fn)))
+
+    def add_product(self, pf, q, intf, fn: int = 0):
+        """intf[faceCells] += pf*q (coupled part of addBoundarySource)"""
+        _chk(lib().mi_patch_add_product(self.h, _ptr(pf), _ptr(q), _ptr(intf), int(fn)))
 
     def flux(self, internal_coeffs, boundary_coeffs, psi, out, patch_neighbour_field=None):
         """boundary part of fvMatrix::flux; patch_neighbour_field only for coupled patches"""

@@ -412,11 +412,15 @@ void fvScalarMatrix::addBoundaryDiag(scalargpuField& diag) const
     for (std::size_t p = 0; p < patchFaceCells_.size(); ++p)
         miCheck(mi_patch_add(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]), internalCoeffs_[p].data(), diag.data(), 0), "fvMatrix::addBoundaryDiag");
 }
-void fvScalarMatrix::addBoundarySource(scalargpuField& source) const
+void fvScalarMatrix::addBoundarySource(scalargpuField& source, const std::vector<const scalargpuField*>& patchNeighbourField) const
 {
-    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p)
+    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p) {
         if (!patchCoupled_[p])
             miCheck(mi_patch_add(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]), boundaryCoeffs_[p].data(), source.data(), 0), "fvMatrix::addBoundarySource");
+        else if (p < patchNeighbourField.size() && patchNeighbourField[p])
+            miCheck(mi_patch_add_product(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]), boundaryCoeffs_[p].data(),
+                                         patchNeighbourField[p]->data(), source.data(), 0), "fvMatrix::addBoundarySource");
+    }
 }
 void fvScalarMatrix::relax(scalar alpha, const scalargpuField& psi)
 {
@@ -522,13 +526,14 @@ void fvScalarMatrix::A(scalargpuField& Aphi, const scalargpuField& V) const
     addBoundaryDiag(Aphi);
     miCheck(mi_vec_div(miEngine::New().ctx, Aphi.size(), Aphi.data(), V.data(), Aphi.data()), "fvMatrix::A");
 }
-void fvScalarMatrix::H(scalargpuField& Hphi, const scalargpuField& psi, const scalargpuField& V) const
+void fvScalarMatrix::H(scalargpuField& Hphi, const scalargpuField& psi, const scalargpuField& V,
+                       const std::vector<const scalargpuField*>& patchNeighbourField) const
 {
     static const FieldFieldScalar none; static const lduInterfaceFieldPtrsList noIfs;
     miCheck(mi_H(handle(none, none, noIfs), psi.data(), Hphi.data()), "lduMatrix::H");
     mi_ctx_t ctx = miEngine::New().ctx;
     miCheck(mi_vec_axpby(ctx, Hphi.size(), 1.0, Hphi.data(), 1.0, source_.data(), Hphi.data()), "fvMatrix::H");
-    addBoundarySource(Hphi);
+    addBoundarySource(Hphi, patchNeighbourField);
     miCheck(mi_vec_div(ctx, Hphi.size(), Hphi.data(), V.data(), Hphi.data()), "fvMatrix::H");
 }
 void fvScalarMatrix::flux(scalargpuField& internalFlux, FieldFieldScalar& boundaryFlux, const scalargpuField& psi,

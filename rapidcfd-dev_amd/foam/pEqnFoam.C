@@ -113,6 +113,20 @@ int main(int argc, char** argv)
                 for (const scalargpuField& b : bfl) for (scalar v : b.asHost()) sb += v;
                 Info << "flux(Ux) sumMag max boundarySum: " << sf << " " << mf << " " << sb << std::endl;
             }
+            {   // fvMatrix::H with a coupled patch: addBoundarySource(couples) adds boundaryCoeffs*patchNeighbourField (fvMatrix.C:318-346)
+                std::vector<bool> cpl(6, false); cpl[1] = true;                                  // x-max treated as a coupled patch
+                fvScalarMatrix CEqn("Ux", addr, patches, cpl);
+                CEqn += UEqn;
+                scalarField bc1(patches[1].size()), nbr1(patches[1].size());
+                for (std::size_t i = 0; i < patches[1].size(); ++i) { bc1[i] = 0.25 * h * (1.0 + 0.5 * splitmixUniform(4242, (label)i)); nbr1[i] = splitmixUniform(4343, (label)i) - 0.5; }
+                CEqn.boundaryCoeffs()[1] = bc1;
+                scalargpuField V(scalarField(n, h * h * h)), Hphi(n), U0(src), nbrField(nbr1);
+                std::vector<const scalargpuField*> pnf(6, nullptr); pnf[1] = &nbrField;
+                CEqn.H(Hphi, U0, V, pnf);
+                scalar sh = 0, mh = 0;
+                for (scalar v : Hphi.asHost()) { sh += v; mh = std::max(mh, std::fabs(v)); }
+                Info << "H(Ux) coupled sum max: " << sh << " " << mh << std::endl;
+            }
             scalargpuField psi(n);
             UEqn.relax(0.7, psi);
             UEqn.solve(psi, dictionary{{"solver", "PBiCG"}, {"preconditioner", "diagonal"}, {"tolerance", "1e-10"}, {"relTol", "0"}});

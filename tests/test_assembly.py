@@ -116,6 +116,13 @@ def test_engine_assembly_bit_exact(pkg, orc, dims):
     asm.relax(0.7, d, dev(case.lower), dev(case.upper), s, dev(psi), ph, [dev(a) for a in ic], [dev(a) for a in bc], coupled)
     rd, rs = orc.relax(n, lo, up, 0.7, case.diag, case.lower, case.upper, case.source, psi, patches, ic, bc, coupled)
     assert np.array_equal(host(d), rd) and np.array_equal(host(s), rs)
+    # coupled part of addBoundarySource (fvMatrix::H): source[faceCells] += boundaryCoeffs * patchNeighbourField
+    srcd, sref = dev(case.source), case.source.copy()
+    for k, (p, h) in enumerate(zip(patches, ph)):
+        nbr = syn.splitmix_uniform(70 + k, p.shape[0])
+        h.add_product(dev(bc[k]), dev(nbr), srcd, k % 2)
+        sref = orc.patch_add_product(p, bc[k], nbr, sref, k % 2)
+    assert np.array_equal(host(srcd), sref)
     # boundary part of fvMatrix::flux: coupled patches multiply boundaryCoeffs by the neighbour field, the others do not
     for k, (p, h) in enumerate(zip(patches, ph)):
         nbr = syn.splitmix_uniform(60 + k, p.shape[0]) if coupled[k] else None

@@ -76,6 +76,15 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     assert m, out.stdout
     assert abs(float(m.group(1)) - np.abs(fh).sum()) < 1e-11 * np.abs(fh).sum() and abs(float(m.group(2)) - np.max(np.abs(fh))) < 1e-14 * np.max(np.abs(fh))
     assert abs(float(m.group(3)) - bsum) < 1e-11 * np.abs(src[xmin]).sum() * 2.0 * h
+    # fvMatrix::H with x-max as a coupled patch: + boundaryCoeffs * patchNeighbourField on its cells
+    xmax_c = np.nonzero(np.arange(n) % dims[0] == dims[0] - 1)[0]
+    idx = np.arange(xmax_c.shape[0])
+    bc1 = 0.25 * h * (1.0 + 0.5 * syn.splitmix_at(4242, idx)); nbr1 = syn.splitmix_at(4343, idx) - 0.5
+    hc = orc.System([syn.LduCase(n, case.lower_addr, case.upper_addr, ud, uu, ul, src)]).H(src) + src
+    hc = orc.patch_add_product(xmax_c, bc1, nbr1, hc, 0) / V
+    m = re.search(r"H\(Ux\) coupled sum max: (\S+) (\S+)", out.stdout)
+    assert m, out.stdout
+    assert abs(float(m.group(1)) - hc.sum()) < 1e-9 * np.abs(hc).sum() and abs(float(m.group(2)) - np.max(np.abs(hc))) < 1e-13 * np.max(np.abs(hc))
     rd, rs = orc.relax(n, case.lower_addr, case.upper_addr, 0.7, ud, ul, uu, src, z, [xmin], [np.full(xmin.shape[0], 2.0 * h)],
                        [np.zeros(xmin.shape[0])], [0])
     rd_solve = orc.patch_add(xmin, np.full(xmin.shape[0], 2.0 * h), rd, 0)
