@@ -394,6 +394,11 @@ int mi_comm_allreduce_sum(mi_comm_t comm, double *buf_dev, int64_t n);
 int mi_matrix_attach_comm(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,
                           const int32_t *patch_nbr_patch_or_null, int64_t n_global_cells);
 int mi_matrix_detach_comm(mi_matrix_t m);
+/* coupledFvPatchField::patchNeighbourField (processorFvPatchField.C:107-135, cyclicFvPatchField.C:109-150): psi in the
+ * cell across every interface face, n_ext values in caller patch order.  Cyclic patches read the partner cells;
+ * processor patches exchange over the attached halo communicator (all ranks call together) -- what the coupled parts
+ * of fvMatrix::flux / H consume (mi_patch_flux, mi_patch_add_product).                                           */
+int mi_matrix_patch_neighbour_field(mi_matrix_t m, const double *psi_dev, double *nbr_out_dev);
 int mi_dpcg_comm_begin(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,
                        const int32_t *patch_nbr_patch_or_null, int64_t n_global_cells);
 int mi_dpcg_comm_iterate(mi_matrix_t m, int32_t n_iters, int32_t record_amul_events);

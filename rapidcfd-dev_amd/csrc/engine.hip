@@ -94,6 +94,7 @@ struct mi_addr_s {
     std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
     int32_t nInterior = 0, nBoundary = 0, nLocalPatches = 0;
     std::vector<char> patchIsLocal; // [nPatches] cyclic (local) coupled patch: no exchange
+    DevBuf<int32_t> ifaceNbrCaller; // [nExt] caller cell across every LOCAL interface face, -1 for remote faces (lazy)
     std::vector<std::vector<int32_t>> patchFaceCellsHost, patchNbrCellsHost; // caller order (GAMG interface agglomeration)
     int64_t nEntries = 0, nHaloTot = 0;
 };

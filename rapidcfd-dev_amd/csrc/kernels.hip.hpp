@@ -372,6 +372,15 @@ __global__ void k_halo_pack(const double* __restrict__ x, const int32_t* __restr
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) send[i] = x[cells[i]];
 }
+// patchNeighbourField: local (cyclic) faces read the partner cell, remote faces the received ext value
+__global__ void k_patch_nbr_field(const double* __restrict__ psi, const int32_t* __restrict__ nbrCell, const double* __restrict__ ext,
+                                  double* __restrict__ out, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = nbrCell[i];
+        out[i] = c >= 0 ? psi[c] : ext[i];
+    }
+}
 __global__ void k_faceH(const double* __restrict__ psi, const int32_t* __restrict__ lo, const int32_t* __restrict__ up,
                         const int32_t* __restrict__ faceSlot, const double* __restrict__ upE,
                         const double* __restrict__ lowE, double* __restrict__ out, int nFaces)

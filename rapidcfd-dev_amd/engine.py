@@ -42,7 +42,7 @@ SYMBOLS = [
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
-    "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm",
+    "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm", "mi_matrix_patch_neighbour_field",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
     "mi_addr_create", "mi_addr_create_coupled", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
     "mi_addr_n_ext", "mi_addr_cell_perm", "mi_addr_stats", "mi_addr_patch_offsets",
@@ -297,6 +297,10 @@ class Matrix:
 
     def H1(self, out):
         _chk(lib().mi_H1(self.h, _ptr(out)))
+
+    def patch_neighbour_field(self, psi, out):
+        """psi across every interface face (n_ext values, caller patch order); exchanges when a communicator is attached"""
+        _chk(lib().mi_matrix_patch_neighbour_field(self.h, _ptr(psi), _ptr(out)))
 
     def norm_factor(self, psi, source, Apsi):
         out = C.c_double(0.0)

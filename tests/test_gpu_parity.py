@@ -382,6 +382,9 @@ def test_cyclic_interfaces(pkg, orc, ctx, symmetric):
     mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
     mat.sumA(out); assert np.array_equal(host(out), S.sumA())
     mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
+    nbr = torch.empty(sum(len(f) for f in fcs), dtype=torch.float64, device="cuda:0")
+    mat.patch_neighbour_field(dev(x), nbr)                                   # cyclic: the partner patch's internal values
+    assert np.array_equal(host(nbr), np.concatenate([x[q] for q in nbrs]))
     mat.H(dev(x), out); assert np.array_equal(host(out), S.H(x))           # H and H1 are face sums: no interface terms
     mat.H1(out); assert np.array_equal(host(out), S.H1())
     psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 2)
@@ -483,6 +486,10 @@ def test_attached_comm_operators_and_solvers(pkg, orc, ctx, symmetric):
     mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
     psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 3)
     assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 3))
+    # patchNeighbourField through the halo exchange: the other side of patch p is patch nbr_patch's faceCells
+    nbr = torch.empty(sum(i.face_cells.shape[0] for i in case.interfaces), dtype=torch.float64, device="cuda:0")
+    mat.patch_neighbour_field(dev(x), nbr)
+    assert np.array_equal(host(nbr), np.concatenate([x[case.interfaces[i.nbr_patch].face_cells] for i in case.interfaces]))
 
     def run(fn_eng, fn_orc, **kw):
         psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
