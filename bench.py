@@ -50,10 +50,10 @@ def traffic_from_profile(nx, ny, nz, n_gpus):
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if rec.get("workload") == f"{nx}x{ny}x{nz}" and rec.get("n_gpus") == n_gpus:
-            return float(rec["amul_traffic_bytes_per_launch"])
+            return float(rec["amul_traffic_bytes_per_launch"]), str(rec.get("source", "profiles/traffic_latest.json")).split(" ")[0]
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def cpu_baseline(case, syn, iters):
@@ -243,9 +243,10 @@ def main():
             "kernel": "tile_kernel<OP_AMUL> (lduMatrix::Amul)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": amul_bytes, "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_m_rocprof_summary.md)",
+            "algorithmic_bytes_per_launch": amul_bytes,
+            "traffic_unit": f"bytes per launch (rocprofv3 PMC, {traffic_from_profile(nx, ny, nz, n_gpus)[1]})",
             "avg_launch_us": amul_avg_s * 1e6,
-            "traffic": traffic_from_profile(nx, ny, nz, n_gpus),
+            "traffic": traffic_from_profile(nx, ny, nz, n_gpus)[0],
         },
     }
     if rank == 0:
