@@ -244,6 +244,9 @@ static void prolong_field(const gamg_level *L, const scalar *cf, scalar *ff)
     for (label i = 0; i < L->nFine; i++) ff[i] = cf[L->restrictMap[i]];
 }
 
+void orc_gamg_restrict_level(const gamg_hier *H, int l, const scalar *ff, scalar *cf) { restrict_field(&H->lev[l], ff, cf); }
+void orc_gamg_prolong_level(const gamg_hier *H, int l, const scalar *cf, scalar *ff) { prolong_field(&H->lev[l], cf, ff); }
+
 /* coarse matrix: GAMGSolverAgglomerateMatrix.C:65-72,218-317 (+F.H).  Sums run over the fine
  * faces in ascending index (stable sort by target).                                            */
 static void agglomerate_matrix(const gamg_level *L, int asym, const scalar *fDiag, const scalar *fUpper,

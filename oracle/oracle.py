@@ -265,6 +265,18 @@ class GamgHierarchy:
         return dict(n_fine=nf, n_fine_faces=nff, n_coarse=nc, n_coarse_faces=ncf, restrict=rm, face_restrict=fr,
                     face_flip=ff.astype(bool), lower=cl, upper=cu)
 
+    def restrict(self, l, ff):
+        lv = self.level(l)
+        cf = np.empty(lv["n_coarse"])
+        lib().orc_gamg_restrict_level(self.h, l, _p(_d(ff), C.c_double), _p(cf, C.c_double))
+        return cf
+
+    def prolong(self, l, cf):
+        lv = self.level(l)
+        ff = np.empty(lv["n_fine"])
+        lib().orc_gamg_prolong_level(self.h, l, _p(_d(cf), C.c_double), _p(ff, C.c_double))
+        return ff
+
     def coarse_matrix(self, up_to_level):
         cs = self.case
         lv = self.level(up_to_level)
@@ -576,3 +588,57 @@ def ref_ainv_rows(case, r, transpose=False):
     L.ref_ainv_rows(C.c_int(case.n_cells), _p(_d(r), C.c_double), _p(rD, C.c_double), _p(lower, C.c_double), _p(upper, C.c_double),
                     _p(lo, C.c_int32), _p(up, C.c_int32), _p(os_, C.c_int32), _p(ls_, C.c_int32), _p(losort, C.c_int32), _p(out, C.c_double))
     return out
+
+
+REF_GAMG_FUNCTORS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_gamg_functors.so")
+
+
+def ref_gamg_functors_available() -> bool:
+    return os.path.exists(REF_GAMG_FUNCTORS_LIB)
+
+
+def _sorted_segments(addressing):
+    """createSort / createTarget (GAMGAgglomerateLduAddressing.C:37-120): stable sort of the restrict addressing, one
+    segment per distinct target"""
+    a = _i(addressing)
+    sort = np.argsort(a, kind="stable").astype(np.int32)
+    keys = a[sort]
+    first = np.concatenate([[True], keys[1:] != keys[:-1]]) if a.shape[0] else np.zeros(0, bool)
+    start = np.concatenate([np.nonzero(first)[0], [a.shape[0]]]).astype(np.int32)
+    target = keys[first].astype(np.int32)
+    return target, start, sort
+
+
+def ref_gamg_restrict(restrict_map, n_coarse, ff):
+    """GAMGAgglomeration::restrictField through the REFERENCE's GAMG::restrict functor (GAMGAgglomerationF.H, host-compiled)"""
+    L = C.CDLL(REF_GAMG_FUNCTORS_LIB)
+    target, start, sort = _sorted_segments(restrict_map)
+    cf = np.zeros(n_coarse)
+    L.ref_gamg_restrict(C.c_int(target.shape[0]), _p(target, C.c_int32), _p(start, C.c_int32), _p(sort, C.c_int32), _p(_d(ff), C.c_double), _p(cf, C.c_double))
+    return cf
+
+
+def ref_gamg_prolong(restrict_map, cf):
+    """prolongField through the REFERENCE's GAMG::prolong functor"""
+    L = C.CDLL(REF_GAMG_FUNCTORS_LIB)
+    target, start, sort = _sorted_segments(restrict_map)
+    ff = np.full(_i(restrict_map).shape[0], np.nan)
+    L.ref_gamg_prolong(C.c_int(target.shape[0]), _p(target, C.c_int32), _p(start, C.c_int32), _p(sort, C.c_int32), _p(_d(cf), C.c_double), _p(ff, C.c_double))
+    return ff
+
+
+def ref_gamg_agglomerate_matrix(level, fine_diag, fine_upper, fine_lower=None):
+    """GAMGSolver::agglomerateMatrix (deterministic path, GAMGSolverAgglomerateMatrix.C:65-72,218-317) through the
+    REFERENCE's sym/asym/diag agglomerate functors (GAMGSolverAgglomerateMatrixF.H, host-compiled).  level: dict of
+    GamgHierarchy.level()"""
+    L = C.CDLL(REF_GAMG_FUNCTORS_LIB)
+    asym = fine_lower is not None
+    c_diag = ref_gamg_restrict(level["restrict"], level["n_coarse"], fine_diag)
+    c_up = np.zeros(level["n_coarse_faces"]); c_lo = np.zeros(level["n_coarse_faces"])
+    target, start, sort = _sorted_segments(level["face_restrict"])
+    flip = np.ascontiguousarray(level["face_flip"], dtype=np.bool_)
+    fl = _d(fine_lower if asym else fine_upper)
+    L.ref_gamg_agglomerate_matrix(C.c_int(int(asym)), C.c_int(target.shape[0]), _p(target, C.c_int32), _p(start, C.c_int32), _p(sort, C.c_int32),
+                                  _p(_d(fine_upper), C.c_double), _p(fl, C.c_double), flip.ctypes.data_as(C.c_void_p),
+                                  _p(c_diag, C.c_double), _p(c_up, C.c_double), _p(c_lo, C.c_double))
+    return c_diag, c_up, (c_lo if asym else None)

@@ -147,6 +147,34 @@ def build_functors(pkg, orc):
     return out
 
 
+def gamg_functor_cases(pkg, orc):
+    from conftest import random_graph_case
+    syn = pkg.synthetic
+    g = random_graph_case(pkg, 600, extra=3.0, symmetric=False)
+    return {"box_sym": (syn.box_case(10, 9, 8), None), "box_asym": (syn.box_case(9, 8, 7, symmetric=False), None),
+            "graph_asym": (g, 0.5 + syn.splitmix_uniform(77, g.n_faces)), "box_asym_merge2": (syn.box_case(8, 8, 6, symmetric=False), None)}
+
+
+def build_gamg_functors(pkg, orc):
+    """coarse matrices of the first levels + a restricted / prolonged field, computed by the REFERENCE's inter-level functors
+    (GAMGSolverAgglomerateMatrixF.H, GAMGAgglomerationF.H host-compiled, oracle/_ref/libref_gamg_functors.so) on the
+    oracle's restrict addressing"""
+    out = {}
+    for name, (case, w) in gamg_functor_cases(pkg, orc).items():
+        H = orc.GamgHierarchy(case, orc.box_face_weights(case) if w is None else w, 6, merge_levels=2 if name.endswith("merge2") else 1)
+        d, u, lo = case.diag, case.upper, case.lower
+        for l in range(min(3, H.n_levels)):
+            lv = H.level(l)
+            x = pkg.synthetic.splitmix_uniform(40 + l, lv["n_fine"]) - 0.5
+            out[f"{name}/{l}/restrict"] = orc.ref_gamg_restrict(lv["restrict"], lv["n_coarse"], x)
+            out[f"{name}/{l}/prolong"] = orc.ref_gamg_prolong(lv["restrict"], out[f"{name}/{l}/restrict"])
+            d, u, lo = orc.ref_gamg_agglomerate_matrix(lv, d, u, lo)
+            out[f"{name}/{l}/diag"], out[f"{name}/{l}/upper"] = d, u
+            if lo is not None:
+                out[f"{name}/{l}/lower"] = lo
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
@@ -159,4 +187,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_functors.npz"), **build_functors(pkg, orc))
     assert orc.ref_gamg_available(), "oracle/_ref/libref_gamg.so missing"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg.npz"), **build_gamg(pkg, orc))
+    assert orc.ref_gamg_functors_available(), "oracle/_ref/libref_gamg_functors.so missing"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg_functors.npz"), **build_gamg_functors(pkg, orc))
     print("written")

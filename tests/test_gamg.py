@@ -399,3 +399,34 @@ def test_vcycle_equals_the_reference_source(pkg, orc):
         now = make_golden_ref.build_gamg(pkg, orc)
         for k in G.files:
             assert np.array_equal(now[k], G[k]), k
+
+
+def test_inter_level_functors_equal_the_reference_headers(pkg, orc):
+    """GAMGSolverAgglomerateMatrixF.H (sym/asym/diag agglomerate) and GAMGAgglomerationF.H (restrict, prolong) of the
+    reference, compiled as host code and driven over the stably sorted restrict addressing as GAMGSolverAgglomerateMatrix.C
+    does (oracle/_ref/libref_gamg_functors.so), produced tests/golden/golden_ref_gamg_functors.npz.  Sums of doubles in a
+    fixed order: the oracle's Galerkin-by-summation level matrices and its restrict/prolong must give the SAME BITS,
+    symmetric and asymmetric (flips), plain and merged levels."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_gamg_functors.npz"))
+    n = 0
+    for name, (case, w) in make_golden_ref.gamg_functor_cases(pkg, orc).items():
+        H = orc.GamgHierarchy(case, orc.box_face_weights(case) if w is None else w, 6, merge_levels=2 if name.endswith("merge2") else 1)
+        for l in range(min(3, H.n_levels)):
+            lv = H.level(l)
+            x = pkg.synthetic.splitmix_uniform(40 + l, lv["n_fine"]) - 0.5
+            r = H.restrict(l, x)
+            assert np.array_equal(r, G[f"{name}/{l}/restrict"]) and np.array_equal(H.prolong(l, r), G[f"{name}/{l}/prolong"])
+            d, u, lo = H.coarse_matrix(l)
+            assert np.array_equal(d, G[f"{name}/{l}/diag"]) and np.array_equal(u, G[f"{name}/{l}/upper"])
+            if lo is not None:
+                assert np.array_equal(lo, G[f"{name}/{l}/lower"])
+            n += 1
+    assert n >= 10
+    if orc.ref_gamg_functors_available():
+        now = make_golden_ref.build_gamg_functors(pkg, orc)
+        assert set(now) == set(G.files)
+        for k in G.files:
+            assert np.array_equal(now[k], G[k]), k
