@@ -97,3 +97,130 @@ void exp_variants(TileArgs& a, const TileLayout& L, size_t lds, Run run, Check c
     if (L.compact) { run("compact entries", [&] { tile_kernel<OP_AMUL, false, false, 512, true><<<L.nTiles, 512, lds, 0>>>(a); }, y1); check("compact"); }
 }
 } // namespace mi
+
+// ---------------------------------------------------------------------------------------------------------------------
+// V3: persistent workgroups with REGISTER-STAGED PREFETCH of the next tile (single LDS image per workgroup).
+//     While the rows of tile k are computed out of LDS, the global loads of tile k+1 (coefficients, psi, halo gather) are
+//     already in flight into registers; they are committed to LDS between two barriers once tile k is done.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace mi {
+template <int BS>
+__global__ __launch_bounds__(BS) void k_amul_prefetch(const TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* cU = smem;
+    double* xs = smem + a.offX;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = BS / 64, PRE = 8, CU4 = 4, XV = 2, HV = 2;
+    const int b = blockIdx.x, G = gridDim.x, nT = a.nPos;
+    const int per = G >> 3, xc = b & 7, j = b >> 3;
+    const int x0 = (int)((long long)xc * nT / 8), x1 = (int)((long long)(xc + 1) * nT / 8);
+    const int p0 = x0 + (int)((long long)j * (x1 - x0) / per), p1 = x0 + (int)((long long)(j + 1) * (x1 - x0) / per);
+    if (p0 >= p1) return;
+
+    // registers that carry the NEXT tile
+    double2 rc[CU4]; double rx[XV]; double rh[HV];
+    int c0n, ncn, s0n, nsn, h0n, nhn, sl0n, nsln;
+    auto prefetch = [&](int t) {
+        c0n = a.tileCellStart[t]; ncn = a.tileCellStart[t + 1] - c0n;
+        s0n = a.tileSlotStart[t]; nsn = a.tileSlotStart[t + 1] - s0n;
+        h0n = a.tileHaloStart[t]; nhn = a.tileHaloStart[t + 1] - h0n;
+        sl0n = a.tileSliceStart[t]; nsln = a.tileSliceStart[t + 1] - sl0n;
+        const double2* src = reinterpret_cast<const double2*>(a.up + s0n);
+        const int ns2 = nsn >> 1;
+        int hi[HV];
+#pragma unroll
+        for (int u = 0; u < HV; ++u) { const int k = tid + u * BS; hi[u] = k < nhn ? a.haloCell[h0n + k] : 0; }
+#pragma unroll
+        for (int u = 0; u < CU4; ++u) { const int k = tid + u * BS; rc[u] = k < ns2 ? src[k] : make_double2(0.0, 0.0); }
+#pragma unroll
+        for (int u = 0; u < XV; ++u) { const int k = tid + u * BS; rx[u] = k < ncn ? a.x[c0n + k] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < HV; ++u) { const int k = tid + u * BS; rh[u] = k < nhn ? a.x[hi[u]] : 0.0; }
+    };
+    prefetch(p0);
+    for (int p = p0; p < p1; ++p) {
+        // ---- commit the prefetched tile to LDS
+        const int c0 = c0n, nc = ncn, ns = nsn, nh = nhn, sl0 = sl0n, nsl = nsln, h0 = h0n;
+        __syncthreads(); // everybody is done with the previous image
+        {
+            double2* dC = reinterpret_cast<double2*>(cU);
+            const int ns2 = ns >> 1;
+#pragma unroll
+            for (int u = 0; u < CU4; ++u) { const int k = tid + u * BS; if (k < ns2) dC[k] = rc[u]; }
+#pragma unroll
+            for (int u = 0; u < XV; ++u) { const int k = tid + u * BS; if (k < nc) xs[k] = rx[u]; }
+#pragma unroll
+            for (int u = 0; u < HV; ++u) { const int k = tid + u * BS; if (k < nh) xs[nc + k] = rh[u]; }
+            for (int k = tid + HV * BS; k < nh; k += BS) xs[nc + k] = a.x[a.haloCell[h0 + k]]; // rare: very large halos
+        }
+        // first slice entries of this tile for this wave
+        const uint32_t padEnt = (uint32_t)(ns - 1) << 16;
+        uint32_t ecur[PRE];
+        int wcur = 0, e0cur = 0;
+        auto fetch = [&](int s, uint32_t (&e)[PRE], int& e0, int& width) {
+            e0 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s]);
+            const int e1 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s + 1]);
+            width = (e1 - e0) >> 6;
+            const uint32_t* ent = a.entries + e0 + lane;
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) e[q] = (q < width) ? ent[q * 64] : padEnt;
+        };
+        if (wave < nsl) fetch(wave, ecur, e0cur, wcur);
+        __syncthreads();
+        // ---- the next tile's loads go out now and stay in flight during the row loop
+        if (p + 1 < p1) prefetch(p + 1);
+        for (int s = wave; s < nsl; s += NW) {
+            uint32_t enext[PRE];
+            int wnext = 0, e0next = 0;
+            if (s + NW < nsl) fetch(s + NW, enext, e0next, wnext);
+            else {
+#pragma unroll
+                for (int q = 0; q < PRE; ++q) enext[q] = padEnt;
+            }
+            const int i = s * 64 + lane;
+            const bool live = i < nc;
+            const int gi = c0 + (live ? i : 0);
+            const double xi = live ? xs[i] : 0.0;
+            double acc = a.diag[gi] * xi;
+            auto accumulate = [&](uint32_t en) { acc = fma(cU[(en >> 16) & 0x7FFFu], xs[en & 0xFFFFu], acc); };
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) if (q < wcur) accumulate(ecur[q]);
+            if (wcur > PRE) {
+                const uint32_t* ent = a.entries + e0cur + lane;
+                for (int q = PRE; q < wcur; ++q) accumulate(ent[q * 64]);
+            }
+            if (live) a.y[gi] = acc;
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) ecur[q] = enext[q];
+            wcur = wnext; e0cur = e0next;
+        }
+    }
+}
+
+template <class Run, class Check>
+void exp_prefetch(TileArgs& a, const TileLayout& L, size_t ldsX, Run run, Check check, double* y1)
+{
+    static bool once = false;
+    if (!once) {
+        once = true;
+        (void)hipFuncSetAttribute((const void*)k_amul_prefetch<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_amul_prefetch<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_amul_prefetch<512>, 512, ldsX);
+        printf("   prefetch kernel BS512: %d workgroups per CU by the runtime\n", nb);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_amul_prefetch<1024>, 1024, ldsX);
+        printf("   prefetch kernel BS1024: %d workgroups per CU by the runtime\n", nb);
+    }
+    for (int wg : {1, 2, 3, 4}) {
+        char name[64]; snprintf(name, sizeof(name), "prefetch BS512 %d WG/CU", wg);
+        run(name, [&] { k_amul_prefetch<512><<<256 * wg, 512, ldsX, 0>>>(a); }, y1);
+        check(name);
+    }
+    for (int wg : {1, 2}) {
+        char name[64]; snprintf(name, sizeof(name), "prefetch BS1024 %d WG/CU", wg);
+        run(name, [&] { k_amul_prefetch<1024><<<256 * wg, 1024, ldsX, 0>>>(a); }, y1);
+        check(name);
+    }
+}
+} // namespace mi
