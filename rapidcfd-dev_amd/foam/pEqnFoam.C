@@ -76,6 +76,12 @@ int main(int argc, char** argv)
                                        {"nCellsInCoarsestLevel", "10"}, {"mergeLevels", "1"}, {"tolerance", "1e-08"}, {"relTol", "0"},
                                        {"cacheAgglomeration", "true"}});
         }
+        {   // mergeLevels 2: every level folds two pair steps (GAMGAgglomeration::combineLevels); the cached hierarchy is rebuilt
+            scalargpuField psi(n);
+            pEqn.solve(psi, dictionary{{"solver", "GAMG"}, {"smoother", "GaussSeidel"}, {"agglomerator", "faceAreaPair"},
+                                       {"nCellsInCoarsestLevel", "10"}, {"mergeLevels", "2"}, {"tolerance", "1e-08"}, {"relTol", "0"},
+                                       {"cacheAgglomeration", "true"}});
+        }
         {
             scalargpuField psi(n);
             pEqn.solve(psi, dictionary{{"solver", "smoothSolver"}, {"smoother", "GaussSeidel"}, {"nSweeps", "2"}, {"tolerance", "1e-03"}, {"maxIter", "400"}});

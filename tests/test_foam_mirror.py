@@ -49,6 +49,9 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     H = orc.GamgHierarchy(syn.LduCase(n, case.lower_addr, case.upper_addr, pdiag, upper, None, src, dims=dims),
                           orc.box_face_weights(case), 10)
     _, p = H.solve(z, src, tolerance=1e-8); exp.append(("GAMG", "p", p))
+    H2 = orc.GamgHierarchy(syn.LduCase(n, case.lower_addr, case.upper_addr, pdiag, upper, None, src, dims=dims),
+                           orc.box_face_weights(case), 10, merge_levels=2)
+    _, p = H2.solve(z, src, tolerance=1e-8); exp.append(("GAMG", "p", p))
     _, p = P.smooth_solve(z, src, n_sweeps=2, tolerance=1e-3, maxIter=400); exp.append(("smoothSolver", "p", p))
     # UEqn = ddt + div(phi) - laplacian
     direction = np.where(case.upper_addr - case.lower_addr == 1, 0, 1)
