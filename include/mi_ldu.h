@@ -269,6 +269,18 @@ int mi_gamg_solve(mi_gamg_t g, mi_matrix_t m, double *psi_dev, const double *sou
  * (GAMGSolverAgglomerateMatrix.C:218-317); used by the parity tests                          */
 int mi_gamg_restrict(mi_gamg_t g, int32_t level, const double *fine_dev, double *coarse_dev);
 int mi_gamg_prolong(mi_gamg_t g, int32_t level, const double *coarse_dev, double *fine_dev);
+/* The pieces of the V-cycle as operators, for a caller that keeps the reference's GAMGSolverSolve.C and swaps only the
+ * primitives (tests/ref_dropin runs exactly that):
+ *   mi_gamg_update        agglomerateMatrix of every level from the matrix's current coefficients + the coarsest direct
+ *                         solver (the GAMGSolver constructor, GAMGSolver.C:88-172); mi_gamg_solve does it itself.
+ *   mi_gamg_level_matrix  matrixLevels_[level] as a BORROWED handle (vectors in the hierarchy's coarse-cell numbering):
+ *                         mi_amul / mi_jacobi_smooth / mi_residual ... work on it.
+ *   mi_gamg_scale         GAMGSolver::scale (GAMGSolverScale.C:59-171) on the fine or a level matrix.
+ *   mi_gamg_solve_coarsest  solveCoarsestLevel with directSolveCoarsest (GAMGSolverSolve.C:552-570), on the device.    */
+int mi_gamg_update(mi_gamg_t g, mi_matrix_t m);
+int mi_gamg_level_matrix(mi_gamg_t g, int32_t level, mi_matrix_t *level_matrix_out);
+int mi_gamg_scale(mi_matrix_t m, double *field_dev, double *Acf_dev, const double *source_dev);
+int mi_gamg_solve_coarsest(mi_gamg_t g, const double *source_dev, double *corr_dev);
 int mi_gamg_level_coeffs(mi_gamg_t g, mi_matrix_t m, int32_t level, double *diag_out_dev,
                          double *upper_out_dev, double *lower_out_dev);
 

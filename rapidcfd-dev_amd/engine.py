@@ -56,7 +56,7 @@ SYMBOLS = [
     "mi_bench_amul", "mi_bench_pcg_iters", "mi_debug_occupancy",
     "mi_layout_build_host", "mi_layout_array", "mi_layout_free",
     "mi_dpcg_set_buffers", "mi_dpcg_phase", "mi_dpcg_status", "mi_event_record", "mi_event_elapsed_ms",
-    "mi_gamg_create", "mi_gamg_destroy", "mi_gamg_n_levels", "mi_gamg_forward_out", "mi_gamg_level_sizes",
+    "mi_gamg_create", "mi_gamg_update", "mi_gamg_level_matrix", "mi_gamg_scale", "mi_gamg_solve_coarsest", "mi_gamg_destroy", "mi_gamg_n_levels", "mi_gamg_forward_out", "mi_gamg_level_sizes",
     "mi_gamg_solve", "mi_gamg_restrict", "mi_gamg_prolong", "mi_gamg_level_coeffs",
     "mi_gamg_host_build", "mi_gamg_host_n_levels", "mi_gamg_host_array", "mi_gamg_host_free",
     "mi_row_face_op", "mi_fvm_laplacian", "mi_fvm_div", "mi_surface_integrate", "mi_face_interpolate",

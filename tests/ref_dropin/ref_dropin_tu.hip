@@ -10,7 +10,7 @@
 #define REF_STR2(x) #x
 #define REF_STR(x) REF_STR2(x)
 #define REF_FILE(rel) REF_STR(REF_LDU/rel)
-namespace Foam { refContext ctx = {0, 0, 1, 0.9, 0}; int lduMatrix::debug = 0;
+namespace Foam { refContext ctx = {0, 0, 1, 0.9, 0, false}; int lduMatrix::debug = 0;
 const scalar solverPerformance::great_ = 1e20; const scalar solverPerformance::small_ = 1e-20; const scalar solverPerformance::vsmall_ = 1e-300; }
 #include REF_FILE(lduMatrix/lduMatrixSolverFunctors.H)
 #include REF_FILE(lduMatrix/lduMatrixFunctors.H)

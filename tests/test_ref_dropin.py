@@ -143,3 +143,37 @@ def test_norm_factor_matches_solver_prologue(pkg, orc, ctx):
     assert nf == perf["normFactor"]                                   # same kernels, same order: same bits
     _, perf_orc = orc.System([case]).pcg(x.copy(), case.source, "diagonal", tolerance=0.0, maxIter=1)
     assert abs(nf - perf_orc["normFactor"]) <= 1e-13 * perf_orc["normFactor"]
+
+
+@pytest.mark.parametrize("sym,kw", [(True, {}), (True, dict(nPreSweeps=1)), (True, dict(scaleCorrection=0)), (False, {}),
+                                    (True, dict(merge_levels=2))])
+def test_reference_GAMG_Vcycle_on_engine(pkg, orc, ctx, dropin, sym, kw):
+    """The reference's GAMGSolverSolve.C (solve, Vcycle, initVcycle, solveCoarsestLevel) compiled in place for gfx950 runs its
+    V-cycle on the engine's level operators: mi_gamg_level_matrix + mi_amul / mi_jacobi_smooth, mi_gamg_restrict / prolong,
+    mi_gamg_scale, mi_gamg_solve_coarsest.  Same cycles, residuals and solution as mi_gamg_solve and as the oracle."""
+    eng = pkg.engine
+    case = pkg.synthetic.box_case(24, 20, 16, symmetric=sym)
+    w = orc.box_face_weights(case)
+    addr, mat = build(pkg, ctx, case)
+    args = dict(tolerance=1e-9, maxIter=60); args.update(kw)
+    merge = args.pop("merge_levels", 1)
+    G = eng.Gamg(addr, w, 10, merge_levels=merge)
+    n = case.n_cells
+    ctl = eng.gamg_controls(**args)
+    psi = dev(np.zeros(n)); src = dev(case.source)
+    out5 = (C.c_double * 5)()
+    dropin.ref_dropin_gamg_solve.restype = None
+    dropin.ref_dropin_gamg_solve(ctx.h, G.h, mat.h, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_int(n), C.c_int(0 if sym else 1),
+                                 C.c_void_p(psi.data_ptr()), C.c_void_p(src.data_ptr()), C.byref(ctl), out5)
+    torch.cuda.synchronize()
+    psi_ref = psi.cpu().numpy()
+    pe = dev(np.zeros(n))
+    perf_eng = G.solve(mat, pe, src, **args)
+    psi_orc, perf_orc = orc.GamgHierarchy(case, w, 10, merge_levels=merge).solve(np.zeros(n), case.source, **args)
+    assert int(out5[2]) == perf_eng["nIterations"] == perf_orc["nIterations"]
+    assert bool(out5[3]) == bool(perf_eng["converged"]) == bool(perf_orc["converged"])
+    for other in (perf_eng, perf_orc):
+        assert abs(out5[0] - other["initialResidual"]) <= 1e-12 * abs(other["initialResidual"])
+        assert abs(out5[1] - other["finalResidual"]) <= 1e-6 * abs(other["finalResidual"]) + 1e-16
+    scale = np.max(np.abs(psi_orc))
+    assert np.max(np.abs(psi_ref - psi_orc)) / scale < 1e-9 and np.max(np.abs(psi_ref - pe.cpu().numpy())) / scale < 1e-9
