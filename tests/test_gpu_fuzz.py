@@ -122,3 +122,57 @@ def test_random_coupled_matrices_gamg(pkg, orc, seed, n, extra, sym, merge, kw, 
     h, hr = perf["history"], ref["history"]
     assert h.shape == hr.shape and np.max(np.abs(h - hr)) <= 1e-9 * hr[0]
     assert np.max(np.abs(host(psi) - ref_psi)) <= 1e-8 * np.max(np.abs(ref_psi))
+
+
+@pytest.mark.parametrize("seed,n,extra,sym", [(31, 500, 2.0, True), (32, 1800, 1.5, False), (33, 120, 4.0, True), (34, 2600, 2.2, False)])
+def test_random_matrices_over_rccl_self_exchange(pkg, orc, seed, n, extra, sym, monkeypatch):
+    """The same kind of ragged coupled matrix posed as a DECOMPOSED case: the two patches are processor patches whose
+    neighbour rank is this rank (1-rank RCCL communicator), so every operator packs, sends, receives and reduces for real."""
+    syn, eng = pkg.synthetic, pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    case = copy.copy(random_graph_case(pkg, n, extra=extra, seed=seed, symmetric=sym))
+    npair = max(1, n // 12)
+    u = syn.splitmix_uniform(seed + 11, 2 * npair)
+    a = (u[:npair] * n).astype(np.int32); b = (u[npair:] * n).astype(np.int32)
+    kb = -(0.05 + 0.3 * syn.splitmix_uniform(seed + 12, npair))
+    ki = kb if sym else -(0.05 + 0.3 * syn.splitmix_uniform(seed + 13, npair))
+    case.interfaces = [syn.Interface(0, 1, a, kb, ki), syn.Interface(0, 0, b, kb, ki)]
+    case.diag = case.diag + np.bincount(a, -kb, n) + np.bincount(b, -kb, n)
+    monkeypatch.setenv("MI_TILE_CELLS", "96")
+    addr = eng.Addressing(ctx, n, case.lower_addr, case.upper_addr, [a, b])            # no partner cells: processor patches
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if sym else dev(case.lower))
+    for p, itf in enumerate(case.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if sym else dev(itf.int_coeffs))
+    comm = eng.Comm(ctx, 1, 0, eng.Comm.unique_id())
+    mat.attach_comm(comm, comm, [0, 0], [1, 0], n_global=n)
+    S = orc.System([case])
+    x = syn.splitmix_uniform(seed + 7, n) - 0.5
+    xd, bd = dev(x), dev(case.source)
+    out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    mat.amul(xd, out); assert np.array_equal(host(out), S.amul(x))
+    mat.tmul(xd, out); assert np.array_equal(host(out), S.tmul(x))
+    mat.residual(xd, bd, out); assert np.array_equal(host(out), S.residual(x, case.source))
+    psi = dev(x.copy()); mat.jacobi_smooth(psi, bd, 2)
+    assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 2))
+    nbr = torch.empty(2 * npair, dtype=torch.float64, device="cuda:0")
+    mat.patch_neighbour_field(xd, nbr); assert np.array_equal(host(nbr), np.concatenate([x[b], x[a]]))
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    if sym:
+        perf = mat.pcg(psi, bd, "AINV", tolerance=1e-10, maxIter=40); ref_psi, ref = S.pcg(np.zeros(n), case.source, "AINV", tolerance=1e-10, maxIter=40)
+    else:
+        perf = mat.pbicg(psi, bd, "AINV", tolerance=1e-10, maxIter=30); ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV", tolerance=1e-10, maxIter=30)
+    assert perf["nIterations"] == ref["nIterations"]
+    assert np.max(np.abs(perf["history"] - ref["history"])) <= 1e-9 * ref["history"][0]
+    assert np.max(np.abs(host(psi) - ref_psi)) <= 1e-8 * np.max(np.abs(ref_psi))
+    w = 0.5 + syn.splitmix_uniform(seed + 5, case.n_faces)
+    H = orc.GamgSysHierarchy(S, [w], 8)
+    ref_psi, ref = H.solve(np.zeros(n), case.source, tolerance=1e-9, maxIter=30)
+    G = eng.Gamg(addr, w, 8, comms=(comm, comm), patch_rank=[0, 0], patch_nbr_patch=[1, 0])
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    perf = G.solve(mat, psi, bd, tolerance=1e-9, maxIter=30)
+    assert perf["nIterations"] == ref["nIterations"] and G.n_levels == H.n_levels
+    assert np.max(np.abs(perf["history"] - ref["history"])) <= 1e-9 * ref["history"][0]
+    assert np.max(np.abs(host(psi) - ref_psi)) <= 1e-8 * np.max(np.abs(ref_psi))
+    del G
+    mat.detach_comm(); comm.close()
