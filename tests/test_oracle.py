@@ -314,3 +314,27 @@ def test_row_functors_match_the_reference_headers(pkg, orc):
         now = make_golden_ref.build_functors(pkg, orc)
         for k in G.files:
             assert np.array_equal(now[k], G[k]), k
+
+
+def test_cg_iteration_count_obeys_the_spectral_bound(pkg, orc):
+    """sanity of the oracle's PCG against theory.  For the SPD matrix -A of a small box the classical bound
+    says the A-norm error falls by 2((sqrt(k)-1)/(sqrt(k)+1))^i; with the exact spectrum from numpy the unpreconditioned
+    oracle CG must reach a 1e-8 residual within that many iterations (plus slack for the different norm), converge to the
+    dense solution, and need FEWER iterations with the diagonal and AINV preconditioners' better-conditioned operators."""
+    case = pkg.synthetic.box_case(9, 7, 5)
+    n = case.n_cells
+    A = np.zeros((n, n)); A[np.arange(n), np.arange(n)] = case.diag
+    A[case.lower_addr, case.upper_addr] = case.upper; A[case.upper_addr, case.lower_addr] = case.upper
+    lam = np.linalg.eigvalsh(-A) if np.all(np.linalg.eigvalsh(A) < 0) else np.linalg.eigvalsh(A)
+    assert lam.min() > 0
+    kappa = lam.max() / lam.min()
+    eps = 1e-8
+    bound = int(np.ceil(0.5 * np.sqrt(kappa) * np.log(2.0 / eps)))
+    S = orc.System([case])
+    psi, p = S.pcg(np.zeros(n), case.source, "none", tolerance=eps, maxIter=10 * n)
+    assert p["converged"] and p["nIterations"] <= int(1.5 * bound) + 5, (p["nIterations"], bound, kappa)
+    ref = np.linalg.solve(A, case.source)
+    assert np.max(np.abs(psi - ref)) < 1e-6 * np.max(np.abs(ref))
+    _, pd = S.pcg(np.zeros(n), case.source, "diagonal", tolerance=eps, maxIter=10 * n)
+    _, pa = S.pcg(np.zeros(n), case.source, "AINV", tolerance=eps, maxIter=10 * n)
+    assert pd["converged"] and pa["converged"] and pa["nIterations"] < pd["nIterations"] <= p["nIterations"] + 2
