@@ -179,6 +179,22 @@ void lduMatrix::sumA(scalargpuField& s, const FieldFieldScalar& b, const lduInte
 {
     sync(&b, nullptr, &ifs); miCheck(mi_sumA(mat_, s.data()), "lduMatrix::sumA");
 }
+void lduMatrix::patchNeighbourField(FieldFieldScalar& nbr, const scalargpuField& psi, const FieldFieldScalar& b, const lduInterfaceFieldPtrsList& ifs) const
+{
+    sync(&b, nullptr, &ifs);
+    label nExt = 0;
+    for (const lduInterfaceField* f : ifs) nExt += (label)f->faceCells.size();
+    scalargpuField all(nExt);
+    miCheck(mi_matrix_patch_neighbour_field(mat_, psi.data(), all.data()), "coupledFvPatchField::patchNeighbourField");
+    const std::vector<scalar> h = all.asHost();
+    nbr.clear();
+    std::size_t off = 0;
+    for (const lduInterfaceField* f : ifs) {
+        const std::size_t n = f->faceCells.size();
+        nbr.push_back(scalargpuField(scalarField(h.begin() + (std::ptrdiff_t)off, h.begin() + (std::ptrdiff_t)(off + n))));
+        off += n;
+    }
+}
 void lduMatrix::residual(scalargpuField& rA, const scalargpuField& psi, const scalargpuField& source, const FieldFieldScalar& b,
                          const lduInterfaceFieldPtrsList& ifs, direction) const
 {
@@ -632,6 +648,14 @@ void Pstream::exit()
     if (P.halo) mi_comm_destroy(P.halo);
     if (P.red) mi_comm_destroy(P.red);
     P = PstreamState();
+}
+scalar Pstream::returnReduceSum(scalar v)
+{
+    if (!parRun()) return v;
+    scalargpuField t(1);
+    t = scalarField(1, v);
+    miCheck(mi_comm_allreduce_sum(reduceComm(), t.data(), 1), "returnReduce");
+    return t.asHost()[0];
 }
 label Pstream::returnReduceSum(label v)
 {

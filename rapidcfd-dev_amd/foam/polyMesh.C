@@ -246,6 +246,21 @@ void polyMesh::calcGeometry()
     }
 }
 
+void polyMesh::coupledPatchGeometry(label patchi, const vectorField& Cn, scalarField& dc, scalarField& w) const
+{
+    const polyPatch& P = boundary[(std::size_t)patchi];
+    if ((label)Cn.size() != P.nFaces) FatalErrorIn("polyMesh::coupledPatchGeometry", "neighbour cell centres do not match patch " + P.name);
+    dc.resize((std::size_t)P.nFaces); w.resize((std::size_t)P.nFaces);
+    for (label i = 0; i < P.nFaces; ++i) {
+        const std::size_t f = (std::size_t)(P.startFace + i);
+        const vector n = (1.0 / magSf[f]) * Sf[f];
+        const vector d = Cn[(std::size_t)i] - C[owner[f]];
+        dc[(std::size_t)i] = 1.0 / std::max(dot(n, d), 0.05 * mag(d));
+        const scalar sOwn = dot(n, Cf[f] - C[owner[f]]), sNei = dot(n, Cn[(std::size_t)i] - Cf[f]);
+        w[(std::size_t)i] = sNei / (sOwn + sNei);
+    }
+}
+
 scalarField polyMesh::faceAreaPairWeights() const
 {
     // |Sf/sqrt|Sf| o (1, 1.01, 1.02)|  (faceAreaPairGAMGAgglomeration.C:54-81)

@@ -39,6 +39,8 @@ def make_box_mesh(dims, seed=5):
     X = x + 0.08 * np.sin(2 * y + 1.0) * x * (1 - x) + 0.1 / nx * (rng.random(x.shape) - 0.5) * (gx > 0) * (gx < nx)
     Y = y + 0.05 * np.sin(3 * x) * y * (ny / nx - y) + 0.1 / nx * (rng.random(x.shape) - 0.5) * (gy > 0) * (gy < ny)
     Z = z * (1 + 0.2 * x) + 0.1 / nx * (rng.random(x.shape) - 0.5) * (gz > 0) * (gz < nz)
+    if seed is None:                       # undistorted box (the periodic self-coupling test needs matching faces)
+        X, Y, Z = x, y, z
     pid = lambda i, j, k: i + (nx + 1) * (j + (ny + 1) * k)
     pts = np.zeros(((nx + 1) * (ny + 1) * (nz + 1), 3))
     pts[pid(gx, gy, gz).ravel()] = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
@@ -105,9 +107,11 @@ def write_case(case_dir, pts, faces, owner, neighbour, patches, source, binary):
     with open(os.path.join(pm, "boundary"), "w") as f:
         f.write(HEADER.format(fmt="ascii", cls="polyBoundaryMesh", note=note, obj="boundary"))
         f.write(f"{len(patches)}\n(\n")
-        for name, ptype, n, start in patches:
+        for pt in patches:
+            name, ptype, n, start = pt[:4]
             f.write(f"    {name}\n    {{\n        type            {ptype};\n" + ("        inGroups        1(wall);\n" if ptype == "wall" else "")
-                    + f"        nFaces          {n};\n        startFace       {start};\n    }}\n")
+                    + f"        nFaces          {n};\n        startFace       {start};\n"
+                    + (f"        matchTolerance  0.0001;\n        myProcNo        {pt[4]};\n        neighbProcNo    {pt[5]};\n" if ptype == "processor" else "") + "    }\n")
         f.write(")\n")
     with open(os.path.join(case_dir, "0", "S"), "w") as f:
         f.write(HEADER.format(fmt="ascii", cls="volScalarField", note="", obj="S").replace('location    "constant/polyMesh"', 'location    "0"'))
@@ -211,3 +215,144 @@ def test_reader_rejects_broken_meshes(pkg, tmp_path):
     assert out.returncode == 1 and "do not cover the boundary faces" in out.stderr
     out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), str(tmp_path / "missing")], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "cannot open file" in out.stderr
+
+
+# ---- decomposed cases (processorN directories) -----------------------------------------------------------------------
+def decompose_box_mesh(dims, nproc, pts, faces, owner, neighbour, patches):
+    """what decomposePar (simple, n = (nproc 1 1)) writes: per processor the local points / faces / owner / neighbour, the
+    physical patches (kept, possibly empty) and one processor patch per neighbouring processor, cut faces in global order,
+    flipped on the side that holds the global neighbour cell"""
+    nx = dims[0]
+    n = int(owner.max()) + 1
+    proc_of = (np.arange(n) % nx) * nproc // nx
+    nI = len(neighbour)
+    out = []
+    for p in range(nproc):
+        cells = np.nonzero(proc_of == p)[0]
+        cmap = -np.ones(n, np.int64); cmap[cells] = np.arange(len(cells))
+        lf, lo, ln, lp = [], [], [], []
+        for f in range(nI):
+            if proc_of[owner[f]] == p and proc_of[neighbour[f]] == p:
+                lf.append(faces[f]); lo.append(cmap[owner[f]]); ln.append(cmap[neighbour[f]])
+        for name, ptype, cnt, start in patches:
+            s0 = len(lf)
+            for f in range(start, start + cnt):
+                if proc_of[owner[f]] == p:
+                    lf.append(faces[f]); lo.append(cmap[owner[f]])
+            lp.append((name, ptype, len(lf) - s0, s0))
+        for q in range(nproc):
+            if q == p:
+                continue
+            s0 = len(lf)
+            for f in range(nI):
+                a, b = proc_of[owner[f]], proc_of[neighbour[f]]
+                if a == p and b == q:
+                    lf.append(faces[f]); lo.append(cmap[owner[f]])
+                elif a == q and b == p:
+                    lf.append(faces[f][::-1]); lo.append(cmap[neighbour[f]])
+            if len(lf) > s0:
+                lp.append((f"procBoundary{p}to{q}", "processor", len(lf) - s0, s0, p, q))
+        lf = np.array(lf, dtype=np.int64)
+        used = np.unique(lf)
+        pmap = -np.ones(len(pts), np.int64); pmap[used] = np.arange(len(used))
+        out.append(dict(pts=pts[used], faces=pmap[lf].astype(np.int32), owner=np.array(lo, np.int32), neighbour=np.array(ln, np.int32),
+                        patches=lp, cells=cells))
+    return out
+
+
+CHECK = re.compile(r"processor(\d+): nPoints (\d+) nCells (\d+) nFaces (\d+) nInternalFaces (\d+) sumV (\S+)")
+
+
+def test_reader_reads_a_decomposed_case(pkg, tmp_path):
+    """CPU: processor0/ and processor1/ of a 2-way decomposition in decomposePar's layout; the reader's statistics per
+    processor against numpy (cells, faces, volumes, every patch incl. the processor patch entries and their areas)."""
+    dims = (8, 5, 4)
+    pts, faces, owner, neighbour, patches = make_box_mesh(dims)
+    G = geometry(pts, faces, owner, neighbour)
+    parts = decompose_box_mesh(dims, 2, pts, faces, owner, neighbour, patches)
+    case_dir = str(tmp_path / "dec")
+    for p, P in enumerate(parts):
+        write_case(os.path.join(case_dir, f"processor{p}"), P["pts"], P["faces"], P["owner"], P["neighbour"], P["patches"], np.zeros(len(P["cells"])), binary=(p == 1))
+    cut_area = None
+    for p, P in enumerate(parts):
+        out = subprocess.run([os.path.join(PKG, "polyMeshFoamPar"), case_dir, "-check", str(p)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        m = CHECK.search(out.stdout)
+        assert m and int(m.group(1)) == p
+        assert (int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))) == (len(P["pts"]), len(P["cells"]), len(P["faces"]), len(P["neighbour"]))
+        assert abs(float(m.group(6)) - G["V"][P["cells"]].sum()) < 1e-12 * G["V"].sum()
+        for pt in P["patches"]:
+            mm = re.search(rf"patch {pt[0]} type {pt[1]} nFaces {pt[2]} startFace {pt[3]} myProcNo (-?\d+) neighbProcNo (-?\d+) area (\S+)", out.stdout)
+            assert mm, (pt, out.stdout)
+            if pt[1] == "processor":
+                assert (int(mm.group(1)), int(mm.group(2))) == (pt[4], pt[5])
+                cut_area = float(mm.group(3)) if cut_area is None else cut_area
+                assert abs(float(mm.group(3)) - cut_area) < 1e-13 * cut_area        # both sides see the same faces
+    assert sum(len(P["cells"]) for P in parts) == int(owner.max()) + 1
+
+
+@pytest.mark.gpu
+def test_polyMeshFoamPar_solves_a_processor_coupled_case(pkg, orc, tmp_path):
+    """One GPU, one rank: processor0/ holds the whole (undistorted) box whose y-min / y-max faces are two `processor` patches
+    towards rank 0 itself, so the neighbours' cell centres and every solver's halo travel through RCCL; the coupled
+    deltaCoeffs, the assembled Laplacian and both solves are recomputed with numpy + the oracle (cyclic interfaces)."""
+    dims = (10, 8, 6)
+    nx, ny, nz = dims
+    pts, faces, owner, neighbour, patches = make_box_mesh(dims, seed=None)
+    nI = len(neighbour)
+    (inl, outl, walls) = patches
+    w0 = walls[3]
+    ymin = np.arange(w0, w0 + nz * nx); ymax = np.arange(w0 + nz * nx, w0 + 2 * nz * nx); zz = np.arange(w0 + 2 * nz * nx, walls[3] + walls[2])
+    order = np.concatenate([np.arange(nI), np.arange(inl[3], inl[3] + inl[2]), np.arange(outl[3], outl[3] + outl[2]), zz, ymin, ymax])
+    faces2, owner2 = faces[order], owner[order]
+    s = nI
+    pl = [("inlet", "patch", inl[2], s)]; s += inl[2]
+    pl.append(("outlet", "patch", outl[2], s)); s += outl[2]
+    pl.append(("walls", "wall", len(zz), s)); s += len(zz)
+    sA = s; pl.append(("procBoundary0to0a", "processor", len(ymin), s, 0, 0)); s += len(ymin)
+    sB = s; pl.append(("procBoundary0to0b", "processor", len(ymax), s, 0, 0)); s += len(ymax)
+    n = int(owner.max()) + 1
+    G = geometry(pts, faces2, owner2, neighbour)
+    S = np.sin(4 * G["C"][:, 0]) * np.cos(3 * G["C"][:, 1]) + G["C"][:, 2]
+    case_dir = str(tmp_path / "self")
+    write_case(os.path.join(case_dir, "processor0"), pts, faces2, owner2, neighbour, pl, S, False)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MI_COMM_ID_FILE=str(tmp_path / "ids"))
+    out = subprocess.run([os.path.join(PKG, "polyMeshFoamPar"), case_dir], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr + out.stdout
+    # coupled geometry: the cell across face i of patch A is the owner of face i of patch B and vice versa
+    fcA, fcB = owner2[sA:sA + len(ymin)], owner2[sB:sB + len(ymax)]
+    def coupled(start, fc, fn):
+        nhat = G["Sf"][start:start + len(fc)] / G["magSf"][start:start + len(fc), None]
+        d = G["C"][fn] - G["C"][fc]
+        dc = 1.0 / np.maximum((nhat * d).sum(axis=1), 0.05 * np.sqrt((d * d).sum(axis=1)))
+        son = (nhat * (G["Cf"][start:start + len(fc)] - G["C"][fc])).sum(axis=1); sne = (nhat * (G["C"][fn] - G["Cf"][start:start + len(fc)])).sum(axis=1)
+        return dc, sne / (son + sne)
+    dcA, wA = coupled(sA, fcA, fcB); dcB, wB = coupled(sB, fcB, fcA)
+    m = re.search(r"coupled geometry: sumDeltaCoeffs (\S+) sumWeights (\S+)", out.stdout)
+    assert m, out.stdout
+    assert abs(float(m.group(1)) - (dcA.sum() + dcB.sum())) < 1e-12 * (dcA.sum() + dcB.sum())
+    assert abs(float(m.group(2)) - (wA.sum() + wB.sum())) < 1e-12 * np.abs(np.concatenate([wA, wB])).sum()
+    syn = pkg.synthetic
+    lo, up = owner2[:nI], neighbour
+    upper, diag = orc.fvm_laplacian(n, lo, up, G["delta"], G["magSf"][:nI])
+    for name, ptype, cnt, start in pl[:2]:
+        ic = -(G["magSf"][start:start + cnt] * G["delta_b"][start - nI:start - nI + cnt])
+        diag = orc.patch_add(owner2[start:start + cnt], ic, diag, 0)
+    bouA = -(G["magSf"][sA:sA + len(fcA)] * dcA); bouB = -(G["magSf"][sB:sB + len(fcB)] * dcB)
+    diag = orc.patch_add(fcA, bouA, diag, 0); diag = orc.patch_add(fcB, bouB, diag, 0)
+    src = S * G["V"]
+    case = syn.LduCase(n, lo, up, diag, upper, None, src)
+    case.interfaces = [syn.Interface(0, 1, fcA, bouA, bouA), syn.Interface(0, 0, fcB, bouB, bouB)]
+    Sys = orc.System([case])
+    z = np.zeros(n)
+    _, p1 = Sys.pcg(z, src, "AINV", tolerance=1e-9)
+    w = np.sqrt(((G["Sf"][:nI] / np.sqrt(G["magSf"][:nI])[:, None] * np.array([1.0, 1.01, 1.02])) ** 2).sum(axis=1))
+    x2, p2 = orc.GamgSysHierarchy(Sys, [w], 10).solve(z, src, tolerance=1e-9)
+    got = [(mm.group(1), float(mm.group(3)), float(mm.group(4)), int(mm.group(5))) for mm in map(LINE.match, out.stdout.splitlines()) if mm]
+    assert [g[0] for g in got] == ["AINVPCG", "GAMG"], out.stdout
+    for g, p in zip(got, (p1, p2)):
+        assert g[3] == p["nIterations"], (g, p["nIterations"])
+        assert abs(g[1] - p["initialResidual"]) < 1e-10 and abs(g[2] - p["finalResidual"]) < 1e-9 * max(p["initialResidual"], 1e-30) + 1e-10
+    mm = re.search(r"p sum \(global\) max \(rank 0\): (\S+) (\S+)", out.stdout)
+    assert abs(float(mm.group(1)) - x2.sum()) < 1e-6 * np.abs(x2).sum() and abs(float(mm.group(2)) - np.abs(x2).max()) < 1e-6 * np.abs(x2).max()
+    assert out.stdout.strip().endswith("End")
