@@ -368,6 +368,11 @@ public:
         const label nCoarsest = controlDict_.lookupOrDefault<label>("nCellsInCoarsestLevel", -1);
         if (nCoarsest < 0) FatalErrorIn("GAMGAgglomeration::GAMGAgglomeration", "keyword nCellsInCoarsestLevel is undefined in dictionary"); // GAMGAgglomeration.C:96-99
         if (!controlDict_.found("mergeLevels")) FatalErrorIn("pairGAMGAgglomeration::pairGAMGAgglomeration", "keyword mergeLevels is undefined in dictionary");
+        {   // GAMGSolver.C:75: interpolateCorrection (default false).  The reference's interpolate() overload that every level
+            // with a coarser level calls starts with notImplemented() (GAMGSolverInterpolate.C:180), i.e. it aborts: same here.
+            const word ic = controlDict_.lookupOrDefault<word>("interpolateCorrection", "false");
+            if (ic == "true" || ic == "on" || ic == "yes" || ic == "y" || ic == "t") FatalErrorIn("GAMGSolver::interpolate()", "Not implemented");
+        }
         const label mergeLevels = controlDict_.lookupOrDefault<label>("mergeLevels", 1);
         if (mergeLevels < 1) FatalErrorIn("pairGAMGAgglomeration::pairGAMGAgglomeration", "mergeLevels must be positive");
         const word sm = controlDict_.lookupOrDefault<word>("smoother", "GaussSeidel");

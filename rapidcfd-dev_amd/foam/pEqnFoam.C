@@ -166,6 +166,11 @@ int main(int argc, char** argv)
             scalargpuField psi(n);
             pEqn.solve(psi, dictionary{{"solver", "PCGG"}, {"preconditioner", "DIC"}});
         } catch (const Foam::error& e) { Info << e.what() << std::endl; }
+        try {   // interpolateCorrection aborts in the reference (GAMGSolverInterpolate.C:180 notImplemented): same outcome
+            scalargpuField psi(n);
+            pEqn.solve(psi, dictionary{{"solver", "GAMG"}, {"smoother", "GaussSeidel"}, {"agglomerator", "faceAreaPair"}, {"nCellsInCoarsestLevel", "10"},
+                                       {"mergeLevels", "1"}, {"interpolateCorrection", "true"}});
+        } catch (const Foam::error& e) { Info << e.what() << std::endl; }
         Info << "End" << std::endl;
         return 0;
     } catch (const Foam::error& e) { std::cerr << e.what() << std::endl; return 1; }
