@@ -242,6 +242,8 @@ typedef struct {
     int32_t nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps;  /* 2, 1, 4 */
     int32_t nFinestSweeps, scaleCorrection;                         /* 2, -1   */
     double omega;                                                   /* 0.9     */
+    int32_t directSolveCoarsest;  /* 1 (GAMGSolver.C:77): dense solve on the device; 0: ICCG / BICCG (PCG / PBiCG + AINV, */
+    int32_t reserved;             /* GAMG's tolerance and relTol, zero start) on the coarsest level, GAMGSolverSolve.C:572-613 */
 } mi_gamg_controls;
 int mi_gamg_create(mi_addr_t fine_addr, const double *face_weights_host, int32_t n_cells_in_coarsest_level,
                    int32_t merge_levels, int forward_init, mi_gamg_t *out);

@@ -41,6 +41,12 @@ void orc_amul(const orc_system *s, const scalar *psi, scalar *Apsi);
 void orc_jacobi_smooth(const orc_system *s, scalar omega, scalar *psi, const scalar *source, int nSweeps);
 scalar orc_norm_factor(const orc_system *s, const scalar *psi, const scalar *source, const scalar *Apsi, scalar *tmp);
 scalar orc_gSumMag(const orc_system *s, const scalar *a);
+/* the Krylov solvers of ldu_oracle.c (their control / performance records, ldu_oracle.c:669-678) */
+typedef struct { scalar initialResidual, finalResidual, normFactor; int32_t nIterations, converged, singular; } orc_perf;
+typedef struct { scalar tolerance, relTol; int32_t maxIter, minIter; } orc_controls;
+void orc_pcg_solve(const orc_system *s, scalar *psi, const scalar *source, const orc_controls *ctl, int precondKind, orc_perf *perf, scalar *hist, int histLen);
+void orc_pbicg_solve(const orc_system *s, scalar *psi, const scalar *source, const orc_controls *ctl, int precondKind, orc_perf *perf, scalar *hist, int histLen);
+
 
 #define G_GREAT 1e20
 #define G_SMALL 1e-20
@@ -297,6 +303,7 @@ typedef struct {
     int32_t nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps;
     int32_t nFinestSweeps, scaleCorrection; /* scaleCorrection < 0: default = symmetric (GAMGSolver.C:76) */
     scalar omega; /* Jacobi relaxation, JacobiSmoother.C:34-36 */
+    int32_t directSolveCoarsest, reserved; /* GAMGSolver.C:77,232: default true; false = ICCG / BICCG on the coarsest level */
 } gamg_controls;
 
 typedef struct {
@@ -313,6 +320,19 @@ static void scale_field(const orc_system *A, const scalar *D, label n, scalar *f
     scalar d = (scalar)den;
     scalar sf = (scalar)num / (d >= 0 ? d + G_VSMALL : d - G_VSMALL); /* stabilise(), Scalar.H:295-305 */
     for (label i = 0; i < n; i++) field[i] = fma(sf, field[i], fma(-sf, Acf[i], source[i]) / D[i]);
+}
+
+/* solveCoarsestLevel without the direct solver (GAMGSolverSolve.C:572-613): ICCG (= PCG + DIC, here AINV) on a symmetric,
+ * BICCG (= PBiCG + DILU) on an asymmetric coarsest matrix, zero initial guess, GAMG's own tolerance and relTol
+ * (ICCG.C solverDict), default maxIter 1000 */
+static void coarsest_iterative(const orc_system *Ac, int asym, const gamg_controls *ctl, const scalar *src, scalar *corr)
+{
+    orc_controls c; orc_perf p;
+    memset(&c, 0, sizeof(c));
+    c.tolerance = ctl->tolerance; c.relTol = ctl->relTol; c.maxIter = 1000; c.minIter = 0;
+    memset(corr, 0, sizeof(scalar) * (size_t)Ac->nTotal);
+    if (asym) orc_pbicg_solve(Ac, corr, src, &c, 2, &p, NULL, 0);
+    else orc_pcg_solve(Ac, corr, src, &c, 2, &p, NULL, 0);
 }
 
 static int conv_check(gamg_perf *p, const gamg_controls *c)
@@ -401,8 +421,10 @@ void orc_gamg_solve(const gamg_hier *H, const label *lower, const label *upper, 
                 }
                 restrict_field(&H->lev[l + 1], src[l], src[l + 1]);
             }
-            memcpy(corr[coarsest], src[coarsest], sizeof(scalar) * (size_t)nc);
-            lu_solve(nc, dense, piv, corr[coarsest]);
+            if (ctl->directSolveCoarsest) {
+                memcpy(corr[coarsest], src[coarsest], sizeof(scalar) * (size_t)nc);
+                lu_solve(nc, dense, piv, corr[coarsest]);
+            } else coarsest_iterative(A[nL], asym, ctl, src[coarsest], corr[coarsest]);
             for (int l = coarsest - 1; l >= 0; l--) {
                 const label nl = H->lev[l].nCoarse;
                 if (ctl->nPreSweeps) memcpy(scr2, corr[l], sizeof(scalar) * (size_t)nl);
@@ -741,8 +763,10 @@ void orc_gamg_solve_sys(const gamg_sys_hier *H, const orc_system *S, scalar *psi
                 }
                 sys_restrict(H, l + 1, A[l + 1], A[l + 2], src[l], src[l + 1]);
             }
-            memcpy(corr[coarsest], src[coarsest], sizeof(scalar) * (size_t)nc);
-            lu_solve(nc, dense, piv, corr[coarsest]);
+            if (ctl->directSolveCoarsest) {
+                memcpy(corr[coarsest], src[coarsest], sizeof(scalar) * (size_t)nc);
+                lu_solve(nc, dense, piv, corr[coarsest]);
+            } else coarsest_iterative(A[nL], asym, ctl, src[coarsest], corr[coarsest]);
             for (int l = coarsest - 1; l >= 0; l--) {
                 const int64_t nl = A[l + 1]->nTotal;
                 if (ctl->nPreSweeps) memcpy(scr2, corr[l], sizeof(scalar) * (size_t)nl);

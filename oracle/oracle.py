@@ -211,15 +211,17 @@ class GamgControls(C.Structure):
     _fields_ = [("tolerance", C.c_double), ("relTol", C.c_double), ("maxIter", C.c_int32), ("minIter", C.c_int32),
                 ("nPreSweeps", C.c_int32), ("preSweepsLevelMultiplier", C.c_int32), ("maxPreSweeps", C.c_int32),
                 ("nPostSweeps", C.c_int32), ("postSweepsLevelMultiplier", C.c_int32), ("maxPostSweeps", C.c_int32),
-                ("nFinestSweeps", C.c_int32), ("scaleCorrection", C.c_int32), ("omega", C.c_double)]
+                ("nFinestSweeps", C.c_int32), ("scaleCorrection", C.c_int32), ("omega", C.c_double),
+                ("directSolveCoarsest", C.c_int32), ("reserved", C.c_int32)]
 
 
 def gamg_controls(tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0, nPreSweeps=0, preSweepsLevelMultiplier=1,
                   maxPreSweeps=4, nPostSweeps=2, postSweepsLevelMultiplier=1, maxPostSweeps=4, nFinestSweeps=2,
-                  scaleCorrection=-1, omega=0.9):
+                  scaleCorrection=-1, omega=0.9, directSolveCoarsest=True):
     """defaults of GAMGSolver.C:67-77 and lduMatrixSolver.C:167-173"""
     return GamgControls(tolerance, relTol, maxIter, minIter, nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps,
-                        nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection, omega)
+                        nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection, omega,
+                        int(bool(directSolveCoarsest)), 0)
 
 
 def box_face_weights(case):

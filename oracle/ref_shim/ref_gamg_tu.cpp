@@ -16,7 +16,7 @@ void orc_lu_free(orc_lu *L);
 void orc_sys_destroy(orc_system *s);
 int orc_gamg_sys_n_levels(const gamg_sys_hier *H);
 }
-struct gamg_controls_c { double tolerance, relTol; int32_t maxIter, minIter, nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps, nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection; double omega; };
+struct gamg_controls_c { double tolerance, relTol; int32_t maxIter, minIter, nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps, nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection; double omega; int32_t directSolveCoarsest, reserved; };
 
 // C entry point: the reference's GAMGSolver::solve on the oracle's hierarchy H and fine system S; out5 as in ref_krylov_solve
 extern "C" void ref_gamg_solve(const gamg_sys_hier* H, const orc_system* S, double* psi, const double* source, const gamg_controls_c* c, double* out5)

@@ -396,6 +396,11 @@ public:
         c.nFinestSweeps = controlDict_.lookupOrDefault<label>("nFinestSweeps", 2);
         c.scaleCorrection = controlDict_.found("scaleCorrection") ? controlDict_.lookupOrDefault<label>("scaleCorrection", 1) : -1;
         c.omega = controlDict_.lookupOrDefault<scalar>("omega", 0.9);
+        {   // GAMGSolver.C:77,232: directSolveCoarsest (default true in this code base); false = ICCG / BICCG on the coarsest level
+            const word ds = controlDict_.lookupOrDefault<word>("directSolveCoarsest", "true");
+            c.directSolveCoarsest = (ds == "false" || ds == "off" || ds == "no" || ds == "n" || ds == "f") ? 0 : 1;
+            c.reserved = 0;
+        }
         mi_solver_perf r;
         miCheck(mi_gamg_solve(g, matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c, &r, nullptr, 0), "GAMGSolver::solve");
         return perfOf("GAMG", fieldName_, r);

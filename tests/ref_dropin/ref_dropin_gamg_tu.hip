@@ -8,7 +8,7 @@
 namespace Foam { label UPstream::warnComm = -1; const word GAMGSolver::typeName("GAMG"); int GAMGSolver::debug = 0; }
 #include REF_FILE(solvers/GAMG/GAMGSolverSolve.C)
 
-struct gamg_controls_c { double tolerance, relTol; int32_t maxIter, minIter, nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps, nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection; double omega; };
+struct gamg_controls_c { double tolerance, relTol; int32_t maxIter, minIter, nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps, nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection; double omega; int32_t directSolveCoarsest, reserved; };
 
 // C entry point: the reference's GAMGSolver::solve with the engine's hierarchy g over matrix mat; out5 as in ref_dropin_solve
 extern "C" void ref_dropin_gamg_solve(mi_ctx_t eng, mi_gamg_t g, mi_matrix_t mat, void* stream, int n_cells, int asym, double* psi_dev,

@@ -73,6 +73,21 @@ def test_merge_levels_folds_consecutive_pair_steps(pkg, orc, kind, merge):
         assert np.array_equal(np.diff(e["cellChildStart"]), cnt) and cnt.min() >= 1
 
 
+def test_iterative_coarsest_solver_matches_the_direct_one(pkg, orc):
+    """directSolveCoarsest false (GAMGSolverSolve.C:572-613): ICCG / BICCG to GAMG's tolerance on the coarsest level instead of
+    the LU.  With a tight tolerance the coarsest correction is the same to rounding, so the cycle counts agree and the
+    histories stay close; symmetric and asymmetric."""
+    for sym in (True, False):
+        case = pkg.synthetic.box_case(14, 12, 10, symmetric=sym)
+        w = orc.box_face_weights(case)
+        H = orc.GamgHierarchy(case, w, 10)
+        _, pd = H.solve(np.zeros(case.n_cells), case.source, tolerance=1e-10, maxIter=100)
+        _, pi = H.solve(np.zeros(case.n_cells), case.source, tolerance=1e-10, maxIter=100, directSolveCoarsest=False)
+        assert pd["converged"] and pi["converged"] and abs(pd["nIterations"] - pi["nIterations"]) <= 1
+        k = min(len(pd["history"]), len(pi["history"]), 6)
+        assert np.max(np.abs(pd["history"][:k] - pi["history"][:k])) < 1e-6 * pd["history"][0]
+
+
 def test_merge_levels_oracle_solves(pkg, orc):
     case = pkg.synthetic.box_case(16, 12, 10)
     w = orc.box_face_weights(case)
@@ -171,7 +186,8 @@ def test_engine_gamg_operators_bit_exact(pkg, orc, name):
 @pytest.mark.parametrize("name,kw", [("box_sym", {}), ("box_sym", dict(nPreSweeps=1)), ("box_sym", dict(scaleCorrection=0)),
                                      ("box_asym", {}), ("graph_sym", {}), ("box_sym", dict(tolerance=0.0, maxIter=4)),
                                      ("box_sym", dict(tolerance=1e30, minIter=2)), ("box_sym", dict(merge_levels=2)),
-                                     ("box_asym", dict(merge_levels=2)), ("graph_sym", dict(merge_levels=3, nPreSweeps=1))])
+                                     ("box_asym", dict(merge_levels=2)), ("graph_sym", dict(merge_levels=3, nPreSweeps=1)),
+                                     ("box_sym", dict(directSolveCoarsest=False)), ("box_asym", dict(directSolveCoarsest=False))])
 def test_engine_gamg_history(pkg, orc, name, kw):
     import torch
     eng = pkg.engine
@@ -254,7 +270,8 @@ def test_oracle_gamg_cyclic(pkg, orc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["cyclic", "processor_to_self"])
-@pytest.mark.parametrize("symmetric,kw", [(True, {}), (True, dict(nPreSweeps=1)), (False, {}), (True, dict(merge_levels=2)), (False, dict(merge_levels=2))])
+@pytest.mark.parametrize("symmetric,kw", [(True, {}), (True, dict(nPreSweeps=1)), (False, {}), (True, dict(merge_levels=2)), (False, dict(merge_levels=2)),
+                                          (True, dict(directSolveCoarsest=False)), (False, dict(directSolveCoarsest=False))])
 def test_engine_gamg_coupled_patches(pkg, orc, mode, symmetric, kw):
     """GAMG on a matrix with coupled patches: 'cyclic' = local patches (cyclicGAMGInterface), 'processor_to_self' = the
     same periodic box posed with processor patches whose neighbour rank is this rank, on a 1-rank RCCL communicator --
