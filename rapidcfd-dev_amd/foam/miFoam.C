@@ -414,7 +414,12 @@ void setFaceAreaPairWeights(const scalarField* w) { GAMGSolver::faceWeights_ = w
 static lduMatrix::solver::addsymMatrixConstructorToTable<PCG> addPCGSymMatrixConstructorToTable_("PCG");
 static lduMatrix::solver::addasymMatrixConstructorToTable<PBiCG> addPBiCGAsymMatrixConstructorToTable_("PBiCG");
 static lduMatrix::solver::addasymMatrixConstructorToTable<PBiCGStab> addPBiCGStabAsymMatrixConstructorToTable_("PBiCGStab");
-static lduMatrix::solver::addsymMatrixConstructorToTable<PBiCGStab> addPBiCGStabSymMatrixConstructorToTable_("PBiCGStab");
+// ICCG / BICCG (solvers/ICCG/ICCG.C:34-35, solvers/BICCG/BICCG.C:34-35): PCG / PBiCG under another run-time name; constructed
+// from a dictionary they pass it on unchanged, so the preconditioner is the dictionary's and the printed name is PCG's / PBiCG's
+class ICCG : public PCG { public: using PCG::PCG; };
+class BICCG : public PBiCG { public: using PBiCG::PBiCG; };
+static lduMatrix::solver::addsymMatrixConstructorToTable<ICCG> addICCGSymMatrixConstructorToTable_("ICCG");
+static lduMatrix::solver::addasymMatrixConstructorToTable<BICCG> addBICCGSymMatrixConstructorToTable_("BICCG");
 static lduMatrix::solver::addsymMatrixConstructorToTable<smoothSolver> addsmoothSolverSymMatrixConstructorToTable_("smoothSolver");
 static lduMatrix::solver::addasymMatrixConstructorToTable<smoothSolver> addsmoothSolverAsymMatrixConstructorToTable_("smoothSolver");
 static lduMatrix::solver::addsymMatrixConstructorToTable<GAMGSolver> addGAMGSolverMatrixConstructorToTable_("GAMG");

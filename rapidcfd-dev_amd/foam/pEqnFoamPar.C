@@ -119,6 +119,7 @@ int main(int argc, char** argv)
         };
         for (const dictionary& d : dicts) {
             scalargpuField psi(n);
+            if (d.lookupOrDefault<word>("solver", "") == "PBiCGStab") A.lower();   // PBiCGStab is in the asymMatrix table only (PBiCGStab.C:36): store a lower triangle
             solverPerformance sp = lduMatrix::solver::New("p", A, bouCoeffs, intCoeffs, interfaces, d)->solve(psi, source);
             if (talk) sp.print(Info);
         }
