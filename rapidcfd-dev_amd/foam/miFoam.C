@@ -210,8 +210,18 @@ word lduMatrix::preconditioner::getName(const dictionary& d)
     word name = d.lookup("preconditioner");
     // DIC / DILU (and friends) are replaced by the approximate inverse in the reference
     // (DICPreconditioner.C:42-58, DILUPreconditioner.C:42-58): the reported name becomes AINV
-    if (name == "DIC" || name == "DILU" || name == "FDIC" || name == "GAMG") name = "AINV";
+    if (name == "DIC" || name == "DILU") name = "AINV";
     return name;
+}
+int lduMatrix::preconditioner::kindFor(const dictionary& d, bool sym)
+{
+    const word name = d.lookup("preconditioner");
+    const bool ok = name == "AINV" || name == "diagonal" || name == "none" || name == (sym ? "DIC" : "DILU");
+    if (!ok)
+        FatalErrorIn("lduMatrix::preconditioner::New(const solver&, const dictionary&)",
+                     word("Unknown ") + (sym ? "symmetric" : "asymmetric") + " matrix preconditioner " + name + "\n\nValid " + (sym ? "symmetric" : "asymmetric")
+                     + " matrix preconditioners :\n" + (sym ? "4(AINV DIC diagonal none)" : "4(AINV DILU diagonal none)"));
+    return kind(getName(d));
 }
 int lduMatrix::preconditioner::kind(const word& n)
 {
@@ -303,7 +313,7 @@ public:
         const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
         mi_solver_perf r;
         miCheck(mi_pcg_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
-                             lduMatrix::preconditioner::kind(pre), &r, nullptr, 0), "PCG::solve");
+                             lduMatrix::preconditioner::kindFor(controlDict_, matrix_.symmetric()), &r, nullptr, 0), "PCG::solve");
         return perfOf(pre + "PCG", fieldName_, r); // PCG.C:75-80
     }
 };
@@ -318,7 +328,7 @@ public:
         const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
         mi_solver_perf r;
         miCheck(mi_pbicg_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
-                               lduMatrix::preconditioner::kind(pre), &r, nullptr, 0), "PBiCG::solve");
+                               lduMatrix::preconditioner::kindFor(controlDict_, matrix_.symmetric()), &r, nullptr, 0), "PBiCG::solve");
         return perfOf(pre + "PBiCG", fieldName_, r);
     }
 };
@@ -335,7 +345,7 @@ public:
         // keep the reference's `psi += omega*yA` (PBiCGStab.C:263-270) unless the case asks for the textbook update
         const int quirk = controlDict_.lookupOrDefault<label>("textbookOmegaUpdate", 0) ? 0 : 1;
         miCheck(mi_pbicgstab_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
-                                   lduMatrix::preconditioner::kind(pre), quirk, &r, nullptr, 0), "PBiCGStab::solve");
+                                   lduMatrix::preconditioner::kindFor(controlDict_, matrix_.symmetric()), quirk, &r, nullptr, 0), "PBiCGStab::solve");
         return perfOf(pre + "PBiCGStab", fieldName_, r);
     }
 };

@@ -166,6 +166,10 @@ int main(int argc, char** argv)
             scalargpuField psi(n);
             pEqn.solve(psi, dictionary{{"solver", "PCGG"}, {"preconditioner", "DIC"}});
         } catch (const Foam::error& e) { Info << e.what() << std::endl; }
+        try {   // a preconditioner of the other symmetry's table (lduMatrixPreconditioner.C:83-101): DILU on a symmetric matrix
+            scalargpuField psi(n);
+            pEqn.solve(psi, dictionary{{"solver", "PCG"}, {"preconditioner", "DILU"}});
+        } catch (const Foam::error& e) { Info << e.what() << std::endl; }
         try {   // interpolateCorrection aborts in the reference (GAMGSolverInterpolate.C:180 notImplemented): same outcome
             scalargpuField psi(n);
             pEqn.solve(psi, dictionary{{"solver", "GAMG"}, {"smoother", "GaussSeidel"}, {"agglomerator", "faceAreaPair"}, {"nCellsInCoarsestLevel", "10"},

@@ -114,6 +114,7 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     # error behaviour of the run-time selection table (lduMatrixSolver.C:84-100)
     assert "Unknown symmetric matrix solver PCGG" in out.stdout and "Valid symmetric matrix solvers are" in out.stdout
     assert re.search(r"\(GAMG ICCG PCG smoothSolver\)", out.stdout)                       # the reference's symMatrix table
+    assert "Unknown symmetric matrix preconditioner DILU" in out.stdout and "4(AINV DIC diagonal none)" in out.stdout
     assert "GAMGSolver::interpolate()" in out.stdout and "Not implemented" in out.stdout    # interpolateCorrection true
     assert out.stdout.strip().endswith("End")
 
