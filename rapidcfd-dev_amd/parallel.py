@@ -164,6 +164,13 @@ class DistributedPCG:
                 p2p.append(dist.P2POp(dist.isend, o.send[a:b], nbr))
                 p2p.append(dist.P2POp(dist.irecv, vec[self.n + a:self.n + b], nbr))
             self._p2p[id(vec)] = p2p
+        if self.is_cuda and dist.get_backend() == "gloo":
+            # test configuration only (several ranks sharing one GPU, tests/test_distributed.py): gloo's send/recv touch
+            # the device buffers from the host without any stream ordering, so order them by hand
+            torch.cuda.current_stream().synchronize()
+            for r in dist.batch_isend_irecv(p2p):
+                r.wait()
+            return lambda: None
         if self.is_cuda:
             main = torch.cuda.current_stream()
             self.comm_stream.wait_stream(main)          # the pack kernel has to finish first
