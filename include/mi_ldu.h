@@ -353,6 +353,19 @@ int mi_relax(mi_addr_t addr, double alpha, double *diag_dev, const double *lower
 int mi_gamg_host_build(int32_t n_cells, int32_t n_faces, const int32_t *lower_addr_host,
                        const int32_t *upper_addr_host, const double *face_weights_host,
                        int32_t n_cells_in_coarsest_level, int32_t merge_levels, int forward_init, void **hierarchy_out);
+/* every domain of a DECOMPOSED case in one process (one thread per domain runs the per-rank builder, a barrier and a shared
+ * table stand in for the communicator): patch p of domain d couples to patch patch_nbr_patch[d][p] of domain
+ * patch_nbr_domain[d][p].  hierarchies_out[n_domains]; mi_gamg_host_patch_array: faceRestrict / faceCells / nbrCells of a
+ * coupled patch on a level.  CPU tests compare with the oracle's multi-domain builder.                                  */
+int mi_gamg_host_build_domains(int32_t n_domains, const int32_t *n_cells, const int32_t *n_faces,
+                               const int32_t *const *lower_addr_host, const int32_t *const *upper_addr_host,
+                               const double *const *face_weights_host, const int32_t *n_patches,
+                               const int32_t *const *patch_sizes, const int32_t *const *const *patch_face_cells,
+                               const int32_t *const *patch_nbr_domain, const int32_t *const *patch_nbr_patch,
+                               int32_t n_cells_in_coarsest_level, int32_t merge_levels, int forward_init,
+                               void **hierarchies_out);
+int mi_gamg_host_patch_array(void *hierarchy, int32_t level, int32_t patch, const char *name, const void **data,
+                             int64_t *len);
 int32_t mi_gamg_host_n_levels(void *hierarchy);
 int mi_gamg_host_array(void *hierarchy, int32_t level, const char *name, const void **data,
                        int64_t *len, int32_t *elem_size);

@@ -58,7 +58,7 @@ SYMBOLS = [
     "mi_dpcg_set_buffers", "mi_dpcg_phase", "mi_dpcg_status", "mi_event_record", "mi_event_elapsed_ms",
     "mi_gamg_create", "mi_gamg_update", "mi_gamg_level_matrix", "mi_gamg_scale", "mi_gamg_solve_coarsest", "mi_gamg_destroy", "mi_gamg_n_levels", "mi_gamg_forward_out", "mi_gamg_level_sizes",
     "mi_gamg_solve", "mi_gamg_restrict", "mi_gamg_prolong", "mi_gamg_level_coeffs",
-    "mi_gamg_host_build", "mi_gamg_host_n_levels", "mi_gamg_host_array", "mi_gamg_host_free",
+    "mi_gamg_host_build", "mi_gamg_host_build_domains", "mi_gamg_host_patch_array", "mi_gamg_host_n_levels", "mi_gamg_host_array", "mi_gamg_host_free",
     "mi_row_face_op", "mi_fvm_laplacian", "mi_fvm_div", "mi_surface_integrate", "mi_face_interpolate",
     "mi_patch_create", "mi_patch_destroy", "mi_patch_add", "mi_patch_add_product", "mi_patch_flux", "mi_relax",
 ]
@@ -494,6 +494,56 @@ class Gamg:
         if self.h:
             lib().mi_gamg_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def gamg_host_hierarchy_domains(domains, face_weights_per_domain, n_cells_in_coarsest_level=10, forward=True, merge_levels=1):
+    """Host-only build of the per-rank GAMG hierarchies of a decomposed case (list of LduCase sub-domains with interfaces), all
+    domains in this process; returns [domain][level] dicts incl. "patches": [{faceRestrict, faceCells, nbrCells}] (tests)."""
+    I32P, F64P = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    D = len(domains)
+    keep = []
+    def i32(a):
+        a = np.ascontiguousarray(a, dtype=np.int32); keep.append(a); return a.ctypes.data_as(I32P)
+    n_cells = (C.c_int32 * D)(*[d.n_cells for d in domains]); n_faces = (C.c_int32 * D)(*[d.n_faces for d in domains])
+    lower = (I32P * D)(*[i32(d.lower_addr) for d in domains]); upper = (I32P * D)(*[i32(d.upper_addr) for d in domains])
+    ws = [np.ascontiguousarray(w, dtype=np.float64) for w in face_weights_per_domain]; keep.append(ws)
+    weights = (F64P * D)(*[w.ctypes.data_as(F64P) for w in ws])
+    n_patches = (C.c_int32 * D)(*[len(d.interfaces) for d in domains])
+    sizes = (I32P * D)(*[i32([len(i.face_cells) for i in d.interfaces] or [0]) for d in domains])
+    nbr_d = (I32P * D)(*[i32([i.nbr_domain for i in d.interfaces] or [0]) for d in domains])
+    nbr_p = (I32P * D)(*[i32([i.nbr_patch for i in d.interfaces] or [0]) for d in domains])
+    fcs = []
+    for d in domains:
+        arr = (I32P * max(len(d.interfaces), 1))(*[i32(i.face_cells) for i in d.interfaces]); keep.append(arr); fcs.append(arr)
+    PP = C.POINTER(I32P)
+    fc = (PP * D)(*[C.cast(a, PP) for a in fcs])
+    out = (C.c_void_p * D)()
+    _chk(lib().mi_gamg_host_build_domains(C.c_int32(D), n_cells, n_faces, lower, upper, weights, n_patches, sizes, fc, nbr_d, nbr_p,
+                                          C.c_int32(n_cells_in_coarsest_level), C.c_int32(merge_levels), int(forward), out))
+    res = []
+    try:
+        for d in range(D):
+            h = C.c_void_p(out[d]); levels = []
+            for lvl in range(int(lib().mi_gamg_host_n_levels(h))):
+                lv = {}
+                for name in ("restrictMap", "faceRestrict", "cLower", "cUpper"):
+                    data, ln, es = C.c_void_p(), C.c_int64(), C.c_int32()
+                    _chk(lib().mi_gamg_host_array(h, C.c_int32(lvl), name.encode(), C.byref(data), C.byref(ln), C.byref(es)))
+                    lv[name] = np.frombuffer((C.c_char * (ln.value * 4)).from_address(data.value), dtype=np.int32).copy() if ln.value else np.zeros(0, np.int32)
+                lv["patches"] = []
+                for p in range(len(domains[d].interfaces)):
+                    pd = {}
+                    for name in ("faceRestrict", "faceCells", "nbrCells"):
+                        data, ln = C.c_void_p(), C.c_int64()
+                        _chk(lib().mi_gamg_host_patch_array(h, C.c_int32(lvl), C.c_int32(p), name.encode(), C.byref(data), C.byref(ln)))
+                        pd[name] = np.frombuffer((C.c_char * (ln.value * 4)).from_address(data.value), dtype=np.int32).copy() if ln.value else np.zeros(0, np.int32)
+                    lv["patches"].append(pd)
+                levels.append(lv)
+            res.append(levels)
+    finally:
+        for d in range(D):
+            lib().mi_gamg_host_free(C.c_void_p(out[d]))
+    return res
 
 
 def gamg_host_hierarchy(n_cells, lower_addr, upper_addr, face_weights, n_cells_in_coarsest_level=10, forward=True, merge_levels=1):

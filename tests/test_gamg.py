@@ -447,3 +447,35 @@ def test_inter_level_functors_equal_the_reference_headers(pkg, orc):
         assert set(now) == set(G.files)
         for k in G.files:
             assert np.array_equal(now[k], G[k]), k
+
+
+@pytest.mark.parametrize("parts,merge", [((2, 1, 1), 1), ((2, 2, 1), 1), ((2, 2, 2), 1), ((1, 3, 2), 2)])
+def test_per_rank_hierarchies_of_a_decomposed_case_equal_the_oracle(pkg, orc, parts, merge):
+    """The per-rank GAMG builder a real rank runs (pair agglomeration per processor, `continueAgglomerating` agreed over all
+    processors, restrict addressing of the patch cells exchanged with the neighbour, coarse processor interfaces from the
+    distinct (mine, theirs) pairs) for EVERY domain of a decomposed box -- all domains in one process, a barrier and a shared
+    table as the communicator -- against the oracle's multi-domain restatement: cell maps, coarse addressing and the
+    agglomerated processor patches of every level and domain."""
+    syn = pkg.synthetic
+    case = syn.box_case(12, 10, 8)
+    subs = syn.decompose_box(case, parts)
+    ws = [orc.box_face_weights(s) for s in subs]
+    S = orc.System(subs)
+    H = orc.GamgSysHierarchy(S, ws, 6, merge_levels=merge)
+    E = pkg.engine.gamg_host_hierarchy_domains(subs, ws, 6, True, merge_levels=merge)
+    assert len(E) == len(subs)
+    for d, sub in enumerate(subs):
+        assert len(E[d]) == H.n_levels >= 2
+        n_patch = [len(i.face_cells) for i in sub.interfaces]
+        for l in range(H.n_levels):
+            o, e = H.level(d, l), E[d][l]
+            assert np.array_equal(o["restrict"], e["restrictMap"])
+            assert np.array_equal(o["lower"], e["cLower"]) and np.array_equal(o["upper"], e["cUpper"])
+            for p in range(len(sub.interfaces)):
+                op = H.patch(d, l, p, n_patch[p])
+                ep = e["patches"][p]
+                assert np.array_equal(op["face_restrict"], ep["faceRestrict"]) and np.array_equal(op["face_cells"], ep["faceCells"])
+                # both sides of a processor patch agree: my nbrCells are the neighbour's faceCells, face for face
+                nd, npch = sub.interfaces[p].nbr_domain, sub.interfaces[p].nbr_patch
+                assert np.array_equal(ep["nbrCells"], E[nd][l]["patches"][npch]["faceCells"])
+                n_patch[p] = len(ep["faceCells"])
