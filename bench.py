@@ -100,11 +100,20 @@ def main():
     n_gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    # MI_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, the
+    # exchange goes through gloo and the torch.distributed loop; timings of such a run mean nothing).  Default: RCCL.
+    backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("MI_BENCH_FORCE_DIST") == "2":  # "2": also run the RCCL calls on a 1-rank group
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            os.environ.setdefault("MI_DPCG_DRIVER", "torch")
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if world > 1:          # one rank compiles (if anything is stale), the others wait: no concurrent writers of the .so files
         if rank == 0:

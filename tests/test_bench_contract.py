@@ -1,0 +1,56 @@
+"""GPU (-m gpu): bench.py's driver contract on a small box -- the single-GPU line, and a rehearsal of the N > 1 path with
+several ranks sharing the one GPU over gloo (what the driver launches with torch.distributed.run on a multi-GPU node)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline", "cpu_baseline"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _check(line, n):
+    d = json.loads(line)
+    assert KEYS - ({"cpu_baseline"} if n > 1 else set()) <= set(d), set(d) ^ KEYS      # the CPU leg runs at N = 1 only
+    assert d["n_gpus"] == n and d["steps"] == 12 and d["warmup"] == 3 and d["value"] > 0 and d["higher_is_better"] is True
+    assert abs(d["ms_per_step"] * d["value"] - 1e3) < 1e-6 * 1e3
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    return d
+
+
+def test_single_gpu_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--dims", "40", "32", "24", "--cpu-iters", "5"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout                       # ONE JSON line on stdout, everything else on stderr
+    d = _check(lines[0], 1)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_multi_rank_rehearsal_over_gloo(n):
+    env = dict(os.environ, MI_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "12", "--warmup", "3",
+           "--dims", "40", "32", "24", "--no-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 only
+    d = _check(lines[0], n)
+    assert d["scaling"] == "strong" and "domain-decomposition" in d["config"]["parallelism"]
+    assert d["config"]["weak_scaling_supplement"]["cells_per_gpu"] == 40 * 32 * 24
