@@ -1431,7 +1431,6 @@ extern "C" int mi_smooth_solve(mi_matrix_t m, double* psi_io, const double* sour
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
     hipStream_t s = a->ctx->stream;
-    const int64_t n = a->L.nCells;
     double *psi, *src, *tmp, *wA, *rA, *psi2;
     MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &tmp)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
     MICHK(m->vec(8, &psi2));
