@@ -341,6 +341,7 @@ extern "C" int mi_addr_stats(mi_addr_t a, int64_t st[8])
 // ---------------------------------------------------------------------------
 // matrix
 // ---------------------------------------------------------------------------
+extern "C" mi_addr_t mi_matrix_addr(mi_matrix_t m) { return m ? m->addr : nullptr; }
 extern "C" int mi_matrix_create(mi_addr_t a, mi_matrix_t* out)
 {
     if (!a || !out) return fail(MI_ERR_ARG, "mi_matrix_create: bad argument");
@@ -551,12 +552,14 @@ extern "C" int mi_amul_engine(mi_matrix_t m, const double* psi_e, double* Apsi_e
 {
     if (!m || !psi_e || !Apsi_e) return fail(MI_ERR_ARG, "mi_amul_engine: bad argument");
     HIPCHK(hipSetDevice(m->addr->ctx->device));
+    if (which == 0) return tile_op<OP_AMUL>(m, false, psi_e, nullptr, nullptr, Apsi_e, 0.0); // exchanges the halo when attached
     return launch_tile<OP_AMUL>(m, false, psi_e, nullptr, nullptr, Apsi_e, 0.0, which);
 }
 extern "C" int mi_tmul_engine(mi_matrix_t m, const double* psi_e, double* Tpsi_e, int which)
 {
     if (!m || !psi_e || !Tpsi_e) return fail(MI_ERR_ARG, "mi_tmul_engine: bad argument");
     HIPCHK(hipSetDevice(m->addr->ctx->device));
+    if (which == 0) return tile_op<OP_AMUL>(m, true, psi_e, nullptr, nullptr, Tpsi_e, 0.0);
     return launch_tile<OP_AMUL>(m, true, psi_e, nullptr, nullptr, Tpsi_e, 0.0, which);
 }
 
@@ -720,28 +723,57 @@ namespace {
 int reduce_sync_fwd(mi_matrix_s* m, const double* a, double* out);
 }
 
+// ---- engine-order primitives for a caller that keeps its solver loop (level-1 integration) but lets its work vectors live
+//      in engine order for the duration of a solve (mi_vec_to_engine once, mi_vec_from_engine once): no permutation passes.
+//      Vectors are n_cells + n_ext long.
+namespace { int precond_engine(mi_matrix_s* m, int kind, bool transpose, const double* r, double* w); }
+extern "C" int mi_precondition_engine(mi_matrix_t m, int kind, int transpose, const double* rA_e, double* wA_e)
+{
+    if (!m || !rA_e || !wA_e) return fail(MI_ERR_ARG, "mi_precondition_engine: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    return precond_engine(m, kind, transpose != 0, rA_e, wA_e);
+}
+extern "C" int mi_residual_engine(mi_matrix_t m, const double* psi_e, const double* source_e, double* rA_e)
+{
+    if (!m || !psi_e || !source_e || !rA_e) return fail(MI_ERR_ARG, "mi_residual_engine: bad argument");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    return tile_op<OP_RESIDUAL>(m, false, psi_e, source_e, nullptr, rA_e, 0.0);
+}
+extern "C" int mi_jacobi_smooth_engine(mi_matrix_t m, double omega, double* psi_e, const double* source_e, int32_t n_sweeps)
+{
+    if (!m || !psi_e || !source_e || n_sweeps < 0) return fail(MI_ERR_ARG, "mi_jacobi_smooth_engine: bad argument");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    double* scratch;
+    MICHK(m->vec(1, &scratch));
+    double *cur = psi_e, *nxt = scratch;
+    for (int sw = 0; sw < n_sweeps; ++sw) {
+        if (a->L.nExt > 0 && sw > 0 && !comm_remote(m))
+            HIPCHK(hipMemcpyAsync(cur + a->L.nCells, nxt + a->L.nCells, sizeof(double) * (size_t)a->L.nExt, hipMemcpyDeviceToDevice, s));
+        MICHK(tile_op<OP_JACOBI>(m, false, cur, source_e, nullptr, nxt, omega));
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != psi_e) HIPCHK(hipMemcpyAsync(psi_e, cur, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s));
+    return MI_OK;
+}
+
 // lduMatrix::solver::normFactor (lduMatrixSolver.C:182-236) for caller-order psi/source/Apsi. The
 // vectors are gathered into engine order first, so the value is bit-identical to the normFactor
 // the solvers' own prologue computes (and global when a communicator is attached).
-extern "C" int mi_norm_factor(mi_matrix_t m, const double* psi, const double* source, const double* Apsi, double* out)
+namespace {
+int norm_factor_engine(mi_matrix_s* m, const double* psi_e, const double* src_e, const double* Apsi_e, double* sumA_scratch, double* out)
 {
-    if (!m || !psi || !source || !Apsi || !out) return fail(MI_ERR_ARG, "mi_norm_factor: bad argument");
-    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
     mi_addr_s* a = m->addr;
     mi_ctx_s* c = a->ctx;
-    HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int64_t n = a->L.nCells;
-    double *v0, *v1, *v2, *v3;
-    MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1)); MICHK(m->vec(2, &v2)); MICHK(m->vec(3, &v3));
-    k_gather_perm<<<RG, RB, 0, s>>>(Apsi, a->e2c.p, v0, n);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, v2, n);
-    k_gather_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, v3, n);
-    MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, v1, 0.0, 0));
+    MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, sumA_scratch, 0.0, 0));
     double sumPsi = 0;
-    MICHK(reduce_sync_fwd(m, v3, &sumPsi));
+    MICHK(reduce_sync_fwd(m, psi_e, &sumPsi));
     const double avg = sumPsi / (double)(comm_attached(m) ? comm_n_global(m) : n);
-    k_normfactor<<<RG, RB, 0, s>>>(v0, v2, v1, avg, n, c->partial.p);
+    k_normfactor<<<RG, RB, 0, s>>>(Apsi_e, src_e, sumA_scratch, avg, n, c->partial.p);
     k_reduce_final<<<1, RB, 0, s>>>(c->partial.p, c->scalars.p);
     HIPCHK(hipGetLastError());
     if (comm_attached(m)) MICHK(comm_allreduce(m, c->scalars.p, 1));
@@ -749,6 +781,31 @@ extern "C" int mi_norm_factor(mi_matrix_t m, const double* psi, const double* so
     HIPCHK(hipStreamSynchronize(s));
     *out = c->hostScal[0] + SP_SMALL; // + matrix.small_ (lduMatrixSolver.C:228)
     return MI_OK;
+}
+} // namespace
+extern "C" int mi_norm_factor(mi_matrix_t m, const double* psi, const double* source, const double* Apsi, double* out)
+{
+    if (!m || !psi || !source || !Apsi || !out) return fail(MI_ERR_ARG, "mi_norm_factor: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    mi_addr_s* a = m->addr;
+    HIPCHK(hipSetDevice(a->ctx->device));
+    hipStream_t s = a->ctx->stream;
+    const int64_t n = a->L.nCells;
+    double *v0, *v1, *v2, *v3;
+    MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1)); MICHK(m->vec(2, &v2)); MICHK(m->vec(3, &v3));
+    k_gather_perm<<<RG, RB, 0, s>>>(Apsi, a->e2c.p, v0, n);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, v2, n);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, v3, n);
+    return norm_factor_engine(m, v3, v2, v0, v1, out);
+}
+extern "C" int mi_norm_factor_engine(mi_matrix_t m, const double* psi_e, const double* source_e, const double* Apsi_e, double* out)
+{
+    if (!m || !psi_e || !source_e || !Apsi_e || !out) return fail(MI_ERR_ARG, "mi_norm_factor_engine: bad argument");
+    if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    HIPCHK(hipSetDevice(m->addr->ctx->device));
+    double* v1;
+    MICHK(m->vec(1, &v1));
+    return norm_factor_engine(m, psi_e, source_e, Apsi_e, v1, out);
 }
 
 namespace {

@@ -46,11 +46,12 @@ SYMBOLS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
     "mi_addr_create", "mi_addr_create_coupled", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
     "mi_addr_n_ext", "mi_addr_cell_perm", "mi_addr_stats", "mi_addr_patch_offsets",
-    "mi_matrix_create", "mi_matrix_destroy", "mi_matrix_set_coeffs", "mi_matrix_set_interface_coeffs",
+    "mi_matrix_create", "mi_matrix_addr", "mi_matrix_destroy", "mi_matrix_set_coeffs", "mi_matrix_set_interface_coeffs",
     "mi_matrix_set_ext", "mi_halo_pack_engine", "mi_vec_to_engine", "mi_vec_from_engine",
     "mi_amul", "mi_tmul", "mi_sumA", "mi_residual", "mi_H", "mi_H1", "mi_faceH",
     "mi_amul_engine", "mi_tmul_engine", "mi_precondition", "mi_jacobi_smooth",
-    "mi_sum", "mi_sum_prod", "mi_sum_mag", "mi_norm_factor",
+    "mi_sum", "mi_sum_prod", "mi_sum_mag", "mi_norm_factor", "mi_norm_factor_engine", "mi_precondition_engine",
+    "mi_residual_engine", "mi_jacobi_smooth_engine",
     "mi_pcg_solve", "mi_pcg_begin", "mi_pcg_iterate", "mi_pcg_end",
     "mi_pbicg_solve", "mi_pbicgstab_solve", "mi_smooth_solve",
     "mi_bench_amul", "mi_bench_pcg_iters", "mi_debug_occupancy",

@@ -177,3 +177,25 @@ def test_reference_GAMG_Vcycle_on_engine(pkg, orc, ctx, dropin, sym, kw):
         assert abs(out5[1] - other["finalResidual"]) <= 1e-6 * abs(other["finalResidual"]) + 1e-16
     scale = np.max(np.abs(psi_orc))
     assert np.max(np.abs(psi_ref - psi_orc)) / scale < 1e-9 and np.max(np.abs(psi_ref - pe.cpu().numpy())) / scale < 1e-9
+
+
+@pytest.mark.parametrize("kind,sym,precond", [(0, True, "diagonal"), (0, True, "AINV"), (1, False, "AINV"), (2, False, "diagonal"), (3, True, "none")])
+def test_reference_solvers_on_engine_order_primitives(pkg, orc, ctx, dropin, kind, sym, precond):
+    """Same reference solver sources, but their work vectors live in ENGINE order for the duration of the solve
+    (mi_vec_to_engine once, mi_*_engine primitives, mi_vec_from_engine once): no permutation pass per operator.  Same answers."""
+    case = pkg.synthetic.box_case(21, 17, 13, symmetric=sym)
+    addr, mat = build(pkg, ctx, case)
+    n = case.n_cells
+    iters = 10
+    psi_c, perf_c = run_ref(dropin, pkg, ctx, mat, kind, n, np.zeros(n), case.source, precond, iters, n_sweeps=2)
+    psi = dev(np.zeros(n)); src = dev(case.source)
+    out5 = (C.c_double * 5)()
+    dropin.ref_dropin_solve_order.restype = None
+    dropin.ref_dropin_solve_order(C.c_int(kind), ctx.h, mat.h, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_int(n),
+                                  C.c_void_p(psi.data_ptr()), C.c_void_p(src.data_ptr()), C.c_int(pkg.engine.PRECOND[precond]),
+                                  C.c_double(0.0), C.c_double(0.0), C.c_int(iters), C.c_int(0), C.c_int(2), C.c_double(0.9), C.c_int(1), out5)
+    torch.cuda.synchronize()
+    assert int(out5[2]) == perf_c["nIterations"]
+    assert abs(out5[0] - perf_c["initialResidual"]) <= 1e-12 * perf_c["initialResidual"]
+    assert abs(out5[1] - perf_c["finalResidual"]) <= 1e-7 * perf_c["finalResidual"] + 1e-16
+    assert np.max(np.abs(psi.cpu().numpy() - psi_c)) <= 1e-9 * np.max(np.abs(psi_c))

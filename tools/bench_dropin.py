@@ -11,7 +11,7 @@ graft.build()
 pkg = graft.load_package()
 syn, eng = pkg.synthetic, pkg.engine
 lib = C.CDLL(os.path.join(ROOT, "tests", "ref_dropin", "_ref", "libref_dropin.so"))
-lib.ref_dropin_solve.restype = None; lib.ref_dropin_gamg_solve.restype = None
+lib.ref_dropin_solve.restype = None; lib.ref_dropin_gamg_solve.restype = None; lib.ref_dropin_solve_order.restype = None
 dims = [int(v) for v in os.environ.get("DIMS", "216,216,216").split(",")]
 case = syn.box_case(*dims)
 n = case.n_cells
@@ -25,15 +25,16 @@ src = t(case.source)
 out = {}
 for precond in ("diagonal", "AINV"):
     iters = 200
-    for name in ("reference PCG::solve on engine primitives (level 1)", "mi_pcg_solve (level 2)"):
+    for name in ("reference PCG::solve on engine primitives (level 1)", "reference PCG::solve on ENGINE-ORDER primitives (level 1)", "mi_pcg_solve (level 2)"):
         best = 1e9
         for rep in range(3):
             psi = torch.zeros(n, dtype=torch.float64, device=dev)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             if name.startswith("reference"):
                 o5 = (C.c_double * 5)()
-                lib.ref_dropin_solve(C.c_int(0), ctx.h, mat.h, C.c_void_p(stream), C.c_int(n), C.c_void_p(psi.data_ptr()), C.c_void_p(src.data_ptr()),
-                                     C.c_int(eng.PRECOND[precond]), C.c_double(0.0), C.c_double(0.0), C.c_int(iters), C.c_int(0), C.c_int(1), C.c_double(0.9), o5)
+                lib.ref_dropin_solve_order(C.c_int(0), ctx.h, mat.h, C.c_void_p(stream), C.c_int(n), C.c_void_p(psi.data_ptr()), C.c_void_p(src.data_ptr()),
+                                           C.c_int(eng.PRECOND[precond]), C.c_double(0.0), C.c_double(0.0), C.c_int(iters), C.c_int(0), C.c_int(1), C.c_double(0.9),
+                                           C.c_int(1 if "ENGINE-ORDER" in name else 0), o5)
                 nit = int(o5[2])
             else:
                 nit = mat.pcg(psi, src, precond, tolerance=0.0, maxIter=iters)["nIterations"]
