@@ -253,7 +253,8 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": amul_bytes,
-            "traffic_unit": f"bytes per launch (rocprofv3 PMC, {traffic_from_profile(nx, ny, nz, n_gpus)[1]})",
+            "traffic_unit": (f"bytes per launch (rocprofv3 PMC, {traffic_from_profile(nx, ny, nz, n_gpus)[1]})"
+                             if traffic_from_profile(nx, ny, nz, n_gpus)[0] is not None else "not measured for this configuration"),
             "avg_launch_us": amul_avg_s * 1e6,
             "traffic": traffic_from_profile(nx, ny, nz, n_gpus)[0],
         },
