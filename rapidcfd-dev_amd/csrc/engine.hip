@@ -1072,9 +1072,13 @@ extern "C" int mi_pcg_solve(mi_matrix_t m, double* psi, const double* source, co
         return mi_pcg_end(m, psi, perf, hist_host, hist_len);
     }
     // bodies run for it = 0 .. maxIter inclusive at most (nIterations++ < maxIter, PCG.C:197-204)
+    // batches grow 2, 4, 8 ... batch: a solve that converges in a few iterations (every momentum predictor) does not pay
+    // for a full batch of launches that exit at their first instruction; a long solve polls `done` 3 times more in total
+    int nb = batch < 2 ? batch : 2;
     while (!c->hostState->done && m->pcgIt <= limit) {
-        MICHK(mi_pcg_iterate(m, batch, nullptr));
+        MICHK(mi_pcg_iterate(m, nb, nullptr));
         MICHK(fetch_state(c));
+        nb = nb * 2 > batch ? batch : nb * 2;
     }
     return mi_pcg_end(m, psi, perf, hist_host, hist_len);
 }
@@ -1282,11 +1286,12 @@ int pbicg_solve_device(mi_matrix_s* m, double* psi_io, const double* source, con
     k_sub<<<RG, RB, 0, s>>>(rT, src, wT, n);
     MICHK(fetch_state(c));
     const int batch = env_int("MI_PCG_BATCH", 16);
-    int it = 0;
+    int it = 0, nb = batch < 2 ? batch : 2;   // growing batches, as in mi_pcg_solve
     while (!c->hostState->done && it <= ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0)) {
-        MICHK(bicg_enqueue(m, it, batch, precond, psi, pA, wA, rA, pT, wT, rT));
-        it += batch;
+        MICHK(bicg_enqueue(m, it, nb, precond, psi, pA, wA, rA, pT, wT, rT));
+        it += nb;
         MICHK(fetch_state(c));
+        nb = nb * 2 > batch ? batch : nb * 2;
     }
     k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, psi_io, a->L.nCells);
     HIPCHK(hipGetLastError());
@@ -1399,11 +1404,12 @@ int pbicgstab_solve_device(mi_matrix_s* m, double* psi_io, const double* source,
     HIPCHK(hipMemcpyAsync(rA0, rA, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     MICHK(fetch_state(c));
     const int batch = env_int("MI_PCG_BATCH", 16);
-    int it = 0;
+    int it = 0, nb = batch < 2 ? batch : 2;   // growing batches, as in mi_pcg_solve
     while (!c->hostState->done && it <= ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0)) {
-        MICHK(stab_enqueue(m, it, batch, precond, replicate_quirk != 0, psi, pA, yA, rA, AyA, sA, zA, tA, rA0));
-        it += batch;
+        MICHK(stab_enqueue(m, it, nb, precond, replicate_quirk != 0, psi, pA, yA, rA, AyA, sA, zA, tA, rA0));
+        it += nb;
         MICHK(fetch_state(c));
+        nb = nb * 2 > batch ? batch : nb * 2;
     }
     k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, psi_io, a->L.nCells);
     HIPCHK(hipGetLastError());
