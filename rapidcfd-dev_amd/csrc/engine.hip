@@ -8,6 +8,7 @@
 #include "tiling.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -110,6 +111,7 @@ struct mi_matrix_s {
     mi_dpcg_s dp; // buffers of a distributed PCG session (owned by the caller)
     DevBuf<double> diagE, upE, lowE, rD;
     bool asym = false, bound = false, rDValid = false;
+    uint64_t epoch = 0; // bumped whenever coefficients are (re)bound: lets a GAMG hierarchy keep its level matrices between solves
     std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
     DevBuf<double> hist, tilePartial;
     int histLen = 0;
@@ -341,6 +343,8 @@ extern "C" int mi_addr_stats(mi_addr_t a, int64_t st[8])
 // ---------------------------------------------------------------------------
 // matrix
 // ---------------------------------------------------------------------------
+// process-wide stamp of a coefficient binding: (matrix, epoch) never repeats, even when a new matrix reuses an old address
+static uint64_t next_epoch() { static std::atomic<uint64_t> e{0}; return ++e; }
 extern "C" mi_addr_t mi_matrix_addr(mi_matrix_t m) { return m ? m->addr : nullptr; }
 extern "C" int mi_matrix_create(mi_addr_t a, mi_matrix_t* out)
 {
@@ -380,6 +384,7 @@ extern "C" int mi_matrix_set_coeffs(mi_matrix_t m, const double* diag, const dou
     HIPCHK(hipGetLastError());
     m->bound = true;
     m->rDValid = false;
+    m->epoch = next_epoch();
     return MI_OK;
 }
 
@@ -392,6 +397,7 @@ extern "C" int mi_matrix_set_interface_coeffs(mi_matrix_t m, int32_t patch, cons
     if (n == 0) return MI_OK;
     k_fill_iface<<<(n + 255) / 256, 256, 0, a->ctx->stream>>>(bou, inte, a->extSlot.p + off, m->upE.p, m->asym ? m->lowE.p : nullptr, n);
     HIPCHK(hipGetLastError());
+    m->epoch = next_epoch();
     return MI_OK;
 }
 

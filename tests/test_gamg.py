@@ -218,6 +218,14 @@ def test_engine_gamg_history(pkg, orc, name, kw):
     psi2 = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf2 = G.solve(mat, psi2, dev(case.source), **args)
     assert np.array_equal(perf2["history"], perf["history"])
+    # ... and re-binding other coefficients invalidates the kept level matrices: the next solve is the new matrix's
+    import copy
+    case2 = copy.copy(case); case2.diag = case.diag * 1.07
+    mat.set_coeffs(dev(case2.diag), dev(case2.upper), None if case2.lower is None else dev(case2.lower))
+    psi3 = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+    perf3 = G.solve(mat, psi3, dev(case.source), **args)
+    _, ref3 = orc.GamgHierarchy(case2, w, 10, merge_levels=merge).solve(np.zeros(case.n_cells), case.source, **args)
+    assert perf3["nIterations"] == ref3["nIterations"] and np.max(np.abs(perf3["history"] - ref3["history"])) < 1e-10 * ref3["history"][0]
 
 
 # ---- coupled patches / decomposed cases -------------------------------------------------------------------
