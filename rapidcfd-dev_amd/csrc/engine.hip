@@ -109,8 +109,8 @@ struct mi_dpcg_s { double *psi = nullptr, *src = nullptr, *pA = nullptr, *wA = n
 struct mi_matrix_s {
     mi_addr_s* addr = nullptr;
     mi_dpcg_s dp; // buffers of a distributed PCG session (owned by the caller)
-    DevBuf<double> diagE, upE, lowE, rD;
-    bool asym = false, bound = false, rDValid = false;
+    DevBuf<double> diagE, upE, lowE, rD, sumAE; // sumAE: lduMatrix::sumA of the bound coefficients (normFactor), kept per binding
+    bool asym = false, bound = false, rDValid = false, sumAValid = false;
     uint64_t epoch = 0; // bumped whenever coefficients are (re)bound: lets a GAMG hierarchy keep its level matrices between solves
     std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
     DevBuf<double> hist, tilePartial;
@@ -383,7 +383,7 @@ extern "C" int mi_matrix_set_coeffs(mi_matrix_t m, const double* diag, const dou
     k_fill_slots<<<2048, 256, 0, s>>>(upper, lower, a->slotFace.p, m->upE.p, asym ? m->lowE.p : nullptr, a->L.totalSlots);
     HIPCHK(hipGetLastError());
     m->bound = true;
-    m->rDValid = false;
+    m->rDValid = false; m->sumAValid = false;
     m->epoch = next_epoch();
     return MI_OK;
 }
@@ -397,6 +397,7 @@ extern "C" int mi_matrix_set_interface_coeffs(mi_matrix_t m, int32_t patch, cons
     if (n == 0) return MI_OK;
     k_fill_iface<<<(n + 255) / 256, 256, 0, a->ctx->stream>>>(bou, inte, a->extSlot.p + off, m->upE.p, m->asym ? m->lowE.p : nullptr, n);
     HIPCHK(hipGetLastError());
+    m->sumAValid = false;
     m->epoch = next_epoch();
     return MI_OK;
 }
@@ -865,12 +866,17 @@ int solve_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* 
     HIPCHK(hipMemcpyAsync(c->state.p, c->hostState, sizeof(PcgState), hipMemcpyHostToDevice, s));
     MICHK(tile_op<OP_AMUL>(m, false, psi_e, nullptr, nullptr, wA, 0.0));
     k_sub<<<RG, RB, 0, s>>>(rA, src_e, wA, n);
-    MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, tmp, 0.0, 0));
+    (void)tmp;
+    if (!m->sumAValid) { // sumA depends on the coefficients only: once per binding, not once per solve
+        if (m->sumAE.n != (size_t)n) MICHK(m->sumAE.alloc((size_t)n));
+        MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, m->sumAE.p, 0.0, 0));
+        m->sumAValid = true;
+    }
     // gAverage(psi) (gpuFieldCommonFunctions.C:611-634): needs the host for the division by N
     double sumPsi = 0;
     MICHK(reduce_sync<RED_SUM>(m, psi_e, nullptr, &sumPsi));
     const double avg = sumPsi / (double)(comm_attached(m) ? comm_n_global(m) : n);
-    k_normfactor<<<RG, RB, 0, s>>>(wA, src_e, tmp, avg, n, c->partial.p);
+    k_normfactor<<<RG, RB, 0, s>>>(wA, src_e, m->sumAE.p, avg, n, c->partial.p);
     k_reduce<RED_MAG><<<RG, RB, 0, s>>>(rA, nullptr, n, c->partial.p + RG);
     if (comm_attached(m)) { // the two sums are global (lduMatrixSolver.C:182-236, gSumMag)
         k_reduce_final2<<<2, RB, 0, s>>>(c->partial.p, c->scalars.p + 1, c->partial.p + RG, c->scalars.p + 2);
