@@ -79,6 +79,7 @@ struct mi_ctx_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int amulBS = 0;
     int tileFlags = 0;
+    int xcdRows = 1;      // MI_XCD_ROWS: XCD-aware block mapping of the caller-order row passes
     int persist = 0;      // MI_TILE_PERSIST: persistent tile launches (workgroups = resident slots, each walks a run of tiles)
     int nCU = 0;
     int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
@@ -194,6 +195,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->tileFlags = env_int("MI_TILE_FLAGS", 0);
     c->attachEvents = env_int("MI_EVENT_ATTACH", 1);
     c->persist = env_int("MI_TILE_PERSIST", 0);
+    c->xcdRows = env_int("MI_XCD_ROWS", 1);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
