@@ -24,6 +24,7 @@
 namespace mi {
 
 constexpr int RG = 1024;      // blocks of every streaming/reduction kernel (fixed => deterministic)
+static_assert(RG == 1024, "the fold kernels (k_fold_partials / k_fold_final: one 1024-thread workgroup, one slot per thread) assume RG == 1024; 2048 was tried and is NOT a drop-in change");
 constexpr int RB = 256;       // threads per block of the streaming kernels
 
 // ---------------------------------------------------------------------------
