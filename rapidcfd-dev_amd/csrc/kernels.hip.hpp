@@ -157,6 +157,25 @@ __device__ __forceinline__ void stage_gather(const double* __restrict__ x, const
     for (; k < n; k += BS) dst[k] = x[idx[k]];
 }
 
+// Direct-to-LDS staging (global_load_lds_dwordx4): every lane fetches 16 bytes from its own global address and the wave's
+// 1 KiB lands contiguously in LDS at a wave-uniform base -- no VGPR round trip, one instruction per KiB per wave.  Measured
+// in the standalone harness on one box: 155.7 -> 147.8 us for the symmetric Amul (profiles/r01_t_direct_to_lds.md).
+typedef __attribute__((address_space(1))) const void* mi_gptr_t;
+typedef __attribute__((address_space(3))) void* mi_lptr_t;
+template <int BS>
+__device__ __forceinline__ void stage_dma16(const double2* __restrict__ src, double2* __restrict__ dst, int n2, int wave, int lane)
+{
+    for (int base = wave * 64; base < n2; base += BS)
+        if (base + lane < n2) __builtin_amdgcn_global_load_lds((mi_gptr_t)(src + base + lane), (mi_lptr_t)(dst + base), 16, 0, 0);
+}
+// n doubles (8-byte aligned source): pairs through the DMA path, an odd last element by hand
+template <int BS>
+__device__ __forceinline__ void stage_dma8(const double* __restrict__ src, double* __restrict__ dst, int n, int tid)
+{
+    stage_dma16<BS>(reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst), n >> 1, tid >> 6, tid & 63);
+    if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
+}
+
 // one tile: position p of the launch (p indexes tileList / dotPartial)
 template <int OP, bool ASYM, bool TRANS, int BS, bool C16>
 __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double* __restrict__ smem)
@@ -178,6 +197,30 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     // ---- stage: coefficients (16-byte coalesced), psi, halo -------------------
     // All global loads of a phase are issued before the first LDS store (4-deep
     // unroll) so that every wave keeps several KiB in flight.
+#ifndef MI_STAGE_THROUGH_REGISTERS   // A/B build switch (tools/ab_dma.sh): the register-staged copies this kernel used before
+    // measured per variant on one box (profiles/r01_t_direct_to_lds.md): faster everywhere except the asymmetric AINV pass
+    // (four LDS arrays, one 1024-thread workgroup per CU), which keeps the register path
+    constexpr bool DMA = !(OP == OP_AINV && ASYM);
+    if (DMA) {
+    stage_dma16<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid >> 6, tid & 63);
+    if (ASYM) stage_dma16<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
+    if (NEEDX) {
+        stage_dma8<BS>(a.x + c0, xs, nc, tid);
+        stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
+        if (OP == OP_AINV) {
+            stage_dma8<BS>(a.rD + c0, rDs, nc, tid);
+            stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
+        }
+    }
+    } else {
+        stage_copy_nt<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid, false);
+        stage_copy_nt<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid, false);
+        stage_copy<BS>(a.x + c0, xs, nc, tid);
+        stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
+        stage_copy<BS>(a.rD + c0, rDs, nc, tid);
+        stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
+    }
+#else
     const bool nt = (a.flags & 1) != 0;
     stage_copy_nt<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid, nt);
     if (ASYM) stage_copy_nt<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid, nt);
@@ -189,6 +232,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
             stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
         }
     }
+#endif
     if (C16) { // slot bases of the tile's cells, halo cells and the pad cell (whose x is 0 and whose slot is the zero slot)
         const int w0 = a.tileSbStart[t], nw = a.tileSbStart[t + 1] - w0;
 #pragma unroll 2

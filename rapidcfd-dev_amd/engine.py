@@ -15,6 +15,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librapidcfd_amd.so")
+if os.environ.get("MI_ENGINE_LIB"):   # A/B builds of the engine (tools/ab_dma.sh); the product path is the in-tree library above
+    LIB_PATH = os.environ["MI_ENGINE_LIB"]
 _lib = None
 
 PRECOND = {"none": 0, "diagonal": 1, "AINV": 2,

@@ -77,7 +77,8 @@ int main(int argc, char** argv)
         run("explicit BS1024 (own LDS)", [&] { tile_kernel<OP_AMUL, false, false, 1024, false><<<L.nTiles, 1024, ldsX, 0>>>(a); }, y1);
         run("baseline 512 explicit", [&] { tile_kernel<OP_AMUL, false, false, 512, false><<<L.nTiles, 512, lds, 0>>>(a); }, y0);
         exp_variants(a, L, lds, run, check, y1);
-        exp_prefetch(a, L, ldsX, run, check, y1);
+        if (getenv("EXP_PREFETCH")) exp_prefetch(a, L, ldsX, run, check, y1);
+        exp_dma(a, L, ldsX, run, check, y1);
     }
     return 0;
 }

@@ -224,3 +224,95 @@ void exp_prefetch(TileArgs& a, const TileLayout& L, size_t ldsX, Run run, Check 
     }
 }
 } // namespace mi
+
+// ---------------------------------------------------------------------------------------------------------------------
+// V4: coefficient segment and the tile's own psi range staged with direct-to-LDS loads (global_load_lds_dwordx4: no VGPR
+//     round trip, one instruction per 1 KiB per wave); the halo gather stays on the register path.  One workgroup per tile.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace mi {
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int BS>
+__global__ __launch_bounds__(BS) void k_amul_dma(const TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* cU = smem;
+    double* xs = smem + a.offX;
+    const int b = blockIdx.x, perx = gridDim.x >> 3;
+    const int t = (b < (perx << 3)) ? (b & 7) * perx + (b >> 3) : b;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = BS / 64, PRE = 8;
+    const int c0 = a.tileCellStart[t], nc = a.tileCellStart[t + 1] - c0;
+    const int s0 = a.tileSlotStart[t], ns = a.tileSlotStart[t + 1] - s0;
+    const int h0 = a.tileHaloStart[t], nh = a.tileHaloStart[t + 1] - h0;
+    {   // coefficients: ns/2 double2, wave w of pass q copies elements [q*BS + w*64, +64)
+        const double2* src = reinterpret_cast<const double2*>(a.up + s0);
+        double2* dst = reinterpret_cast<double2*>(cU);
+        const int n2 = ns >> 1;
+        for (int base = wave * 64; base < n2; base += BS)
+            if (base + lane < n2) __builtin_amdgcn_global_load_lds((gptr_t)(src + base + lane), (lptr_t)(dst + base), 16, 0, 0);
+        // psi of the tile's own cells: pairs, the odd last one by hand
+        const double2* xsrc = reinterpret_cast<const double2*>(a.x + c0);
+        double2* xdst = reinterpret_cast<double2*>(xs);
+        const int x2 = nc >> 1;
+        for (int base = wave * 64; base < x2; base += BS)
+            if (base + lane < x2) __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + base + lane), (lptr_t)(xdst + base), 16, 0, 0);
+        if ((nc & 1) && tid == 0) xs[nc - 1] = a.x[c0 + nc - 1];
+    }
+    stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
+    const int sl0 = a.tileSliceStart[t], nsl = a.tileSliceStart[t + 1] - sl0;
+    const uint32_t padEnt = (uint32_t)(ns - 1) << 16;
+    uint32_t ecur[PRE];
+    int wcur = 0, e0cur = 0;
+    auto fetch = [&](int s, uint32_t (&e)[PRE], int& e0, int& width) {
+        e0 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s]);
+        const int e1 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s + 1]);
+        width = (e1 - e0) >> 6;
+        const uint32_t* ent = a.entries + e0 + lane;
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) e[q] = (q < width) ? ent[q * 64] : padEnt;
+    };
+    if (wave < nsl) fetch(wave, ecur, e0cur, wcur);
+    __syncthreads();
+    for (int s = wave; s < nsl; s += NW) {
+        uint32_t enext[PRE];
+        int wnext = 0, e0next = 0;
+        if (s + NW < nsl) fetch(s + NW, enext, e0next, wnext);
+        else {
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) enext[q] = padEnt;
+        }
+        const int i = s * 64 + lane;
+        const bool live = i < nc;
+        const int gi = c0 + (live ? i : 0);
+        const double xi = live ? xs[i] : 0.0;
+        double acc = a.diag[gi] * xi;
+        auto accumulate = [&](uint32_t en) { acc = fma(cU[(en >> 16) & 0x7FFFu], xs[en & 0xFFFFu], acc); };
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) if (q < wcur) accumulate(ecur[q]);
+        if (wcur > PRE) {
+            const uint32_t* ent = a.entries + e0cur + lane;
+            for (int q = PRE; q < wcur; ++q) accumulate(ent[q * 64]);
+        }
+        if (live) a.y[gi] = acc;
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) ecur[q] = enext[q];
+        wcur = wnext; e0cur = e0next;
+    }
+}
+
+template <class Run, class Check>
+void exp_dma(TileArgs& a, const TileLayout& L, size_t ldsX, Run run, Check check, double* y1)
+{
+    static bool once = false;
+    if (!once) {
+        once = true;
+        (void)hipFuncSetAttribute((const void*)k_amul_dma<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_amul_dma<512>, 512, ldsX);
+        printf("   direct-to-LDS kernel BS512: %d workgroups per CU by the runtime\n", nb);
+    }
+    run("direct-to-LDS staging BS512", [&] { k_amul_dma<512><<<L.nTiles, 512, ldsX, 0>>>(a); }, y1);
+    check("direct-to-LDS");
+}
+} // namespace mi
