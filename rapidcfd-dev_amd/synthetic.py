@@ -73,6 +73,7 @@ class LduCase:
     dims: tuple = ()
     interfaces: List[Interface] = field(default_factory=list)
     global_cells: Optional[np.ndarray] = None  # for decomposed cases: global cell id of each local cell
+    global_faces: Optional[np.ndarray] = None  # ... and global face id of each local internal face
 
     @property
     def n_faces(self) -> int:
@@ -140,8 +141,9 @@ def box_case(nx: int, ny: int, nz: int, *, symmetric: bool = True, vary: float =
     return LduCase(n, lo, up, diag, upper, lower, source, dims=(nx, ny, nz))
 
 
-def decompose_box(case: LduCase, parts) -> List[LduCase]:
-    """Split a box case into px*py*pz sub-domains with processor interfaces.
+def decompose(case: LduCase, dom, n_domains: Optional[int] = None) -> List[LduCase]:
+    """Split ANY case into sub-domains with processor interfaces, given the domain of every cell (what a
+    ``decomposePar`` cellDecomposition file holds).
 
     Mirrors what ``decomposePar`` produces for the solver: every cut face
     becomes a face of a processor patch whose ``boundaryCoeffs`` hold minus
@@ -150,22 +152,13 @@ def decompose_box(case: LduCase, parts) -> List[LduCase]:
     ``Apsi[faceCells] -= bouCoeffs*psiNbr`` (coupledFvPatchField.C:236-257)
     reproduces the undecomposed product.  Local cells and faces keep their
     relative global order (what decomposePar does), so local addressing is
-    again upper-triangular and owner-sorted.
+    again upper-triangular and owner-sorted; one patch per neighbouring domain, ordered by domain number, its faces in
+    global face order on both sides.  Domains may be empty of cut faces but not of cells.
     """
-    nx, ny, nz = case.dims
-    px, py, pz = parts
     n = case.n_cells
-    c = np.arange(n, dtype=np.int64)
-    i = c % nx
-    j = (c // nx) % ny
-    k = c // (nx * ny)
-
-    def chunk(idx, nd, p):
-        b = (np.arange(p + 1) * nd) // p
-        return np.searchsorted(b, idx, side="right") - 1
-
-    dom = chunk(i, nx, px) + px * (chunk(j, ny, py) + py * chunk(k, nz, pz))
-    nd = px * py * pz
+    dom = np.asarray(dom, dtype=np.int64)
+    assert dom.shape[0] == n and dom.min() >= 0
+    nd = int(dom.max()) + 1 if n_domains is None else int(n_domains)
     lo = case.lower_addr.astype(np.int64)
     up = case.upper_addr.astype(np.int64)
     lower_c = case.upper if case.lower is None else case.lower
@@ -173,6 +166,7 @@ def decompose_box(case: LduCase, parts) -> List[LduCase]:
     cells_of = []
     for d in range(nd):
         ids = np.nonzero(dom == d)[0]
+        assert ids.shape[0] > 0, f"domain {d} has no cells"
         cells_of.append(ids)
         local_id[ids] = np.arange(ids.shape[0])
     dl, du = dom[lo], dom[up]
@@ -198,15 +192,14 @@ def decompose_box(case: LduCase, parts) -> List[LduCase]:
             upper=case.upper[fint].copy(),
             lower=None if case.lower is None else case.lower[fint].copy(),
             source=case.source[ids].copy(),
-            dims=(int(i[ids].max() - i[ids].min() + 1), int(j[ids].max() - j[ids].min() + 1), int(k[ids].max() - k[ids].min() + 1)),
             global_cells=ids.astype(np.int64),
         )
+        sub.global_faces = fint.astype(np.int64)       # internal faces of the sub-domain in global numbering
         for nb in sorted(pair_faces[d]):
             fcs, bou, inte = [], [], []
             # faces ordered by global face id on both sides so the two patches match 1:1
-            entries = sorted(pair_faces[d][nb], key=lambda t: int(t[1][0]) if len(t[1]) else 0)
-            allf = np.concatenate([e[1] for e in entries])
-            side = np.concatenate([np.full(len(e[1]), e[0] == "own") for e in entries])
+            allf = np.concatenate([e[1] for e in pair_faces[d][nb]])
+            side = np.concatenate([np.full(len(e[1]), e[0] == "own") for e in pair_faces[d][nb]])
             order = np.argsort(allf, kind="stable")
             allf, side = allf[order], side[order]
             for f, is_own in zip(allf.tolist(), side.tolist()):
@@ -221,6 +214,27 @@ def decompose_box(case: LduCase, parts) -> List[LduCase]:
                 int_coeffs=np.asarray(inte, dtype=np.float64)))
         out.append(sub)
     return out
+
+
+def decompose_box(case: LduCase, parts) -> List[LduCase]:
+    """``decompose`` with decomposePar's `simple` method on a box: px*py*pz blocks."""
+    nx, ny, nz = case.dims
+    px, py, pz = parts
+    c = np.arange(case.n_cells, dtype=np.int64)
+    i = c % nx
+    j = (c // nx) % ny
+    k = c // (nx * ny)
+
+    def chunk(idx, nd, p):
+        b = (np.arange(p + 1) * nd) // p
+        return np.searchsorted(b, idx, side="right") - 1
+
+    dom = chunk(i, nx, px) + px * (chunk(j, ny, py) + py * chunk(k, nz, pz))
+    subs = decompose(case, dom, px * py * pz)
+    for sub in subs:
+        ids = sub.global_cells
+        sub.dims = (int(i[ids].max() - i[ids].min() + 1), int(j[ids].max() - j[ids].min() + 1), int(k[ids].max() - k[ids].min() + 1))
+    return subs
 
 
 def add_cyclic_y(case: LduCase, kappa_scale: float = 1.0, asym_shift: float = 0.0) -> LduCase:

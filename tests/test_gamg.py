@@ -491,3 +491,61 @@ def test_per_rank_hierarchies_of_a_decomposed_case_equal_the_oracle(pkg, orc, pa
                 nd, npch = sub.interfaces[p].nbr_domain, sub.interfaces[p].nbr_patch
                 assert np.array_equal(ep["nbrCells"], E[nd][l]["patches"][npch]["faceCells"])
                 n_patch[p] = len(ep["faceCells"])
+
+
+def test_per_rank_hierarchies_on_ragged_graphs_with_arbitrary_partitions(pkg, orc):
+    """The same comparison on what decomposePar can produce for an unstructured mesh: ragged graphs cut by ARBITRARY
+    cell-to-processor maps (contiguous chunks, interleaved stripes, random labels -> many small patches, several neighbours
+    per domain, domains without a common boundary), symmetric and asymmetric, plain and merged levels.  The multi-domain
+    system must also still be the global matrix (Amul of the pieces = Amul of the whole)."""
+    syn = pkg.synthetic
+    for seed, n, extra, nd, kind, merge in [(1, 300, 2.0, 3, "chunks", 1), (2, 500, 1.5, 4, "stripes", 1), (3, 400, 3.0, 5, "random", 1),
+                                            (4, 700, 2.5, 2, "random", 2), (5, 260, 1.0, 6, "chunks", 3)]:
+        case = random_graph_case(pkg, n, extra=extra, seed=seed, symmetric=(seed % 2 == 1))
+        c = np.arange(n)
+        dom = {"chunks": c * nd // n, "stripes": (c // 7) % nd, "random": (syn.splitmix_uniform(90 + seed, n) * nd).astype(np.int64)}[kind]
+        subs = syn.decompose(case, dom, nd)
+        S = orc.System(subs)
+        x = syn.splitmix_uniform(seed, n) - 0.5
+        xs = np.concatenate([x[s.global_cells] for s in subs])
+        got = S.amul(xs)
+        ref = orc.System([case]).amul(x)
+        off = 0
+        for s in subs:
+            assert np.max(np.abs(got[off:off + s.n_cells] - ref[s.global_cells])) <= 1e-13 * np.max(np.abs(ref))
+            off += s.n_cells
+        w = 0.5 + syn.splitmix_uniform(77 + seed, case.n_faces)
+        ws = [w[s.global_faces] for s in subs]
+        H = orc.GamgSysHierarchy(S, ws, 4, merge_levels=merge)
+        E = pkg.engine.gamg_host_hierarchy_domains(subs, ws, 4, True, merge_levels=merge)
+        assert H.n_levels >= 1
+        for d, sub in enumerate(subs):
+            assert len(E[d]) == H.n_levels
+            n_patch = [len(i.face_cells) for i in sub.interfaces]
+            for l in range(H.n_levels):
+                o, e = H.level(d, l), E[d][l]
+                assert np.array_equal(o["restrict"], e["restrictMap"])
+                assert np.array_equal(o["lower"], e["cLower"]) and np.array_equal(o["upper"], e["cUpper"])
+                for p in range(len(sub.interfaces)):
+                    op, ep = H.patch(d, l, p, n_patch[p]), e["patches"][p]
+                    assert np.array_equal(op["face_restrict"], ep["faceRestrict"]) and np.array_equal(op["face_cells"], ep["faceCells"])
+                    nbd, nbp = sub.interfaces[p].nbr_domain, sub.interfaces[p].nbr_patch
+                    assert np.array_equal(ep["nbrCells"], E[nbd][l]["patches"][nbp]["faceCells"])
+                    n_patch[p] = len(ep["faceCells"])
+        # and the multi-domain GAMG solves the same problem as the single-domain one (different hierarchy, same answer)
+        if case.lower is None:
+            psi, p = H.solve(np.zeros(n), np.concatenate([case.source[s.global_cells] for s in subs]), tolerance=1e-10, maxIter=200)
+            ref_psi = np.linalg.solve(_dense(case), case.source)
+            assert p["converged"]
+            off = 0
+            for s in subs:
+                assert np.max(np.abs(psi[off:off + s.n_cells] - ref_psi[s.global_cells])) < 1e-7 * np.max(np.abs(ref_psi))
+                off += s.n_cells
+
+
+def _dense(case):
+    n = case.n_cells
+    A = np.zeros((n, n)); A[np.arange(n), np.arange(n)] = case.diag
+    lo = case.upper if case.lower is None else case.lower
+    A[case.lower_addr, case.upper_addr] = case.upper; A[case.upper_addr, case.lower_addr] = lo
+    return A
