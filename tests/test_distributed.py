@@ -95,7 +95,14 @@ def _gpu_worker(rank, world, port, parts, dims, kw, out_dir, driver):
     par = import_module(graft.PKG_NAME + ".parallel")
     torch.cuda.set_device(0)
     ctx = pkg.engine.Context(0, torch.cuda.current_stream().cuda_stream)
-    sub = pkg.synthetic.box_subdomain(dims, parts, rank)
+    if parts == "graph":   # ragged graph cut by a random cell-to-processor map: many small patches, several neighbours per rank
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import random_graph_case
+        case = random_graph_case(pkg, dims[0], extra=2.0, seed=11)
+        dom = (pkg.synthetic.splitmix_uniform(5, case.n_cells) * world).astype(np.int64)
+        sub = pkg.synthetic.decompose(case, dom, world)[rank]
+    else:
+        sub = pkg.synthetic.box_subdomain(dims, parts, rank)
     solver = par.DistributedPCG(ctx, sub, "cuda:0", precond=kw.pop("precond", "diagonal"))
     perf = solver.solve(**kw)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), psi=solver.ops.solution(), cells=sub.global_cells, hist=perf["history"],
@@ -126,6 +133,25 @@ def test_distributed_pcg_real_engine_ranks_share_one_gpu(pkg, orc, tmp_path, par
         psi[d["cells"]] = d["psi"]
         assert str(d["driver"]) == "torch"
         assert int(d["n_global"]) == case.n_cells
+        assert int(d["nit"]) == ref["nIterations"] and int(d["conv"]) == ref["converged"]
+        assert np.max(np.abs(d["hist"] - ref["history"])) < 1e-10 * ref["history"][0]
+    assert np.max(np.abs(psi - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+@pytest.mark.gpu
+def test_distributed_pcg_real_engine_ragged_graph_random_partition(pkg, orc, tmp_path):
+    """3 ranks on one GPU over gloo, an unstructured (ragged-graph) matrix cut by a RANDOM cell-to-processor map: every rank
+    has patches to both others, faces scattered all over its cells."""
+    from conftest import random_graph_case
+    n, world = 3000, 3
+    kw = dict(tolerance=1e-9, max_iter=400)
+    mp.spawn(_gpu_worker, args=(world, _free_port(), "graph", (n,), dict(kw), str(tmp_path), "torch"), nprocs=world, join=True)
+    case = random_graph_case(pkg, n, extra=2.0, seed=11)
+    ref_psi, ref = orc.System([case]).pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-9, maxIter=400)
+    psi = np.zeros(n)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        psi[d["cells"]] = d["psi"]
         assert int(d["nit"]) == ref["nIterations"] and int(d["conv"]) == ref["converged"]
         assert np.max(np.abs(d["hist"] - ref["history"])) < 1e-10 * ref["history"][0]
     assert np.max(np.abs(psi - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
