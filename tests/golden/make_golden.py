@@ -114,6 +114,51 @@ def build_v2(pkg, orc):
     return out
 
 
+def v3_cases(pkg):
+    syn = pkg.synthetic
+    return {"sym": syn.box_case(16, 12, 12), "asym": syn.box_case(14, 12, 10, symmetric=False)}
+
+
+def build_v3(pkg, orc):
+    """third fixture set: GAMG options (mergeLevels, directSolveCoarsest false), fvMatrix::flux / coupled H pieces, and a ragged
+    graph cut by an arbitrary cell-to-processor map"""
+    syn = pkg.synthetic
+    out = {}
+    for tag, case in v3_cases(pkg).items():
+        w = orc.box_face_weights(case)
+        z = np.zeros(case.n_cells)
+        for merge in (2, 3):
+            out[f"{tag}/gamg_merge{merge}"] = orc.GamgHierarchy(case, w, 10, merge_levels=merge).solve(z, case.source, tolerance=1e-9, maxIter=100)[1]["history"]
+        out[f"{tag}/gamg_iterative_coarsest"] = orc.GamgHierarchy(case, w, 10).solve(z, case.source, tolerance=1e-9, maxIter=100, directSolveCoarsest=False)[1]["history"]
+        S = orc.System([case])
+        x = syn.splitmix_uniform(2024, case.n_cells) - 0.5
+        stepf = max(1, case.n_faces // 257)
+        out[f"{tag}/faceH"] = S.faceH(x)[::stepf]
+        nx = case.dims[0]
+        fc = np.nonzero(np.arange(case.n_cells) % nx == nx - 1)[0].astype(np.int32)
+        ic, bc, nbr = syn.splitmix_uniform(31, fc.shape[0]) - 0.5, syn.splitmix_uniform(32, fc.shape[0]) - 0.5, syn.splitmix_uniform(33, fc.shape[0])
+        out[f"{tag}/patch_flux_coupled"] = orc.patch_flux(fc, ic, bc, x, nbr)
+        out[f"{tag}/patch_flux_plain"] = orc.patch_flux(fc, ic, bc, x, None)
+        out[f"{tag}/patch_add_product"] = orc.patch_add_product(fc, bc, nbr, case.source, 0)[fc]
+    cyc = cyclic_case(pkg, False)
+    x = syn.splitmix_uniform(2024, cyc.n_cells) - 0.5
+    step = max(1, cyc.n_cells // 257)
+    out["cyclic_asym/H"] = orc.System([cyc]).H(x)[::step]          # face sums only: no interface terms
+    out["cyclic_asym/H1"] = orc.System([cyc]).H1()[::step]
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from conftest import random_graph_case
+    g = random_graph_case(pkg, 600, extra=2.0, seed=7)
+    dom = (syn.splitmix_uniform(91, g.n_cells) * 3).astype(np.int64)
+    subs = syn.decompose(g, dom, 3)
+    wg = 0.5 + syn.splitmix_uniform(78, g.n_faces)
+    S = orc.System(subs)
+    H = orc.GamgSysHierarchy(S, [wg[s.global_faces] for s in subs], 6)
+    out["graph_3way/gamg"] = H.solve(np.zeros(S.n), np.concatenate([s.source for s in subs]), tolerance=1e-9, maxIter=100)[1]["history"]
+    out["graph_3way/level0_coarse_cells"] = np.array([H.level(d, 0)["n_coarse"] for d in range(3)])
+    out["graph_3way/pcg_diagonal"] = S.pcg(np.zeros(S.n), np.concatenate([s.source for s in subs]), "diagonal", tolerance=1e-9, maxIter=1000)[1]["history"]
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
@@ -121,5 +166,7 @@ if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
     if "--v1" in sys.argv:   # v1 is frozen; regenerate only on purpose
         np.savez_compressed(os.path.join(here, "golden_v1.npz"), **build(pkg, orc))
-    np.savez_compressed(os.path.join(here, "golden_v2.npz"), **build_v2(pkg, orc))
+    if "--v2" in sys.argv or not os.path.exists(os.path.join(here, "golden_v2.npz")):   # frozen as well
+        np.savez_compressed(os.path.join(here, "golden_v2.npz"), **build_v2(pkg, orc))
+    np.savez_compressed(os.path.join(here, "golden_v3.npz"), **build_v3(pkg, orc))
     print("written")
