@@ -549,3 +549,31 @@ def _dense(case):
     lo = case.upper if case.lower is None else case.lower
     A[case.lower_addr, case.upper_addr] = case.upper; A[case.upper_addr, case.lower_addr] = lo
     return A
+
+
+def test_merged_levels_galerkin_and_the_flip_rule(pkg, orc):
+    """What combineLevels' flip rule (only the last pair step's flip survives) means for the level matrices: with a symmetric
+    fine matrix the merged coarse matrix is exactly R A R^T; with an asymmetric one the diagonal and the SYMMETRIC part
+    (upper + lower per coarse face) are still Galerkin, while upper and lower of a coarse face may be interchanged for the
+    fine faces whose earlier flip was dropped -- the reference's behaviour, reproduced on purpose."""
+    for sym in (True, False):
+        case = pkg.synthetic.box_case(8, 7, 6, symmetric=sym)
+        n = case.n_cells
+        A = _dense(case)
+        H = orc.GamgHierarchy(case, orc.box_face_weights(case), 4, merge_levels=2)
+        Af = A
+        for l in range(min(2, H.n_levels)):
+            lv = H.level(l)
+            R = np.zeros((lv["n_coarse"], lv["n_fine"])); R[lv["restrict"], np.arange(lv["n_fine"])] = 1.0
+            G = R @ Af @ R.T                                     # Galerkin with piecewise-constant restriction
+            d, u, lo = H.coarse_matrix(l)
+            Ac = np.zeros_like(G); Ac[np.arange(len(d)), np.arange(len(d))] = d
+            Ac[lv["lower"], lv["upper"]] = u; Ac[lv["upper"], lv["lower"]] = u if lo is None else lo
+            tol = 1e-12 * np.max(np.abs(G))
+            assert np.max(np.abs(np.diag(Ac) - np.diag(G))) < tol
+            assert np.max(np.abs((Ac + Ac.T) - (G + G.T))) < tol              # symmetric part: always Galerkin
+            if sym:
+                assert np.max(np.abs(Ac - G)) < tol
+            Af = Ac if sym else G                                               # next level from the true Galerkin operator would differ: stop after comparing
+            if not sym:
+                break
