@@ -338,3 +338,38 @@ def test_cg_iteration_count_obeys_the_spectral_bound(pkg, orc):
     _, pd = S.pcg(np.zeros(n), case.source, "diagonal", tolerance=eps, maxIter=10 * n)
     _, pa = S.pcg(np.zeros(n), case.source, "AINV", tolerance=eps, maxIter=10 * n)
     assert pd["converged"] and pa["converged"] and pa["nIterations"] < pd["nIterations"] <= p["nIterations"] + 2
+
+
+def test_arbitrarily_partitioned_system_matches_serial(pkg, orc):
+    """The multi-domain oracle (the judge of every decomposed engine path) on ragged graphs cut by arbitrary cell-to-processor
+    maps (synthetic.decompose: contiguous chunks, stripes, random labels): every operator and the Krylov histories equal the
+    single-domain ones.  Interface terms are added after the face terms in the decomposed rows, so products agree to rounding,
+    not bitwise."""
+    from conftest import random_graph_case
+    syn = pkg.synthetic
+    for seed, n, nd, kind, sym in [(1, 400, 3, "chunks", True), (2, 350, 4, "stripes", False), (3, 500, 5, "random", True), (4, 450, 2, "random", False)]:
+        case = random_graph_case(pkg, n, extra=2.0, seed=seed, symmetric=sym)
+        c = np.arange(n)
+        dom = {"chunks": c * nd // n, "stripes": (c // 5) % nd, "random": (syn.splitmix_uniform(70 + seed, n) * nd).astype(np.int64)}[kind]
+        parts = syn.decompose(case, dom, nd)
+        assert sum(p.n_cells for p in parts) == n and all(len(p.interfaces) >= 1 for p in parts)
+        for d, p in enumerate(parts):                           # both sides of every patch pair see the same faces
+            for k, itf in enumerate(p.interfaces):
+                other = parts[itf.nbr_domain].interfaces[itf.nbr_patch]
+                assert other.nbr_domain == d and other.nbr_patch == k and len(other.face_cells) == len(itf.face_cells)
+                assert np.array_equal(itf.bou_coeffs, other.int_coeffs)
+        S, SD = orc.System([case]), orc.System(parts)
+        pick = lambda v: np.concatenate([v[p.global_cells] for p in parts])
+        x = syn.splitmix_uniform(seed, n) - 0.5
+        scale = np.max(np.abs(S.amul(x)))
+        for name, a, b in (("amul", SD.amul(pick(x)), S.amul(x)), ("tmul", SD.tmul(pick(x)), S.tmul(x)), ("sumA", SD.sumA(), S.sumA()),
+                           ("residual", SD.residual(pick(x), pick(case.source)), S.residual(x, case.source))):
+            assert np.max(np.abs(a - pick(b))) < 1e-13 * scale, name
+        b = pick(case.source)
+        if sym:
+            _, p1 = S.pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-9); _, p2 = SD.pcg(np.zeros(n), b, "diagonal", tolerance=1e-9)
+        else:
+            _, p1 = S.pbicgstab(np.zeros(n), case.source, "diagonal", tolerance=1e-9); _, p2 = SD.pbicgstab(np.zeros(n), b, "diagonal", tolerance=1e-9)
+        assert abs(p1["nIterations"] - p2["nIterations"]) <= 1
+        k = min(len(p1["history"]), len(p2["history"]))
+        assert np.max(np.abs(p1["history"][:k] - p2["history"][:k])) < 1e-9 * p1["history"][0]
