@@ -644,3 +644,40 @@ def ref_gamg_agglomerate_matrix(level, fine_diag, fine_upper, fine_lower=None):
                                   _p(_d(fine_upper), C.c_double), _p(fl, C.c_double), flip.ctypes.data_as(C.c_void_p),
                                   _p(c_diag, C.c_double), _p(c_up, C.c_double), _p(c_lo, C.c_double))
     return c_diag, c_up, (c_lo if asym else None)
+
+
+REF_GAMG_SCALE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_gamg_scale.so")
+
+
+def ref_gamg_scale_available() -> bool:
+    return os.path.exists(REF_GAMG_SCALE_LIB)
+
+
+def gamg_sys_scale(system: "System", field, source):
+    """the oracle's GAMGSolver::scale (gamg_oracle.c sys_scale): returns (scaled field, A*field before scaling)"""
+    L = lib()
+    f = np.array(_d(field), copy=True)
+    acf = np.empty(system.n)
+    L.orc_gamg_sys_scale.restype = None
+    L.orc_gamg_sys_scale(system.h, _p(f, C.c_double), _p(acf, C.c_double), _p(_d(source), C.c_double))
+    return f, acf
+
+
+def ref_gamg_scale_pointwise(sf, field, source, acf, diag):
+    """field = sf*field + (source - sf*Acf)/D through the REFERENCE's GAMGSolverScaleFunctor (GAMGSolverScale.C:36-55,
+    compiled where it lies: oracle/ref_shim/ref_gamg_scale_tu.cpp)"""
+    L = C.CDLL(REF_GAMG_SCALE_LIB)
+    f = _d(field)
+    out = np.empty(f.shape[0])
+    L.ref_gamg_scale_pointwise(C.c_int(f.shape[0]), C.c_double(float(sf)), _p(f, C.c_double), _p(_d(source), C.c_double),
+                               _p(_d(acf), C.c_double), _p(_d(diag), C.c_double), _p(out, C.c_double))
+    return out
+
+
+def ref_gamg_scale_terms(a, b):
+    """the terms a*b of the two scaling sums through the REFERENCE's multiplyTupleFunctor (GAMGSolverScale.C:46-55)"""
+    L = C.CDLL(REF_GAMG_SCALE_LIB)
+    a = _d(a)
+    out = np.empty(a.shape[0])
+    L.ref_gamg_scale_terms(C.c_int(a.shape[0]), _p(a, C.c_double), _p(_d(b), C.c_double), _p(out, C.c_double))
+    return out

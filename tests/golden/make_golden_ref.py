@@ -175,6 +175,37 @@ def build_gamg_functors(pkg, orc):
     return out
 
 
+def gamg_scale_cases(pkg, orc):
+    syn = pkg.synthetic
+    return {"box_sym": [syn.box_case(9, 8, 7)], "box_asym": [syn.box_case(8, 7, 6, symmetric=False)],
+            "box_sym_2dom": syn.decompose_box(syn.box_case(10, 8, 6), (2, 1, 1)),
+            "box_asym_4dom": syn.decompose_box(syn.box_case(8, 8, 6, symmetric=False), (2, 2, 1))}
+
+
+def scale_factor(source, field, acf):
+    """GAMGSolverScale.C:113-142 as the oracle restates it: both sums accumulated in order in long double, rounded to
+    double, sf = num/stabilise(den, VSMALL)"""
+    num = float(np.cumsum(np.asarray(source, np.longdouble) * np.asarray(field, np.longdouble))[-1])
+    den = float(np.cumsum(np.asarray(acf, np.longdouble) * np.asarray(field, np.longdouble))[-1])
+    return num / (den + 1e-300 if den >= 0 else den - 1e-300)
+
+
+def build_gamg_scale(pkg, orc):
+    """GAMGSolver::scale's pointwise update through the REFERENCE's GAMGSolverScaleFunctor (GAMGSolverScale.C compiled where
+    it lies, oracle/_ref/libref_gamg_scale.so) on A*field of the oracle and the scaling factor of scale_factor()"""
+    out = {}
+    for name, subs in gamg_scale_cases(pkg, orc).items():
+        S = orc.System(subs)
+        field = pkg.synthetic.splitmix_uniform(61, S.n) - 0.5
+        source = pkg.synthetic.splitmix_uniform(62, S.n) - 0.5
+        _, acf = orc.gamg_sys_scale(S, field, source)
+        sf = scale_factor(source, field, acf)
+        out[f"{name}/sf"] = np.array([sf])
+        out[f"{name}/field"] = orc.ref_gamg_scale_pointwise(sf, field, source, acf, np.concatenate([c.diag for c in subs]))
+        out[f"{name}/terms"] = orc.ref_gamg_scale_terms(source, field)
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
@@ -189,4 +220,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg.npz"), **build_gamg(pkg, orc))
     assert orc.ref_gamg_functors_available(), "oracle/_ref/libref_gamg_functors.so missing"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg_functors.npz"), **build_gamg_functors(pkg, orc))
+    assert orc.ref_gamg_scale_available(), "oracle/_ref/libref_gamg_scale.so missing"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg_scale.npz"), **build_gamg_scale(pkg, orc))
     print("written")

@@ -461,6 +461,33 @@ def test_inter_level_functors_equal_the_reference_headers(pkg, orc):
             assert np.array_equal(now[k], G[k]), k
 
 
+def test_scale_update_equals_the_reference_functor(pkg, orc):
+    """GAMGSolver::scale (GAMGSolverScale.C:59-171): field = sf*field + (source - sf*A field)/D with
+    sf = sum(source*field)/stabilise(sum(A field*field)).  The reference's GAMGSolverScaleFunctor, compiled from
+    GAMGSolverScale.C where it lies (oracle/_ref/libref_gamg_scale.so), produced tests/golden/golden_ref_gamg_scale.npz; the
+    oracle's scale must give the SAME BITS on one, two and four domains, symmetric and asymmetric (the contraction of
+    `sf*field + ...` and `source - sf*Acf` to fused multiply-adds included)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_gamg_scale.npz"))
+    for name, subs in make_golden_ref.gamg_scale_cases(pkg, orc).items():
+        S = orc.System(subs)
+        field = pkg.synthetic.splitmix_uniform(61, S.n) - 0.5
+        source = pkg.synthetic.splitmix_uniform(62, S.n) - 0.5
+        scaled, acf = orc.gamg_sys_scale(S, field, source)
+        assert np.array_equal(acf, S.amul(field))
+        assert make_golden_ref.scale_factor(source, field, acf) == G[f"{name}/sf"][0]
+        assert np.array_equal(scaled, G[f"{name}/field"]), name
+        assert np.array_equal(source * field, G[f"{name}/terms"])
+        assert not np.array_equal(scaled, field)
+    if orc.ref_gamg_scale_available():
+        now = make_golden_ref.build_gamg_scale(pkg, orc)
+        assert set(now) == set(G.files)
+        for k in G.files:
+            assert np.array_equal(now[k], G[k]), k
+
+
 @pytest.mark.parametrize("parts,merge", [((2, 1, 1), 1), ((2, 2, 1), 1), ((2, 2, 2), 1), ((1, 3, 2), 2)])
 def test_per_rank_hierarchies_of_a_decomposed_case_equal_the_oracle(pkg, orc, parts, merge):
     """The per-rank GAMG builder a real rank runs (pair agglomeration per processor, `continueAgglomerating` agreed over all
