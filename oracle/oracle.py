@@ -681,3 +681,35 @@ def ref_gamg_scale_terms(a, b):
     out = np.empty(a.shape[0])
     L.ref_gamg_scale_terms(C.c_int(a.shape[0]), _p(a, C.c_double), _p(_d(b), C.c_double), _p(out, C.c_double))
     return out
+
+
+REF_ATMUL_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_atmul.so")
+
+
+def ref_atmul_available() -> bool:
+    return os.path.exists(REF_ATMUL_LIB)
+
+
+def ref_atmul(case, which, psi=None, source=None, favour_speed=0, level=0, coarsest=False):
+    """The REFERENCE's lduMatrix::Amul / Tmul / residual / sumA / H1 (lduMatrixATmul.C compiled where it lies and run on the
+    host, oracle/ref_shim/ref_atmul_tu.cpp) on a serial case.  which: "amul" | "tmul" | "residual" | "sumA" | "H1";
+    favour_speed is lduMatrixSolutionCache::favourSpeed (0: losort-indirect path, 1-2: the pre-sorted fast paths)."""
+    L = C.CDLL(REF_ATMUL_LIB)
+    lo, up = _i(case.lower_addr), _i(case.upper_addr)
+    n, nf = case.n_cells, lo.shape[0]
+    losort = np.argsort(up, kind="stable").astype(np.int32)                       # lduAddressing::calcLosort
+    owner_start = np.searchsorted(lo, np.arange(n + 1)).astype(np.int32)          # calcOwnerStart
+    losort_start = np.searchsorted(up[losort], np.arange(n + 1)).astype(np.int32)  # calcLosortStart
+    owner_sort = np.ascontiguousarray(lo[losort])                                 # ownerSortAddr
+    upper = _d(case.upper)
+    lower = upper if case.lower is None else _d(case.lower)
+    lower_sort, upper_sort = np.ascontiguousarray(lower[losort]), np.ascontiguousarray(upper[losort])   # lduMatrix::lowerSort()
+    x = np.zeros(n) if psi is None else _d(psi)
+    b = np.zeros(n) if source is None else _d(source)
+    out = np.full(n, np.nan)
+    k = {"amul": 0, "tmul": 1, "residual": 2, "sumA": 3, "H1": 4}[which]
+    L.ref_atmul(C.c_int(k), C.c_int(favour_speed), C.c_int(level), C.c_int(int(coarsest)), C.c_int(n), C.c_int(nf), _p(lo, C.c_int32), _p(up, C.c_int32),
+                _p(owner_sort, C.c_int32), _p(owner_start, C.c_int32), _p(losort_start, C.c_int32), _p(losort, C.c_int32), _p(_d(case.diag), C.c_double),
+                _p(lower, C.c_double), _p(upper, C.c_double), _p(lower_sort, C.c_double), _p(upper_sort, C.c_double), _p(x, C.c_double), _p(b, C.c_double),
+                _p(out, C.c_double))
+    return out

@@ -175,6 +175,30 @@ def build_gamg_functors(pkg, orc):
     return out
 
 
+def atmul_cases(pkg, orc):
+    from conftest import random_graph_case
+    syn = pkg.synthetic
+    return {"box_sym": syn.box_case(9, 8, 7), "box_asym": syn.box_case(8, 7, 6, symmetric=False),
+            "graph_sym": random_graph_case(pkg, 700), "graph_asym": random_graph_case(pkg, 600, extra=3.0, symmetric=False)}
+
+
+def build_atmul(pkg, orc):
+    """lduMatrix::Amul / Tmul / residual / sumA / H1 computed by the REFERENCE's lduMatrixATmul.C (+ lduAddressingFunctors.H,
+    lduMatrixFunctors.H, ops.H) compiled where it lies and run on the host (oracle/_ref/libref_atmul.so); fs = favourSpeed"""
+    out = {}
+    for name, case in atmul_cases(pkg, orc).items():
+        x = pkg.synthetic.splitmix_uniform(5, case.n_cells) - 0.5
+        b = pkg.synthetic.splitmix_uniform(6, case.n_cells) - 0.5
+        for fs in (0, 1, 2):
+            out[f"{name}/amul/fs{fs}"] = orc.ref_atmul(case, "amul", x, favour_speed=fs)
+            out[f"{name}/tmul/fs{fs}"] = orc.ref_atmul(case, "tmul", x, favour_speed=fs)
+        for fs in (0, 1):
+            out[f"{name}/residual/fs{fs}"] = orc.ref_atmul(case, "residual", x, b, favour_speed=fs)
+            out[f"{name}/H1/fs{fs}"] = orc.ref_atmul(case, "H1", favour_speed=fs)
+        out[f"{name}/sumA"] = orc.ref_atmul(case, "sumA")
+    return out
+
+
 def gamg_scale_cases(pkg, orc):
     syn = pkg.synthetic
     return {"box_sym": [syn.box_case(9, 8, 7)], "box_asym": [syn.box_case(8, 7, 6, symmetric=False)],
@@ -222,4 +246,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg_functors.npz"), **build_gamg_functors(pkg, orc))
     assert orc.ref_gamg_scale_available(), "oracle/_ref/libref_gamg_scale.so missing"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg_scale.npz"), **build_gamg_scale(pkg, orc))
+    assert orc.ref_atmul_available(), "oracle/_ref/libref_atmul.so missing"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_atmul.npz"), **build_atmul(pkg, orc))
     print("written")

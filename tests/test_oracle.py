@@ -316,6 +316,54 @@ def test_row_functors_match_the_reference_headers(pkg, orc):
             assert np.array_equal(now[k], G[k]), k
 
 
+def test_spmv_family_against_the_reference_source_run_on_the_host(pkg, orc):
+    """lduMatrixATmul.C of the reference (Amul / Tmul / residual / sumA / H1 with callMultiply, matrixMultiplyFunctor<fast,3>,
+    matrixOperation / matrixFastOperation of lduAddressingFunctors.H, lduMatrixFunctors.H and ops.H), compiled where it lies
+    and RUN on the host over a sequential thrust (oracle/_ref/libref_atmul.so), produced tests/golden/golden_ref_atmul.npz for
+    favourSpeed 0, 1, 2 (losort-indirect and pre-sorted paths).
+      * sumA and H1 (sums of coefficients in row order) and the oracle's LITERAL reading of the multiply functor
+        (orc_amul_functor_literal: staged products rounded separately, extras fused, nExtra last) give the reference's BITS,
+        on boxes and ragged graphs, symmetric and asymmetric, on every favourSpeed path;
+      * the oracle's default one-fma-per-term Amul / Tmul / residual stay within 2 ulp of the row magnitude of it;
+      * the reference's FAST residual and H1 drop the neighbour-side terms beyond the third (nExtra is accumulated and never
+        added, lduAddressingFunctors.H:132-139): no effect on hex meshes, and on ragged rows exactly those terms are missing.
+        Oracle and engine compute the full row (reference behaviours not replicated)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_atmul.npz"))
+    eps = np.finfo(float).eps
+    for name, case in make_golden_ref.atmul_cases(pkg, orc).items():
+        S = orc.System([case])
+        n = case.n_cells
+        x = pkg.synthetic.splitmix_uniform(5, n) - 0.5
+        b = pkg.synthetic.splitmix_uniform(6, n) - 0.5
+        lower = case.upper if case.lower is None else case.lower
+        row_mag = np.abs(case.diag * x)
+        np.add.at(row_mag, case.lower_addr, np.abs(case.upper * x[case.upper_addr])); np.add.at(row_mag, case.upper_addr, np.abs(lower * x[case.lower_addr]))
+        for fs in (0, 1, 2):
+            assert np.array_equal(S.amul_functor_literal(x), G[f"{name}/amul/fs{fs}"]), (name, fs)
+            assert np.max(np.abs(S.amul(x) - G[f"{name}/amul/fs{fs}"]) / row_mag) < 2 * eps
+            assert np.max(np.abs(S.tmul(x) - G[f"{name}/tmul/fs{fs}"]) / row_mag) < 2 * eps
+        assert np.array_equal(S.sumA(), G[f"{name}/sumA"]) and np.array_equal(S.H1(), G[f"{name}/H1/fs0"])
+        assert np.max(np.abs(S.residual(x, b) - G[f"{name}/residual/fs0"]) / (row_mag + np.abs(b))) < 2 * eps
+        # the fast paths: neighbour-side faces of a row in losort order, those from the fourth on are dropped by the reference
+        losort = np.argsort(case.upper_addr, kind="stable")
+        rank_in_row = np.arange(losort.shape[0]) - np.searchsorted(case.upper_addr[losort], case.upper_addr[losort])
+        dropped = losort[rank_in_row >= 3]
+        miss_r, miss_h = np.zeros(n), np.zeros(n)
+        np.add.at(miss_r, case.upper_addr[dropped], lower[dropped] * x[case.lower_addr[dropped]])
+        np.add.at(miss_h, case.upper_addr[dropped], lower[dropped])
+        assert (dropped.shape[0] == 0) == name.startswith("box")
+        assert np.max(np.abs(G[f"{name}/residual/fs1"] - (G[f"{name}/residual/fs0"] + miss_r)) / (row_mag + np.abs(b))) < 4 * eps
+        assert np.max(np.abs(G[f"{name}/H1/fs1"] - (G[f"{name}/H1/fs0"] + miss_h))) < 4 * eps * np.max(np.abs(G[f"{name}/H1/fs0"]))
+    if orc.ref_atmul_available():
+        now = make_golden_ref.build_atmul(pkg, orc)
+        assert set(now) == set(G.files)
+        for k in G.files:
+            assert np.array_equal(now[k], G[k]), k
+
+
 def test_cg_iteration_count_obeys_the_spectral_bound(pkg, orc):
     """sanity of the oracle's PCG against theory.  For the SPD matrix -A of a small box the classical bound
     says the A-norm error falls by 2((sqrt(k)-1)/(sqrt(k)+1))^i; with the exact spectrum from numpy the unpreconditioned
