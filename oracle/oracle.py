@@ -713,3 +713,31 @@ def ref_atmul(case, which, psi=None, source=None, favour_speed=0, level=0, coars
                 _p(lower, C.c_double), _p(upper, C.c_double), _p(lower_sort, C.c_double), _p(upper_sort, C.c_double), _p(x, C.c_double), _p(b, C.c_double),
                 _p(out, C.c_double))
     return out
+
+
+REF_LDU_OPS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_ldu_ops.so")
+
+
+def ref_ldu_ops_available() -> bool:
+    return os.path.exists(REF_LDU_OPS_LIB)
+
+
+def ref_ldu_ops(case, which, vec=None, favour_speed=0):
+    """The REFERENCE's lduMatrixOperations.C (compiled where it lies and run on the host, oracle/ref_shim/ref_ldu_ops_tu.cpp) on a
+    serial case.  which: "sumDiag" | "negSumDiag" -> new diag; "sumMagOffDiag" | "H" (vec = psi) -> field; "scale" (operator*=(vec))
+    and "addNegate" (B = A; B *= 0.5; A += B; A.negate()) -> (diag, upper, lower)"""
+    L = C.CDLL(REF_LDU_OPS_LIB)
+    lo, up = _i(case.lower_addr), _i(case.upper_addr)
+    n, nf = case.n_cells, lo.shape[0]
+    losort = np.argsort(up, kind="stable").astype(np.int32)
+    owner_start = np.searchsorted(lo, np.arange(n + 1)).astype(np.int32)
+    losort_start = np.searchsorted(up[losort], np.arange(n + 1)).astype(np.int32)
+    owner_sort = np.ascontiguousarray(lo[losort])
+    x = np.zeros(n) if vec is None else _d(vec)
+    out, ou, ol = np.full(n, np.nan), np.full(nf, np.nan), np.full(nf, np.nan)
+    k = {"sumDiag": 0, "negSumDiag": 1, "sumMagOffDiag": 2, "H": 3, "scale": 4, "addNegate": 5}[which]
+    L.ref_ldu_ops(C.c_int(k), C.c_int(favour_speed), C.c_int(n), C.c_int(nf), _p(lo, C.c_int32), _p(up, C.c_int32), _p(owner_sort, C.c_int32),
+                  _p(owner_start, C.c_int32), _p(losort_start, C.c_int32), _p(losort, C.c_int32), _p(_d(case.diag), C.c_double),
+                  None if case.lower is None else _p(_d(case.lower), C.c_double), _p(_d(case.upper), C.c_double), _p(x, C.c_double),
+                  _p(out, C.c_double), _p(ou, C.c_double), _p(ol, C.c_double))
+    return (out, ou, ol) if k >= 4 else out

@@ -8,117 +8,9 @@
 // ref_functors_tu.cpp, `textures<T>` is a pointer view and the mul/add contraction is the host compiler's choice, so tests
 // compare within a few ulp of the row magnitude; the face order, the coefficient/neighbour pairing, the signs and the
 // fast path's handling of rows with more than three neighbour-side faces are the reference's own.
-#include <cmath>
-#include <cstdint>
-#include <cstdlib>
-#include <functional>
-#include <tuple>
-#include <utility>
-#define __device__
-#define __host__
-#define __HOST____DEVICE__
-namespace thrust
-{
-using std::tuple; using std::get; using std::make_tuple; using std::unary_function; using std::binary_function;
-struct counting_iterator
-{
-    int v;
-    int operator*() const { return v; }
-    counting_iterator& operator++() { ++v; return *this; }
-    counting_iterator operator+(int n) const { return counting_iterator{v + n}; }
-    bool operator!=(const counting_iterator& o) const { return v != o.v; }
-};
-inline counting_iterator make_counting_iterator(int v) { return counting_iterator{v}; }
-template <class... P> struct zip_iterator
-{
-    std::tuple<P...> p;
-    template <std::size_t... I> auto deref(std::index_sequence<I...>) const { return std::make_tuple(*std::get<I>(p)...); }
-    template <std::size_t... I> void inc(std::index_sequence<I...>) { int d[] = {(++std::get<I>(p), 0)...}; (void)d; }
-    auto operator*() const { return deref(std::index_sequence_for<P...>()); }
-    zip_iterator& operator++() { inc(std::index_sequence_for<P...>()); return *this; }
-};
-template <class... P> zip_iterator<P...> make_zip_iterator(const std::tuple<P...>& t) { return zip_iterator<P...>{t}; }
-template <class It, class F> struct transform_iterator
-{
-    It it; mutable F f;
-    auto operator*() const { return f(*it); }
-    transform_iterator& operator++() { ++it; return *this; }
-};
-template <class It, class F> transform_iterator<It, F> make_transform_iterator(It it, F f) { return transform_iterator<It, F>{it, f}; }
-template <class B, class I> struct permutation_iterator
-{
-    B base; I idx;
-    auto& operator*() const { return base[*idx]; }
-    permutation_iterator& operator++() { ++idx; return *this; }
-};
-template <class B, class I> permutation_iterator<B, I> make_permutation_iterator(B b, I i) { return permutation_iterator<B, I>{b, i}; }
-template <class In, class Out, class F> void transform(In first, In last, Out out, F f) { for (; first != last; ++first, ++out) *out = f(*first); }
-template <class In, class In2, class Out, class F> void transform(In first, In last, In2 in2, Out out, F f)
-{
-    for (; first != last; ++first, ++in2, ++out) *out = f(*first, *in2);
-}
-}
+#include "foam_host_shim.H"
 namespace Foam
 {
-typedef int32_t label; typedef double scalar; typedef unsigned char direction;
-#define forAll(list, i) for (Foam::label i = 0; i < (list).size(); i++)
-template <class T> struct textures { const T* p; textures(const T* q) : p(q) {} T operator[](const int& i) const { return p[i]; } };
-template <class T> class gpuList
-{
-    T* p_; label n_; bool own_;
-public:
-    gpuList() : p_(0), n_(0), own_(false) {}
-    gpuList(T* p, label n) : p_(p), n_(n), own_(false) {}
-    explicit gpuList(label n) : p_((T*)std::calloc(n ? n : 1, sizeof(T))), n_(n), own_(true) {}
-    gpuList(label n, const T& t) : p_((T*)std::malloc((n ? n : 1) * sizeof(T))), n_(n), own_(true) { *this = t; }
-    gpuList(const gpuList&) = delete;
-    ~gpuList() { if (own_) std::free(p_); }
-    void setSize(label n) { if (own_) std::free(p_); p_ = (T*)std::calloc(n ? n : 1, sizeof(T)); n_ = n; own_ = true; }
-    label size() const { return n_; }
-    T* begin() { return p_; } const T* begin() const { return p_; }
-    T* end() { return p_ + n_; } const T* end() const { return p_ + n_; }
-    T* data() { return p_; } const T* data() const { return p_; }
-    void operator=(const T& t) { for (label i = 0; i < n_; i++) p_[i] = t; }
-};
-template <class T> using gpuField = gpuList<T>;
-typedef gpuList<scalar> scalargpuField; typedef gpuList<label> labelgpuList;
-template <class T> struct textureBind { const T* d; textureBind(const gpuList<T>& l) : d(l.data()) {} textures<T> operator()() const { return textures<T>(d); } };
-template <class T> class tmp
-{
-    mutable T* p_; bool own_;
-public:
-    tmp(T* p) : p_(p), own_(true) {}
-    tmp(T& r) : p_(&r), own_(false) {}
-    tmp(const tmp& t) : p_(t.p_), own_(t.own_) { t.p_ = 0; }
-    ~tmp() { if (own_) delete p_; }
-    T& operator()() { return *p_; } const T& operator()() const { return *p_; }
-    T* release() { T* p = p_; p_ = 0; return p; }
-    void clear() const {}
-};
-inline tmp<scalargpuField> operator-(const scalargpuField& f) { scalargpuField* r = new scalargpuField(f.size()); for (label i = 0; i < f.size(); i++) r->data()[i] = -f.data()[i]; return tmp<scalargpuField>(r); }
-template <template <class> class F, class T> struct FieldField
-{
-    label n; FieldField() : n(0) {} explicit FieldField(label m) : n(m) {}
-    label size() const { return n; }
-    const F<T>& operator[](label) const { static F<T> e; return e; }
-    void set(label, const tmp<F<T> >&) {}
-};
-struct lduInterfaceFieldPtrsList { label size() const { return 0; } bool set(label) const { return false; } };
-class lduAddressing
-{
-public:
-    label n; labelgpuList lower, upper, ownerSort, ownerStart, losortStart, losort, none;
-    label size() const { return n; }
-    const labelgpuList& lowerAddr() const { return lower; }
-    const labelgpuList& upperAddr() const { return upper; }
-    const labelgpuList& ownerSortAddr() const { return ownerSort; }
-    const labelgpuList& ownerStartAddr() const { return ownerStart; }
-    const labelgpuList& losortStartAddr() const { return losortStart; }
-    const labelgpuList& losortAddr() const { return losort; }
-    const labelgpuList& patchSortCells(label) const { return none; }
-    const labelgpuList& patchSortAddr(label) const { return none; }
-    const labelgpuList& patchSortStartAddr(label) const { return none; }
-};
 class lduMatrix
 {
 public:
@@ -142,8 +34,6 @@ public:
     void H1(scalargpuField&) const;
     tmp<scalargpuField> H1() const;
 };
-// GENERATE_UNARY_OPERATOR_FUNCTORS(-,negate) of fields/Fields/gpuField/gpuFieldM.H:116-124 (that header needs all of gpuField)
-template <class Type, class RType> struct negateUnaryOperatorFunctor { RType operator()(const Type& t) { return -t; } };
 }
 #define lduMatrix_H
 #define lduAddressing_H

@@ -199,6 +199,19 @@ def build_atmul(pkg, orc):
     return out
 
 
+def build_ldu_ops(pkg, orc):
+    """sumDiag / negSumDiag / sumMagOffDiag / H computed by the REFERENCE's lduMatrixOperations.C compiled where it lies and run
+    on the host (oracle/_ref/libref_ldu_ops.so), on the cases of atmul_cases(); fs = favourSpeed (H only)"""
+    out = {}
+    for name, case in atmul_cases(pkg, orc).items():
+        x = pkg.synthetic.splitmix_uniform(5, case.n_cells) - 0.5
+        for which in ("sumDiag", "negSumDiag", "sumMagOffDiag"):
+            out[f"{name}/{which}"] = orc.ref_ldu_ops(case, which)
+        for fs in (0, 1):
+            out[f"{name}/H/fs{fs}"] = orc.ref_ldu_ops(case, "H", x, favour_speed=fs)
+    return out
+
+
 def gamg_scale_cases(pkg, orc):
     syn = pkg.synthetic
     return {"box_sym": [syn.box_case(9, 8, 7)], "box_asym": [syn.box_case(8, 7, 6, symmetric=False)],
@@ -248,4 +261,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_gamg_scale.npz"), **build_gamg_scale(pkg, orc))
     assert orc.ref_atmul_available(), "oracle/_ref/libref_atmul.so missing"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_atmul.npz"), **build_atmul(pkg, orc))
+    assert orc.ref_ldu_ops_available(), "oracle/_ref/libref_ldu_ops.so missing"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_ldu_ops.npz"), **build_ldu_ops(pkg, orc))
     print("written")

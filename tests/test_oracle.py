@@ -364,6 +364,49 @@ def test_spmv_family_against_the_reference_source_run_on_the_host(pkg, orc):
             assert np.array_equal(now[k], G[k]), k
 
 
+def test_matrix_operations_equal_the_reference_source_run_on_the_host(pkg, orc):
+    """lduMatrixOperations.C of the reference (sumDiag, negSumDiag, sumMagOffDiag, H; operator=, negate, +=, *= compiled and run
+    too), compiled where it lies and run on the host like lduMatrixATmul.C (oracle/_ref/libref_ldu_ops.so), produced
+    tests/golden/golden_ref_ldu_ops.npz.  The oracle's row sweeps (orc_row_face_op: which triangle goes with which side of
+    the row, signs, magnitudes) and its H operator give the reference's BITS on boxes and ragged graphs, symmetric and
+    asymmetric.  The reference's fast H (favourSpeed) stages the first 3+3 products and, like the fast residual, drops the
+    neighbour-side terms beyond the third; the full row is what oracle and engine compute."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_ldu_ops.npz"))
+    eps = np.finfo(float).eps
+    for name, case in make_golden_ref.atmul_cases(pkg, orc).items():
+        S = orc.System([case])
+        n = case.n_cells
+        x = pkg.synthetic.splitmix_uniform(5, n) - 0.5
+        sweep = lambda kind, inout: orc.row_face_op(kind, n, case.lower_addr, case.upper_addr, case.lower, case.upper, inout)
+        assert np.array_equal(sweep(0, case.diag), G[f"{name}/sumDiag"])
+        assert np.array_equal(sweep(1, case.diag), G[f"{name}/negSumDiag"])
+        assert np.array_equal(sweep(2, np.zeros(n)), G[f"{name}/sumMagOffDiag"])
+        assert np.array_equal(S.H(x), G[f"{name}/H/fs0"])
+        lower = case.upper if case.lower is None else case.lower
+        row_mag = np.zeros(n)
+        np.add.at(row_mag, case.lower_addr, np.abs(case.upper * x[case.upper_addr])); np.add.at(row_mag, case.upper_addr, np.abs(lower * x[case.lower_addr]))
+        losort = np.argsort(case.upper_addr, kind="stable")
+        rank_in_row = np.arange(losort.shape[0]) - np.searchsorted(case.upper_addr[losort], case.upper_addr[losort])
+        dropped = losort[rank_in_row >= 3]
+        miss = np.zeros(n)
+        np.add.at(miss, case.upper_addr[dropped], lower[dropped] * x[case.lower_addr[dropped]])
+        assert np.max(np.abs(G[f"{name}/H/fs1"] - (G[f"{name}/H/fs0"] + miss)) / row_mag) < 4 * eps
+    if orc.ref_ldu_ops_available():
+        now = make_golden_ref.build_ldu_ops(pkg, orc)
+        assert set(now) == set(G.files)
+        for k in G.files:
+            assert np.array_equal(now[k], G[k]), k
+        case = make_golden_ref.atmul_cases(pkg, orc)["graph_asym"]          # the coefficient algebra of the same file, run once
+        x = pkg.synthetic.splitmix_uniform(5, case.n_cells) - 0.5
+        d, u, lo = orc.ref_ldu_ops(case, "scale", x)                         # operator*=(field): row scaling, upper by sf[l], lower by sf[u]
+        assert np.array_equal(d, case.diag * x) and np.array_equal(u, case.upper * x[case.lower_addr]) and np.array_equal(lo, case.lower * x[case.upper_addr])
+        d, u, lo = orc.ref_ldu_ops(case, "addNegate")                        # B = A; B *= 0.5; A += B; A.negate()
+        assert np.array_equal(d, -(1.5 * case.diag)) and np.array_equal(u, -(1.5 * case.upper)) and np.array_equal(lo, -(1.5 * case.lower))
+
+
 def test_cg_iteration_count_obeys_the_spectral_bound(pkg, orc):
     """sanity of the oracle's PCG against theory.  For the SPD matrix -A of a small box the classical bound
     says the A-norm error falls by 2((sqrt(k)-1)/(sqrt(k)+1))^i; with the exact spectrum from numpy the unpreconditioned
