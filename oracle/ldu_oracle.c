@@ -14,14 +14,20 @@
  * Tmul(A) == Amul(A'), face-loop order vs row-gather order), (ii) the
  * golden fixtures it generated itself (tests/golden/golden_v1/v2.npz), and
  * (iii) THE REFERENCE'S OWN SOURCES wherever they are host code: PCG.C,
- * PBiCG.C, PBiCGStab.C (+ their functor headers), GAMGSolverSolve.C and
- * pairGAMGAgglomerate.C are compiled from /root/reference against
- * oracle/ref_shim/ into oracle/_ref/ (Makefile target `ref`); the solver
- * loops here and the V-cycle in gamg_oracle.c reproduce the reference's
- * solve()/Vcycle() functions bit for bit
+ * PBiCG.C, PBiCGStab.C, smoothSolver.C (+ their functor headers),
+ * GAMGSolverSolve.C, GAMGSolverScale.C, the GAMG inter-level functor
+ * headers, pairGAMGAgglomerate.C, and the SpMV family itself --
+ * lduMatrixATmul.C and lduMatrixOperations.C with
+ * lduAddressingFunctors.H, run on the host over a sequential stand-in for
+ * Thrust -- are compiled from /root/reference against oracle/ref_shim/
+ * into oracle/_ref/ (Makefile target `ref`); the solver loops here and the
+ * V-cycle in gamg_oracle.c reproduce the reference's solve()/Vcycle()
+ * functions bit for bit, sumA / H / H1 / sumDiag & co. and the literal
+ * Amul reading give the bits of the reference's text
  * (tests/golden/golden_ref_*.npz, make_golden_ref.py).  Still an
- * assumption: the rounding inside the device row functors (see
- * orc_amul_functor_literal).
+ * assumption: which multiply-add pairs nvcc fuses inside the device row
+ * functors (see orc_amul_functor_literal; the two readings differ by
+ * < 2 ulp of the row magnitude).
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference/src/OpenFOAM/matrices/lduMatrix/ unless noted).
