@@ -707,7 +707,7 @@ def ref_atmul(case, which, psi=None, source=None, favour_speed=0, level=0, coars
     x = np.zeros(n) if psi is None else _d(psi)
     b = np.zeros(n) if source is None else _d(source)
     out = np.full(n, np.nan)
-    k = {"amul": 0, "tmul": 1, "residual": 2, "sumA": 3, "H1": 4}[which]
+    k = {"amul": 0, "tmul": 1, "residual": 2, "sumA": 3, "H1": 4, "ainv": 5, "ainvT": 6}[which]   # 5, 6: AINVPreconditioner.C, psi = r
     L.ref_atmul(C.c_int(k), C.c_int(favour_speed), C.c_int(level), C.c_int(int(coarsest)), C.c_int(n), C.c_int(nf), _p(lo, C.c_int32), _p(up, C.c_int32),
                 _p(owner_sort, C.c_int32), _p(owner_start, C.c_int32), _p(losort_start, C.c_int32), _p(losort, C.c_int32), _p(_d(case.diag), C.c_double),
                 _p(lower, C.c_double), _p(upper, C.c_double), _p(lower_sort, C.c_double), _p(upper_sort, C.c_double), _p(x, C.c_double), _p(b, C.c_double),

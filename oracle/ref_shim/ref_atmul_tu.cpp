@@ -33,7 +33,26 @@ public:
     tmp<scalargpuField> residual(const scalargpuField&, const scalargpuField&, const FieldField<gpuField, scalar>&, const lduInterfaceFieldPtrsList&, const direction) const;
     void H1(scalargpuField&) const;
     tmp<scalargpuField> H1() const;
+    // what preconditioners/AINVPreconditioner/AINVPreconditioner.{H,C} need of lduMatrix.H:99-269,438-520
+    class solver { const lduMatrix& m_; public: solver(const lduMatrix& m) : m_(m) {} const lduMatrix& matrix() const { return m_; } };
+    class preconditioner
+    {
+    protected:
+        const solver& solver_;
+    public:
+        preconditioner(const solver& s) : solver_(s) {}
+        virtual ~preconditioner() {}
+        virtual void precondition(scalargpuField&, const scalargpuField&, const direction = 0) const = 0;
+        virtual void preconditionT(scalargpuField&, const scalargpuField&, const direction = 0) const = 0;
+        template <class T> struct addsymMatrixConstructorToTable {};
+        template <class T> struct addasymMatrixConstructorToTable {};
+    };
 };
+class dictionary {};
+#define TypeName(name) static const char* typeName_() { return name; }
+#define defineTypeNameAndDebug(T, d)
+// GENERATE_OPERATOR_FUNCTORS(/,divide) of fields/Fields/gpuField/gpuFieldM.H:151-159 (scalar op field)
+template <class T1, class T2, class R> struct divideOperatorSFFunctor { const T1 t1; divideOperatorSFFunctor(T1 t) : t1(t) {} R operator()(const T2& t2) { return t1 / t2; } };
 }
 #define lduMatrix_H
 #define lduAddressing_H
@@ -44,9 +63,10 @@ public:
 #include REF_FILE(lduAddressing/lduAddressingFunctors.H)
 #include REF_FILE(lduMatrix/lduMatrixFunctors.H)
 #include REF_FILE(lduMatrix/lduMatrixATmul.C)
+#include REF_FILE(preconditioners/AINVPreconditioner/AINVPreconditioner.C)
 namespace Foam { label lduMatrixSolutionCache::favourSpeed = 0; scalargpuField lduMatrixSolutionCache::first_; scalargpuField lduMatrixSolutionCache::second_; }
 
-// which: 0 Amul, 1 Tmul, 2 residual (in = psi, in2 = source), 3 sumA, 4 H1.  lowerSort[j] = lower[losort[j]] etc. is the caller's
+// which: 0 Amul, 1 Tmul, 2 residual (in = psi, in2 = source), 3 sumA, 4 H1, 5 / 6 AINVPreconditioner::precondition / preconditionT (in = r).  lowerSort[j] = lower[losort[j]] etc. is the caller's
 // (lduMatrix::lowerSort(), lduMatrix.C); favourSpeed / level / coarsest select the reference's fast paths.
 extern "C" void ref_atmul(int which, int favourSpeed, int level, int coarsest, int n, int nFaces, const int32_t* lower, const int32_t* upper, const int32_t* ownerSort,
                           const int32_t* ownerStart, const int32_t* losortStart, const int32_t* losort, const double* diag, const double* lowerC, const double* upperC,
@@ -68,5 +88,11 @@ extern "C" void ref_atmul(int which, int favourSpeed, int level, int coarsest, i
     else if (which == 1) m.Tmul(o, tmp<S>(x), noCoeffs, noInterfaces, 0);
     else if (which == 2) m.residual(o, x, b, noCoeffs, noInterfaces, 0);
     else if (which == 3) m.sumA(o, noCoeffs, noInterfaces);
-    else m.H1(o);
+    else if (which == 4) m.H1(o);
+    else
+    {
+        lduMatrix::solver sol(m); dictionary dict;
+        AINVPreconditioner P(sol, dict);            // rD = 1/diag into the solution cache (AINVPreconditioner.C:18-41)
+        if (which == 5) P.precondition(o, x); else P.preconditionT(o, x);
+    }
 }

@@ -192,6 +192,9 @@ def build_atmul(pkg, orc):
         for fs in (0, 1, 2):
             out[f"{name}/amul/fs{fs}"] = orc.ref_atmul(case, "amul", x, favour_speed=fs)
             out[f"{name}/tmul/fs{fs}"] = orc.ref_atmul(case, "tmul", x, favour_speed=fs)
+            if fs < 2:      # AINVPreconditioner.C (ctor rD = 1/diag, precondition / preconditionT) of the same translation unit
+                out[f"{name}/ainv/fs{fs}"] = orc.ref_atmul(case, "ainv", x, favour_speed=fs)
+                out[f"{name}/ainvT/fs{fs}"] = orc.ref_atmul(case, "ainvT", x, favour_speed=fs)
         for fs in (0, 1):
             out[f"{name}/residual/fs{fs}"] = orc.ref_atmul(case, "residual", x, b, favour_speed=fs)
             out[f"{name}/H1/fs{fs}"] = orc.ref_atmul(case, "H1", favour_speed=fs)

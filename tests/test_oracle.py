@@ -346,6 +346,14 @@ def test_spmv_family_against_the_reference_source_run_on_the_host(pkg, orc):
             assert np.max(np.abs(S.amul(x) - G[f"{name}/amul/fs{fs}"]) / row_mag) < 2 * eps
             assert np.max(np.abs(S.tmul(x) - G[f"{name}/tmul/fs{fs}"]) / row_mag) < 2 * eps
         assert np.array_equal(S.sumA(), G[f"{name}/sumA"]) and np.array_equal(S.H1(), G[f"{name}/H1/fs0"])
+        # AINVPreconditioner.C of the reference, run the same way: rD = 1/diag in the constructor, precondition / preconditionT
+        # with the triangles swapped for the transpose; the oracle's apply agrees within rounding on both favourSpeed paths
+        for fs in (0, 1):
+            for key, tr in (("ainv", False), ("ainvT", True)):
+                ref = G[f"{name}/{key}/fs{fs}"]
+                assert np.max(np.abs(S.precondition("AINV", x, transpose=tr) - ref)) < 4e-15 * np.max(np.abs(ref)), (name, key, fs)
+        if case.lower is not None:
+            assert np.max(np.abs(G[f"{name}/ainv/fs0"] - G[f"{name}/ainvT/fs0"])) > 1e-6 * np.max(np.abs(G[f"{name}/ainv/fs0"]))
         assert np.max(np.abs(S.residual(x, b) - G[f"{name}/residual/fs0"]) / (row_mag + np.abs(b))) < 2 * eps
         # the fast paths: neighbour-side faces of a row in losort order, those from the fourth on are dropped by the reference
         losort = np.argsort(case.upper_addr, kind="stable")
