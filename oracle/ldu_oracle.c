@@ -197,6 +197,35 @@ static void update_interfaces(const orc_system *s, int d, int useIntCoeffs,
     }
 }
 
+
+/* Speed only (the 216^3 parity tests run this oracle for >1000 iterations): rows / vector elements are independent, so
+ * an OpenMP loop over them gives the same bits as the serial loop.  The long-double sums of domains above 2^20 cells are
+ * evaluated in fixed blocks of 65536 elements (block sums in element order, then the block sums in block order, all in
+ * long double): independent of the thread count, and equal to the plain left-to-right long-double sum to ~1e-19
+ * relative; every golden fixture and small test case stays on the plain loop.                                        */
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_PAR_ROWS(n) ORC_PRAGMA(omp parallel for schedule(static) if ((n) > 200000))
+#define ORC_PAR_ROWS_J(n) ORC_PRAGMA(omp parallel for schedule(static) private(j) if ((n) > 200000))
+#define ORC_BLOCKED_SUM_MIN (1 << 20)
+static long double blocked_ld_sum(const scalar *x, const scalar *y, int64_t n, int kind) /* 0: sum x, 1: sum x*y, 2: sum |x| */
+{
+    const int64_t B = 65536, nb = (n + B - 1) / B;
+    long double *part = (long double *)malloc(sizeof(long double) * (size_t)nb), tot = 0;
+    int64_t b;
+    ORC_PRAGMA(omp parallel for schedule(static))
+    for (b = 0; b < nb; b++) {
+        const int64_t i0 = b * B, i1 = (i0 + B < n) ? i0 + B : n; int64_t i;
+        long double acc = 0;
+        if (kind == 0) for (i = i0; i < i1; i++) acc += x[i];
+        else if (kind == 1) for (i = i0; i < i1; i++) acc += (long double)x[i] * (long double)y[i];
+        else for (i = i0; i < i1; i++) acc += fabsl((long double)x[i]);
+        part[b] = acc;
+    }
+    for (b = 0; b < nb; b++) tot += part[b];
+    free(part);
+    return tot;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Amul / Tmul: row-gather in the reference's summation order               */
 /* lduMatrix/lduMatrixATmul.C:42-138 (matrixMultiplyFunctor<fast,3>):       */
@@ -211,6 +240,7 @@ static void dom_mul_rows(const orc_domain *m, const scalar *Lower,
                          const scalar *Upper, const scalar *psi, scalar *Apsi)
 {
     label c, j;
+    ORC_PAR_ROWS_J(m->nCells)
     for (c = 0; c < m->nCells; c++) {
         scalar out = m->diag[c] * psi[c];
         for (j = m->ownerStart[c]; j < m->ownerStart[c + 1]; j++)
@@ -303,6 +333,7 @@ void orc_sumA(const orc_system *s, scalar *sumA)
     for (d = 0; d < s->nDomains; d++) {
         const orc_domain *m = &s->dom[d];
         scalar *o = sumA + m->offset;
+        ORC_PAR_ROWS_J(m->nCells)
         for (c = 0; c < m->nCells; c++) {
             scalar out = m->diag[c];
             for (j = m->ownerStart[c]; j < m->ownerStart[c + 1]; j++) out += m->upperC[j];
@@ -323,6 +354,7 @@ void orc_residual(const orc_system *s, const scalar *psi, const scalar *source, 
     for (d = 0; d < s->nDomains; d++) {
         const orc_domain *m = &s->dom[d];
         const scalar *x = psi + m->offset; scalar *r = rA + m->offset;
+        ORC_PAR_ROWS_J(m->nCells)
         for (c = 0; c < m->nCells; c++) {
             scalar out = source[m->offset + c] - m->diag[c] * x[c];
             for (j = m->ownerStart[c]; j < m->ownerStart[c + 1]; j++)
@@ -420,7 +452,8 @@ static scalar g_sum_prod(const orc_system *s, const scalar *a, const scalar *b)
         const scalar *x = a + m->offset, *y = b + m->offset;
         if (s->accurate_sums) {
             long double acc = 0;
-            for (i = 0; i < m->nCells; i++) acc += (long double)x[i] * (long double)y[i];
+            if (m->nCells > ORC_BLOCKED_SUM_MIN) acc = blocked_ld_sum(x, y, m->nCells, 1);
+            else for (i = 0; i < m->nCells; i++) acc += (long double)x[i] * (long double)y[i];
             total += (scalar)acc;
         } else {
             scalar a0 = 0, a1 = 0, a2 = 0, a3 = 0; label n4 = m->nCells & ~3;
@@ -440,7 +473,8 @@ static scalar g_sum_mag(const orc_system *s, const scalar *a)
         const scalar *x = a + m->offset;
         if (s->accurate_sums) {
             long double acc = 0;
-            for (i = 0; i < m->nCells; i++) acc += fabsl((long double)x[i]);
+            if (m->nCells > ORC_BLOCKED_SUM_MIN) acc = blocked_ld_sum(x, NULL, m->nCells, 2);
+            else for (i = 0; i < m->nCells; i++) acc += fabsl((long double)x[i]);
             total += (scalar)acc;
         } else {
             scalar a0 = 0, a1 = 0, a2 = 0, a3 = 0; label n4 = m->nCells & ~3;
@@ -459,7 +493,8 @@ static scalar g_sum(const orc_system *s, const scalar *a)
         const orc_domain *m = &s->dom[d];
         const scalar *x = a + m->offset;
         long double acc = 0;
-        for (i = 0; i < m->nCells; i++) acc += x[i];
+        if (m->nCells > ORC_BLOCKED_SUM_MIN) acc = blocked_ld_sum(x, NULL, m->nCells, 0);
+        else for (i = 0; i < m->nCells; i++) acc += x[i];
         total += (scalar)acc;
     }
     return total;
@@ -534,6 +569,7 @@ static void ainv_apply(const orc_domain *m, const scalar *rD, const scalar *Lowe
                        const scalar *Upper, const scalar *r, scalar *w)
 {
     label c, j;
+    ORC_PAR_ROWS_J(m->nCells)
     for (c = 0; c < m->nCells; c++) {
         scalar out = 0;
         for (j = m->ownerStart[c]; j < m->ownerStart[c + 1]; j++) {
@@ -558,9 +594,11 @@ static void precondition(const orc_system *s, const orc_precond *P, int transpos
         scalar *ww = w + m->offset;
         switch (P->kind) {
         case ORC_PRECOND_NONE: /* noPreconditioner.C:66-71 */
+            ORC_PAR_ROWS(m->nCells)
             for (i = 0; i < m->nCells; i++) ww[i] = rr[i];
             break;
         case ORC_PRECOND_DIAGONAL: /* diagonalPreconditioner.C:74-89 */
+            ORC_PAR_ROWS(m->nCells)
             for (i = 0; i < m->nCells; i++) ww[i] = rD[i] * rr[i];
             break;
         case ORC_PRECOND_AINV:
@@ -716,6 +754,7 @@ void orc_pcg_solve(const orc_system *s, scalar *psi, const scalar *source,
     memset(perf, 0, sizeof(*perf));
 
     orc_amul(s, psi, wA);
+    ORC_PAR_ROWS(n)
     for (i = 0; i < n; i++) rA[i] = source[i] - wA[i];
     scalar normFactor = orc_norm_factor(s, psi, source, wA, pA);
     perf->normFactor = normFactor;
@@ -733,14 +772,15 @@ void orc_pcg_solve(const orc_system *s, scalar *psi, const scalar *source,
                 memcpy(pA, wA, sizeof(scalar) * (size_t)n);
             } else {
                 scalar beta = wArA / wArAold;
+                ORC_PAR_ROWS(n)
                 for (i = 0; i < n; i++) pA[i] = fma(beta, pA[i], wA[i]);
             }
             orc_amul(s, pA, wA);
             scalar wApA = g_sum_prod(s, wA, pA);
             if (check_singularity(perf, fabs(wApA) / normFactor)) break;
             scalar alpha = wArA / wApA;
-            for (i = 0; i < n; i++) psi[i] = fma(alpha, pA[i], psi[i]);
-            for (i = 0; i < n; i++) rA[i] = fma(-alpha, wA[i], rA[i]);
+            ORC_PAR_ROWS(n)
+            for (i = 0; i < n; i++) { psi[i] = fma(alpha, pA[i], psi[i]); rA[i] = fma(-alpha, wA[i], rA[i]); }
             perf->finalResidual = g_sum_mag(s, rA) / normFactor;
             hist_put(hist, histLen, perf->nIterations + 1, perf->finalResidual);
         } while ((perf->nIterations++ < ctl->maxIter && !check_convergence(perf, ctl)) ||

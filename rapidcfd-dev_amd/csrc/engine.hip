@@ -192,7 +192,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c; return fail(MI_ERR_DEVICE, "pinned host / event allocation failed");
     }
-    c->tileFlags = env_int("MI_TILE_FLAGS", 0);
+    c->tileFlags = env_int("MI_TILE_FLAGS", 1); // bit0: coefficient segments are staged with non-temporal loads (read once per launch): Amul -4 % (profiles/r02_b_cache_policy_ab.md)
     c->attachEvents = env_int("MI_EVENT_ATTACH", 1);
     c->persist = env_int("MI_TILE_PERSIST", 0);
     c->xcdRows = env_int("MI_XCD_ROWS", 1);

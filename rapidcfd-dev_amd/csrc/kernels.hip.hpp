@@ -25,7 +25,13 @@ namespace mi {
 
 constexpr int RG = 1024;      // blocks of every streaming/reduction kernel (fixed => deterministic)
 static_assert(RG == 1024, "the fold kernels (k_fold_partials / k_fold_final: one 1024-thread workgroup, one slot per thread) assume RG == 1024; 2048 was tried and is NOT a drop-in change");
-constexpr int RB = 256;       // threads per block of the streaming kernels
+#ifndef MI_RB
+#define MI_RB 512   // 1024 x 512 threads = 32 waves per CU: +2 % PCG iterations/s over 256 (profiles/r02_b_cache_policy_ab.md)
+#endif
+#ifndef MI_VEC_NT
+#define MI_VEC_NT 0
+#endif
+constexpr int RB = MI_RB;     // threads per block of the streaming kernels
 
 // ---------------------------------------------------------------------------
 // wavefront (64 lanes) sum: xor butterfly.  Steps 1..16 stay inside a 32-lane
@@ -109,7 +115,7 @@ struct TileArgs {
     double* dotPartial; // Amul only: per-workgroup partial of sum(y*x) (fused gSumProd), or nullptr
     double omega;
     int32_t offLow, offX, offRD, offSB; // LDS offsets in doubles
-    int32_t flags;               // bit0: non-temporal coefficient loads, bit1: non-temporal entry loads, bit2: nt result stores
+    int32_t flags;               // bit0: non-temporal coefficient loads, bit1: non-temporal entry loads, bit2: nt result stores, bit3: nt diagonal loads (Amul)
 };
 
 // cooperative global -> LDS staging, 4 loads in flight per lane
@@ -162,11 +168,11 @@ __device__ __forceinline__ void stage_gather(const double* __restrict__ x, const
 // in the standalone harness on one box: 155.7 -> 147.8 us for the symmetric Amul (profiles/r01_t_direct_to_lds.md).
 typedef __attribute__((address_space(1))) const void* mi_gptr_t;
 typedef __attribute__((address_space(3))) void* mi_lptr_t;
-template <int BS>
+template <int BS, bool NT = false>
 __device__ __forceinline__ void stage_dma16(const double2* __restrict__ src, double2* __restrict__ dst, int n2, int wave, int lane)
 {
     for (int base = wave * 64; base < n2; base += BS)
-        if (base + lane < n2) __builtin_amdgcn_global_load_lds((mi_gptr_t)(src + base + lane), (mi_lptr_t)(dst + base), 16, 0, 0);
+        if (base + lane < n2) __builtin_amdgcn_global_load_lds((mi_gptr_t)(src + base + lane), (mi_lptr_t)(dst + base), 16, 0, NT ? 2 : 0); // aux 2 = nt
 }
 // n doubles (8-byte aligned source): pairs through the DMA path, an odd last element by hand
 template <int BS>
@@ -202,8 +208,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     // (four LDS arrays, one 1024-thread workgroup per CU), which keeps the register path
     constexpr bool DMA = !(OP == OP_AINV && ASYM);
     if (DMA) {
-    stage_dma16<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid >> 6, tid & 63);
-    if (ASYM) stage_dma16<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
+    if (a.flags & 1) { // coefficients are read once per launch: non-temporal
+        stage_dma16<BS, true>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid >> 6, tid & 63);
+        if (ASYM) stage_dma16<BS, true>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
+    } else {
+        stage_dma16<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid >> 6, tid & 63);
+        if (ASYM) stage_dma16<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
+    }
     if (NEEDX) {
         stage_dma8<BS>(a.x + c0, xs, nc, tid);
         stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
@@ -284,7 +295,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
         const double xi = (NEEDX && live) ? xs[i] : 0.0;
         double acc, accI = 0.0;
         if (OP == OP_JACOBI) accI = a.b[gi];
-        if (OP == OP_AMUL) acc = a.diag[gi] * xi;
+        if (OP == OP_AMUL) acc = ((a.flags & 8) ? __builtin_nontemporal_load(a.diag + gi) : a.diag[gi]) * xi;
         else if (OP == OP_SUMA) acc = a.diag[gi];
         else if (OP == OP_RESIDUAL) acc = a.b[gi] - a.diag[gi] * xi;
         else acc = 0.0;
@@ -461,8 +472,38 @@ __device__ __forceinline__ void chunk_loop(int64_t n, F2 body2, F1 body1)
     for (int64_t q = threadIdx.x; q < np; q += RB) body2(ck.lo + 2 * q);
     if (((ck.hi - ck.lo) & 1) && threadIdx.x == 0) body1(ck.hi - 1);
 }
-__device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return *reinterpret_cast<const double2*>(p + i); }
-__device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { *reinterpret_cast<double2*>(p + i) = v; }
+typedef double mi_dvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2(const double* p, int64_t i)
+{
+#if MI_VEC_NT
+    const mi_dvec2 v = __builtin_nontemporal_load(reinterpret_cast<const mi_dvec2*>(p + i));
+    return make_double2(v.x, v.y);
+#else
+    return *reinterpret_cast<const double2*>(p + i);
+#endif
+}
+#ifndef MI_RD_NT
+#define MI_RD_NT 0
+#endif
+// rD (reciprocal diagonal) is read twice per PCG iteration and never written inside a solve
+__device__ __forceinline__ double2 ld2_rd(const double* p, int64_t i)
+{
+#if MI_RD_NT
+    const mi_dvec2 v = __builtin_nontemporal_load(reinterpret_cast<const mi_dvec2*>(p + i));
+    return make_double2(v.x, v.y);
+#else
+    return ld2(p, i);
+#endif
+}
+__device__ __forceinline__ void st2(double* p, int64_t i, double2 v)
+{
+#if MI_VEC_NT
+    mi_dvec2 w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<mi_dvec2*>(p + i));
+#else
+    *reinterpret_cast<double2*>(p + i) = v;
+#endif
+}
 
 enum { RED_SUM = 0, RED_PROD = 1, RED_MAG = 2 };
 template <int KIND>
@@ -643,7 +684,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
     chunk_loop(n, [&](int64_t i) {
             double2 w;
             if (PMODE == 0) w = ld2(wA, i);
-            else if (PMODE == 1) { const double2 d = ld2(rD, i), r = ld2(rA, i); w = make_double2(d.x * r.x, d.y * r.y); }
+            else if (PMODE == 1) { const double2 d = ld2_rd(rD, i), r = ld2(rA, i); w = make_double2(d.x * r.x, d.y * r.y); }
             else w = ld2(rA, i);
             if (first) st2(pA, i, w);
             else { const double2 p = ld2(pA, i); st2(pA, i, make_double2(fma(beta, p.x, w.x), fma(beta, p.y, w.y))); }
@@ -681,7 +722,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
             x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y);
             r.x = fma(-alpha, w.x, r.x); r.y = fma(-alpha, w.y, r.y);
             st2(psi, i, x); st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y);
-            if (PMODE == 1) { const double2 d = ld2(rD, i); d0 = fma(d.x * r.x, r.x, d0); d1 = fma(d.y * r.y, r.y, d1); }
+            if (PMODE == 1) { const double2 d = ld2_rd(rD, i); d0 = fma(d.x * r.x, r.x, d0); d1 = fma(d.y * r.y, r.y, d1); }
             else if (PMODE == 2) { d0 = fma(r.x, r.x, d0); d1 = fma(r.y, r.y, d1); }
         },
         [&](int64_t i) {

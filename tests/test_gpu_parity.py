@@ -256,16 +256,21 @@ def test_decomposed_pcg_on_one_gpu(pkg, orc, ctx, parts):
     """N sub-domains emulated on one GPU: the distributed phases (mi_dpcg_phase), interface slots,
     interior/boundary tile split and halo pack, with the exchange done by device copies and the
     all-reduce by summing the ranks' scalar blocks -- against the serial oracle."""
+    case = pkg.synthetic.box_case(20, 18, 14)
+    kw = dict(tolerance=1e-9, relTol=0.0, maxIter=300, minIter=0)
+    ref_psi, ref = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-9, maxIter=300)
+    run_decomposed_pcg(pkg, case, parts, kw, ref_psi, ref)
+
+
+def run_decomposed_pcg(pkg, case, parts, kw, ref_psi, ref):
     from importlib import import_module
     import __graft_entry__ as graft
     par = import_module(graft.PKG_NAME + ".parallel")
     syn = pkg.synthetic
-    case = syn.box_case(20, 18, 14)
     subs = syn.decompose_box(case, parts)
     # one engine context per emulated rank (each owns its device-side solver state), same stream
     ctxs = [pkg.engine.Context(0, torch.cuda.current_stream().cuda_stream) for _ in subs]
     ops = [par.HipOps(c, s, torch.device("cuda:0")) for c, s in zip(ctxs, subs)]
-    kw = dict(tolerance=1e-9, relTol=0.0, maxIter=300, minIter=0)
 
     def exchange(field):
         for d, s in enumerate(subs):
@@ -310,7 +315,6 @@ def test_decomposed_pcg_on_one_gpu(pkg, orc, ctx, parts):
             o.phase(14, it - 1)
         if all(o.status()["done"] for o in ops):
             break
-    ref_psi, ref = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-9, maxIter=300)
     psi = np.zeros(case.n_cells)
     for o, s in zip(ops, subs):
         st = o.status(kw["maxIter"] + 2)

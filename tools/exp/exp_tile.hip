@@ -71,6 +71,26 @@ int main(int argc, char** argv)
     CK(hipFuncSetAttribute((const void*)tile_kernel<OP_AMUL, false, false, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     CK(hipFuncSetAttribute((const void*)tile_kernel<OP_AMUL, false, false, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     CK(hipFuncSetAttribute((const void*)tile_kernel<OP_AMUL, false, false, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    CK(hipFuncSetAttribute((const void*)tile_kernel<OP_AMUL, false, false, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    CK(hipFuncSetAttribute((const void*)tile_kernel<OP_AMUL, false, false, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    if (getenv("EXP_SWEEP")) { // entry form x workgroup size x cache-policy flags (bit0 nt coefficients, bit1 nt entries, bit2 nt stores)
+        a.flags = 0;
+        run("reference: explicit BS512 flags 0", [&] { tile_kernel<OP_AMUL, false, false, 512, false><<<L.nTiles, 512, ldsX, 0>>>(a); }, y0);
+        for (int pass = 0; pass < 2; ++pass)
+            for (int form = 0; form < (L.compact ? 2 : 1); ++form)
+                for (int bs : {256, 512})
+                    for (int fl : {0, 1, 2, 3, 7}) {
+                        a.flags = fl;
+                        char nm[96]; snprintf(nm, sizeof nm, "%s BS%d flags %d", form ? "compact " : "explicit", bs, fl);
+                        const size_t l = form ? lds : ldsX;
+                        if (form == 0 && bs == 256) run(nm, [&] { tile_kernel<OP_AMUL, false, false, 256, false><<<L.nTiles, 256, l, 0>>>(a); }, y1);
+                        if (form == 0 && bs == 512) run(nm, [&] { tile_kernel<OP_AMUL, false, false, 512, false><<<L.nTiles, 512, l, 0>>>(a); }, y1);
+                        if (form == 1 && bs == 256) run(nm, [&] { tile_kernel<OP_AMUL, false, false, 256, true><<<L.nTiles, 256, l, 0>>>(a); }, y1);
+                        if (form == 1 && bs == 512) run(nm, [&] { tile_kernel<OP_AMUL, false, false, 512, true><<<L.nTiles, 512, l, 0>>>(a); }, y1);
+                        if (pass == 0) check(nm);
+                    }
+        return 0;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         run("explicit BS512 (own LDS)", [&] { tile_kernel<OP_AMUL, false, false, 512, false><<<L.nTiles, 512, ldsX, 0>>>(a); }, y0);
         run("explicit BS256 (own LDS)", [&] { tile_kernel<OP_AMUL, false, false, 256, false><<<L.nTiles, 256, ldsX, 0>>>(a); }, y1);
