@@ -43,13 +43,25 @@ def parts_for(n):
     return {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(n) or (1, 1, n)
 
 
+def layout_source_hash():
+    """hash of the sources that decide the bytes an Amul launch moves (tile layout + tile kernel): the committed PMC figure
+    is only quoted while these are the files it was measured with"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tiling.cpp", "tiling.hpp", "kernels.hip.hpp"):
+        h.update(open(os.path.join(ROOT, "rapidcfd-dev_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profile(nx, ny, nz, n_gpus):
     """HBM bytes per Amul launch from the committed rocprofv3 PMC passes (profiles/traffic_latest.json: FETCH_SIZE x 2 +
     WRITE_SIZE as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read inside this process, so the value is the
-    one measured on this exact workload/layout; null for any other configuration."""
+    one measured on this exact workload AND this exact layout/kernel source (sha256 prefix stored with the figure by
+    tools/prof_round.sh); null for any other configuration or once those sources have changed."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        if rec.get("workload") == f"{nx}x{ny}x{nz}" and rec.get("n_gpus") == n_gpus:
+        if rec.get("workload") == f"{nx}x{ny}x{nz}" and rec.get("n_gpus") == n_gpus and rec.get("layout_source_sha256_16") == layout_source_hash() \
+                and not any(os.environ.get(k) for k in ("MI_TILE_CELLS", "MI_TILE_SLOTS", "MI_ENTRY16", "MI_TILE_FLAGS", "MI_ENGINE_LIB")):
             return float(rec["amul_traffic_bytes_per_launch"]), str(rec.get("source", "profiles/traffic_latest.json")).split(" ")[0]
     except Exception:
         pass
@@ -81,7 +93,20 @@ def main():
     ap.add_argument("--precond", default="diagonal")
     ap.add_argument("--cpu-iters", type=int, default=int(os.environ.get("MI_BENCH_CPU_ITERS", "0")))  # 0: about 10 s
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5)   # median of 5 repeats of the timed region
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (one rank per GPU, as the driver's
+    # `python -m torch.distributed.run --nproc-per-node N ... bench.py` does) instead of silently measuring one GPU
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"[bench] --gpus {args.gpus} without a launcher: re-executing under torch.distributed.run")
+        raise SystemExit(subprocess.call(cmd))
 
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner through C stdio at exit)
     # write to fd 1 behind Python's back, so fd 1 is pointed at stderr and the JSON goes to a private copy.
@@ -100,6 +125,9 @@ def main():
     n_gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    if os.environ.get("MI_BENCH_BACKEND", "nccl") == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU over RCCL; "
+                         "MI_BENCH_BACKEND=gloo rehearses the code path with ranks sharing devices)")
     # MI_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices, the
     # exchange goes through gloo and the torch.distributed loop; timings of such a run mean nothing).  Default: RCCL.
     backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
@@ -143,8 +171,9 @@ def main():
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
         ctx = eng.Context(local_rank, stream.cuda_stream)
-    K, W = args.steps, args.warmup
+    K, W, R = args.steps, args.warmup, max(1, args.repeats)
     amul_ms = None
+    rep_s, rep_amul_ms, amul_alone_us = [], [], None
     host_enqueue_us = None
     host_loop = "single-GPU device-resident pipeline (mi_pcg_iterate)"
     weak = None
@@ -157,43 +186,63 @@ def main():
         psi0 = torch.zeros(N, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
         log(f"[bench] engine layout: {addr.stats()} in {time.perf_counter() - t0:.1f}s")
-        mat.pcg_begin(psi0, src, args.precond, tolerance=0.0, relTol=0.0, maxIter=W + K + 8, history_len=W + K + 2)
+        mat.pcg_begin(psi0, src, args.precond, tolerance=0.0, relTol=0.0, maxIter=W + R * K + 8, history_len=W + R * K + 2)
         mat.pcg_iterate(W)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         ev_stride = int(os.environ.get("MI_BENCH_EVENT_STRIDE", "4"))
-        amul_ms = mat.pcg_iterate(K, time_amul=True, event_stride=ev_stride)  # HIP events around every 4th Amul launch of the timed region
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        perf = mat.pcg_end(None, history_len=W + K + 2)
-        assert perf["nIterations"] == W + K, perf
+        for _ in range(R):                       # R repeats of the timed region of EXACTLY K steps; the median is reported
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            a_ms = mat.pcg_iterate(K, time_amul=True, event_stride=ev_stride)  # HIP events around every 4th Amul launch of the timed region
+            torch.cuda.synchronize()
+            rep_s.append(time.perf_counter() - t0); rep_amul_ms.append(a_ms)
+        perf = mat.pcg_end(None, history_len=W + R * K + 2)
+        assert perf["nIterations"] == W + R * K, perf          # every timed step really iterated (no device-side early exit)
         assert np.all(np.isfinite(perf["history"])) and perf["history"][-1] < perf["history"][0]
         n_amul_cells, n_amul_faces = N, F
+        # Amul alone, out of the solver loop: rotating vectors (4 input/output pairs = 645 MB > the 256 MiB Infinity Cache),
+        # so that no sample finds its vectors on-die; kernel-bracketing events on the engine's stream
+        nrot, nl = 4, 40
+        xs = [torch.full((N,), 1.0 + 0.1 * i, dtype=torch.float64, device=dev) for i in range(nrot)]
+        ys = [torch.empty(N, dtype=torch.float64, device=dev) for _ in range(nrot)]
+        for i in range(nrot):
+            mat.amul_engine(xs[i], ys[i])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        samples = []
+        for _ in range(R):
+            torch.cuda.synchronize(); e0.record()
+            for i in range(nl):
+                mat.amul_engine(xs[i % nrot], ys[i % nrot])
+            e1.record(); torch.cuda.synchronize()
+            samples.append(e0.elapsed_time(e1) * 1e3 / nl)
+        amul_alone_us = float(np.median(samples))
+        del xs, ys
     else:
         from importlib import import_module
         par = import_module(graft.PKG_NAME + ".parallel")
         sub = syn.box_subdomain((nx, ny, nz), parts_for(world), rank)   # == decompose_box(box_case(...))[rank], built directly
         solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
         host_loop = {"native": "C++ loop over RCCL (mi_dpcg_comm_iterate)", "torch": "torch.distributed loop (parallel.py)"}[solver.driver]
-        solver.begin(tolerance=0.0, max_iter=W + K + 8)
+        solver.begin(tolerance=0.0, max_iter=W + R * K + 8)
         solver.iterate(W)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        amul_ms = solver.iterate(K, time_amul=True, event_stride=8)   # sampled: event records cost ~3 us each in this latency-bound loop
-        host_enqueue_us = 1e6 * solver.last_enqueue_s / K   # host time to enqueue one iteration (incl. collectives)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+        for _ in range(R):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            a_ms = solver.iterate(K, time_amul=True, event_stride=8)   # sampled: event records cost ~3 us each in this latency-bound loop
+            host_enqueue_us = 1e6 * solver.last_enqueue_s / K   # host time to enqueue one iteration (incl. collectives)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if world > 1:                                          # the slowest rank's clock, per repeat
+                tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            rep_s.append(el); rep_amul_ms.append(a_ms)
         perf = solver.end()
-        assert perf["nIterations"] == W + K, perf
+        assert perf["nIterations"] == W + R * K, perf
         n_amul_cells, n_amul_faces = sub.n_cells, sub.n_faces + sum(len(i.face_cells) for i in sub.interfaces)
         # supplement (not `value`): the same solver with the per-GPU work held at the N = 1 size (weak scaling;
         # at 8 GPUs this is the 80 M-cell box of BASELINE config 5), so that the latency-bound strong-scaling number
@@ -223,6 +272,8 @@ def main():
             weak = {"cells_per_gpu": wsub.n_cells, "global_cells": nx * px * ny * py * nz * pz, "iterations_per_s": K / wel,
                     "ms_per_step": 1e3 * wel / K, "cell_iterations_per_s": nx * px * ny * py * nz * pz * K / wel}
 
+    mid = int(np.argsort(rep_s)[len(rep_s) // 2])             # the median repeat: its wall clock and ITS Amul events
+    elapsed, amul_ms = rep_s[mid], rep_amul_ms[mid]
     its = K / elapsed
     amul_avg_s = (amul_ms / 1e3) / K
     amul_bytes = 24 * n_amul_cells + 16 * n_amul_faces  # symmetric Amul, per launch (per rank)
@@ -246,6 +297,10 @@ def main():
             "cells": N, "faces": F, "parallelism": f"domain-decomposition {parts_for(world)}" if world > 1 else "single GPU",
             "pcg_algorithmic_GBps": (160 * N + 16 * F) * its / 1e9,
             "host_enqueue_us_per_step": host_enqueue_us, "host_loop": host_loop,
+            "timing": f"median of {R} repeats of the timed region of {K} steps (barrier + synchronize on both sides of each repeat, max over ranks)",
+            "repeat_ms_per_step": [1e3 * t / K for t in rep_s], "repeat_amul_us_in_loop": [1e3 * a / K for a in rep_amul_ms],
+            "amul_alone_us_rotating_buffers": amul_alone_us,
+            "amul_alone_frac_of_peak": (None if amul_alone_us is None else (24 * N + 16 * F) / (amul_alone_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
             "weak_scaling_supplement": weak,
         },
         "roofline": {

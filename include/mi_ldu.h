@@ -219,7 +219,11 @@ int mi_pcg_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
  * device-side no-ops, so the result equals the reference loop; end = fetch psi,
  * solverPerformance and the residual history.  If amul_ms_sum != NULL, every
  * Amul launch of this call is bracketed by HIP events on the stream and the sum
- * of their durations is returned (this synchronises).                           */
+ * of their durations is returned (this synchronises).
+ * One session per context: between mi_pcg_begin and mi_pcg_end the session owns the context's solver scratch
+ * (device-side solver state, reduction partials) and the matrix's work vectors; until mi_pcg_end the reductions
+ * (mi_sum*), mi_norm_factor*, every mi_*_solve and a mi_pcg_begin on another matrix of the same context return
+ * MI_ERR_STATE instead of corrupting the running solve.  The operators (mi_amul ... mi_precondition) stay usable. */
 int mi_pcg_begin(mi_matrix_t m, const double *psi0_dev, const double *source_dev,
                  const mi_solver_controls *controls, int precond, int32_t history_len);
 int mi_pcg_iterate(mi_matrix_t m, int32_t n_iters, float *amul_ms_sum);
@@ -428,7 +432,7 @@ int mi_comm_allreduce_sum(mi_comm_t comm, double *buf_dev, int64_t n);
  * (init/updateMatrixInterfaces), every global sum inside the solvers is all-reduced, and
  * mi_pcg_solve / mi_pbicg_solve / mi_pbicgstab_solve / mi_smooth_solve solve the GLOBAL system; all ranks call
  * them together, like the MPI ranks of the reference.  (mi_pcg_solve: diagonal/none run the device-resident
- * phase pipeline, AINV a host-stepped loop.)  GAMG is not communicator-aware yet.                          */
+ * phase pipeline, AINV a host-stepped loop.)  GAMG on such a matrix: mi_gamg_create_coupled.                 */
 int mi_matrix_attach_comm(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,
                           const int32_t *patch_nbr_patch_or_null, int64_t n_global_cells);
 int mi_matrix_detach_comm(mi_matrix_t m);

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -84,6 +86,10 @@ struct mi_ctx_s {
     int nCU = 0;
     int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
+    struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
+    int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0; // MI_* switches, read once per context
+    std::set<const void*> ldsAttrSet;                         // kernels whose dynamic-LDS limit has been raised on THIS device
+    std::map<std::pair<const void*, size_t>, int> occCache;  // (kernel, LDS bytes) -> resident workgroups per CU on this device
 };
 
 struct mi_addr_s {
@@ -199,6 +205,8 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
+    c->pcgBatch = env_int("MI_PCG_BATCH", 16); c->pcgGraph = env_int("MI_PCG_GRAPH", -1); c->pbicgHostStepped = env_int("MI_PBICG_HOST_STEPPED", 0);
+    c->gamgDeviceInvert = env_int("MI_GAMG_DEVICE_INVERT", -1); c->gamgAlwaysAgglomerate = env_int("MI_GAMG_ALWAYS_AGGLOMERATE", 0);
     if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 0;
     *out = c;
     return MI_OK;
@@ -421,20 +429,21 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
     if (nTiles <= 0) return MI_OK;
 #define MI_LAUNCH(BS)                                                                                                   \
     {                                                                                                                   \
-        static bool attr##BS = false;                                                                                   \
-        if (!attr##BS) {                                                                                                \
-            HIPCHK(hipFuncSetAttribute((const void*)tile_kernel<OP, ASYM, TRANS, BS, C16>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); \
-            attr##BS = true;                                                                                            \
+        mi_ctx_s* cx = m->addr->ctx;                                                                                    \
+        const void* fn = (const void*)tile_kernel<OP, ASYM, TRANS, BS, C16>;                                            \
+        if (!cx->ldsAttrSet.count(fn)) { /* per context = per device: a process may drive several devices */          \
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));                    \
+            cx->ldsAttrSet.insert(fn);                                                                                  \
         }                                                                                                               \
         int grid = nTiles;                                                                                              \
-        if (m->addr->ctx->persist) {                                                                                    \
-            static int occ##BS = 0; static size_t occLds##BS = 0;                                                       \
-            if (occ##BS == 0 || occLds##BS != lds) {                                                                    \
+        if (cx->persist) {                                                                                              \
+            int& occ = cx->occCache[std::make_pair(fn, lds)];                                                           \
+            if (occ == 0) {                                                                                             \
                 int nb = 0;                                                                                             \
-                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP, ASYM, TRANS, BS, C16>, BS, lds)); \
-                occ##BS = nb > 0 ? nb : 1; occLds##BS = lds;                                                            \
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BS, lds));                                 \
+                occ = nb > 0 ? nb : 1;                                                                                  \
             }                                                                                                           \
-            const int slots = ((occ##BS * m->addr->ctx->nCU * m->addr->ctx->persist) / 8) * 8;                          \
+            const int slots = ((occ * cx->nCU * cx->persist) / 8) * 8;                                                  \
             if (slots >= 8 && nTiles > 2 * slots) grid = slots;                                                         \
         }                                                                                                               \
         if (m->kevStart) /* start/stop events stamped by the kernel's own begin/end: the profiler's clock */           \
@@ -705,6 +714,7 @@ template <int KIND>
 int reduce_host(mi_ctx_s* c, const double* a, const double* b, int64_t n, double* out)
 {
     if (!c || !a || !out || n < 0) return fail(MI_ERR_ARG, "reduction: bad argument");
+    if (c->session) return fail(MI_ERR_STATE, "reduction: a PCG session (mi_pcg_begin) is active on this context and owns its reduction scratch; call mi_pcg_end first");
     if (!aligned16(a) || (b && !aligned16(b))) return fail(MI_ERR_ARG, "reduction inputs must be 16-byte aligned");
     HIPCHK(hipSetDevice(c->device));
     k_reduce<KIND><<<RG, RB, 0, c->stream>>>(a, b, n, c->partial.p);
@@ -796,6 +806,7 @@ extern "C" int mi_norm_factor(mi_matrix_t m, const double* psi, const double* so
 {
     if (!m || !psi || !source || !Apsi || !out) return fail(MI_ERR_ARG, "mi_norm_factor: bad argument");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_norm_factor: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
     hipStream_t s = a->ctx->stream;
@@ -811,6 +822,7 @@ extern "C" int mi_norm_factor_engine(mi_matrix_t m, const double* psi_e, const d
 {
     if (!m || !psi_e || !source_e || !Apsi_e || !out) return fail(MI_ERR_ARG, "mi_norm_factor_engine: bad argument");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_norm_factor_engine: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     HIPCHK(hipSetDevice(m->addr->ctx->device));
     double* v1;
     MICHK(m->vec(1, &v1));
@@ -979,6 +991,8 @@ extern "C" int mi_pcg_begin(mi_matrix_t m, const double* psi0, const double* sou
     if (!m || !psi0 || !source || !ctl) return fail(MI_ERR_ARG, "mi_pcg_begin: bad argument");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
     if (comm_attached(m)) return fail(MI_ERR_STATE, "mi_pcg_begin: a communicator is attached; use mi_pcg_solve or the mi_dpcg_* session");
+    if (m->addr->ctx->session && m->addr->ctx->session != m)
+        return fail(MI_ERR_STATE, "mi_pcg_begin: another matrix has a PCG session open on this context (one session per context: it owns the solver scratch)");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
     hipStream_t s = a->ctx->stream;
@@ -995,7 +1009,7 @@ extern "C" int mi_pcg_begin(mi_matrix_t m, const double* psi0, const double* sou
         k_pcg_precond_dot<false><<<RG, RB, 0, s>>>(a->ctx->state.p, nullptr, rA, wA, a->L.nCells, a->ctx->partial.p);
     }
     HIPCHK(hipGetLastError());
-    m->pcgIt = 0; m->pcgPrecond = precond; m->pcgActive = true;
+    m->pcgIt = 0; m->pcgPrecond = precond; m->pcgActive = true; a->ctx->session = m;
     return MI_OK;
 }
 
@@ -1037,8 +1051,8 @@ extern "C" int mi_pcg_end(mi_matrix_t m, double* psi_out, mi_solver_perf* perf, 
     HIPCHK(hipGetLastError());
     MICHK(fetch_state(a->ctx));
     if (perf) fill_perf(*a->ctx->hostState, perf);
+    m->pcgActive = false; a->ctx->session = nullptr; // closed even if the history copy below fails
     MICHK(copy_hist(m, hist_host, hist_len, a->ctx->hostState->nIterations));
-    m->pcgActive = false;
     return MI_OK;
 }
 
@@ -1049,15 +1063,17 @@ extern "C" int mi_pcg_solve(mi_matrix_t m, double* psi, const double* source, co
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
     if (comm_attached(m)) return pcg_solve_attached(m, psi, source, ctl, precond, perf, hist_host, hist_len);
     const int histLen = ctl->maxIter + 2;
+    if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_pcg_solve: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     MICHK(mi_pcg_begin(m, psi, source, ctl, precond, histLen));
     mi_ctx_s* c = m->addr->ctx;
+    struct SessionGuard { mi_matrix_s* m; ~SessionGuard() { if (m->pcgActive) { m->pcgActive = false; m->addr->ctx->session = nullptr; } } } sessionGuard{m};
     MICHK(fetch_state(c));
-    const int batch = env_int("MI_PCG_BATCH", 16);
+    const int batch = m->addr->ctx->pcgBatch;
     const int limit = ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0);
     // Launch-bound regime (small meshes: a 32^3 cavity iteration is five ~5 us launches): one batch of iterations is
     // captured ONCE into a hipGraph -- the iteration counter lives in PcgState, so the kernel arguments never change --
     // and replayed until the device reports done.  Same kernels, same order: results are bit-identical.
-    const int wantGraph = env_int("MI_PCG_GRAPH", -1);
+    const int wantGraph = c->pcgGraph;
     const bool useGraph = (precond == MI_PRECOND_DIAGONAL || precond == MI_PRECOND_NONE) && !c->fuseFinal &&
                           (wantGraph == 1 || (wantGraph < 0 && m->addr->L.nCells <= 4000000));
     if (useGraph && !c->hostState->done) {
@@ -1299,7 +1315,7 @@ int pbicg_solve_device(mi_matrix_s* m, double* psi_io, const double* source, con
     MICHK(launch_tile<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0, 0));
     k_sub<<<RG, RB, 0, s>>>(rT, src, wT, n);
     MICHK(fetch_state(c));
-    const int batch = env_int("MI_PCG_BATCH", 16);
+    const int batch = m->addr->ctx->pcgBatch;
     int it = 0, nb = batch < 2 ? batch : 2;   // growing batches, as in mi_pcg_solve
     while (!c->hostState->done && it <= ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0)) {
         MICHK(bicg_enqueue(m, it, nb, precond, psi, pA, wA, rA, pT, wT, rT));
@@ -1321,9 +1337,10 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
 {
     if (!m || !psi_io || !source || !ctl) return fail(MI_ERR_ARG, "mi_pbicg_solve: bad argument");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_pbicg_solve: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
-    if (!comm_attached(m) && env_int("MI_PBICG_HOST_STEPPED", 0) == 0)
+    if (!comm_attached(m) && m->addr->ctx->pbicgHostStepped == 0)
         return pbicg_solve_device(m, psi_io, source, ctl, precond, perf, hist_host, hist_len);
     hipStream_t s = a->ctx->stream;
     const int64_t n = a->L.nCells;
@@ -1417,7 +1434,7 @@ int pbicgstab_solve_device(mi_matrix_s* m, double* psi_io, const double* source,
     MICHK(solve_prologue(m, ctl, psi, src, yA, rA, pA, histLen));
     HIPCHK(hipMemcpyAsync(rA0, rA, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     MICHK(fetch_state(c));
-    const int batch = env_int("MI_PCG_BATCH", 16);
+    const int batch = m->addr->ctx->pcgBatch;
     int it = 0, nb = batch < 2 ? batch : 2;   // growing batches, as in mi_pcg_solve
     while (!c->hostState->done && it <= ctl->maxIter + (ctl->minIter > ctl->maxIter ? ctl->minIter : 0)) {
         MICHK(stab_enqueue(m, it, nb, precond, replicate_quirk != 0, psi, pA, yA, rA, AyA, sA, zA, tA, rA0));
@@ -1439,9 +1456,10 @@ extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* s
 {
     if (!m || !psi_io || !source || !ctl) return fail(MI_ERR_ARG, "mi_pbicgstab_solve: bad argument");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_pbicgstab_solve: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
-    if (!comm_attached(m) && env_int("MI_PBICG_HOST_STEPPED", 0) == 0)
+    if (!comm_attached(m) && m->addr->ctx->pbicgHostStepped == 0)
         return pbicgstab_solve_device(m, psi_io, source, ctl, precond, replicate_quirk, perf, hist_host, hist_len);
     hipStream_t s = a->ctx->stream;
     const int64_t n = a->L.nCells;
@@ -1505,6 +1523,7 @@ extern "C" int mi_smooth_solve(mi_matrix_t m, double* psi_io, const double* sour
 {
     if (!m || !psi_io || !source || !ctl || n_sweeps == 0) return fail(MI_ERR_ARG, "mi_smooth_solve: bad argument");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_smooth_solve: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
     hipStream_t s = a->ctx->stream;
@@ -1595,7 +1614,7 @@ extern "C" int mi_bench_pcg_iters(mi_matrix_t m, const double* source, int32_t i
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
-    m->pcgActive = false;
+    m->pcgActive = false; c->session = nullptr;
     if (amul_ms_out) { float t = 0; MICHK(mi_bench_amul(m, iters, &t)); *amul_ms_out = t; }
     return MI_OK;
 }

@@ -203,7 +203,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     // ---- stage: coefficients (16-byte coalesced), psi, halo -------------------
     // All global loads of a phase are issued before the first LDS store (4-deep
     // unroll) so that every wave keeps several KiB in flight.
-#ifndef MI_STAGE_THROUGH_REGISTERS   // A/B build switch (tools/ab_dma.sh): the register-staged copies this kernel used before
     // measured per variant on one box (profiles/r01_t_direct_to_lds.md): faster everywhere except the asymmetric AINV pass
     // (four LDS arrays, one 1024-thread workgroup per CU), which keeps the register path
     constexpr bool DMA = !(OP == OP_AINV && ASYM);
@@ -231,19 +230,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
         stage_copy<BS>(a.rD + c0, rDs, nc, tid);
         stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
     }
-#else
-    const bool nt = (a.flags & 1) != 0;
-    stage_copy_nt<BS>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid, nt);
-    if (ASYM) stage_copy_nt<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid, nt);
-    if (NEEDX) {
-        stage_copy<BS>(a.x + c0, xs, nc, tid);
-        stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
-        if (OP == OP_AINV) {
-            stage_copy<BS>(a.rD + c0, rDs, nc, tid);
-            stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
-        }
-    }
-#endif
     if (C16) { // slot bases of the tile's cells, halo cells and the pad cell (whose x is 0 and whose slot is the zero slot)
         const int w0 = a.tileSbStart[t], nw = a.tileSbStart[t + 1] - w0;
 #pragma unroll 2

@@ -15,6 +15,7 @@ struct IFstream
     std::string buf, name;
     std::size_t pos = 0;
     bool binary = false;
+    std::string arch;   // FoamFile "arch" entry, if present
     explicit IFstream(const std::string& file) : name(file)
     {
         std::ifstream f(file, std::ios::binary);
@@ -59,12 +60,29 @@ struct IFstream
             if (k == "}") break;
             std::string v = token();
             if (k == "format") binary = (v == "binary");
+            else if (k == "arch") arch = v;   // e.g. "LSB;label=32;scalar=64" (written by OpenFOAM >= v1612 / 4.x)
             while (v != ";") v = token();
         }
+    }
+    // a binary list is a memory image in the writer's label / scalar widths: refuse widths other than this build's
+    // (a WM_LABEL_SIZE=64 or single-precision case would otherwise be mis-parsed silently)
+    void checkArch() const
+    {
+        if (arch.empty()) return;          // older writers do not state it: the build's widths are assumed, as OpenFOAM does
+        const auto width = [&](const char* key) -> long {
+            const std::size_t at = arch.find(key);
+            return at == std::string::npos ? -1 : std::strtol(arch.c_str() + at + std::strlen(key), nullptr, 10);
+        };
+        const long lw = width("label="), sw = width("scalar=");
+        if ((lw > 0 && lw != 8 * (long)sizeof(label)) || (sw > 0 && sw != 8 * (long)sizeof(scalar)))
+            FatalErrorIn("IFstream::raw", "binary file " + name + " was written with arch \"" + arch + "\"; this build reads label=" +
+                         std::to_string(8 * sizeof(label)) + " scalar=" + std::to_string(8 * sizeof(scalar)) + " only");
+        if (arch.find("MSB") != std::string::npos) FatalErrorIn("IFstream::raw", "binary file " + name + " is big-endian (arch \"" + arch + "\")");
     }
     // raw bytes of a binary list: the cursor stands right after "N("
     void raw(void* dst, std::size_t bytes)
     {
+        checkArch();
         if (pos + bytes > buf.size()) FatalErrorIn("IFstream::raw", "binary list truncated in " + name);
         std::memcpy(dst, buf.data() + pos, bytes); pos += bytes;
     }
@@ -156,8 +174,10 @@ polyMesh::polyMesh(const std::string& caseDir)
     }
     if (owner.size() != faces.size()) FatalErrorIn("polyMesh::polyMesh", "owner and faces differ in size");
     if (neighbour.size() > owner.size()) FatalErrorIn("polyMesh::polyMesh", "more neighbours than faces");
+    // polyMeshInitMesh.C:59-86: nCells = max over owner AND neighbour (a cell may own no face at all)
     nCells = 0;
-    for (label c : owner) nCells = std::max(nCells, c + 1);
+    for (label c : owner) { if (c < 0) FatalErrorIn("polyMesh::polyMesh", "negative cell label in owner"); nCells = std::max(nCells, c + 1); }
+    for (label c : neighbour) { if (c < 0) FatalErrorIn("polyMesh::polyMesh", "negative cell label in neighbour"); nCells = std::max(nCells, c + 1); }
     for (std::size_t f = 0; f < neighbour.size(); ++f)
         if (!(owner[f] < neighbour[f])) FatalErrorIn("polyMesh::polyMesh", "internal faces are not in upper-triangular order");
     label next = nInternalFaces();

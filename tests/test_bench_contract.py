@@ -54,3 +54,25 @@ def test_multi_rank_rehearsal_over_gloo(n):
     d = _check(lines[0], n)
     assert d["scaling"] == "strong" and "domain-decomposition" in d["config"]["parallelism"]
     assert d["config"]["weak_scaling_supplement"]["cells_per_gpu"] == 40 * 32 * 24
+
+
+def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) must not fall back to one GPU silently: it re-executes
+    itself under the launcher.  Rehearsed over gloo (two ranks share this box's GPU); over RCCL it refuses when fewer GPUs than
+    ranks are visible."""
+    env = dict(os.environ, MI_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--dims", "40", "32", "24", "--no-cpu"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = _check(lines[0], 2)
+    assert d["config"]["timing"].startswith("median of 5 repeats")
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("MI_BENCH_BACKEND")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dims", "40", "32", "24", "--no-cpu"],
+                             capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert out.returncode != 0 and "GPU(s) visible" in out.stderr

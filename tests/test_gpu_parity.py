@@ -533,3 +533,30 @@ def test_distributed_matrix_single_rank(pkg, orc, ctx):
     ref_psi, ref = orc.GamgSysHierarchy(S, [w], 10).solve(np.zeros(n), case.source, tolerance=1e-9, maxIter=60)
     assert perf["nIterations"] == ref["nIterations"]
     assert np.max(np.abs(perf["history"] - ref["history"])) < 1e-10 * ref["history"][0]
+
+
+def test_pcg_session_owns_the_context_scratch(pkg, orc, ctx):
+    """mi_pcg_begin ... mi_pcg_end owns the context's solver scratch: calls that would overwrite it are refused with
+    MI_ERR_STATE instead of corrupting the running solve, the operators stay usable, and the solve is the oracle's."""
+    eng, syn = pkg.engine, pkg.synthetic
+    case = syn.box_case(15, 12, 9)
+    _, mat = make(pkg, ctx, case)
+    _, other = make(pkg, ctx, case)
+    n = case.n_cells
+    b = dev(case.source)
+    psi0 = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    mat.pcg_begin(psi0, b, "diagonal", tolerance=1e-9, relTol=0.0, maxIter=300, history_len=302)
+    mat.pcg_iterate(5)
+    x = dev(syn.splitmix_uniform(3, n)); y = torch.empty_like(x)
+    for call in (lambda: ctx.sum(x), lambda: ctx.sum_prod(x, x), lambda: other.pcg(y, b), lambda: other.pbicg(y, b, "diagonal"),
+                 lambda: other.pcg_begin(psi0, b, "diagonal", tolerance=1e-9, relTol=0.0, maxIter=10, history_len=12),
+                 lambda: mat.smooth_solve(y, b, n_sweeps=1, tolerance=1e-3, maxIter=5)):
+        with pytest.raises(eng.MiError, match="PCG session"):
+            call()
+    other.amul(x, y)                                         # operators do not touch the session's scratch
+    assert np.array_equal(host(y), orc.System([case]).amul(host(x)))
+    mat.pcg_iterate(400)
+    perf = mat.pcg_end(psi0, history_len=302)
+    _, ref = orc.System([case]).pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-9, maxIter=300)
+    _check_hist(perf, ref)
+    assert abs(ctx.sum(x) - float(np.sum(host(x).astype(np.longdouble)))) < 1e-12 * n   # usable again after mi_pcg_end

@@ -215,6 +215,25 @@ def test_reader_rejects_broken_meshes(pkg, tmp_path):
     assert out.returncode == 1 and "do not cover the boundary faces" in out.stderr
     out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), str(tmp_path / "missing")], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "cannot open file" in out.stderr
+    # a cell that owns no face (its faces are all owned by lower cells) still counts: nCells = max over owner AND neighbour
+    # (polyMeshInitMesh.C:59-86); negative labels are refused before any geometry is computed
+    neg = owner.copy(); neg[0] = -1
+    case_dir = str(tmp_path / "neg")
+    write_case(case_dir, pts, faces, neg, neighbour, patches, S, False)
+    out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "negative cell label" in out.stderr
+    # a binary case written by a 64-bit-label build is a different memory image: refused, not mis-parsed
+    case_dir = str(tmp_path / "arch64")
+    write_case(case_dir, pts, faces, owner, neighbour, patches, S, True)
+    f = os.path.join(case_dir, "constant", "polyMesh", "owner")
+    raw = open(f, "rb").read().replace(b"    format      binary;", b"    format      binary;\n    arch        \"LSB;label=64;scalar=64\";", 1)
+    open(f, "wb").write(raw)
+    out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "label=64" in out.stderr and "this build reads label=32" in out.stderr
+    # the same file with the widths of this build is accepted by the reader (it then needs a device to go on)
+    open(f, "wb").write(raw.replace(b"label=64", b"label=32"))
+    out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir], capture_output=True, text=True, timeout=60)
+    assert "was written with arch" not in out.stderr
 
 
 # ---- decomposed cases (processorN directories) -----------------------------------------------------------------------
