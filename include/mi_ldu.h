@@ -345,6 +345,26 @@ int mi_gauss_grad(mi_addr_t addr, const double *sfx_dev, const double *sfy_dev, 
 int mi_vec_axpby(mi_ctx_t ctx, int64_t n, double a, const double *x_dev, double b, const double *y_dev, double *out_dev);
 /* out = x / y element-wise (fvMatrix::A = D/V, fvMatrix::H /= V; fvMatrix.C:1424-1506); out may alias x */
 int mi_vec_div(mi_ctx_t ctx, int64_t n, const double *x_dev, const double *y_dev, double *out_dev);
+/* Non-orthogonal correction of fvm::laplacian (row a22): gaussLaplacianScheme<Type, scalar>::fvmLaplacian with a `corrected`
+ * snGrad scheme (laplacianSchemes/gaussLaplacianScheme/gaussLaplacianSchemes.C:64-90):
+ *     source -= V * fvc::div( gammaMagSf * snGradScheme.correction(vf) ),
+ * correction(vf) = nonOrthCorrectionVectors & linear.interpolate(grad(vf))  (snGradSchemes/correctedSnGrad/correctedSnGrad.C:45-65,
+ * vectors of surfaceInterpolation.C:498-630: Sf/|Sf| - delta*nonOrthDeltaCoeffs on internal faces and coupled patches, zero on the others).
+ * mi_sngrad_correction_flux is the face pass over the internal faces (the reference: an interpolated gradient field, a dot-product
+ * field and a product field); mi_patch_sngrad_correction_flux the same on one COUPLED patch, with the patchNeighbourField of the gradient
+ * (mi_matrix_patch_neighbour_field per component).  Then mi_surface_integrate(flux, NULL, div) + mi_patch_add(patch flux) + mi_vec_div(V)
+ * is fvc::div and mi_vec_submul(V, div, source) the `source -= V*div`.  gamma_magsf NULL: the bare correction (snGrad, fvc::laplacian). */
+int mi_sngrad_correction_flux(mi_addr_t addr, const double *corr_vec_x_dev, const double *corr_vec_y_dev, const double *corr_vec_z_dev,
+                              const double *weights_dev, const double *grad_x_dev, const double *grad_y_dev, const double *grad_z_dev,
+                              const double *gamma_magsf_dev_or_null, double *flux_out_dev);
+int mi_patch_sngrad_correction_flux(mi_patch_t patch, const double *corr_vec_x_dev, const double *corr_vec_y_dev, const double *corr_vec_z_dev,
+                                    const double *patch_weights_dev, const double *grad_x_dev, const double *grad_y_dev, const double *grad_z_dev,
+                                    const double *nbr_grad_x_dev, const double *nbr_grad_y_dev, const double *nbr_grad_z_dev,
+                                    const double *gamma_magsf_dev_or_null, double *flux_out_dev);
+/* fvPatchField::patchInternalField: out[i] = psi[faceCells[i]] (zeroGradient boundary values for the Gauss gradient, fvMatrix::flux ...) */
+int mi_patch_internal_field(mi_patch_t patch, const double *psi_dev, double *out_dev);
+/* inout -= x*y, the product rounded before the subtraction (a temporary field, then operator-=) */
+int mi_vec_submul(mi_ctx_t ctx, int64_t n, const double *x_dev, const double *y_dev, double *inout_dev);
 int mi_patch_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_patch_faces, const int32_t *face_cells_host, mi_patch_t *out);
 int mi_patch_destroy(mi_patch_t patch);
 int mi_patch_add(mi_patch_t patch, const double *pf_dev, double *intf_dev, int fn);

@@ -227,3 +227,40 @@ void orc_axpby(label n, scalar a, const scalar *x, scalar b, const scalar *y, sc
 {
     for (label i = 0; i < n; i++) out[i] = fma(a, x[i], b * y[i]);
 }
+
+/* ---- non-orthogonal correction of fvm::laplacian (gaussLaplacianSchemes.C:64-90, correctedSnGrad.C:45-65):
+ *   flux[f] = gammaMagSf[f] * ( corrVec[f] & (lambda[f]*(grad[P] - grad[N]) + grad[N]) )        internal faces
+ * the interpolate is one fma per component (surfaceInterpolationScheme.C:275-280), the dot product ax*bx + ay*by + az*bz
+ * contracted left to right, the product with gammaMagSf a separate (rounded) field operation.                       */
+void orc_sngrad_correction_flux(label nf, const label *lo, const label *up, const scalar *cvx, const scalar *cvy, const scalar *cvz,
+                                const scalar *lambda, const scalar *gx, const scalar *gy, const scalar *gz, const scalar *gammaMagSf,
+                                scalar *flux)
+{
+    for (label f = 0; f < nf; f++) {
+        const label P = lo[f], N = up[f];
+        const scalar fx = fma(lambda[f], gx[P] - gx[N], gx[N]), fy = fma(lambda[f], gy[P] - gy[N], gy[N]), fz = fma(lambda[f], gz[P] - gz[N], gz[N]);
+        const scalar corr = fma(cvz[f], fz, fma(cvy[f], fy, cvx[f] * fx));
+        flux[f] = gammaMagSf ? gammaMagSf[f] * corr : corr;
+    }
+}
+/* the same on a coupled patch: pLambda*patchInternalField + (1 - pLambda)*patchNeighbourField as separate field operations
+ * (surfaceInterpolationScheme.C:360-365)                                                                            */
+void orc_patch_sngrad_correction_flux(label n, const label *faceCells, const scalar *cvx, const scalar *cvy, const scalar *cvz,
+                                      const scalar *w, const scalar *gx, const scalar *gy, const scalar *gz, const scalar *nx,
+                                      const scalar *ny, const scalar *nz, const scalar *gammaMagSf, scalar *flux)
+{
+    for (label i = 0; i < n; i++) {
+        const label c = faceCells[i];
+        const scalar m = 1.0 - w[i];
+        const scalar ax = w[i] * gx[c], ay = w[i] * gy[c], az = w[i] * gz[c];
+        const scalar bx = m * nx[i], by = m * ny[i], bz = m * nz[i];
+        const scalar fx = ax + bx, fy = ay + by, fz = az + bz;
+        const scalar corr = fma(cvz[i], fz, fma(cvy[i], fy, cvx[i] * fx));
+        flux[i] = gammaMagSf ? gammaMagSf[i] * corr : corr;
+    }
+}
+/* inout -= x*y (product rounded first) */
+void orc_submul(label n, const scalar *x, const scalar *y, scalar *io)
+{
+    for (label i = 0; i < n; i++) { const scalar t = x[i] * y[i]; io[i] -= t; }
+}

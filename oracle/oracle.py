@@ -741,3 +741,31 @@ def ref_ldu_ops(case, which, vec=None, favour_speed=0):
                   None if case.lower is None else _p(_d(case.lower), C.c_double), _p(_d(case.upper), C.c_double), _p(x, C.c_double),
                   _p(out, C.c_double), _p(ou, C.c_double), _p(ol, C.c_double))
     return (out, ou, ol) if k >= 4 else out
+
+
+def sngrad_correction_flux(lower_addr, upper_addr, corr_vecs, weights, grad, gamma_magsf=None):
+    """flux of the non-orthogonal correction on the internal faces (gaussLaplacianSchemes.C:64-90, correctedSnGrad.C:45-65)"""
+    lo, up = _i(lower_addr), _i(upper_addr)
+    cv = [_d(x) for x in corr_vecs]; g = [_d(x) for x in grad]
+    out = np.empty(lo.shape[0])
+    lib().orc_sngrad_correction_flux(C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(cv[0], C.c_double), _p(cv[1], C.c_double),
+                                     _p(cv[2], C.c_double), _p(_d(weights), C.c_double), _p(g[0], C.c_double), _p(g[1], C.c_double), _p(g[2], C.c_double),
+                                     _p(_d(gamma_magsf), C.c_double) if gamma_magsf is not None else None, _p(out, C.c_double))
+    return out
+
+
+def patch_sngrad_correction_flux(face_cells, corr_vecs, weights, grad, nbr_grad, gamma_magsf=None):
+    fc = _i(face_cells)
+    cv = [_d(x) for x in corr_vecs]; g = [_d(x) for x in grad]; nb = [_d(x) for x in nbr_grad]
+    out = np.empty(fc.shape[0])
+    lib().orc_patch_sngrad_correction_flux(C.c_int32(fc.shape[0]), _p(fc, C.c_int32), _p(cv[0], C.c_double), _p(cv[1], C.c_double), _p(cv[2], C.c_double),
+                                           _p(_d(weights), C.c_double), _p(g[0], C.c_double), _p(g[1], C.c_double), _p(g[2], C.c_double),
+                                           _p(nb[0], C.c_double), _p(nb[1], C.c_double), _p(nb[2], C.c_double),
+                                           _p(_d(gamma_magsf), C.c_double) if gamma_magsf is not None else None, _p(out, C.c_double))
+    return out
+
+
+def submul(x, y, inout):
+    io = _d(inout).copy()
+    lib().orc_submul(C.c_int32(io.shape[0]), _p(_d(x), C.c_double), _p(_d(y), C.c_double), _p(io, C.c_double))
+    return io

@@ -64,6 +64,7 @@ SYMBOLS = [
     "mi_gamg_host_build", "mi_gamg_host_build_domains", "mi_gamg_host_patch_array", "mi_gamg_host_n_levels", "mi_gamg_host_array", "mi_gamg_host_free",
     "mi_row_face_op", "mi_fvm_laplacian", "mi_fvm_div", "mi_surface_integrate", "mi_face_interpolate",
     "mi_patch_create", "mi_patch_destroy", "mi_patch_add", "mi_patch_add_product", "mi_patch_flux", "mi_relax",
+    "mi_sngrad_correction_flux", "mi_patch_sngrad_correction_flux", "mi_patch_internal_field", "mi_vec_submul",
 ]
 
 
@@ -598,6 +599,16 @@ class Patch:
         """boundary part of fvMatrix::flux; patch_neighbour_field only for coupled patches"""
         _chk(lib().mi_patch_flux(self.h, _ptr(internal_coeffs), _ptr(boundary_coeffs), _ptr(psi), _ptr(patch_neighbour_field), _ptr(out)))
 
+    def internal_field(self, psi, out):
+        """fvPatchField::patchInternalField: out[i] = psi[faceCells[i]]"""
+        _chk(lib().mi_patch_internal_field(self.h, _ptr(psi), _ptr(out)))
+
+    def sngrad_correction_flux(self, corr_vecs, weights, grad, nbr_grad, gamma_magsf, out):
+        """non-orthogonal correction flux on a COUPLED patch (gaussLaplacianSchemes.C:64-90 + surfaceInterpolationScheme.C:360-365)"""
+        _chk(lib().mi_patch_sngrad_correction_flux(self.h, _ptr(corr_vecs[0]), _ptr(corr_vecs[1]), _ptr(corr_vecs[2]), _ptr(weights), _ptr(grad[0]),
+                                                   _ptr(grad[1]), _ptr(grad[2]), _ptr(nbr_grad[0]), _ptr(nbr_grad[1]), _ptr(nbr_grad[2]),
+                                                   _ptr(gamma_magsf), _ptr(out)))
+
     def close(self):
         if self.h:
             lib().mi_patch_destroy(self.h)
@@ -639,6 +650,15 @@ class Assembly:
     def gauss_grad(self, sf, ssf, vol, grad_out):
         _chk(lib().mi_gauss_grad(self.addr.h, _ptr(sf[0]), _ptr(sf[1]), _ptr(sf[2]), _ptr(ssf), _ptr(vol), _ptr(grad_out[0]), _ptr(grad_out[1]),
                                  _ptr(grad_out[2])))
+
+    def sngrad_correction_flux(self, corr_vecs, weights, grad, gamma_magsf, out):
+        """gammaMagSf * (nonOrthCorrectionVectors & interpolate(grad)) on the internal faces (gaussLaplacianSchemes.C:64-90)"""
+        _chk(lib().mi_sngrad_correction_flux(self.addr.h, _ptr(corr_vecs[0]), _ptr(corr_vecs[1]), _ptr(corr_vecs[2]), _ptr(weights), _ptr(grad[0]),
+                                             _ptr(grad[1]), _ptr(grad[2]), _ptr(gamma_magsf), _ptr(out)))
+
+    def submul(self, x, y, inout):
+        """inout -= x*y (source -= V*div(...))"""
+        _chk(lib().mi_vec_submul(self.addr.ctx.h, C.c_int64(inout.numel()), _ptr(x), _ptr(y), _ptr(inout)))
 
     def axpby(self, a, x, b, y, out):
         _chk(lib().mi_vec_axpby(self.addr.ctx.h, C.c_int64(x.numel()), C.c_double(a), _ptr(x), C.c_double(b), _ptr(y), _ptr(out)))

@@ -591,6 +591,36 @@ void fvScalarMatrix::flux(scalargpuField& internalFlux, FieldFieldScalar& bounda
                               psi.data(), nbr ? nbr->data() : nullptr, boundaryFlux[p].data()), "fvMatrix::flux");
     }
 }
+void fvScalarMatrix::nonOrthCorrection(const scalargpuField& vf, const std::vector<const scalargpuField*>& patchValues, const vectorgpuField& Sf,
+                                       const std::vector<const vectorgpuField*>& patchSf, const scalargpuField& weights, const vectorgpuField& corrVecs,
+                                       const scalargpuField& gammaMagSf, const scalargpuField& V)
+{
+    const lduAddressing& a = lduAddr();
+    const label n = a.size(), nI = weights.size();
+    mi_ctx_t ctx = miEngine::New().ctx;
+    scalargpuField ssf(nI);
+    miCheck(mi_face_interpolate(a.handle(), weights.data(), vf.data(), ssf.data()), "linear::interpolate");
+    vectorgpuField g(n);                                                          // gaussGrad::gradf: internal faces, then every patch
+    miCheck(mi_gauss_grad(a.handle(), Sf.component(0).data(), Sf.component(1).data(), Sf.component(2).data(), ssf.data(), nullptr,
+                          g.component(0).data(), g.component(1).data(), g.component(2).data()), "gaussGrad::gradf");
+    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p) {
+        const label np = (label)patchFaceCells_[p].size();
+        if (np == 0) continue;
+        mi_patch_t P = patchOf(patches_, p, n, patchFaceCells_[p]);
+        scalargpuField pif(np);
+        const scalargpuField* pv = p < patchValues.size() ? patchValues[p] : nullptr;
+        if (!pv) { miCheck(mi_patch_internal_field(P, vf.data(), pif.data()), "fvPatchField::patchInternalField"); pv = &pif; }
+        for (direction d = 0; d < 3; ++d)
+            miCheck(mi_patch_add_product(P, patchSf[p]->component(d).data(), pv->data(), g.component(d).data(), 0), "gaussGrad::gradf (patch)");
+    }
+    for (direction d = 0; d < 3; ++d) miCheck(mi_vec_div(ctx, n, g.component(d).data(), V.data(), g.component(d).data()), "gaussGrad /= V");
+    scalargpuField flux(nI), div(n);
+    miCheck(mi_sngrad_correction_flux(a.handle(), corrVecs.component(0).data(), corrVecs.component(1).data(), corrVecs.component(2).data(), weights.data(),
+                                      g.component(0).data(), g.component(1).data(), g.component(2).data(), gammaMagSf.data(), flux.data()),
+            "correctedSnGrad::correction");
+    miCheck(mi_surface_integrate(a.handle(), flux.data(), V.data(), div.data()), "fvc::div");
+    miCheck(mi_vec_submul(ctx, n, V.data(), div.data(), source_.data()), "fvm::laplacian: source -= V*div(correction)");
+}
 fvScalarMatrix& fvScalarMatrix::operator+=(const fvScalarMatrix& B) { axpyFrom(B, 1.0); return *this; }
 fvScalarMatrix& fvScalarMatrix::operator-=(const fvScalarMatrix& B) { axpyFrom(B, -1.0); return *this; }
 fvScalarMatrix& fvScalarMatrix::operator*=(scalar s)

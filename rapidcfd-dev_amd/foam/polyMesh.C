@@ -252,6 +252,12 @@ void polyMesh::calcGeometry()
         const vector n = (1.0 / magSf[f]) * Sf[f];
         nonOrthDeltaCoeffs[f] = 1.0 / std::max(dot(n, d), 0.05 * mag(d));
     }
+    nonOrthCorrectionVectors.resize(nI);                             // surfaceInterpolation.C:498-580
+    for (std::size_t f = 0; f < nI; ++f) {
+        const vector unitArea = (1.0 / magSf[f]) * Sf[f];
+        const vector delta = C[neighbour[f]] - C[owner[f]];
+        nonOrthCorrectionVectors[f] = unitArea - nonOrthDeltaCoeffs[f] * delta;
+    }
     patchDeltaCoeffs.clear(); patchMagSf.clear();
     for (const polyPatch& P : boundary) {
         scalarField dc((std::size_t)P.nFaces), ms((std::size_t)P.nFaces);

@@ -4,7 +4,9 @@
 // caller of the hot path; this application shows the path fed from OpenFOAM's own on-disk format instead of the synthetic
 // box (tests/test_polymesh.py writes the case, recomputes geometry and coefficients with numpy and checks every line).
 //
-// usage: polyMeshFoam <caseDir>      (source term: <caseDir>/0/S, volScalarField)
+// usage: polyMeshFoam <caseDir> [-nonOrthCorrectors N]      (source term: <caseDir>/0/S, volScalarField)
+// -nonOrthCorrectors N: afterwards, laplacianFoam's non-orthogonal corrector loop (laplacianFoam.C:60-70) with the `corrected`
+// snGrad scheme: N times { assemble fvm::laplacian incl. the explicit correction from the current p; solve with PCG + DIC }.
 #include "polyMesh.H"
 
 #include <cmath>
@@ -57,6 +59,35 @@ int main(int argc, char** argv)
             scalar s = 0, m = 0;
             for (scalar v : h) { s += v; m = std::max(m, std::fabs(v)); }
             Info << "p sum max: " << s << " " << m << std::endl;
+        }
+        label nCorr = 0;
+        for (int k = 2; k + 1 < argc; ++k) if (std::string(argv[k]) == "-nonOrthCorrectors") nCorr = (label)std::atoi(argv[k + 1]);
+        if (nCorr > 0) {
+            auto comp = [&](const vectorField& v, std::size_t b, std::size_t e) {
+                vectorgpuField out((label)(e - b));
+                for (direction d = 0; d < 3; ++d) { scalarField h(e - b); for (std::size_t i = b; i < e; ++i) h[i - b] = v[i][d]; out.component(d) = h; }
+                return out;
+            };
+            const vectorgpuField SfI = comp(mesh.Sf, 0, (std::size_t)nI), corrVecs = comp(mesh.nonOrthCorrectionVectors, 0, (std::size_t)nI);
+            std::vector<vectorgpuField> pSfStore;
+            for (const polyPatch& P : mesh.boundary) pSfStore.push_back(comp(mesh.Sf, (std::size_t)P.startFace, (std::size_t)(P.startFace + P.nFaces)));
+            std::vector<const vectorgpuField*> pSf;
+            for (const vectorgpuField& v : pSfStore) pSf.push_back(&v);
+            std::vector<scalargpuField> zeros;
+            for (const polyPatch& P : mesh.boundary) zeros.emplace_back(P.nFaces);
+            std::vector<const scalargpuField*> pv;                        // fixedValue 0 on `patch`, zeroGradient (patchInternalField) on `wall`
+            for (std::size_t p = 0; p < patches.size(); ++p) pv.push_back(mesh.boundary[p].type == "patch" ? &zeros[p] : nullptr);
+            const scalargpuField weights(mesh.weights), gammaMagSf(magSfI), V(mesh.V);
+            scalargpuField p(n);
+            for (label corr = 0; corr < nCorr; ++corr) {
+                pEqn.source() = S;
+                pEqn.nonOrthCorrection(p, pv, SfI, pSf, weights, corrVecs, gammaMagSf, V);
+                pEqn.solve(p, dictionary{{"solver", "PCG"}, {"preconditioner", "DIC"}, {"tolerance", "1e-10"}, {"relTol", "0"}});
+            }
+            std::vector<scalar> h = p.asHost();
+            scalar s = 0, m = 0;
+            for (scalar v : h) { s += v; m = std::max(m, std::fabs(v)); }
+            Info << "corrected p sum max: " << s << " " << m << std::endl;
         }
         Info << "End" << std::endl;
         return 0;

@@ -170,7 +170,7 @@ def test_polyMeshFoam_reads_a_case_and_matches_the_oracle(pkg, orc, tmp_path, bi
     S = np.sin(4 * G["C"][:, 0]) * np.cos(3 * G["C"][:, 1]) + G["C"][:, 2]
     case_dir = str(tmp_path / "case")
     write_case(case_dir, pts, faces, owner, neighbour, patches, S, binary)
-    out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir, "-nonOrthCorrectors", "3"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     assert f"nCells {n} nFaces {len(faces)} nInternalFaces {len(neighbour)}" in out.stdout
     m = GEOM.search(out.stdout)
@@ -194,8 +194,34 @@ def test_polyMeshFoam_reads_a_case_and_matches_the_oracle(pkg, orc, tmp_path, bi
     w = np.sqrt(((G["Sf"][:nI] / np.sqrt(G["magSf"][:nI])[:, None] * np.array([1.0, 1.01, 1.02])) ** 2).sum(axis=1))
     x2, p2 = orc.GamgHierarchy(case, w, 10).solve(z, src, tolerance=1e-9)
     got = [(mm.group(1), float(mm.group(3)), float(mm.group(4)), int(mm.group(5))) for mm in map(LINE.match, out.stdout.splitlines()) if mm]
-    assert [g[0] for g in got] == ["AINVPCG", "GAMG"]
-    for g, p in zip(got, (p1, p2)):
+    assert [g[0] for g in got] == ["AINVPCG", "GAMG"] + ["AINVPCG"] * 3
+    # the non-orthogonal corrector loop (gaussLaplacianSchemes.C:64-90 + correctedSnGrad.C:45-65): the same sweeps on the oracle
+    Sf = [np.ascontiguousarray(G["Sf"][:nI, k]) for k in range(3)]
+    nhat = G["Sf"][:nI] / G["magSf"][:nI, None]
+    cv = nhat - (G["C"][up] - G["C"][lo]) * G["delta"][:, None]
+    cv = [np.ascontiguousarray(cv[:, k]) for k in range(3)]
+    S_sys = orc.System([case])
+    ph, corrected = np.zeros(n), []
+    for _ in range(3):
+        ssf = orc.face_interpolate(lo, up, G["weights"], ph)
+        g3 = orc.gauss_grad(n, lo, up, Sf, ssf, None)
+        for name, ptype, cnt, start in patches:
+            fc = owner[start:start + cnt]
+            bv = np.zeros(cnt) if ptype == "patch" else ph[fc]
+            for k in range(3):
+                g3[k] = orc.patch_add_product(fc, np.ascontiguousarray(G["Sf"][start:start + cnt, k]), bv, g3[k], 0)
+        g3 = [x / G["V"] for x in g3]
+        flux = orc.sngrad_correction_flux(lo, up, cv, G["weights"], g3, G["magSf"][:nI])
+        srcc = orc.submul(G["V"], orc.surface_integrate(n, lo, up, flux, G["V"]), src)
+        ph, pc = S_sys.pcg(ph, srcc, "AINV", tolerance=1e-10)
+        corrected.append(pc)
+    for g, p in zip(got[2:], corrected):
+        assert g[3] == p["nIterations"], (g, p["nIterations"])
+        assert abs(g[1] - p["initialResidual"]) < 1e-9 * max(p["initialResidual"], 1e-30) + 1e-12 and abs(g[2] - p["finalResidual"]) < 1e-8 * max(p["initialResidual"], 1e-30) + 1e-12
+    assert corrected[1]["initialResidual"] < 0.5 * corrected[0]["initialResidual"]        # the correctors converge
+    mc = re.search(r"corrected p sum max: (\S+) (\S+)", out.stdout)
+    assert abs(float(mc.group(1)) - ph.sum()) < 1e-6 * np.abs(ph).sum() and abs(float(mc.group(2)) - np.abs(ph).max()) < 1e-6 * np.abs(ph).max()
+    for g, p in zip(got[:2], (p1, p2)):
         assert g[3] == p["nIterations"], (g, p["nIterations"])
         assert abs(g[1] - p["initialResidual"]) < 1e-10 and abs(g[2] - p["finalResidual"]) < 1e-9 * max(p["initialResidual"], 1e-30) + 1e-10
     mm = re.search(r"p sum max: (\S+) (\S+)", out.stdout)
