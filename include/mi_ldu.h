@@ -446,6 +446,22 @@ int mi_dpcg_status(mi_matrix_t m, mi_solver_perf *perf_out, int32_t *done_out,
 int mi_comm_unique_id(void *id_out, int32_t len);
 int mi_comm_create(mi_ctx_t ctx, int32_t n_ranks, int32_t rank, const void *id, mi_comm_t *out);
 int mi_comm_destroy(mi_comm_t comm);
+/* A communicator over the CALLER's transport instead of RCCL -- the reference's own is MPI through Pstream
+ * (src/Pstream/mpi/UPstream.C:185-262 reduce, processorLduInterfaceTemplates.C:127-298 send/receive), so a shim inside a running
+ * OpenFOAM application can hand its Pstream calls in here and needs no second launcher-level bootstrap.  Blocking by contract:
+ * before every callback the engine synchronises the stream that produced the buffers; a callback returns (0 = ok) once its
+ * results are in place in DEVICE memory.  allreduce: in-place sum over all ranks of n doubles.  exchange: one grouped
+ * neighbour exchange (init/updateMatrixInterfaces): n_send messages (peer rank, tag, device pointer, count) and n_recv
+ * messages; a message is matched by (peer, tag) -- the tag is the SENDER's patch index on both ends, so several patches per
+ * peer and a rank that is its own neighbour work.  Everything the RCCL communicators do (attached operators and solvers,
+ * mi_dpcg_comm_*, mi_gamg_create_coupled) runs over such a communicator too, without the compute/exchange overlap.          */
+typedef int (*mi_comm_allreduce_fn)(void *user, double *buf_dev, int64_t n);
+typedef int (*mi_comm_exchange_fn)(void *user, int32_t n_send, const int32_t *send_peer, const int32_t *send_tag,
+                                   const double *const *send_dev, const int64_t *send_count, int32_t n_recv,
+                                   const int32_t *recv_peer, const int32_t *recv_tag, double *const *recv_dev,
+                                   const int64_t *recv_count);
+int mi_comm_create_external(mi_ctx_t ctx, int32_t n_ranks, int32_t rank, mi_comm_allreduce_fn allreduce,
+                            mi_comm_exchange_fn exchange, void *user, mi_comm_t *out);
 int mi_comm_allreduce_sum(mi_comm_t comm, double *buf_dev, int64_t n);
 /* Attach communicators to a matrix: from here on it behaves like the reference's lduMatrix on a decomposed
  * case -- mi_amul/tmul/residual/H/jacobi_smooth exchange the processor-patch values themselves

@@ -65,6 +65,7 @@ SYMBOLS = [
     "mi_row_face_op", "mi_fvm_laplacian", "mi_fvm_div", "mi_surface_integrate", "mi_face_interpolate",
     "mi_patch_create", "mi_patch_destroy", "mi_patch_add", "mi_patch_add_product", "mi_patch_flux", "mi_relax",
     "mi_sngrad_correction_flux", "mi_patch_sngrad_correction_flux", "mi_patch_internal_field", "mi_vec_submul",
+    "mi_comm_create_external",
 ]
 
 
@@ -266,6 +267,38 @@ class Comm:
         if self.h:
             lib().mi_comm_destroy(self.h)
             self.h = C.c_void_p()
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                          C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+
+
+class ExternalComm(Comm):
+    """A communicator over the CALLER's transport (mi_comm_create_external) -- MPI through Pstream in an OpenFOAM shim, gloo
+    in the tests.  ``allreduce(ptr, n)`` sums n doubles at device pointer ptr over the ranks in place; ``exchange(sends, recvs)``
+    gets lists of (peer, tag, device pointer, count) and returns when the received data is in device memory."""
+
+    def __init__(self, ctx: "Context", n_ranks: int, rank: int, allreduce, exchange):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.n_ranks, self.rank = n_ranks, rank
+        self.errors = []
+
+        def _ar(_user, buf, n):
+            try:
+                allreduce(int(buf), int(n)); return 0
+            except Exception as e:  # an exception must not unwind through the C frames
+                self.errors.append(e); return 1
+
+        def _ex(_user, ns, sp, st, sb, sc, nr, rp, rt, rb, rc):
+            try:
+                exchange([(sp[i], st[i], int(sb[i]), int(sc[i])) for i in range(ns)], [(rp[i], rt[i], int(rb[i]), int(rc[i])) for i in range(nr)]); return 0
+            except Exception as e:
+                self.errors.append(e); return 1
+
+        self._cb = (ALLREDUCE_FN(_ar), EXCHANGE_FN(_ex))      # keep the trampolines alive as long as the communicator
+        _chk(lib().mi_comm_create_external(ctx.h, C.c_int32(n_ranks), C.c_int32(rank), self._cb[0], self._cb[1], None, C.byref(self.h)))
 
 
 class Matrix:

@@ -269,6 +269,54 @@ def make_comms(ctx, device=None):
     return reduce_c, halo_c
 
 
+def make_host_comms(ctx):
+    """(reduce, halo) communicators over torch.distributed's HOST transport (gloo): the engine's external-transport hook
+    (mi_comm_create_external) fed with device<->host copies + gloo collectives -- the shape of the reference's own path
+    (host-staged MPI, processorFvPatchScalarField.C:77-84) and of a Pstream-backed shim.  Used where RCCL cannot connect the
+    ranks: several engine ranks sharing one GPU (tests), or a process group that was initialised with gloo only."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    world, rank = dist.get_world_size(), dist.get_rank()
+
+    def d2h(ptr, n):
+        t = torch.empty(n, dtype=torch.float64)
+        if n and hip.hipMemcpy(t.data_ptr(), ptr, 8 * n, 2) != 0:
+            raise RuntimeError("hipMemcpy D2H failed")
+        return t
+
+    def h2d(ptr, t):
+        if t.numel() and hip.hipMemcpy(ptr, t.data_ptr(), 8 * t.numel(), 1) != 0:
+            raise RuntimeError("hipMemcpy H2D failed")
+
+    def allreduce(ptr, n):
+        t = d2h(ptr, n)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        h2d(ptr, t)
+
+    def exchange(sends, recvs):
+        reqs, landed = [], []
+        for peer, tag, ptr, n in recvs:
+            t = torch.empty(n, dtype=torch.float64)
+            landed.append((ptr, t))
+            if peer != rank:
+                reqs.append(dist.irecv(t, src=peer, tag=tag))
+        selfbox = {}
+        for peer, tag, ptr, n in sends:
+            t = d2h(ptr, n)
+            if peer == rank:
+                selfbox[tag] = t                     # a rank that is its own neighbour (cyclic posed as processor patches)
+            else:
+                reqs.append(dist.isend(t, dst=peer, tag=tag))
+        for r in reqs:
+            r.wait()
+        for (peer, tag, ptr, n), (_, t) in zip(recvs, landed):
+            h2d(ptr, selfbox[tag] if peer == rank else t)
+
+    c = eng.ExternalComm(ctx, world, rank, allreduce, exchange)
+    return c, c
+
+
 class DistributedMatrix:
     """This rank's part of a decomposed lduMatrix with its communicators attached (mi_matrix_attach_comm): the object
     the reference's solvers see on every MPI rank.  ``sub`` is an LduCase with processor interfaces; every solver entry
