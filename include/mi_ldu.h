@@ -110,6 +110,23 @@ int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
                            int32_t n_patches, const int32_t *patch_sizes,
                            const int32_t *const *patch_face_cells_host,
                            const int32_t *const *patch_nbr_cells_host, mi_addr_t *out);
+/* ORDERED addressing -- the caller's numbering is kept: engine order == caller order, mi_addr_cell_perm is the identity and the
+ * caller-order operators (mi_amul, mi_tmul, mi_residual, mi_H, mi_sumA, mi_precondition, mi_jacobi_smooth) run straight on the
+ * caller's arrays, with no permutation passes (only an n_cells copy of the input where an operator reads coupled-patch
+ * neighbour values, which live behind the owned values of an engine vector).  This is how fields "live in engine order for
+ * the life of the mesh": renumber the mesh ONCE with the cell order an ordinary mi_addr_create proposes (mi_addr_cell_perm =
+ * new-to-old cell map, the `cellMap` renumberMesh's manual method reads; src/renumber/renumberMethods/manualRenumber), keep
+ * mi_addr_tile_starts with it, and create the addressing of the renumbered mesh here.  tile_cell_start NULL: consecutive
+ * cells are cut into tiles greedily (any numbering with locality, e.g. after a Cuthill-McKee renumberMesh).
+ * lduAddressing itself is unchanged by this (lowerAddr/upperAddr of the renumbered mesh, upper-triangular as always).        */
+int mi_addr_create_ordered(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t *lower_host, const int32_t *upper_host,
+                           int32_t n_patches, const int32_t *patch_sizes, const int32_t *const *patch_face_cells_host,
+                           const int32_t *const *patch_nbr_cells_host_or_null, int32_t n_tiles, const int32_t *tile_cell_start_host_or_null,
+                           mi_addr_t *out);
+/* the tiles of a layout as ranges of ENGINE cells: n_tiles + 1 offsets (mi_addr_n_tiles) */
+int mi_addr_tile_starts(mi_addr_t addr, int32_t *tile_cell_start_out_host);
+/* 1 when engine order == caller order (mi_addr_create_ordered, or a numbering that happened to be tile-contiguous) */
+int mi_addr_is_ordered(mi_addr_t addr);
 int mi_addr_destroy(mi_addr_t addr);
 int32_t mi_addr_n_cells(mi_addr_t addr);
 int32_t mi_addr_n_faces(mi_addr_t addr);

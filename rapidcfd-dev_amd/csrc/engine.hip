@@ -109,6 +109,8 @@ struct mi_addr_s {
     DevBuf<int32_t> ifaceNbrCaller; // [nExt] caller cell across every LOCAL interface face, -1 for remote faces (lazy)
     std::vector<std::vector<int32_t>> patchFaceCellsHost, patchNbrCellsHost; // caller order (GAMG interface agglomeration)
     int64_t nEntries = 0, nHaloTot = 0;
+    bool identity = false; // engine order == caller order (ordered addressing, or a mesh whose numbering happens to be tile-contiguous)
+    const int32_t* perm() const { return identity ? nullptr : e2c.p; } // nullptr: the permutation kernels degenerate to copies
 };
 
 struct mi_dpcg_s { double *psi = nullptr, *src = nullptr, *pA = nullptr, *wA = nullptr, *rA = nullptr, *scal = nullptr, *send = nullptr; int precond = 0; };
@@ -249,10 +251,40 @@ extern "C" int mi_addr_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
     return mi_addr_create_coupled(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, nullptr, out);
 }
 
+static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches,
+                            const int32_t* patch_sizes, const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells,
+                            bool ordered, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out);
+
 extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
                                       const int32_t* lower, const int32_t* upper, int32_t n_patches,
                                       const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
                                       const int32_t* const* patch_nbr_cells, mi_addr_t* out)
+{
+    return addr_create_impl(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, false, 0, nullptr, out);
+}
+
+// ORDERED addressing: the caller's numbering is kept (engine order == caller order, mi_addr_cell_perm is the identity), so the
+// caller-order operators pay no permutation passes.  tile_cell_start (n_tiles + 1 offsets, from mi_addr_tile_starts of the
+// layout whose mi_addr_cell_perm renumbered the mesh) names the tiles; NULL: consecutive cells are cut into tiles greedily.
+extern "C" int mi_addr_create_ordered(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper,
+                                      int32_t n_patches, const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
+                                      const int32_t* const* patch_nbr_cells, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out)
+{
+    if (tile_cell_start && n_tiles <= 0) return fail(MI_ERR_ARG, "mi_addr_create_ordered: n_tiles must be positive when tile_cell_start is given");
+    return addr_create_impl(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, true, n_tiles, tile_cell_start, out);
+}
+
+extern "C" int mi_addr_tile_starts(mi_addr_t a, int32_t* tile_cell_start_out)
+{
+    if (!a || !tile_cell_start_out) return fail(MI_ERR_ARG, "mi_addr_tile_starts: bad argument");
+    memcpy(tile_cell_start_out, a->L.tileCellStart.data(), sizeof(int32_t) * a->L.tileCellStart.size());
+    return MI_OK;
+}
+extern "C" int mi_addr_is_ordered(mi_addr_t a) { return a && a->identity ? 1 : 0; }
+
+static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches,
+                            const int32_t* patch_sizes, const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells,
+                            bool ordered, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out)
 {
     if (!ctx || !out || (n_faces > 0 && (!lower || !upper)) || n_patches < 0)
         return fail(MI_ERR_ARG, "mi_addr_create: bad argument");
@@ -263,8 +295,11 @@ extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
     prm.tileCells = env_int("MI_TILE_CELLS", 1024);
     prm.slotCap = env_int("MI_TILE_SLOTS", 4094);
     prm.compact = env_int("MI_ENTRY16", 0) != 0; // opt-in: half the entry bytes, measured 2-4 % slower (profiles/r01_n_compact_entries_ab.md)
+    prm.keepOrder = ordered; prm.givenTileStart = tile_cell_start; prm.nGivenTiles = n_tiles;
     const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L, patch_nbr_cells);
     if (!err.empty()) { delete a; return fail(MI_ERR_LIMIT, "mi_addr_create: " + err); }
+    a->identity = true;
+    for (int32_t e = 0; e < n_cells; ++e) if (a->L.e2c[(size_t)e] != e) { a->identity = false; break; }
     a->nLocalPatches = 0;
     a->patchIsLocal.assign((size_t)std::max(n_patches, 0), 0);
     if (patch_nbr_cells) for (int32_t p = 0; p < n_patches; ++p) if (patch_nbr_cells[p]) { a->nLocalPatches++; a->patchIsLocal[(size_t)p] = 1; }
@@ -389,7 +424,7 @@ extern "C" int mi_matrix_set_coeffs(mi_matrix_t m, const double* diag, const dou
         HIPCHK(hipMemcpyAsync(m->lowE.p, m->upE.p, sizeof(double) * (size_t)a->L.totalSlots, hipMemcpyDeviceToDevice, s));
     }
     m->asym = asym;
-    k_gather_perm<<<RG, RB, 0, s>>>(diag, a->e2c.p, m->diagE.p, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(diag, a->perm(), m->diagE.p, a->L.nCells);
     k_fill_slots<<<2048, 256, 0, s>>>(upper, lower, a->slotFace.p, m->upE.p, asym ? m->lowE.p : nullptr, a->L.totalSlots);
     HIPCHK(hipGetLastError());
     m->bound = true;
@@ -539,7 +574,7 @@ extern "C" int mi_vec_to_engine(mi_addr_t a, const double* x, double* xe)
 {
     if (!a || !x || !xe) return fail(MI_ERR_ARG, "mi_vec_to_engine: bad argument");
     HIPCHK(hipSetDevice(a->ctx->device));
-    k_gather_perm<<<RG, RB, 0, a->ctx->stream>>>(x, a->e2c.p, xe, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, a->ctx->stream>>>(x, a->perm(), xe, a->L.nCells);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -548,7 +583,7 @@ extern "C" int mi_vec_from_engine(mi_addr_t a, const double* xe, double* x)
 {
     if (!a || !x || !xe) return fail(MI_ERR_ARG, "mi_vec_from_engine: bad argument");
     HIPCHK(hipSetDevice(a->ctx->device));
-    k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(xe, a->e2c.p, x, a->L.nCells);
+    k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(xe, a->perm(), x, a->L.nCells);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -603,11 +638,18 @@ int caller_op(mi_matrix_s* m, bool trans, const double* x, const double* b, doub
     HIPCHK(hipSetDevice(a->ctx->device));
     hipStream_t s = a->ctx->stream;
     double *v0, *v1, *v2 = nullptr;
+    if (a->identity) {
+        // ordered addressing: no permutation passes.  The input only has to be copied when the operator reads an ext
+        // region (coupled patches whose neighbour values live behind the n_cells owned values of an engine vector).
+        const double* xin = x;
+        if (x && a->L.nExt > 0) { MICHK(m->vec(0, &v0)); HIPCHK(hipMemcpyAsync(v0, x, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s)); xin = v0; }
+        return tile_op<OP>(m, trans, xin, b, nullptr, y, 0.0);
+    }
     MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1));
-    if (x) k_gather_perm<<<RG, RB, 0, s>>>(x, a->e2c.p, v0, a->L.nCells);
-    if (b) { MICHK(m->vec(2, &v2)); k_gather_perm<<<RG, RB, 0, s>>>(b, a->e2c.p, v2, a->L.nCells); }
+    if (x) k_gather_perm<<<RG, RB, 0, s>>>(x, a->perm(), v0, a->L.nCells);
+    if (b) { MICHK(m->vec(2, &v2)); k_gather_perm<<<RG, RB, 0, s>>>(b, a->perm(), v2, a->L.nCells); }
     MICHK(tile_op<OP>(m, trans, v0, v2, nullptr, v1, 0.0));
-    k_scatter_perm<<<RG, RB, 0, s>>>(v1, a->e2c.p, y, a->L.nCells);
+    k_scatter_perm<<<RG, RB, 0, s>>>(v1, a->perm(), y, a->L.nCells);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -667,8 +709,15 @@ extern "C" int mi_precondition(mi_matrix_t m, int kind, int transpose, const dou
     HIPCHK(hipSetDevice(a->ctx->device));
     hipStream_t s = a->ctx->stream;
     double *v0, *v1;
+    if (a->identity && wA != rA) { // ordered addressing: straight on the caller's arrays (the preconditioners read no ext region)
+        if (kind == MI_PRECOND_NONE) { HIPCHK(hipMemcpyAsync(wA, rA, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s)); return MI_OK; }
+        if (kind != MI_PRECOND_DIAGONAL && kind != MI_PRECOND_AINV) return fail(MI_ERR_ARG, "unknown preconditioner kind");
+        MICHK(ensure_rD(m));
+        if (kind == MI_PRECOND_DIAGONAL && aligned16(rA) && aligned16(wA)) { k_mul<<<RG, RB, 0, s>>>(wA, m->rD.p, rA, a->L.nCells); HIPCHK(hipGetLastError()); return MI_OK; }
+        if (kind == MI_PRECOND_AINV) return launch_tile<OP_AINV>(m, transpose != 0, rA, nullptr, m->rD.p, wA, 0.0, 0);
+    }
     MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1));
-    k_gather_perm<<<RG, RB, 0, s>>>(rA, a->e2c.p, v0, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(rA, a->perm(), v0, a->L.nCells);
     if (kind == MI_PRECOND_NONE) {
         HIPCHK(hipMemcpyAsync(v1, v0, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s));
     } else if (kind == MI_PRECOND_DIAGONAL) {
@@ -678,7 +727,7 @@ extern "C" int mi_precondition(mi_matrix_t m, int kind, int transpose, const dou
         MICHK(ensure_rD(m));
         MICHK(launch_tile<OP_AINV>(m, transpose != 0, v0, nullptr, m->rD.p, v1, 0.0, 0));
     } else return fail(MI_ERR_ARG, "unknown preconditioner kind");
-    k_scatter_perm<<<RG, RB, 0, s>>>(v1, a->e2c.p, wA, a->L.nCells);
+    k_scatter_perm<<<RG, RB, 0, s>>>(v1, a->perm(), wA, a->L.nCells);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -691,8 +740,14 @@ extern "C" int mi_jacobi_smooth(mi_matrix_t m, double omega, double* psi, const 
     hipStream_t s = a->ctx->stream;
     double *v0, *v1, *v2;
     MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1)); MICHK(m->vec(2, &v2));
-    k_gather_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, v0, a->L.nCells);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, v2, a->L.nCells);
+    if (a->identity && a->L.nExt == 0) { // ordered addressing, no ext region: ping-pong between the caller's psi and one work vector
+        double *cur = psi, *nxt = v1;
+        for (int sw = 0; sw < n_sweeps; ++sw) { MICHK(tile_op<OP_JACOBI>(m, false, cur, source, nullptr, nxt, omega)); double* t = cur; cur = nxt; nxt = t; }
+        if (cur != psi) HIPCHK(hipMemcpyAsync(psi, cur, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s));
+        return MI_OK;
+    }
+    k_gather_perm<<<RG, RB, 0, s>>>(psi, a->perm(), v0, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), v2, a->L.nCells);
     double *cur = v0, *nxt = v1;
     for (int sw = 0; sw < n_sweeps; ++sw) {
         // ping-pong instead of the reference's `psi = Apsi` copy (JacobiSmoother.C:146)
@@ -701,7 +756,7 @@ extern "C" int mi_jacobi_smooth(mi_matrix_t m, double omega, double* psi, const 
         MICHK(tile_op<OP_JACOBI>(m, false, cur, v2, nullptr, nxt, omega));
         double* t = cur; cur = nxt; nxt = t;
     }
-    k_scatter_perm<<<RG, RB, 0, s>>>(cur, a->e2c.p, psi, a->L.nCells);
+    k_scatter_perm<<<RG, RB, 0, s>>>(cur, a->perm(), psi, a->L.nCells);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -813,9 +868,9 @@ extern "C" int mi_norm_factor(mi_matrix_t m, const double* psi, const double* so
     const int64_t n = a->L.nCells;
     double *v0, *v1, *v2, *v3;
     MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1)); MICHK(m->vec(2, &v2)); MICHK(m->vec(3, &v3));
-    k_gather_perm<<<RG, RB, 0, s>>>(Apsi, a->e2c.p, v0, n);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, v2, n);
-    k_gather_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, v3, n);
+    k_gather_perm<<<RG, RB, 0, s>>>(Apsi, a->perm(), v0, n);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), v2, n);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi, a->perm(), v3, n);
     return norm_factor_engine(m, v3, v2, v0, v1, out);
 }
 extern "C" int mi_norm_factor_engine(mi_matrix_t m, const double* psi_e, const double* source_e, const double* Apsi_e, double* out)
@@ -998,8 +1053,8 @@ extern "C" int mi_pcg_begin(mi_matrix_t m, const double* psi0, const double* sou
     hipStream_t s = a->ctx->stream;
     double *psi, *src, *pA, *wA, *rA;
     MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
-    k_gather_perm<<<RG, RB, 0, s>>>(psi0, a->e2c.p, psi, a->L.nCells);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi0, a->perm(), psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
     MICHK(solve_prologue(m, ctl, psi, src, wA, rA, pA, history_len));
     // wArA partials of iteration 0 (later iterations get them from k_pcg_update_psi_r)
     if (precond == MI_PRECOND_DIAGONAL) {
@@ -1047,7 +1102,7 @@ extern "C" int mi_pcg_end(mi_matrix_t m, double* psi_out, mi_solver_perf* perf, 
     HIPCHK(hipSetDevice(a->ctx->device));
     double* psi;
     MICHK(m->vec(3, &psi));
-    if (psi_out) k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(psi, a->e2c.p, psi_out, a->L.nCells);
+    if (psi_out) k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(psi, a->perm(), psi_out, a->L.nCells);
     HIPCHK(hipGetLastError());
     MICHK(fetch_state(a->ctx));
     if (perf) fill_perf(*a->ctx->hostState, perf);
@@ -1241,7 +1296,7 @@ int finish_host(mi_matrix_s* m, const HostPerf& hp, const std::vector<double>& h
                 mi_solver_perf* perf, double* hist_host, int hist_len)
 {
     mi_addr_s* a = m->addr;
-    k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(psi_e, a->e2c.p, psi_out, a->L.nCells);
+    k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(psi_e, a->perm(), psi_out, a->L.nCells);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(a->ctx->stream));
     if (perf) {
@@ -1308,8 +1363,8 @@ int pbicg_solve_device(mi_matrix_s* m, double* psi_io, const double* source, con
     double *psi, *src, *pA, *wA, *rA, *pT, *wT, *rT;
     MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
     MICHK(m->vec(8, &pT)); MICHK(m->vec(9, &wT)); MICHK(m->vec(10, &rT));
-    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->perm(), psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
     const int histLen = ctl->maxIter + 2;
     MICHK(solve_prologue(m, ctl, psi, src, wA, rA, pA, histLen));     // wA = A psi, rA = src - wA, normFactor, first test
     MICHK(launch_tile<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0, 0));
@@ -1323,7 +1378,7 @@ int pbicg_solve_device(mi_matrix_s* m, double* psi_io, const double* source, con
         MICHK(fetch_state(c));
         nb = nb * 2 > batch ? batch : nb * 2;
     }
-    k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, psi_io, a->L.nCells);
+    k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->perm(), psi_io, a->L.nCells);
     HIPCHK(hipGetLastError());
     if (perf) fill_perf(*c->hostState, perf);
     MICHK(copy_hist(m, hist_host, hist_len, c->hostState->nIterations));
@@ -1347,8 +1402,8 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
     double *psi, *src, *pA, *wA, *rA, *pT, *wT, *rT;
     MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
     MICHK(m->vec(8, &pT)); MICHK(m->vec(9, &wT)); MICHK(m->vec(10, &rT));
-    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->perm(), psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
     HostPerf hp; std::vector<double> hist;
     MICHK(host_prologue(m, ctl, psi, src, wA, rA, pA, hp, hist));
     MICHK(tile_op<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0));
@@ -1427,8 +1482,8 @@ int pbicgstab_solve_device(mi_matrix_s* m, double* psi_io, const double* source,
     double *psi, *src, *pA, *yA, *rA, *AyA, *sA, *zA, *tA, *rA0;
     MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &yA)); MICHK(m->vec(7, &rA));
     MICHK(m->vec(8, &AyA)); MICHK(m->vec(9, &sA)); MICHK(m->vec(10, &zA)); MICHK(m->vec(11, &tA)); MICHK(m->vec(12, &rA0));
-    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->perm(), psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
     if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
     const int histLen = ctl->maxIter + 2;
     MICHK(solve_prologue(m, ctl, psi, src, yA, rA, pA, histLen));
@@ -1442,7 +1497,7 @@ int pbicgstab_solve_device(mi_matrix_s* m, double* psi_io, const double* source,
         MICHK(fetch_state(c));
         nb = nb * 2 > batch ? batch : nb * 2;
     }
-    k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->e2c.p, psi_io, a->L.nCells);
+    k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->perm(), psi_io, a->L.nCells);
     HIPCHK(hipGetLastError());
     if (perf) fill_perf(*c->hostState, perf);
     MICHK(copy_hist(m, hist_host, hist_len, c->hostState->nIterations));
@@ -1467,8 +1522,8 @@ extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* s
     MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &pA)); MICHK(m->vec(6, &yA)); MICHK(m->vec(7, &rA));
     MICHK(m->vec(8, &AyA)); MICHK(m->vec(9, &sA)); MICHK(m->vec(10, &zA)); MICHK(m->vec(11, &tA)); MICHK(m->vec(12, &rA0));
     MICHK(m->vec(13, &res1));
-    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->perm(), psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
     HostPerf hp; std::vector<double> hist;
     MICHK(host_prologue(m, ctl, psi, src, yA, rA, pA, hp, hist));
     if (hp.minIter > 0 || !hp.checkConvergence()) {
@@ -1530,8 +1585,8 @@ extern "C" int mi_smooth_solve(mi_matrix_t m, double* psi_io, const double* sour
     double *psi, *src, *tmp, *wA, *rA, *psi2;
     MICHK(m->vec(3, &psi)); MICHK(m->vec(4, &src)); MICHK(m->vec(5, &tmp)); MICHK(m->vec(6, &wA)); MICHK(m->vec(7, &rA));
     MICHK(m->vec(8, &psi2));
-    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->e2c.p, psi, a->L.nCells);
-    k_gather_perm<<<RG, RB, 0, s>>>(source, a->e2c.p, src, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->perm(), psi, a->L.nCells);
+    k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
     HostPerf hp; std::vector<double> hist;
     hp.tolerance = ctl->tolerance; hp.relTol = ctl->relTol; hp.maxIter = ctl->maxIter; hp.minIter = ctl->minIter;
     double *cur = psi, *nxt = psi2;

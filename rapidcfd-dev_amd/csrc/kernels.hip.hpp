@@ -380,12 +380,25 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
 // ---------------------------------------------------------------------------
 // layout kernels
 // ---------------------------------------------------------------------------
+// perm == nullptr: engine order == caller order (ordered addressing) -- a plain 16-byte copy
+__device__ __forceinline__ void copy_chunked(const double* __restrict__ in, double* __restrict__ out, int n)
+{
+    const bool al = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    const int stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (al) {
+        const int n2 = n >> 1;
+        for (int i = t; i < n2; i += stride) reinterpret_cast<double2*>(out)[i] = reinterpret_cast<const double2*>(in)[i];
+        if ((n & 1) && t == 0) out[n - 1] = in[n - 1];
+    } else for (int i = t; i < n; i += stride) out[i] = in[i];
+}
 __global__ void k_gather_perm(const double* __restrict__ in, const int32_t* __restrict__ perm, double* __restrict__ out, int n)
 {
+    if (!perm) { copy_chunked(in, out, n); return; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[perm[i]];
 }
 __global__ void k_scatter_perm(const double* __restrict__ in, const int32_t* __restrict__ perm, double* __restrict__ out, int n)
 {
+    if (!perm) { copy_chunked(in, out, n); return; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[perm[i]] = in[i];
 }
 // caller coefficients -> engine slots (K22 calcSortCoeffs, lduMatrix.C:388-401, generalised)

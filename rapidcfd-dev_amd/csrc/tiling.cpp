@@ -151,7 +151,38 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     std::vector<int32_t> part((size_t)nCells);
     std::iota(part.begin(), part.end(), 0);
     int32_t nClusters = nCells;
-    {
+    if (prm.keepOrder) {
+        // ordered layout: tiles are ranges of the caller's numbering (given, or cut greedily under the caps)
+        if (prm.givenTileStart) {
+            if (prm.nGivenTiles <= 0 || prm.givenTileStart[0] != 0 || prm.givenTileStart[prm.nGivenTiles] != nCells) return "tile_cell_start must run from 0 to n_cells";
+            for (int32_t t = 0; t < prm.nGivenTiles; ++t) {
+                const int32_t a = prm.givenTileStart[t], b = prm.givenTileStart[(size_t)t + 1];
+                if (b <= a) return "tile_cell_start must be strictly increasing";
+                int64_t inc = 0, internal = 0;
+                for (int32_t c = a; c < b; ++c) {
+                    part[c] = t;
+                    inc += (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]) + (pfStart[(size_t)c + 1] - pfStart[c]);
+                    for (int32_t j = ownStart[c]; j < ownStart[(size_t)c + 1]; ++j) if (upper[ownFaces[j]] < b) ++internal; // owner < neighbour, both in [a, b)
+                }
+                if (b - a > 65535 - 4096 || inc - internal > prm.slotCap) return "a given tile exceeds the tile caps (cells or coefficient slots)";
+            }
+            nClusters = prm.nGivenTiles;
+        } else {
+            int32_t t = 0, cells = 0; int64_t slots = 0;
+            int32_t a = 0;
+            for (int32_t c = 0; c < nCells; ++c) {
+                int64_t add = (ownStart[(size_t)c + 1] - ownStart[c]) + (pfStart[(size_t)c + 1] - pfStart[c]);
+                for (int32_t j = neiStart[c]; j < neiStart[(size_t)c + 1]; ++j) if (lower[neiFaces[j]] < a) ++add;   // faces to cells of earlier tiles are cut: one more slot here
+                if (add > prm.slotCap) return "a single cell has more faces than a tile can hold";
+                if (cells > 0 && (cells + 1 > prm.tileCells || slots + add > prm.slotCap)) {
+                    ++t; cells = 0; slots = 0; a = c;
+                    add = (ownStart[(size_t)c + 1] - ownStart[c]) + (pfStart[(size_t)c + 1] - pfStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]);
+                }
+                part[c] = t; ++cells; slots += add;
+            }
+            nClusters = t + 1;
+        }
+    } else {
         Graph g;
         g.n = nCells;
         g.xadj.assign((size_t)nCells + 1, 0);

@@ -59,6 +59,13 @@ struct TileParams {
     int32_t tileCells = 1024; // max cells per tile
     int32_t slotCap = 4094;   // max coefficient slots per tile
     bool compact = true;      // also build the 16-bit entry form when the mesh allows it
+    // ORDERED layout: the caller's cell numbering is already tile-contiguous (a mesh renumbered with an earlier layout's
+    // engine order, e.g. by renumberMesh) -- no clustering, engine order == caller order, e2c is the identity.
+    //   keepOrder && givenTileStart: tile t = caller cells [givenTileStart[t], givenTileStart[t+1]), nGivenTiles tiles;
+    //   keepOrder alone: consecutive cells are chunked greedily under the cell / slot caps.
+    bool keepOrder = false;
+    const int32_t* givenTileStart = nullptr;
+    int32_t nGivenTiles = 0;
 };
 
 // returns empty string on success, else an error message

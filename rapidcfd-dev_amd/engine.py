@@ -65,7 +65,7 @@ SYMBOLS = [
     "mi_row_face_op", "mi_fvm_laplacian", "mi_fvm_div", "mi_surface_integrate", "mi_face_interpolate",
     "mi_patch_create", "mi_patch_destroy", "mi_patch_add", "mi_patch_add_product", "mi_patch_flux", "mi_relax",
     "mi_sngrad_correction_flux", "mi_patch_sngrad_correction_flux", "mi_patch_internal_field", "mi_vec_submul",
-    "mi_comm_create_external",
+    "mi_comm_create_external", "mi_addr_create_ordered", "mi_addr_tile_starts", "mi_addr_is_ordered",
 ]
 
 
@@ -192,8 +192,9 @@ class Addressing:
     """lduAddressing: host lowerAddr/upperAddr + coupled-patch faceCells -> tiled engine layout."""
 
     def __init__(self, ctx: Context, n_cells: int, lower_addr, upper_addr, patch_face_cells: Sequence = (),
-                 patch_nbr_cells: Sequence = ()):
-        """patch_nbr_cells[p] (optional): local cells across patch p => cyclic (local) coupling; None => processor patch"""
+                 patch_nbr_cells: Sequence = (), ordered: bool = False, tile_cell_start=None):
+        """patch_nbr_cells[p] (optional): local cells across patch p => cyclic (local) coupling; None => processor patch.
+        ordered: keep the caller's numbering (mi_addr_create_ordered); tile_cell_start: the tiles as cell ranges, or None"""
         self.ctx = ctx
         lo = np.ascontiguousarray(lower_addr, dtype=np.int32)
         up = np.ascontiguousarray(upper_addr, dtype=np.int32)
@@ -206,9 +207,16 @@ class Addressing:
                       else np.ascontiguousarray(patch_nbr_cells[k], dtype=np.int32) for k in range(npatch)]
         nptrs = (C.POINTER(C.c_int32) * max(npatch, 1))(*[q.ctypes.data_as(C.POINTER(C.c_int32)) if q is not None
                                                            else C.POINTER(C.c_int32)() for q in self._nbrs])
-        _chk(lib().mi_addr_create_coupled(ctx.h, C.c_int32(n_cells), C.c_int32(lo.shape[0]),
-                                          lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),
-                                          C.c_int32(npatch), sizes, ptrs, nptrs, C.byref(self.h)))
+        if ordered:
+            ts = None if tile_cell_start is None else np.ascontiguousarray(tile_cell_start, dtype=np.int32)
+            _chk(lib().mi_addr_create_ordered(ctx.h, C.c_int32(n_cells), C.c_int32(lo.shape[0]),
+                                              lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              C.c_int32(npatch), sizes, ptrs, nptrs, C.c_int32(0 if ts is None else ts.shape[0] - 1),
+                                              ts.ctypes.data_as(C.POINTER(C.c_int32)) if ts is not None else C.POINTER(C.c_int32)(), C.byref(self.h)))
+        else:
+            _chk(lib().mi_addr_create_coupled(ctx.h, C.c_int32(n_cells), C.c_int32(lo.shape[0]),
+                                              lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              C.c_int32(npatch), sizes, ptrs, nptrs, C.byref(self.h)))
         self.n_cells = n_cells
         self.n_faces = int(lo.shape[0])
         self.n_ext = int(lib().mi_addr_n_ext(self.h))
@@ -218,6 +226,15 @@ class Addressing:
         out = np.empty(self.n_cells, dtype=np.int32)
         _chk(lib().mi_addr_cell_perm(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
+
+    def tile_starts(self) -> np.ndarray:
+        out = np.empty(self.n_tiles + 1, dtype=np.int32)
+        _chk(lib().mi_addr_tile_starts(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    @property
+    def is_ordered(self) -> bool:
+        return bool(lib().mi_addr_is_ordered(self.h))
 
     def patch_offsets(self) -> np.ndarray:
         out = np.empty(len(self._patches) + 1, dtype=np.int32)

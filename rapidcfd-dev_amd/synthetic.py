@@ -337,3 +337,33 @@ def box_subdomain(global_dims, parts, rank: int, *, vary: float = 0.1, seed: int
         sub.interfaces.append(Interface(nbr_domain=nb, nbr_patch=theirs.index(rank), face_cells=cells.astype(np.int32),
                                         bou_coeffs=-cf, int_coeffs=-cf))
     return sub
+
+
+def renumber(case: LduCase, new_to_old) -> LduCase:
+    """The case after ``renumberMesh`` with cell map ``new_to_old`` (new cell i = old cell new_to_old[i], e.g. the engine
+    order ``mi_addr_cell_perm`` proposes): cells permuted, every face keeps owner < neighbour (a face whose cells swap
+    order is flipped: its lower and upper coefficients swap roles), faces re-sorted into OpenFOAM's upper-triangular order
+    (polyMesh::renumber / renumberMesh.C do exactly this to the mesh; the matrix follows).  Interfaces keep their face order."""
+    new_to_old = np.asarray(new_to_old, dtype=np.int64)
+    n = case.n_cells
+    old_to_new = np.empty(n, dtype=np.int64)
+    old_to_new[new_to_old] = np.arange(n)
+    lo, up = old_to_new[case.lower_addr], old_to_new[case.upper_addr]
+    flip = lo > up
+    nlo, nup = np.where(flip, up, lo), np.where(flip, lo, up)
+    lower_c = case.upper if case.lower is None else case.lower
+    nupper = np.where(flip, lower_c, case.upper)
+    nlower = np.where(flip, case.upper, lower_c)
+    order = np.lexsort((nup, nlo))                      # owner-sorted, then by neighbour: upper-triangular order
+    out = LduCase(n_cells=n, lower_addr=nlo[order].astype(np.int32), upper_addr=nup[order].astype(np.int32), diag=case.diag[new_to_old].copy(),
+                  upper=nupper[order].copy(), lower=None if case.lower is None else nlower[order].copy(), source=case.source[new_to_old].copy(),
+                  dims=case.dims)
+    out.global_cells = new_to_old.copy()                # old cell of every new cell
+    out.global_faces = order.astype(np.int64)           # old face of every new face
+    out.face_flipped = flip[order]
+    for itf in case.interfaces:
+        import copy
+        j = copy.copy(itf)
+        j.face_cells = old_to_new[itf.face_cells].astype(np.int32)
+        out.interfaces.append(j)
+    return out

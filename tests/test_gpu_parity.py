@@ -560,3 +560,80 @@ def test_pcg_session_owns_the_context_scratch(pkg, orc, ctx):
     _, ref = orc.System([case]).pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-9, maxIter=300)
     _check_hist(perf, ref)
     assert abs(ctx.sum(x) - float(np.sum(host(x).astype(np.longdouble)))) < 1e-12 * n   # usable again after mi_pcg_end
+
+
+@pytest.mark.parametrize("name", ["box_sym", "box_asym", "graph_asym"])
+def test_ordered_addressing_runs_on_the_callers_numbering(pkg, orc, ctx, name):
+    """mi_addr_create_ordered (the drop-in operators pay no permutation): the mesh is renumbered ONCE with
+    the cell order an ordinary layout proposes (what renumberMesh does), the addressing of the renumbered mesh keeps that
+    numbering -- identity permutation, same tiles -- and every operator / solver equals the oracle on the renumbered case."""
+    eng, syn = pkg.engine, pkg.synthetic
+    case = cases(pkg)[name]
+    addr0 = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    perm, starts = addr0.cell_perm(), addr0.tile_starts()
+    assert not addr0.is_ordered or np.array_equal(perm, np.arange(case.n_cells))
+    rc = syn.renumber(case, perm)
+    assert np.all(rc.lower_addr < rc.upper_addr) and np.all(np.diff(rc.lower_addr) >= 0)
+    addr = eng.Addressing(ctx, rc.n_cells, rc.lower_addr, rc.upper_addr, ordered=True, tile_cell_start=starts)
+    assert addr.is_ordered and np.array_equal(addr.cell_perm(), np.arange(rc.n_cells))
+    assert addr.n_tiles == addr0.n_tiles and np.array_equal(addr.tile_starts(), starts)
+    assert addr.stats()["slots"] == addr0.stats()["slots"]                      # the same tiles, the same cut faces
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(rc.diag), dev(rc.upper), None if rc.lower is None else dev(rc.lower))
+    S = orc.System([rc])
+    n = rc.n_cells
+    x = syn.splitmix_uniform(99, n) - 0.5
+    xd, bd = dev(x), dev(rc.source)
+    out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    mat.amul(xd, out); assert np.array_equal(host(out), S.amul(x))
+    mat.tmul(xd, out); assert np.array_equal(host(out), S.tmul(x))
+    mat.sumA(out); assert np.array_equal(host(out), S.sumA())
+    mat.residual(xd, bd, out); assert np.array_equal(host(out), S.residual(x, rc.source))
+    mat.H(xd, out); assert np.array_equal(host(out), S.H(x))
+    for kind in ("none", "diagonal", "AINV"):
+        for tr in (False, True):
+            mat.precondition(kind, xd, out, transpose=tr)
+            assert np.array_equal(host(out), S.precondition(kind, x, transpose=tr)), (kind, tr)
+    for sweeps in (1, 2, 3):
+        psi = dev(x.copy()); mat.jacobi_smooth(psi, bd, sweeps, omega=0.9)
+        assert np.array_equal(host(psi), S.jacobi_smooth(x, rc.source, sweeps, omega=0.9))
+    assert np.array_equal(host(xd), x)                                           # the operators did not write to their input
+    # the renumbered product is the original product, renumbered (rows keep their entries; only the order inside a row changes)
+    y0 = orc.System([case]).amul(x[np.argsort(perm)])
+    assert np.max(np.abs(S.amul(x) - y0[perm])) < 1e-13 * np.max(np.abs(y0))
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    if rc.lower is None:
+        perf = mat.pcg(psi, bd, "diagonal", tolerance=1e-9, maxIter=400)
+        ref_psi, ref = S.pcg(np.zeros(n), rc.source, "diagonal", tolerance=1e-9, maxIter=400)
+    else:
+        perf = mat.pbicg(psi, bd, "AINV", tolerance=1e-10, maxIter=300)
+        ref_psi, ref = S.pbicg(np.zeros(n), rc.source, "AINV", tolerance=1e-10, maxIter=300)
+    _check_hist(perf, ref)
+    # greedy tiles (no tile starts given): still the identity, still exact
+    addr_g = eng.Addressing(ctx, rc.n_cells, rc.lower_addr, rc.upper_addr, ordered=True)
+    assert addr_g.is_ordered
+    mg = eng.Matrix(addr_g); mg.set_coeffs(dev(rc.diag), dev(rc.upper), None if rc.lower is None else dev(rc.lower))
+    mg.amul(xd, out); assert np.array_equal(host(out), S.amul(x))
+    with pytest.raises(eng.MiError, match="tile_cell_start"):
+        eng.Addressing(ctx, rc.n_cells, rc.lower_addr, rc.upper_addr, ordered=True, tile_cell_start=starts[:-1])
+
+
+def test_ordered_addressing_with_coupled_patches(pkg, orc, ctx):
+    # cyclic (local) patches + ordered addressing: operators that read the coupled-patch neighbour values copy the input once
+    eng, syn = pkg.engine, pkg.synthetic
+    case = syn.add_cyclic_y(syn.box_case(18, 12, 10))
+    mk = lambda c, **kw: eng.Addressing(ctx, c.n_cells, c.lower_addr, c.upper_addr, [i.face_cells for i in c.interfaces],
+                                        [c.interfaces[i.nbr_patch].face_cells for i in c.interfaces], **kw)
+    a0 = mk(case)
+    rc = syn.renumber(case, a0.cell_perm())
+    addr = mk(rc, ordered=True, tile_cell_start=a0.tile_starts())
+    assert addr.is_ordered
+    mat = eng.Matrix(addr); mat.set_coeffs(dev(rc.diag), dev(rc.upper), None)
+    for p, itf in enumerate(rc.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None)
+    S = orc.System([rc])
+    x = syn.splitmix_uniform(7, rc.n_cells) - 0.5
+    out = torch.empty(rc.n_cells, dtype=torch.float64, device="cuda:0")
+    mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+    psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(rc.source), 2)
+    assert np.array_equal(host(psi), S.jacobi_smooth(x, rc.source, 2))

@@ -40,6 +40,35 @@ for precond in ("diagonal", "AINV"):
                 nit = mat.pcg(psi, src, precond, tolerance=0.0, maxIter=iters)["nIterations"]
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         out[f"PCG {precond}: {name}"] = {"iterations": nit, "us_per_iteration": 1e6 * best / nit}
+# ---- the same with ORDERED addressing (mesh renumbered once with the engine's cell order; mi_addr_create_ordered): the
+# caller-order primitives the reference's solvers bind to pay no permutation passes any more
+rc = syn.renumber(case, addr.cell_perm())
+addr_o = eng.Addressing(ctx, n, rc.lower_addr, rc.upper_addr, ordered=True, tile_cell_start=addr.tile_starts())
+mat_o = eng.Matrix(addr_o); mat_o.set_coeffs(t(rc.diag), t(rc.upper), None)
+src_o = t(rc.source)
+for precond in ("diagonal", "AINV"):
+    best = 1e9
+    for rep in range(3):
+        psi = torch.zeros(n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        o5 = (C.c_double * 5)()
+        lib.ref_dropin_solve_order(C.c_int(0), ctx.h, mat_o.h, C.c_void_p(stream), C.c_int(n), C.c_void_p(psi.data_ptr()), C.c_void_p(src_o.data_ptr()),
+                                   C.c_int(eng.PRECOND[precond]), C.c_double(0.0), C.c_double(0.0), C.c_int(200), C.c_int(0), C.c_int(1), C.c_double(0.9), C.c_int(0), o5)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    out[f"PCG {precond}: reference PCG::solve on CALLER-ORDER primitives, ordered addressing (level 1)"] = {"iterations": int(o5[2]), "us_per_iteration": 1e6 * best / int(o5[2])}
+alg = 24 * n + 16 * case.n_faces
+x = t(syn.splitmix_uniform(1, n)); y = torch.empty_like(x)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def timed(fn, reps=40):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+for label, M, S in (("clustered addressing (permutation passes)", mat, src), ("ordered addressing", mat_o, src_o)):
+    row = {"mi_amul": timed(lambda: M.amul(x, y)), "mi_residual": timed(lambda: M.residual(x, S, y)),
+           "mi_precondition AINV": timed(lambda: M.precondition("AINV", x, y)), "mi_jacobi_smooth x2": timed(lambda: M.jacobi_smooth(x.clone(), S, 2), 20)}
+    out[f"caller-order operators, {label}"] = {k: {"us": v, "frac_of_8TBps_on_Amul_bytes": alg / (v * 1e-6) / 8e12} for k, v in row.items()}
 d = np.asarray(case.upper_addr, np.int64) - np.asarray(case.lower_addr, np.int64)
 w = (1.0 / dims[0]) * np.array([1.0, 1.01, 1.02])[np.where(d == 1, 0, np.where(d == dims[0], 1, 2))]
 G = eng.Gamg(addr, w, 100)
