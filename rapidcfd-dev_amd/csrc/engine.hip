@@ -87,7 +87,7 @@ struct mi_ctx_s {
     int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
-    int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0; // MI_* switches, read once per context
+    int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1; // MI_* switches, read once per context
     std::set<const void*> ldsAttrSet;                         // kernels whose dynamic-LDS limit has been raised on THIS device
     std::map<std::pair<const void*, size_t>, int> occCache;  // (kernel, LDS bytes) -> resident workgroups per CU on this device
 };
@@ -208,7 +208,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
     c->pcgBatch = env_int("MI_PCG_BATCH", 16); c->pcgGraph = env_int("MI_PCG_GRAPH", -1); c->pbicgHostStepped = env_int("MI_PBICG_HOST_STEPPED", 0);
-    c->gamgDeviceInvert = env_int("MI_GAMG_DEVICE_INVERT", -1); c->gamgAlwaysAgglomerate = env_int("MI_GAMG_ALWAYS_AGGLOMERATE", 0);
+    c->gamgDeviceInvert = env_int("MI_GAMG_DEVICE_INVERT", -1); c->gamgAlwaysAgglomerate = env_int("MI_GAMG_ALWAYS_AGGLOMERATE", 0); c->gamgGraph = env_int("MI_GAMG_GRAPH", 1);
     if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 0;
     *out = c;
     return MI_OK;
@@ -497,7 +497,7 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
 // which: 0 all tiles, 1 interior only, 2 boundary only
 template <int OP>
 int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, const double* rD, double* y,
-                double omega, int which, double* dotPartial = nullptr)
+                double omega, int which, double* dotPartial = nullptr, double* dotPartial2 = nullptr)
 {
     mi_addr_s* a = m->addr;
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound (mi_matrix_set_coeffs)");
@@ -506,7 +506,7 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     t.haloCell = a->haloCell.p; t.tileSliceStart = a->tileSliceStart.p; t.sliceEntryStart = a->sliceEntryStart.p;
     t.entries = a->entries.p; t.entries16 = a->entries16.p; t.sliceEntryStart16 = a->sliceEntryStart16.p; t.slotBase = reinterpret_cast<const uint32_t*>(a->slotBase.p); t.tileSbStart = a->tileSbStart.p;
     t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
-    t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega; t.dotPartial = dotPartial; t.flags = a->ctx->tileFlags;
+    t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega; t.dotPartial = dotPartial; t.dotPartial2 = dotPartial2; t.flags = a->ctx->tileFlags;
     const size_t lds = lds_bytes(a->L, m->asym, OP == OP_AINV, &t.offLow, &t.offX, &t.offRD, &t.offSB);
     if (lds > 159 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 159 KiB of LDS");
     int nTiles = a->L.nTiles;
@@ -552,17 +552,17 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // one the ext region holds whatever the caller placed there (mi_matrix_set_ext).
 template <int OP>
 int tile_op(mi_matrix_s* m, bool trans, const double* x, const double* b, const double* rD, double* y, double omega,
-            double* dotPartial = nullptr)
+            double* dotPartial = nullptr, double* dotPartial2 = nullptr)
 {
     constexpr bool readsNbr = (OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_JACOBI);
-    if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial);
+    if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial, dotPartial2);
     mi_addr_s* a = m->addr;
     if (m->sendBuf.n < (size_t)a->L.nExt) MICHK(m->sendBuf.alloc((size_t)a->L.nExt));
     MICHK(mi_halo_pack_engine(a, x, m->sendBuf.p));
     MICHK(comm_exchange_start(m, m->sendBuf.p, const_cast<double*>(x)));
-    MICHK(launch_tile<OP>(m, trans, x, b, rD, y, omega, 1, dotPartial));
+    MICHK(launch_tile<OP>(m, trans, x, b, rD, y, omega, 1, dotPartial, dotPartial2));
     MICHK(comm_exchange_wait(m));
-    return launch_tile<OP>(m, trans, x, b, rD, y, omega, 2, dotPartial ? dotPartial + a->nInterior : nullptr);
+    return launch_tile<OP>(m, trans, x, b, rD, y, omega, 2, dotPartial ? dotPartial + a->nInterior : nullptr, dotPartial2 ? dotPartial2 + a->nInterior : nullptr);
 }
 
 } // namespace

@@ -112,7 +112,8 @@ struct TileArgs {
     const double* b;  // source (residual, Jacobi)
     const double* rD; // AINV
     double* y;
-    double* dotPartial; // Amul only: per-workgroup partial of sum(y*x) (fused gSumProd), or nullptr
+    double* dotPartial; // per-workgroup partial fused into the pass, or nullptr: Amul sum(y*x) (gSumProd), AINV sum(w*r), residual sum|r| (gSumMag)
+    double* dotPartial2; // Amul only: per-workgroup partial of sum(b*x) with b = the `b` vector (GAMG scale: gSumProd(source, field)), or nullptr
     double omega;
     int32_t offLow, offX, offRD, offSB; // LDS offsets in doubles
     int32_t flags;               // bit0: non-temporal coefficient loads, bit1: non-temporal entry loads, bit2: nt result stores, bit3: nt diagonal loads (Amul)
@@ -266,7 +267,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     }
     __syncthreads();
 
-    double dot = 0.0;
+    double dot = 0.0, dot2 = 0.0;
     for (int s = wave; s < nsl; s += NW) {
         uint32_t enext[PRE];
         int wnext = 0, e0next = 0;
@@ -331,16 +332,21 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
                 a.y[gi] = extra - a.omega * rD * acc;
             } else if (a.flags & 4) __builtin_nontemporal_store(acc, a.y + gi);
             else a.y[gi] = acc;
-            if (OP == OP_AMUL) dot = fma(acc, xi, dot);
+            if (OP == OP_AMUL) { dot = fma(acc, xi, dot); if (a.dotPartial2) dot2 = fma(a.b[gi], xi, dot2); }
+            if (OP == OP_RESIDUAL) dot += fabs(acc);
         }
 #pragma unroll
         for (int j = 0; j < PRE; ++j) ecur[j] = enext[j];
         wcur = wnext; e0cur = e0next;
     }
-    if ((OP == OP_AMUL || OP == OP_AINV) && a.dotPartial) { // fused gSumProd(wA, pA), PCG.C:166 / gSumProd(wA, rA), PCG.C:142
+    if ((OP == OP_AMUL || OP == OP_AINV || OP == OP_RESIDUAL) && a.dotPartial) { // fused gSumProd(wA, pA), PCG.C:166 / gSumProd(wA, rA), PCG.C:142 / gSumMag(rA)
         __shared__ double red[BS / 64];
         const double tsum = block_sum<BS>(dot, red);
         if (tid == 0) a.dotPartial[p] = tsum;
+        if (OP == OP_AMUL && a.dotPartial2) {
+            const double t2 = block_sum<BS>(dot2, red);
+            if (tid == 0) a.dotPartial2[p] = t2;
+        }
     }
 }
 
@@ -375,6 +381,16 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
     double v = 0.0;
     for (int k = threadIdx.x; k < n; k += 1024) v += in[k];
     out[threadIdx.x] = v;
+}
+
+// the same for two arrays in one launch (block 0: inA -> outA, block 1: inB -> outB)
+__global__ __launch_bounds__(1024) void k_fold_partials2(const double* __restrict__ inA, const double* __restrict__ inB, int n,
+                                                         double* __restrict__ outA, double* __restrict__ outB)
+{
+    const double* in = blockIdx.x == 0 ? inA : inB;
+    double v = 0.0;
+    for (int k = threadIdx.x; k < n; k += 1024) v += in[k];
+    (blockIdx.x == 0 ? outA : outB)[threadIdx.x] = v;
 }
 
 // ---------------------------------------------------------------------------
