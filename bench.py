@@ -84,6 +84,85 @@ def cpu_baseline(case, syn, iters):
     return n / sec, n, sec, cores
 
 
+def gamg_cycle_bytes(levels, n0, f0, ctl):
+    """ALGORITHMIC bytes of one V-cycle + finest residual, summed over the levels with the SURVEY.md 8(d) formulas and the
+    reference's UNFUSED op sequence (GAMGSolverSolve.C:181-474), symmetric matrix: Jacobi sweep 32N+16F; Amul 24N+16F;
+    restrict or prolong between levels (8+4)N_fine + 8N_coarse; correction scaling = Amul + two dot products (2 x 16N) + the
+    scaling pass (field, Acf, source, D -> field: 40N); finest: psi += corr (24N), residual = Amul + subtract (24N) + sumMag (8N).
+    levels: [(cells, faces)] of the coarse levels 0..L-1; n0, f0 the finest level."""
+    nL = len(levels)
+    size = [(n0, f0)] + list(levels)                       # size[k]: finest is k = 0, coarse level l is k = l + 1
+    tot = 0.0
+    for k in range(nL):                                    # restrict k -> k+1 on the way down, prolong on the way up
+        tot += 2 * ((8 + 4) * size[k][0] + 8 * size[k + 1][0])
+    for l in range(nL - 1):                                # every coarse level but the coarsest: [scale] + post sweeps
+        n, f = levels[l]
+        sweeps = min(ctl["nPostSweeps"] + ctl["postSweepsLevelMultiplier"] * l, ctl["maxPostSweeps"])
+        tot += sweeps * (32 * n + 16 * f)
+        if l < nL - 2:
+            tot += (24 * n + 16 * f) + 32 * n + 40 * n
+    tot += (24 * n0 + 16 * f0) + 32 * n0 + 40 * n0 + 24 * n0                       # finest: scale + psi update
+    tot += ctl["nFinestSweeps"] * (32 * n0 + 16 * f0)
+    tot += (24 * n0 + 16 * f0) + 24 * n0 + 8 * n0                                   # finest residual
+    nc = levels[-1][0]
+    tot += 8 * nc * nc + 16 * nc                                                    # coarsest: dense inverse times source
+    return tot
+
+
+def bench_gamg(args, eng, syn, ctx, dev, json_fd):
+    """BASELINE config 3: GAMG pressure solve (pair agglomeration, GaussSeidel(=Jacobi) smoother) on the 10 M-cell box, one GPU.
+    A step = one V-cycle incl. its finest residual; value = V-cycles/s inside mi_gamg_solve (tolerance 0, K cycles per solve)."""
+    import torch
+    nx, ny, nz = args.dims
+    K, W, R = args.steps, args.warmup, max(1, args.repeats)
+    case = syn.box_case(nx, ny, nz)
+    N, F = case.n_cells, case.n_faces
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = case.upper_addr.astype(np.int64) - case.lower_addr
+    w = (1.0 / nx) * np.array([1.0, 1.01, 1.02])[np.where(d == 1, 0, np.where(d == nx, 1, 2))]   # faceAreaPair weights of the box
+    t0 = time.perf_counter()
+    addr = eng.Addressing(ctx, N, case.lower_addr, case.upper_addr)
+    mat = eng.Matrix(addr); mat.set_coeffs(t(case.diag), t(case.upper), None)
+    G = eng.Gamg(addr, w, 100)
+    torch.cuda.synchronize()
+    log(f"[bench] layout + GAMG hierarchy ({G.n_levels} levels) in {time.perf_counter() - t0:.1f}s")
+    src = t(case.source)
+    psi = torch.zeros(N, dtype=torch.float64, device=dev)
+    G.solve(mat, psi, src, tolerance=0.0, maxIter=max(W, 2))           # warm-up: level matrices, scratch, the cycle graph
+    rep_s = []
+    for _ in range(R):
+        psi.zero_(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        perf = G.solve(mat, psi, src, tolerance=0.0, maxIter=K)
+        torch.cuda.synchronize()
+        rep_s.append(time.perf_counter() - t0)
+        assert perf["nIterations"] == K and np.all(np.diff(perf["history"]) < 0), perf
+    elapsed = float(np.median(rep_s))
+    levels = [(G.level_sizes(l)["n_coarse"], G.level_sizes(l)["n_coarse_faces"]) for l in range(G.n_levels)]
+    ctl = dict(nPostSweeps=2, postSweepsLevelMultiplier=1, maxPostSweeps=4, nFinestSweeps=2)
+    alg = gamg_cycle_bytes(levels, N, F, ctl)
+    # to convergence, next to diagonal PCG (what the multigrid buys)
+    psi.zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    pc = G.solve(mat, psi, src, tolerance=1e-6, maxIter=200); torch.cuda.synchronize(); t_conv = time.perf_counter() - t0
+    out = {
+        "metric": "PCG iterations/s + HBM GB/s on 10M-cell lduMatrix at 1/2/4/8 MI355X",
+        "value": K / elapsed, "unit": "V-cycles/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3: {nx}x{ny}x{nz} hex box (N={N}, F={F}), GAMG pressure solve: faceAreaPair agglomeration, "
+                               f"{G.n_levels} levels down to {levels[-1][0]} cells, GaussSeidel(=Jacobi) smoother 2 finest / 2..4 post sweeps, "
+                               "correction scaling, direct coarsest solve, 1xMI355X",
+                   "solver": "GAMG", "cells": N, "faces": F, "levels": [n for n, _ in levels],
+                   "timing": f"median of {R} repeats of mi_gamg_solve with {K} V-cycles each (tolerance 0; the solve's prologue -- Amul, normFactor -- is inside the clock)",
+                   "repeat_ms_per_step": [1e3 * x / K for x in rep_s],
+                   "solve_to_1e-6": {"cycles": pc["nIterations"], "seconds": t_conv}},
+        "roofline": {"kernel": "whole V-cycle (tile_kernel<OP_JACOBI> / <OP_AMUL> on every level + transfer and scaling passes)", "bound": "hbm",
+                     "achieved": alg / (elapsed / K) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_cycle": alg, "traffic": None,
+                     "traffic_unit": "not measured (profiles/r02_gamg_rocprof_summary.md has the per-kernel times)"},
+    }
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +173,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=int(os.environ.get("MI_BENCH_CPU_ITERS", "0")))  # 0: about 10 s
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--repeats", type=int, default=5)   # median of 5 repeats of the timed region
+    ap.add_argument("--solver", choices=["pcg", "gamg"], default="pcg")   # gamg: BASELINE config 3 (a second mode, 1 GPU; a step = one V-cycle)
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (one rank per GPU, as the driver's
@@ -171,6 +251,8 @@ def main():
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
         ctx = eng.Context(local_rank, stream.cuda_stream)
+    if args.solver == "gamg":
+        return bench_gamg(args, eng, syn, ctx, dev, json_fd)
     K, W, R = args.steps, args.warmup, max(1, args.repeats)
     amul_ms = None
     rep_s, rep_amul_ms, amul_alone_us = [], [], None

@@ -5,18 +5,61 @@
 
 #include <algorithm>
 #include <cstring>
+#include <atomic>
+#include <cstdlib>
 #include <numeric>
+#include <thread>
+#include <utility>
+#ifdef MI_TIMING
+#include <chrono>
+#include <cstdio>
+#define MI_T(label) do { auto now__ = std::chrono::steady_clock::now(); fprintf(stderr, "[tiling] %-28s %.3f s\n", label, std::chrono::duration<double>(now__ - t__).count()); t__ = now__; } while (0)
+#else
+#define MI_T(label) do {} while (0)
+#endif
 
 namespace mi {
 
 namespace {
 
+// Host threads for the one-time layout build: plain std::thread workers pulling blocks of `grain` indices from an atomic
+// counter (no OpenMP runtime to clash with the caller's).  Everything built under it is independent per index, so the
+// layout does not depend on the number of threads (MI_HOST_THREADS; default: the hardware's, at most 32).
+int host_threads()
+{
+    static int n = [] {
+        const char* e = getenv("MI_HOST_THREADS");
+        int v = (e && *e) ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return v < 1 ? 1 : (v > 32 ? 32 : v);
+    }();
+    return n;
+}
+template <class F>   // fn(begin, end, worker)
+void parallel_blocks(int64_t n, int64_t grain, F fn)
+{
+    const int nt = (int)std::min<int64_t>(host_threads(), (n + grain - 1) / grain);
+    if (nt <= 1) { if (n > 0) fn((int64_t)0, n, 0); return; }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> pool;
+    auto work = [&](int w) { for (;;) { const int64_t b = next.fetch_add(grain); if (b >= n) break; fn(b, std::min(n, b + grain), w); } };
+    for (int w = 1; w < nt; ++w) pool.emplace_back(work, w);
+    work(0);
+    for (auto& t : pool) t.join();
+}
+
+// vector whose resize() leaves new elements uninitialised: the big edge arrays are written completely by the (threaded) fill
+// pass right after, so a zeroing pass over hundreds of MB by one thread would only add page-touch time
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    template <class U, class... A> void construct(U* p, A&&... a) { if (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...); }
+};
 // One level of the multilevel clustering graph (CSR, undirected, both directions stored).
 struct Graph {
     int32_t n = 0;
     std::vector<int64_t> xadj;
-    std::vector<int32_t> adj;
-    std::vector<int32_t> ew;   // edge weight = number of mesh faces between the clusters
+    std::vector<int32_t, NoInitAlloc<int32_t>> adj;
+    std::vector<int32_t, NoInitAlloc<int32_t>> ew;   // edge weight = number of mesh faces between the clusters
     std::vector<int32_t> vw;   // cells in cluster
     std::vector<int32_t> vinc; // face incidences of the cluster's cells (internal counted twice)
     std::vector<int32_t> vint; // faces internal to the cluster
@@ -57,34 +100,51 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, int32_t nc, Graph
         if (first[cv] < 0) first[cv] = v; else second[cv] = v;
         c.vw[cv] += g.vw[v]; c.vinc[cv] += g.vinc[v]; c.vint[cv] += g.vint[v];
     }
+    // Row of a coarse vertex = the neighbours of its members, mapped, merged (weights added) and sorted by id (deterministic
+    // tie-breaking in match_level).  Rows are independent: built twice under OpenMP (count, then fill), merged through a small
+    // per-thread sort instead of a global scratch table, so the result does not depend on the number of threads.
+#ifdef MI_TIMING
+    auto t__ = std::chrono::steady_clock::now();
+#endif
     c.xadj.assign((size_t)nc + 1, 0);
-    c.adj.clear(); c.ew.clear();
-    c.adj.reserve(g.adj.size()); c.ew.reserve(g.adj.size());
-    std::vector<int64_t> pos(nc, -1); // position of neighbour cu in the current row
-    for (int32_t cv = 0; cv < nc; ++cv) {
-        const int64_t rowStart = (int64_t)c.adj.size();
+    std::vector<int32_t> vintAdd((size_t)nc, 0);
+    auto build_row = [&](int32_t cv, std::vector<std::pair<int32_t, int32_t>>& tmp, int32_t& internal) {
+        tmp.clear(); internal = 0;
         for (int k = 0; k < 2; ++k) {
             const int32_t v = k ? second[cv] : first[cv];
             if (v < 0) continue;
             for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
                 const int32_t cu = cmap[g.adj[e]];
-                if (cu == cv) { if (k == 0) c.vint[cv] += g.ew[e]; continue; } // edge inside the pair
-                if (pos[cu] >= rowStart) c.ew[pos[cu]] += g.ew[e];
-                else { pos[cu] = (int64_t)c.adj.size(); c.adj.push_back(cu); c.ew.push_back(g.ew[e]); }
+                if (cu == cv) { if (k == 0) internal += g.ew[e]; continue; } // edge inside the pair
+                tmp.push_back({cu, g.ew[e]});
             }
         }
-        // keep neighbours in ascending id order: deterministic tie-breaking in match_level
-        const int64_t rowEnd = (int64_t)c.adj.size();
-        const int64_t len = rowEnd - rowStart;
-        if (len > 1) {
-            std::vector<std::pair<int32_t, int32_t>> tmp((size_t)len);
-            for (int64_t i = 0; i < len; ++i) tmp[(size_t)i] = {c.adj[rowStart + i], c.ew[rowStart + i]};
-            std::sort(tmp.begin(), tmp.end());
-            for (int64_t i = 0; i < len; ++i) { c.adj[rowStart + i] = tmp[(size_t)i].first; c.ew[rowStart + i] = tmp[(size_t)i].second; }
+        std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
+        size_t w = 0;
+        for (size_t i = 0; i < tmp.size(); ++i) {
+            if (w > 0 && tmp[w - 1].first == tmp[i].first) tmp[w - 1].second += tmp[i].second;
+            else tmp[w++] = tmp[i];
         }
-        for (int64_t i = rowStart; i < rowEnd; ++i) pos[c.adj[i]] = -1;
-        c.xadj[(size_t)cv + 1] = rowEnd;
-    }
+        tmp.resize(w);
+    };
+    parallel_blocks(nc, 16384, [&](int64_t b, int64_t e, int) {
+        std::vector<std::pair<int32_t, int32_t>> tmp;
+        int32_t internal;
+        for (int32_t cv = (int32_t)b; cv < (int32_t)e; ++cv) { build_row(cv, tmp, internal); c.xadj[(size_t)cv + 1] = (int64_t)tmp.size(); vintAdd[(size_t)cv] = internal; }
+    });
+    MI_T("    coarsen: count");
+    for (int32_t cv = 0; cv < nc; ++cv) { c.xadj[(size_t)cv + 1] += c.xadj[cv]; c.vint[cv] += vintAdd[(size_t)cv]; }
+    c.adj.resize((size_t)c.xadj[nc]); c.ew.resize((size_t)c.xadj[nc]);
+    MI_T("    coarsen: prefix+alloc");
+    parallel_blocks(nc, 16384, [&](int64_t b, int64_t e, int) {
+        std::vector<std::pair<int32_t, int32_t>> tmp;
+        int32_t internal;
+        for (int32_t cv = (int32_t)b; cv < (int32_t)e; ++cv) {
+            build_row(cv, tmp, internal);
+            int64_t at = c.xadj[cv];
+            for (const auto& q : tmp) { c.adj[(size_t)at] = q.first; c.ew[(size_t)at] = q.second; ++at; }
+        }
+    });
 }
 
 } // namespace
@@ -100,6 +160,9 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         if (lower[f] < 0 || upper[f] >= nCells || lower[f] >= upper[f])
             return "addressing must satisfy 0 <= lowerAddr[f] < upperAddr[f] < nCells";
     }
+#ifdef MI_TIMING
+    auto t__ = std::chrono::steady_clock::now();
+#endif
     L = TileLayout();
     L.nCells = nCells; L.nFaces = nFaces; L.nPatches = nPatches;
     L.patchOffset.assign((size_t)nPatches + 1, 0);
@@ -147,6 +210,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
                     ifaceLocalNbr[(size_t)L.patchOffset[p] + i] = c;
                 }
 
+    MI_T("face lists");
     // ---- multilevel heavy-edge clustering ------------------------------------
     std::vector<int32_t> part((size_t)nCells);
     std::iota(part.begin(), part.end(), 0);
@@ -188,28 +252,36 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         g.xadj.assign((size_t)nCells + 1, 0);
         for (int32_t c = 0; c < nCells; ++c)
             g.xadj[(size_t)c + 1] = g.xadj[c] + (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]);
-        g.adj.resize((size_t)2 * nFaces); g.ew.assign((size_t)2 * nFaces, 1);
+        g.adj.resize((size_t)2 * nFaces); g.ew.resize((size_t)2 * nFaces);
         g.vw.assign(nCells, 1); g.vint.assign(nCells, 0); g.vinc.resize(nCells);
-        for (int32_t c = 0; c < nCells; ++c) {
-            int64_t k = g.xadj[c];
-            for (int32_t j = ownStart[c]; j < ownStart[(size_t)c + 1]; ++j) g.adj[(size_t)k++] = upper[ownFaces[j]];
-            for (int32_t j = neiStart[c]; j < neiStart[(size_t)c + 1]; ++j) g.adj[(size_t)k++] = lower[neiFaces[j]];
-            g.vinc[c] = (int32_t)(g.xadj[(size_t)c + 1] - g.xadj[c]) + (pfStart[(size_t)c + 1] - pfStart[c]);
-            if (g.vinc[c] > prm.slotCap) return "a single cell has more faces than a tile can hold";
-        }
+        std::atomic<bool> tooMany{false};
+        parallel_blocks(nCells, 65536, [&](int64_t b, int64_t e, int) {
+            for (int32_t c = (int32_t)b; c < (int32_t)e; ++c) {
+                int64_t k = g.xadj[c];
+                for (int32_t j = ownStart[c]; j < ownStart[(size_t)c + 1]; ++j) { g.ew[(size_t)k] = 1; g.adj[(size_t)k++] = upper[ownFaces[j]]; }
+                for (int32_t j = neiStart[c]; j < neiStart[(size_t)c + 1]; ++j) { g.ew[(size_t)k] = 1; g.adj[(size_t)k++] = lower[neiFaces[j]]; }
+                g.vinc[c] = (int32_t)(g.xadj[(size_t)c + 1] - g.xadj[c]) + (pfStart[(size_t)c + 1] - pfStart[c]);
+                if (g.vinc[c] > prm.slotCap) tooMany = true;
+            }
+        });
+        if (tooMany) return "a single cell has more faces than a tile can hold";
         // multi-edges (two faces between the same cell pair) are legal in LDU addressing; merge them
         std::vector<int32_t> cmap;
         for (int level = 0; level < 64; ++level) {
             const int32_t nc = match_level(g, prm.tileCells, prm.slotCap, cmap);
+            MI_T("  match");
             if (nc == g.n) break;
             for (int32_t c = 0; c < nCells; ++c) part[c] = cmap[part[c]];
+            MI_T("  part update");
             Graph cg;
             coarsen(g, cmap, nc, cg);
+            MI_T("  coarsen");
             g = std::move(cg);
             nClusters = nc;
         }
     }
 
+    MI_T("clustering");
     // ---- order tiles by their smallest caller cell, cells inside a tile ascending ----
     const int32_t nT = nClusters;
     L.nTiles = nT;
@@ -232,6 +304,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         for (int32_t c = 0; c < nCells; ++c) { const int32_t e = cur[part[c]]++; L.e2c[e] = c; L.c2e[c] = e; }
     }
 
+    MI_T("renumbering");
     // ---- slots, halos, row entries --------------------------------------------
     // Slot order of a tile: for every local row its owner faces (ascending face id) as one run, then for every halo
     // cell the faces it owns whose neighbour is a local row, then the interface slots, then the zero slot.  Every
@@ -245,8 +318,6 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     L.sliceEntryStart16.clear(); L.sliceEntryStart16.push_back(0);
     L.tileSbStart.assign(1, 0);
     L.slotFace.clear(); L.haloCell.clear(); L.entries.clear(); L.entries16.clear(); L.slotBase.clear();
-    L.slotFace.reserve((size_t)nFaces + nFaces / 4 + 16);
-    L.entries.reserve((size_t)2 * nFaces + nCells);
     L.compact = prm.compact;
     L.extSlot.assign((size_t)L.nExt, -1);
     L.faceSlot.assign((size_t)nFaces, -1);
@@ -257,30 +328,55 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
 
     struct RowEnt { int32_t other, slot, k; bool rule, lowerSide; };
     struct Pending { int32_t ent, halo, id; };
-    std::vector<int32_t> haloStamp((size_t)nCells + L.nExt, -1), haloIdx((size_t)nCells + L.nExt, 0);
+    // Every tile is built on its own (OpenMP over tiles: nothing a tile writes depends on another tile) into local tables;
+    // a sequential pass then lays them end to end.  A cut face gets its faceSlot from the tile of its OWNER cell (both
+    // tiles hold the coefficient), so the result does not depend on the order tiles are visited in.
+    struct TileOut {
+        std::vector<int32_t> slotFace, haloCell, sliceEntryStart, sliceEntryStart16;   // slice starts relative to the tile's first entry
+        std::vector<uint32_t> entries, entries16;
+        std::vector<uint16_t> slotBase;
+        std::vector<std::pair<int32_t, int32_t>> extSlot, faceSlot;                    // (ext / face id, local slot)
+        int32_t ifaceSlot0 = 0, nSlots = 0, nHalo = 0, nc = 0;
+        bool boundary = false, fits16 = true;
+        std::string err;
+    };
+    std::vector<TileOut> outs((size_t)nT);
+    const bool wantCompact = prm.compact;
+    parallel_blocks(nT, 8, [&](int64_t tBegin, int64_t tEnd, int) {
+    // per-block scratch: halo lookup by engine cell (open addressing, rebuilt per tile)
     std::vector<RowEnt> rowEnt;          // entries of the rows of the current tile, row-major
     std::vector<int32_t> rowEntStart, sbLocal, haloCnt, sbHalo;
     std::vector<Pending> cutList, ifaceList;
-
-    for (int32_t t = 0; t < nT; ++t) {
+    std::vector<int32_t> hKey, hVal;      // hash table
+    auto hash_reset = [&](size_t want) { size_t cap = 64; while (cap < 2 * want) cap <<= 1; hKey.assign(cap, -1); hVal.assign(cap, 0); };
+    for (int32_t t = (int32_t)tBegin; t < (int32_t)tEnd; ++t) {
+        TileOut& O = outs[(size_t)t];
         const int32_t cs = L.tileCellStart[t], ce = L.tileCellStart[(size_t)t + 1], nc = ce - cs;
-        const int64_t slotBase = (int64_t)L.slotFace.size();
+        O.nc = nc;
         int32_t nHalo = 0;
         bool boundary = false, fits16 = true;
         rowEnt.clear(); rowEntStart.assign(1, 0);
         cutList.clear(); ifaceList.clear(); haloCnt.clear();
 
         sbLocal.assign((size_t)nc + 1, 0);
-        for (int32_t e = cs; e < ce; ++e) { const int32_t c = L.e2c[e]; sbLocal[(size_t)(e - cs) + 1] = sbLocal[e - cs] + (ownStart[(size_t)c + 1] - ownStart[c]); }
+        int64_t incid = 0;
+        for (int32_t e = cs; e < ce; ++e) {
+            const int32_t c = L.e2c[e];
+            sbLocal[(size_t)(e - cs) + 1] = sbLocal[e - cs] + (ownStart[(size_t)c + 1] - ownStart[c]);
+            incid += (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]) + (pfStart[(size_t)c + 1] - pfStart[c]);
+        }
         const int32_t nLocal = sbLocal[nc];
+        hash_reset((size_t)incid + 8);
+        const size_t hMask = hKey.size() - 1;
         auto halo_of = [&](int32_t engineCell) -> int32_t {
-            if (haloStamp[engineCell] != t) { haloStamp[engineCell] = t; haloIdx[engineCell] = nHalo++; L.haloCell.push_back(engineCell); haloCnt.push_back(0); }
-            return nc + haloIdx[engineCell];
+            size_t h = ((size_t)(uint32_t)engineCell * 2654435761u) & hMask;
+            while (hKey[h] != -1 && hKey[h] != engineCell) h = (h + 1) & hMask;
+            if (hKey[h] == -1) { hKey[h] = engineCell; hVal[h] = nHalo++; O.haloCell.push_back(engineCell); haloCnt.push_back(0); }
+            return nc + hVal[h];
         };
         auto place = [&](int32_t slot, int32_t what) {
-            const size_t at = (size_t)slotBase + (size_t)slot;
-            if (L.slotFace.size() <= at) L.slotFace.resize(at + 1, -1);
-            L.slotFace[at] = what;
+            if (O.slotFace.size() <= (size_t)slot) O.slotFace.resize((size_t)slot + 1, -1);
+            O.slotFace[(size_t)slot] = what;
         };
         for (int32_t e = cs; e < ce; ++e) {
             const int32_t c = L.e2c[e], i = e - cs;
@@ -290,8 +386,9 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
                 const int32_t slot = sbLocal[i] + (j - ownStart[c]);
                 place(slot, f);
                 int32_t other;
-                if (part[o] == t) { other = L.c2e[o] - cs; L.faceSlot[f] = (int32_t)(slotBase + slot); }
-                else { other = halo_of(L.c2e[o]); if (L.faceSlot[f] < 0) L.faceSlot[f] = (int32_t)(slotBase + slot); }
+                if (part[o] == t) other = L.c2e[o] - cs;
+                else other = halo_of(L.c2e[o]);
+                O.faceSlot.push_back({f, slot});       // the owner's tile names the face's slot
                 rowEnt.push_back({other, slot, 0, false, false});
             }
             // neighbour side, losort order: row uses lower[f], other = lower cell (the owner of the face)
@@ -313,7 +410,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
                 const int32_t nb = ifaceLocalNbr[x];
                 int32_t h;
                 if (nb < 0) { h = halo_of(nCells + x) - nc; boundary = true; }          // remote: value arrives in the ext region
-                else { h = nHalo++; L.haloCell.push_back(L.c2e[nb]); haloCnt.push_back(0); } // cyclic partner (any tile): private halo entry
+                else { h = nHalo++; O.haloCell.push_back(L.c2e[nb]); haloCnt.push_back(0); } // cyclic partner (any tile): private halo entry
                 ifaceList.push_back({(int32_t)rowEnt.size(), h, x});
                 rowEnt.push_back({nc + h, -1, 0, true, false});
             }
@@ -327,68 +424,106 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
             RowEnt& re = rowEnt[(size_t)q.ent];
             re.slot = sbHalo[q.halo] + re.k;
             place(re.slot, q.id);
-            if (L.faceSlot[q.id] < 0) L.faceSlot[q.id] = (int32_t)(slotBase + re.slot);
         }
-        L.tileIfaceSlot0[t] = nFaceSlots;
+        O.ifaceSlot0 = nFaceSlots;
         int32_t nSlots = nFaceSlots;
         for (const Pending& q : ifaceList) {
             const int32_t slot = nSlots++;
             rowEnt[(size_t)q.ent].slot = slot;
             place(slot, -(2 + q.id));
-            L.extSlot[q.id] = (int32_t)(slotBase + slot);
+            O.extSlot.push_back({q.id, slot});
             sbHalo[q.halo] = slot;
         }
-        if (nSlots > 32766 || nc + nHalo > 65535) return "tile exceeds the entry field widths";
+        if (nSlots > 32766 || nc + nHalo > 65535) { O.err = "tile exceeds the entry field widths"; continue; }
         if (nc + nHalo + 1 > 4096) fits16 = false;
         for (const RowEnt& re : rowEnt) if (re.rule && re.k > 7) { fits16 = false; break; }
-        if (!fits16) L.compact = false;
         // zero slot + pad the segment to an even length (16-byte aligned double2 loads)
         place(nSlots, -1); // the zero slot, local index nSlots
-        if ((L.slotFace.size() & 1u) != 0) L.slotFace.push_back(-1);
-        L.tileSlotStart[(size_t)t + 1] = (int32_t)L.slotFace.size();
-        L.tileHaloStart[(size_t)t + 1] = (int32_t)L.haloCell.size();
+        if ((O.slotFace.size() & 1u) != 0) O.slotFace.push_back(-1);
         // slot bases: local rows, halo cells, the pad cell (-> zero slot)
-        for (int32_t i = 0; i < nc; ++i) L.slotBase.push_back((uint16_t)sbLocal[i]);
-        for (int32_t h = 0; h < nHalo; ++h) L.slotBase.push_back((uint16_t)sbHalo[h]);
-        L.slotBase.push_back((uint16_t)nSlots);
-        if ((L.slotBase.size() & 1u) != 0) L.slotBase.push_back(0);
-        L.tileSbStart.push_back((int32_t)(L.slotBase.size() / 2));
+        if (wantCompact) {
+            for (int32_t i = 0; i < nc; ++i) O.slotBase.push_back((uint16_t)sbLocal[i]);
+            for (int32_t h = 0; h < nHalo; ++h) O.slotBase.push_back((uint16_t)sbHalo[h]);
+            O.slotBase.push_back((uint16_t)nSlots);
+            if ((O.slotBase.size() & 1u) != 0) O.slotBase.push_back(0);
+        }
         // slices of 64 rows, column-major, padded with {zero slot, other 0} / {pad cell}
         const uint32_t padEnt = ((uint32_t)nSlots << 16);
         const uint32_t pad16 = (uint32_t)((nc + nHalo) & 0xFFF) | 0x8000u;
         const int32_t nSl = (nc + 63) / 64;
+        O.sliceEntryStart.assign(1, 0); O.sliceEntryStart16.assign(1, 0);
         for (int32_t s = 0; s < nSl; ++s) {
             const int32_t r0 = s * 64, r1 = std::min(nc, r0 + 64);
             int32_t width = 0;
             for (int32_t r = r0; r < r1; ++r) width = std::max(width, rowEntStart[(size_t)r + 1] - rowEntStart[r]);
-            const size_t base = L.entries.size();
-            L.entries.resize(base + (size_t)width * 64, padEnt);
+            const size_t base = O.entries.size();
+            O.entries.resize(base + (size_t)width * 64, padEnt);
             const int32_t width2 = (width + 1) / 2;
-            const size_t base16 = L.entries16.size();
-            if (L.compact) L.entries16.resize(base16 + (size_t)width2 * 64, pad16 | (pad16 << 16));
+            const size_t base16 = O.entries16.size();
+            if (wantCompact && fits16) O.entries16.resize(base16 + (size_t)width2 * 64, pad16 | (pad16 << 16));
             for (int32_t r = r0; r < r1; ++r) {
                 const int32_t len = rowEntStart[(size_t)r + 1] - rowEntStart[r];
                 for (int32_t j = 0; j < len; ++j) {
                     const RowEnt& re = rowEnt[(size_t)rowEntStart[r] + j];
-                    L.entries[base + (size_t)j * 64 + (r - r0)] = (uint32_t)re.other | ((uint32_t)re.slot << 16) | (re.lowerSide ? 0x80000000u : 0u);
-                    if (L.compact) {
+                    O.entries[base + (size_t)j * 64 + (r - r0)] = (uint32_t)re.other | ((uint32_t)re.slot << 16) | (re.lowerSide ? 0x80000000u : 0u);
+                    if (wantCompact && fits16) {
                         const uint32_t e16 = (uint32_t)(re.other & 0xFFF) | ((uint32_t)(re.k & 7) << 12) | (re.rule ? 0x8000u : 0u);
-                        uint32_t& w = L.entries16[base16 + (size_t)(j >> 1) * 64 + (r - r0)];
+                        uint32_t& w = O.entries16[base16 + (size_t)(j >> 1) * 64 + (r - r0)];
                         w = (j & 1) ? ((w & 0x0000FFFFu) | (e16 << 16)) : ((w & 0xFFFF0000u) | e16);
                     }
                 }
             }
-            L.sliceEntryStart.push_back((int32_t)L.entries.size());
-            L.sliceEntryStart16.push_back((int32_t)L.entries16.size());
+            O.sliceEntryStart.push_back((int32_t)O.entries.size());
+            O.sliceEntryStart16.push_back((int32_t)O.entries16.size());
         }
-        L.tileSliceStart[(size_t)t + 1] = L.tileSliceStart[t] + nSl;
-        L.maxCells = std::max(L.maxCells, nc);
-        L.maxSlots = std::max(L.maxSlots, nSlots + 2);
-        L.maxHalo = std::max(L.maxHalo, nHalo);
-        (boundary ? L.boundaryTiles : L.interiorTiles).push_back(t);
-        if (L.entries.size() > (size_t)INT32_MAX - 4096 || L.slotFace.size() > (size_t)INT32_MAX - 4096)
-            return "mesh too large for 32-bit layout offsets";
+        O.nSlots = nSlots; O.nHalo = nHalo; O.boundary = boundary; O.fits16 = fits16;
     }
+    });
+    // ---- lay the tiles end to end ----------------------------------------------------------------------------------
+    for (int32_t t = 0; t < nT; ++t) {
+        if (!outs[(size_t)t].err.empty()) return outs[(size_t)t].err;
+        if (!outs[(size_t)t].fits16) L.compact = false;
+    }
+    {
+        size_t nSlotTot = 0, nEntTot = 0, nEnt16Tot = 0, nHaloTot = 0, nSbTot = 0, nSlTot = 0;
+        for (const TileOut& O : outs) { nSlotTot += O.slotFace.size(); nEntTot += O.entries.size(); nEnt16Tot += O.entries16.size(); nHaloTot += O.haloCell.size(); nSbTot += O.slotBase.size(); nSlTot += O.sliceEntryStart.size() - 1; }
+        if (nEntTot > (size_t)INT32_MAX - 4096 || nSlotTot > (size_t)INT32_MAX - 4096) return "mesh too large for 32-bit layout offsets";
+        L.slotFace.resize(nSlotTot); L.entries.resize(nEntTot); L.haloCell.resize(nHaloTot);
+        if (L.compact) { L.entries16.resize(nEnt16Tot); L.slotBase.resize(nSbTot); }
+        L.sliceEntryStart.reserve(nSlTot + 1); L.sliceEntryStart16.reserve(nSlTot + 1);
+    }
+    {
+        size_t sAt = 0, eAt = 0, e16At = 0, hAt = 0, sbAt = 0;
+        for (int32_t t = 0; t < nT; ++t) {
+            TileOut& O = outs[(size_t)t];
+            std::copy(O.slotFace.begin(), O.slotFace.end(), L.slotFace.begin() + (std::ptrdiff_t)sAt);
+            std::copy(O.entries.begin(), O.entries.end(), L.entries.begin() + (std::ptrdiff_t)eAt);
+            std::copy(O.haloCell.begin(), O.haloCell.end(), L.haloCell.begin() + (std::ptrdiff_t)hAt);
+            if (L.compact) {
+                std::copy(O.entries16.begin(), O.entries16.end(), L.entries16.begin() + (std::ptrdiff_t)e16At);
+                std::copy(O.slotBase.begin(), O.slotBase.end(), L.slotBase.begin() + (std::ptrdiff_t)sbAt);
+            }
+            for (size_t k = 1; k < O.sliceEntryStart.size(); ++k) {
+                L.sliceEntryStart.push_back((int32_t)(eAt + (size_t)O.sliceEntryStart[k]));
+                L.sliceEntryStart16.push_back((int32_t)(e16At + (size_t)(L.compact ? O.sliceEntryStart16[k] : 0)));
+            }
+            for (const auto& q : O.extSlot) L.extSlot[(size_t)q.first] = (int32_t)(sAt + (size_t)q.second);
+            for (const auto& q : O.faceSlot) L.faceSlot[(size_t)q.first] = (int32_t)(sAt + (size_t)q.second);
+            L.tileIfaceSlot0[t] = O.ifaceSlot0;
+            sAt += O.slotFace.size(); eAt += O.entries.size(); hAt += O.haloCell.size();
+            if (L.compact) { e16At += O.entries16.size(); sbAt += O.slotBase.size(); }
+            L.tileSlotStart[(size_t)t + 1] = (int32_t)sAt;
+            L.tileHaloStart[(size_t)t + 1] = (int32_t)hAt;
+            L.tileSbStart.push_back((int32_t)(sbAt / 2));
+            L.tileSliceStart[(size_t)t + 1] = L.tileSliceStart[t] + (int32_t)(O.sliceEntryStart.size() - 1);
+            L.maxCells = std::max(L.maxCells, O.nc);
+            L.maxSlots = std::max(L.maxSlots, O.nSlots + 2);
+            L.maxHalo = std::max(L.maxHalo, O.nHalo);
+            (O.boundary ? L.boundaryTiles : L.interiorTiles).push_back(t);
+            TileOut().slotFace.swap(O.slotFace); std::vector<uint32_t>().swap(O.entries); std::vector<uint32_t>().swap(O.entries16); // free as we go
+        }
+    }
+    MI_T("slots / halos / entries");
     if (!L.compact) { std::vector<uint32_t>().swap(L.entries16); std::vector<int32_t>().swap(L.sliceEntryStart16); }
     L.nSlices = L.tileSliceStart[nT];
     L.totalSlots = (int64_t)L.slotFace.size();

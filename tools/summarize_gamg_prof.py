@@ -13,7 +13,7 @@ log = open(os.path.join(d, "bench_gamg.log")).read() if os.path.exists(os.path.j
 print("# GAMG V-cycle on the 216^3 box: rocprofv3 kernel trace\n")
 print("```\n" + "\n".join(l for l in log.splitlines() if l.startswith(("addr", "{", "solve", "PCG")))[:1500] + "\n```\n")
 # find the solve with tolerance 0 / GAMG_CYCLES cycles: cycles are delimited by k_gamg_scale-free marker: the finest residual reduce is followed by a D2H copy; use the finest prolong
-fin = [i for i, r in enumerate(rows) if "k_sub" in r[2]]   # the finest residual (GAMGSolverSolve.C:146-160): once per cycle
+fin = [i for i, r in enumerate(rows) if "k_fold_final" in r[2]]   # the finest residual (GAMGSolverSolve.C:146-160): once per cycle
 ncyc = int(os.environ.get("GAMG_CYCLES", "10"))
 # cycles 4 .. 3+ncyc belong to the timed solve (3 warm-up cycles first); take the middle ones
 sel = fin[3 + 1: 3 + ncyc - 1]
