@@ -1,5 +1,6 @@
 // gamg.cpp -- see gamg.hpp.
 #include "gamg.hpp"
+#include "host_parallel.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -58,33 +59,51 @@ void build_coarse_faces(GamgLevelHost& L, const int32_t* lower, const int32_t* u
     const int32_t nF = L.nFineFaces, nC = L.nCoarse;
     L.faceRestrict.assign((size_t)nF, 0);
     L.faceFlip.assign((size_t)nF, 0);
-    // first pass: provisional ids in order of creation + per-owner lists
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> perOwner((size_t)nC); // (neighbour, provisional id)
-    std::vector<int32_t> provNei;
+    // cut faces bucketed by owner (= smaller coarse cell), ascending fine face inside a bucket (counting sort is stable);
+    // flat arrays and per-owner work only, so the owners are processed by the host threads independently
+    std::vector<int32_t> oStart((size_t)nC + 1, 0);
     for (int32_t f = 0; f < nF; ++f) {
         const int32_t ru = L.restrictMap[upper[f]], rl = L.restrictMap[lower[f]];
-        if (ru == rl) { L.faceRestrict[f] = -(ru + 1); continue; }
-        const int32_t own = std::min(ru, rl), nei = std::max(ru, rl);
-        auto& lst = perOwner[own];
-        int32_t id = -1;
-        for (auto& pr : lst) if (pr.first == nei) { id = pr.second; break; }
-        if (id < 0) { id = (int32_t)provNei.size(); provNei.push_back(nei); lst.emplace_back(nei, id); }
-        L.faceRestrict[f] = id;
+        if (ru == rl) L.faceRestrict[f] = -(ru + 1);
+        else ++oStart[(size_t)std::min(ru, rl) + 1];
     }
-    const int32_t nCF = (int32_t)provNei.size();
+    for (int32_t c = 0; c < nC; ++c) oStart[(size_t)c + 1] += oStart[c];
+    std::vector<int32_t> oFace((size_t)oStart[nC]), fill(oStart.begin(), oStart.end() - 1);
+    for (int32_t f = 0; f < nF; ++f) if (L.faceRestrict[f] >= 0) oFace[(size_t)fill[std::min(L.restrictMap[upper[f]], L.restrictMap[lower[f]])]++] = f;
+    // distinct neighbours of every owner in order of first appearance: first their number ...
+    std::vector<int32_t> base((size_t)nC + 1, 0);
+    auto nei_of = [&](int32_t f) { return std::max(L.restrictMap[upper[f]], L.restrictMap[lower[f]]); };
+    parallel_blocks(nC, 32768, [&](int64_t b, int64_t e, int) {
+        std::vector<int32_t> seen;
+        for (int32_t c = (int32_t)b; c < (int32_t)e; ++c) {
+            seen.clear();
+            for (int32_t j = oStart[c]; j < oStart[(size_t)c + 1]; ++j) {
+                const int32_t nei = nei_of(oFace[j]);
+                if (std::find(seen.begin(), seen.end(), nei) == seen.end()) seen.push_back(nei);
+            }
+            base[(size_t)c + 1] = (int32_t)seen.size();
+        }
+    });
+    for (int32_t c = 0; c < nC; ++c) base[(size_t)c + 1] += base[c];
+    const int32_t nCF = base[nC];
     L.nCoarseFaces = nCF;
     L.cLower.resize(nCF); L.cUpper.resize(nCF);
-    std::vector<int32_t> finalId((size_t)nCF);
-    int32_t k = 0;
-    for (int32_t c = 0; c < nC; ++c)
-        for (auto& pr : perOwner[c]) { L.cLower[k] = c; L.cUpper[k] = pr.first; finalId[pr.second] = k++; }
-    for (int32_t f = 0; f < nF; ++f) {
-        int32_t& t = L.faceRestrict[f];
-        if (t < 0) continue;
-        t = finalId[t];
-        // flipped when the fine (lower -> upper) direction is opposite to the coarse (owner -> neighbour)
-        if (L.cLower[t] == L.restrictMap[upper[f]] && L.cUpper[t] == L.restrictMap[lower[f]]) L.faceFlip[f] = 1;
-    }
+    // ... then the numbering: coarse faces grouped by owner, inside an owner in order of first appearance among the fine faces
+    parallel_blocks(nC, 32768, [&](int64_t b, int64_t e, int) {
+        std::vector<int32_t> seen;
+        for (int32_t c = (int32_t)b; c < (int32_t)e; ++c) {
+            seen.clear();
+            for (int32_t j = oStart[c]; j < oStart[(size_t)c + 1]; ++j) {
+                const int32_t f = oFace[j], nei = nei_of(f);
+                size_t at = std::find(seen.begin(), seen.end(), nei) - seen.begin();
+                if (at == seen.size()) { seen.push_back(nei); L.cLower[(size_t)base[c] + at] = c; L.cUpper[(size_t)base[c] + at] = nei; }
+                const int32_t t = base[c] + (int32_t)at;
+                L.faceRestrict[f] = t;
+                // flipped when the fine (lower -> upper) direction is opposite to the coarse (owner -> neighbour)
+                if (c == L.restrictMap[upper[f]] && nei == L.restrictMap[lower[f]]) L.faceFlip[f] = 1;
+            }
+        }
+    });
 }
 
 void segment(int32_t nTargets, const std::vector<int32_t>& target, std::vector<int32_t>& start, std::vector<int32_t>& child)
