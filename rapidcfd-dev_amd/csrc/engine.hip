@@ -981,6 +981,24 @@ int copy_hist(mi_matrix_s* m, double* hist_host, int len, int nIter)
     return MI_OK;
 }
 
+// Device-resident solver loops on a communicator-attached matrix: a local sum (RG block partials) becomes the GLOBAL sum
+// where the reference calls Foam::reduce (allReduceTemplates.C:195-208) -- final reduction, all-reduce on the engine's stream,
+// spread back as {sum, 0, ...} -- and the consumers read it exactly as they read local partials; the host still only polls
+// `done` once per batch.  Two sums that are due at the same point travel in one all-reduce.
+int globalize(mi_matrix_s* m, double* PA, double* PB = nullptr)
+{
+    if (!comm_attached(m)) return MI_OK;
+    mi_ctx_s* c = m->addr->ctx;
+    hipStream_t s = c->stream;
+    double* sc = c->scalars.p + 10;
+    if (PB) k_reduce_final2<<<2, RB, 0, s>>>(PA, sc, PB, sc + 1);
+    else k_reduce_final<<<1, RB, 0, s>>>(PA, sc);
+    MICHK(comm_allreduce(m, sc, PB ? 2 : 1));
+    k_spread_partials<<<PB ? 2 : 1, RB, 0, s>>>(sc, PA, PB);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
 // enqueue PCG iteration bodies it0 .. it0+count-1 (no host sync).
 // diagonal / none: 5 launches per iteration -- update_p (precondition fused), Amul (+ fused
 // gSumProd partials), fold, update_psi_r (+ next iteration's wArA partials), final.
@@ -1004,6 +1022,7 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
             // AINV apply with sum wA.rA fused into the tile pass (per-tile partials folded into P1): no separate reduction pass
             MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0, m->tilePartial.p));
             k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P1);
+            MICHK(globalize(m, P1));
             k_pcg_update_p<0><<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, nullptr, nullptr, pA, n); // AINV path keeps k_pcg_final (P1 is rewritten before it)
         } else if (precond == MI_PRECOND_DIAGONAL) {
             k_pcg_update_p<1><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, m->rD.p, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen);
@@ -1017,17 +1036,19 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
             if (c->attachEvents) { m->kevStart = m->evPool[ev]; m->kevStop = m->evPool[ev + 1]; }
             else HIPCHK(hipEventRecord(m->evPool[ev], s));
         }
-        const int rcA = launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0, m->tilePartial.p);
+        const int rcA = tile_op<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, m->tilePartial.p);   // exchanges the halo when attached
         m->kevStart = nullptr; m->kevStop = nullptr;
         MICHK(rcA);
         if (rec && !c->attachEvents) HIPCHK(hipEventRecord(m->evPool[ev + 1], s));
         k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P2);
+        MICHK(globalize(m, P2));
         if (precond == MI_PRECOND_AINV)
             k_pcg_update_psi_r<0><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
         else if (precond == MI_PRECOND_DIAGONAL)
             k_pcg_update_psi_r<1><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, m->rD.p, psi, rA, n, P3, P1);
         else
             k_pcg_update_psi_r<2><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
+        MICHK(globalize(m, P3, precond == MI_PRECOND_AINV ? nullptr : P1));   // sum|rA| (+ the next iteration's wA.rA from the same pass)
         // diagonal / none: the convergence test of this iteration is fused into the next k_pcg_update_p
         if (!fuse) k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
     }
@@ -1340,11 +1361,14 @@ int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, d
             k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rT, n, P1);
         } else if (precond == MI_PRECOND_DIAGONAL) k_bicg_precond_dot<true><<<RG, RB, 0, s>>>(c->state.p, m->rD.p, rA, rT, wA, wT, n, P1);
         else k_bicg_precond_dot<false><<<RG, RB, 0, s>>>(c->state.p, nullptr, rA, rT, wA, wT, n, P1);
+        MICHK(globalize(m, P1));
         k_bicg_update_p<<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, wT, pA, pT, n);
-        MICHK(launch_tile<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0, 0));
-        MICHK(launch_tile<OP_AMUL>(m, true, pT, nullptr, nullptr, wT, 0.0, 0));
+        MICHK(tile_op<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0));   // halo exchange inside when attached
+        MICHK(tile_op<OP_AMUL>(m, true, pT, nullptr, nullptr, wT, 0.0));
         k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, pT, n, P2);
+        MICHK(globalize(m, P2));
         k_bicg_update_psi_r<<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, wT, psi, rA, rT, n, P3);
+        MICHK(globalize(m, P3));
         k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
     }
     HIPCHK(hipGetLastError());
@@ -1367,7 +1391,7 @@ int pbicg_solve_device(mi_matrix_s* m, double* psi_io, const double* source, con
     k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
     const int histLen = ctl->maxIter + 2;
     MICHK(solve_prologue(m, ctl, psi, src, wA, rA, pA, histLen));     // wA = A psi, rA = src - wA, normFactor, first test
-    MICHK(launch_tile<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0, 0));
+    MICHK(tile_op<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0));
     k_sub<<<RG, RB, 0, s>>>(rT, src, wT, n);
     MICHK(fetch_state(c));
     const int batch = m->addr->ctx->pcgBatch;
@@ -1395,7 +1419,7 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
     if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_pbicg_solve: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
-    if (!comm_attached(m) && m->addr->ctx->pbicgHostStepped == 0)
+    if (m->addr->ctx->pbicgHostStepped == 0)   // also with a communicator attached: the loop all-reduces its sums on the device (globalize)
         return pbicg_solve_device(m, psi_io, source, ctl, precond, perf, hist_host, hist_len);
     hipStream_t s = a->ctx->stream;
     const int64_t n = a->L.nCells;
@@ -1453,17 +1477,22 @@ int stab_enqueue(mi_matrix_s* m, int it0, int count, int precond, bool quirk, do
     struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
     for (int it = it0; it < it0 + count; ++it) {
         k_reduce<RED_PROD><<<RG, RB, 0, s>>>(rA0, rA, n, P1);
+        MICHK(globalize(m, P1));
         k_stab_update_p<<<RG, RB, 0, s>>>(c->state.p, it, P1, rA, AyA, pA, n);
         MICHK(precond_engine(m, precond, false, pA, yA));
-        MICHK(launch_tile<OP_AMUL>(m, false, yA, nullptr, nullptr, AyA, 0.0, 0));
+        MICHK(tile_op<OP_AMUL>(m, false, yA, nullptr, nullptr, AyA, 0.0));   // halo exchange inside when attached
         k_reduce<RED_PROD><<<RG, RB, 0, s>>>(rA0, AyA, n, P2);
+        MICHK(globalize(m, P2));
         k_stab_s<<<RG, RB, 0, s>>>(c->state.p, it, P2, rA, AyA, sA, n, P3);
+        MICHK(globalize(m, P3));
         k_stab_mid<<<RG, RB, 0, s>>>(c->state.p, P3, yA, psi, n);
         k_stab_mid_final<<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
         MICHK(precond_engine(m, precond, false, sA, zA));
-        MICHK(launch_tile<OP_AMUL>(m, false, zA, nullptr, nullptr, tA, 0.0, 0));
+        MICHK(tile_op<OP_AMUL>(m, false, zA, nullptr, nullptr, tA, 0.0));
         k_reduce_two<<<RG, RB, 0, s>>>(tA, sA, n, P1, P2);
+        MICHK(globalize(m, P1, P2));
         k_stab_update<<<RG, RB, 0, s>>>(c->state.p, P1, P2, yA, quirk ? yA : zA, sA, tA, psi, rA, n, P4);
+        MICHK(globalize(m, P4));
         k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P4, m->hist.p, m->histLen);
     }
     HIPCHK(hipGetLastError());
@@ -1514,7 +1543,7 @@ extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* s
     if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_pbicgstab_solve: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
-    if (!comm_attached(m) && m->addr->ctx->pbicgHostStepped == 0)
+    if (m->addr->ctx->pbicgHostStepped == 0)
         return pbicgstab_solve_device(m, psi_io, source, ctl, precond, replicate_quirk, perf, hist_host, hist_len);
     hipStream_t s = a->ctx->stream;
     const int64_t n = a->L.nCells;

@@ -569,6 +569,14 @@ __global__ __launch_bounds__(RB) void k_reduce_final2(const double* __restrict__
     const double t = sum_partials(blockIdx.x == 0 ? partialA : partialB, red);
     if (threadIdx.x == 0) *(blockIdx.x == 0 ? outA : outB) = t;
 }
+// communicator-attached solver loops: the all-reduced sum goes back into the partial array as {sum, 0, 0, ...}, so that every
+// consumer's own re-reduction (sum_partials: same order in every block) returns exactly the global value (block b: set b)
+__global__ __launch_bounds__(RB) void k_spread_partials(const double* __restrict__ sums, double* __restrict__ PA, double* __restrict__ PB)
+{
+    double* P = blockIdx.x == 0 ? PA : PB;
+    const double v = sums[blockIdx.x];
+    for (int i = threadIdx.x; i < RG; i += RB) P[i] = (i == 0) ? v : 0.0;
+}
 __global__ __launch_bounds__(RB) void k_reduce_final(const double* __restrict__ partial, double* __restrict__ out)
 {
     __shared__ double red[RB / 64];
