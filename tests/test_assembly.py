@@ -132,6 +132,69 @@ def test_engine_assembly_bit_exact(pkg, orc, dims):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fixed256", "fixed1024", "tiles", "tiles_unstaged", "fixed_unstaged"])
+@pytest.mark.parametrize("name", ["box", "graph"])
+def test_row_passes_bit_exact_for_every_block_shape(pkg, orc, monkeypatch, name, mode):
+    """The row passes (row face ops, fvm::laplacian, fvm::div, surfaceIntegrate, Gauss grad) own blocks of consecutive cells:
+    fixed ranges of 256 / 1024 cells in the caller's numbering, the layout's tiles under ordered addressing; neighbour-side
+    faces inside the block come from LDS, cut faces are gathered / recomputed.  Same bits as the oracle in every shape,
+    and on the unstaged path a block takes when its faces do not fit the LDS arrays."""
+    import torch
+    from conftest import random_graph_case
+    eng, syn = pkg.engine, pkg.synthetic
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to("cuda:0")
+    host = lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1]
+    case = syn.box_case(31, 23, 19, symmetric=False) if name == "box" else random_graph_case(pkg, 9000, extra=3.0, seed=5, symmetric=False)
+    if mode.startswith("tiles"):
+        a0 = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+        case = syn.renumber(case, a0.cell_perm())
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, ordered=True, tile_cell_start=a0.tile_starts())
+        assert addr.is_ordered and addr.n_tiles > 4
+    else:
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+        assert not addr.is_ordered
+    for var in ("MI_ROW_BS", "MI_GRAD_BS"):
+        monkeypatch.setenv(var, "1024" if mode == "fixed1024" else "256")
+    if mode.endswith("unstaged"):
+        monkeypatch.setenv("MI_ROW_CAP", "64")
+    n, nf, lo, up = case.n_cells, case.n_faces, case.lower_addr, case.upper_addr
+    asm = eng.Assembly(addr)
+    E = lambda m: torch.empty(m, dtype=torch.float64, device="cuda:0")
+    for kind in (0, 1, 2):
+        start = syn.splitmix_uniform(kind, n)
+        io = dev(start)
+        asm.row_face_op(kind, dev(case.lower), dev(case.upper), io)
+        assert np.array_equal(host(io), orc.row_face_op(kind, n, lo, up, case.lower, case.upper, start)), kind
+        io = dev(start)
+        asm.row_face_op(kind, None, dev(case.upper), io)
+        assert np.array_equal(host(io), orc.row_face_op(kind, n, lo, up, None, case.upper, start)), kind
+    delta, gam = 1.0 + syn.splitmix_uniform(7, nf), 0.5 + syn.splitmix_uniform(8, nf)
+    uo, do = E(nf), E(n)
+    asm.fvm_laplacian(dev(delta), dev(gam), uo, do)
+    ru, rd = orc.fvm_laplacian(n, lo, up, delta, gam)
+    assert np.array_equal(host(uo), ru) and np.array_equal(host(do), rd)
+    w, phi = syn.splitmix_uniform(9, nf), syn.splitmix_uniform(10, nf) - 0.5
+    lo_o, uo, do = E(nf), E(nf), E(n)
+    asm.fvm_div(dev(w), dev(phi), lo_o, uo, do)
+    rl, ru, rd = orc.fvm_div(n, lo, up, w, phi)
+    assert np.array_equal(host(lo_o), rl) and np.array_equal(host(uo), ru) and np.array_equal(host(do), rd)
+    vol = 0.5 + syn.splitmix_uniform(11, n)
+    out = E(n)
+    asm.surface_integrate(dev(phi), None, out); assert np.array_equal(host(out), orc.surface_integrate(n, lo, up, phi))
+    asm.surface_integrate(dev(phi), dev(vol), out); assert np.array_equal(host(out), orc.surface_integrate(n, lo, up, phi, vol))
+    Sf = [syn.splitmix_uniform(20 + k, nf) - 0.5 for k in range(3)]
+    g = [E(n) for _ in range(3)]
+    asm.gauss_grad([dev(x) for x in Sf], dev(phi), dev(vol), g)
+    for a, b in zip(g, orc.gauss_grad(n, lo, up, Sf, phi, vol)):
+        assert np.array_equal(host(a), b)
+    # the fused passes recompute cut faces from their inputs: an output aliasing an input is refused
+    d = dev(delta)
+    with pytest.raises(eng.MiError):
+        asm.fvm_laplacian(d, dev(gam), d, do)
+
+
+@pytest.mark.gpu
 def test_assemble_then_solve_matches_oracle_end_to_end(pkg, orc):
     """config-5 style step on a small box: fused fvm::laplacian + boundary diag on the GPU feeds PCG."""
     import torch
