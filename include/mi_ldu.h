@@ -52,7 +52,8 @@ enum {
     MI_ERR_DEVICE = -2,   /* no gfx950 device / HIP failure */
     MI_ERR_ALLOC = -3,
     MI_ERR_STATE = -4,    /* e.g. coefficients not bound */
-    MI_ERR_LIMIT = -5     /* mesh exceeds a tile-format limit */
+    MI_ERR_LIMIT = -5,    /* mesh exceeds a tile-format limit */
+    MI_ERR_UNSUPPORTED = -6 /* a combination this build does not provide (stated where it can occur) */
 };
 
 /* preconditioner names of lduMatrix::preconditioner::New
@@ -110,6 +111,22 @@ int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
                            int32_t n_patches, const int32_t *patch_sizes,
                            const int32_t *const *patch_face_cells_host,
                            const int32_t *const *patch_nbr_cells_host, mi_addr_t *out);
+/* cyclicAMI patch (row f3; src/finiteVolume/fields/fvPatchFields/constraint/cyclicAMI/cyclicAMIFvPatchField.C:195-224,
+ * src/meshTools/AMIInterpolation/GAMG/interfaceFields/cyclicAMIGAMGInterfaceField/cyclicAMIGAMGInterfaceField.C:97-130,
+ * AMIInterpolation/AMIInterpolationF.H:62-105): `patch` -- created WITHOUT neighbour cells, i.e. with an ext region like a
+ * processor patch -- takes its neighbour values from the cells of `nbr_patch` of the same addressing through the AMI
+ * addressing and weights of its side (srcAddress/srcWeights on the owner patch, tgtAddress/tgtWeights on the other):
+ *     pnf[i] = sum_{k in [start[i], start[i+1])} weights[k] * ( factor * psi[ faceCells(nbr_patch)[ address[k] ] ] )
+ * one fused multiply-add per term in address order (multiplyWeightedOp<plusEqOp> under nvcc's contraction), factor =
+ * mi_matrix_set_patch_transform; low_weight[i] != 0 (weightsSum[i] < lowWeightCorrection, decided by the caller) replaces
+ * the sum by the face's own cell value, the default the reference passes (`pif`).  The two sides may differ in size.  Every
+ * operator and solver that reads coupled-patch neighbour values interpolates them before its tile pass; no exchange.
+ * start/address/weights all NULL: one face to one face with unit weight -- a cyclic (or processorCyclic-on-one-rank) patch
+ * that needs its transformation factor (cyclicLduInterfaceField.C:45-62).  Not agglomerated for GAMG in this build
+ * (AMIInterpolation::agglomerate, AMIInterpolation.C:279-540): mi_gamg_create returns MI_ERR_UNSUPPORTED on such a mesh. */
+int mi_addr_set_ami_patch(mi_addr_t addr, int32_t patch, int32_t nbr_patch, const int32_t *start_host_or_null,
+                          const int32_t *address_host_or_null, const double *weights_host_or_null,
+                          const uint8_t *low_weight_host_or_null);
 /* ORDERED addressing -- the caller's numbering is kept: engine order == caller order, mi_addr_cell_perm is the identity and the
  * caller-order operators (mi_amul, mi_tmul, mi_residual, mi_H, mi_sumA, mi_precondition, mi_jacobi_smooth) run straight on the
  * caller's arrays, with no permutation passes (only an n_cells copy of the input where an operator reads coupled-patch
@@ -156,6 +173,14 @@ int mi_matrix_set_coeffs(mi_matrix_t m, const double *diag_dev, const double *up
  * patch_sizes[p] values each; int_coeffs_dev may be NULL for symmetric matrices). */
 int mi_matrix_set_interface_coeffs(mi_matrix_t m, int32_t patch, const double *bou_coeffs_dev,
                                    const double *int_coeffs_dev);
+/* transformCoupleField of a coupled patch (cyclicLduInterfaceField.C:45-62, processorGAMGInterfaceField.C:213,230,
+ * cyclicAMILduInterfaceField.C:45-62): the neighbour values are multiplied by
+ *     factor = pow(diag(forwardT).component(cmpt), rank)
+ * before they enter result -= coeffs*pnf -- 1 for scalars (rank 0) and untransformed patches, the caller's number for the
+ * component solves of a vector across a rotational cyclic / processorCyclic.  Processor patches: applied to the received
+ * values; cyclicAMI and one-to-one patches declared with mi_addr_set_ami_patch: applied before the interpolation.  A plain
+ * cyclic patch (created with neighbour cells) only accepts 1.  Held per matrix: Ux, Uy, Uz solves set their own.          */
+int mi_matrix_set_patch_transform(mi_matrix_t m, int32_t patch, double factor);
 
 /* ---- halo (replaces init/updateMatrixInterfaces + processorFvPatchField
  *      gather/scatter, lduMatrixUpdateMatrixInterfaces.C:30-276,

@@ -142,8 +142,22 @@ int orc_sys_add_interface(orc_system *s, int d, label nbrDomain, label nbrPatch,
     p->faceCells = (label *)dupmem(faceCells, sizeof(label) * (size_t)nFaces);
     p->bouCoeffs = (scalar *)dupmem(bouCoeffs, sizeof(scalar) * (size_t)nFaces);
     p->intCoeffs = (scalar *)dupmem(intCoeffs, sizeof(scalar) * (size_t)nFaces);
+    p->amiStart = p->amiAddr = NULL; p->amiW = NULL; p->amiLow = NULL; p->factor = 1.0;
     return m->nIfaces++;
 }
+
+/* make interface p of domain d a cyclicAMI one (weights into the faces of its neighbour interface); low may be NULL */
+void orc_sys_set_iface_ami(orc_system *s, int d, int p, const label *start, const label *addr, const scalar *w, const unsigned char *low)
+{
+    orc_iface *q = &s->dom[d].ifaces[p];
+    const label n = q->nFaces, na = start[n];
+    q->amiStart = (label *)dupmem(start, sizeof(label) * (size_t)(n + 1));
+    q->amiAddr = (label *)dupmem(addr, sizeof(label) * (size_t)(na ? na : 1));
+    q->amiW = (scalar *)dupmem(w, sizeof(scalar) * (size_t)(na ? na : 1));
+    q->amiLow = low ? (unsigned char *)dupmem(low, (size_t)(n ? n : 1)) : NULL;
+}
+/* transformCoupleField factor of interface p (cyclicLduInterfaceField.C:45-62, processorGAMGInterfaceField.C:213) */
+void orc_sys_set_iface_transform(orc_system *s, int d, int p, scalar factor) { s->dom[d].ifaces[p].factor = factor; }
 
 void orc_sys_set_accurate(orc_system *s, int on) { s->accurate_sums = on; }
 int64_t orc_sys_size(const orc_system *s) { return s->nTotal; }
@@ -158,6 +172,7 @@ void orc_sys_destroy(orc_system *s)
         if (!m->symmetric) free(m->lowerC);
         for (i = 0; i < m->nIfaces; i++) {
             free(m->ifaces[i].faceCells); free(m->ifaces[i].bouCoeffs); free(m->ifaces[i].intCoeffs);
+            free(m->ifaces[i].amiStart); free(m->ifaces[i].amiAddr); free(m->ifaces[i].amiW); free(m->ifaces[i].amiLow);
         }
         free(m->ifaces);
     }
@@ -190,7 +205,20 @@ static void update_interfaces(const orc_system *s, int d, int useIntCoeffs,
             /* one fused multiply-add per face, like every other term of the row
              * (the contraction nvcc applies to  result -= coeffs*pnf  in the functor) */
             const scalar cs = coeffSign * co[i];
-            const scalar pn = psiN[ot->faceCells[i]];
+            scalar pn;
+            if (me->amiStart) {
+                /* pnf = neighbour internal field, transformCoupleField (*= factor), then AMI interpolation:
+                 * AMIInterpolationF.H:62-105 with multiplyWeightedOp<plusEqOp> (out += w*f, address order, contracted
+                 * to one fma per term like the other device functors); low-weight faces take their own cell's value  */
+                if (me->amiLow && me->amiLow[i]) pn = psiAll[m->offset + me->faceCells[i]];
+                else {
+                    label k; pn = 0.0;
+                    for (k = me->amiStart[i]; k < me->amiStart[i + 1]; k++) {
+                        const scalar t = me->factor * psiN[ot->faceCells[me->amiAddr[k]]];
+                        pn = fma(me->amiW[k], t, pn);
+                    }
+                }
+            } else pn = me->factor * psiN[ot->faceCells[i]]; /* factor 1: exact */
             scalar *r = &resultDom[me->faceCells[i]];
             *r = negate ? fma(cs, pn, *r) : fma(-cs, pn, *r);
         }

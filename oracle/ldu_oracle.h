@@ -12,6 +12,13 @@ typedef struct {
     label *faceCells;  /* [nFaces] local cell touched by each patch face    */
     scalar *bouCoeffs; /* interfaceBouCoeffs (used by Amul)                 */
     scalar *intCoeffs; /* interfaceIntCoeffs (used by Tmul)                 */
+    /* cyclicAMI (cyclicAMIFvPatchField.C:195-224): neighbour value of face i = sum over k in [amiStart[i], amiStart[i+1]) of
+     * amiW[k] * (factor * psi_nbr[nbrFaceCells[amiAddr[k]]]); amiStart NULL = ordinary one-to-one interface.  amiLow[i] != 0:
+     * the face's weight sum is under lowWeightCorrection, its value is the face's own cell (the `pif` default).        */
+    label *amiStart, *amiAddr;
+    scalar *amiW;
+    unsigned char *amiLow;
+    scalar factor;     /* transformCoupleField: pow(diag(forwardT).component(cmpt), rank); 1 = no transformation */
 } orc_iface;
 
 typedef struct {

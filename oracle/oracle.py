@@ -86,6 +86,14 @@ class System:
                 L.orc_sys_add_interface(self.h, d, C.c_int32(itf.nbr_domain), C.c_int32(itf.nbr_patch),
                                         C.c_int32(fc.shape[0]), _p(fc, C.c_int32),
                                         _p(_d(itf.bou_coeffs), C.c_double), _p(_d(itf.int_coeffs), C.c_double))
+        for d, cs in enumerate(self.cases):
+            for p, itf in enumerate(cs.interfaces):
+                if getattr(itf, "ami_start", None) is not None:
+                    low = None if itf.ami_low is None else np.ascontiguousarray(itf.ami_low, dtype=np.uint8)
+                    L.orc_sys_set_iface_ami(self.h, d, p, _p(_i(itf.ami_start), C.c_int32), _p(_i(itf.ami_addr), C.c_int32),
+                                            _p(_d(itf.ami_w), C.c_double), _p(low, C.c_uint8))
+                if getattr(itf, "transform", 1.0) != 1.0:
+                    L.orc_sys_set_iface_transform(self.h, d, p, C.c_double(itf.transform))
         self.n = int(L.orc_sys_size(self.h))
 
     def __del__(self):
@@ -712,6 +720,25 @@ def ref_atmul(case, which, psi=None, source=None, favour_speed=0, level=0, coars
                 _p(owner_sort, C.c_int32), _p(owner_start, C.c_int32), _p(losort_start, C.c_int32), _p(losort, C.c_int32), _p(_d(case.diag), C.c_double),
                 _p(lower, C.c_double), _p(upper, C.c_double), _p(lower_sort, C.c_double), _p(upper_sort, C.c_double), _p(x, C.c_double), _p(b, C.c_double),
                 _p(out, C.c_double))
+    return out
+
+
+REF_AMI_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_ami.so")
+
+
+def ref_ami_available() -> bool:
+    return os.path.exists(REF_AMI_LIB)
+
+
+def ref_ami_interpolate(start, address, weights, fld, low_weight_correction=-1.0, weights_sum=None, default_values=None):
+    """The REFERENCE's AMIInterpolationF.H functors with its own plusEqOp / multiplyWeightedOp (oracle/ref_shim/ref_ami_tu.cpp)"""
+    L = C.CDLL(REF_AMI_LIB)
+    st, ad = _i(start), _i(address)
+    n = st.shape[0] - 1
+    out = np.full(n, np.nan)
+    L.ref_ami_interpolate(C.c_int(n), _p(st, C.c_int32), _p(ad, C.c_int32), _p(_d(weights), C.c_double), _p(_d(fld), C.c_double),
+                          C.c_double(low_weight_correction), None if weights_sum is None else _p(_d(weights_sum), C.c_double),
+                          None if default_values is None else _p(_d(default_values), C.c_double), _p(out, C.c_double))
     return out
 
 

@@ -84,6 +84,7 @@ struct mi_ctx_s {
     int xcdRows = 1;      // MI_XCD_ROWS: XCD-aware block mapping of the caller-order row passes
     int persist = 0;      // MI_TILE_PERSIST: persistent tile launches (workgroups = resident slots, each walks a run of tiles)
     int nCU = 0;
+    bool coarseLevelBuild = false; // set by the GAMG hierarchy builder around its level addressings (tile size choice)
     int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
@@ -110,6 +111,11 @@ struct mi_addr_s {
     DevBuf<int32_t> ifaceNbrCaller; // [nExt] caller cell across every LOCAL interface face, -1 for remote faces (lazy)
     std::vector<std::vector<int32_t>> patchFaceCellsHost, patchNbrCellsHost; // caller order (GAMG interface agglomeration)
     int64_t nEntries = 0, nHaloTot = 0;
+    // cyclicAMI patches (mi_addr_set_ami_patch): declared like processor patches (ext region), their neighbour values are
+    // interpolated locally from the partner patch's cells before every operator that reads them
+    struct AmiPatch { int32_t patch = 0, nbrPatch = 0, n = 0, extOff = 0; DevBuf<int32_t> start, cellE, ownE; DevBuf<double> w; bool hasLow = false; };
+    std::vector<AmiPatch*> ami;
+    ~mi_addr_s() { for (AmiPatch* q : ami) delete q; }
     bool identity = false; // engine order == caller order (ordered addressing, or a mesh whose numbering happens to be tile-contiguous)
     const int32_t* perm() const { return identity ? nullptr : e2c.p; } // nullptr: the permutation kernels degenerate to copies
 };
@@ -121,6 +127,7 @@ struct mi_matrix_s {
     mi_dpcg_s dp; // buffers of a distributed PCG session (owned by the caller)
     DevBuf<double> diagE, upE, lowE, rD, sumAE; // sumAE: lduMatrix::sumA of the bound coefficients (normFactor), kept per binding
     bool asym = false, bound = false, rDValid = false, sumAValid = false;
+    std::vector<double> patchFactor; // transformCoupleField factor of every coupled patch (empty: none set, all 1)
     uint64_t epoch = 0; // bumped whenever coefficients are (re)bound: lets a GAMG hierarchy keep its level matrices between solves
     std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
     DevBuf<double> hist, tilePartial;
@@ -293,7 +300,16 @@ static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, cons
     mi_addr_s* a = new mi_addr_s();
     a->ctx = ctx;
     TileParams prm;
-    prm.tileCells = env_int("MI_TILE_CELLS", 1024);
+    prm.tileCells = env_int("MI_TILE_CELLS", 0);
+    if (prm.tileCells <= 0) {
+        // 1024 cells per tile; the coarse levels of a GAMG hierarchy (ctx->coarseLevelBuild) are cut into enough tiles for
+        // every CU instead -- a shorter staging / row chain per workgroup, down to 128-cell tiles: their tile kernels take
+        // 4.6-5.5 us instead of 7-8 (profiles/r02_gamg_rocprof_summary.md), 2.08 -> 2.02 ms per V-cycle on the 216^3 box.
+        // The caller's own matrices keep 1024 (no gain measured for small PCG cases, and the partial-sum grouping of the
+        // Krylov reductions stays what the parity tests pinned).
+        const int target = (ctx->coarseLevelBuild && env_int("MI_SMALL_TILES", 1)) ? (int)(((int64_t)n_cells / std::max(1, ctx->nCU) + 63) / 64 * 64) : 1024;
+        prm.tileCells = std::min(1024, std::max(128, target));
+    }
     prm.slotCap = env_int("MI_TILE_SLOTS", 4094);
     prm.compact = env_int("MI_ENTRY16", 0) != 0; // opt-in: half the entry bytes, measured 2-4 % slower (profiles/r01_n_compact_entries_ab.md)
     prm.keepOrder = ordered; prm.givenTileStart = tile_cell_start; prm.nGivenTiles = n_tiles;
@@ -344,6 +360,63 @@ static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, cons
 }
 
 extern "C" int mi_addr_destroy(mi_addr_t a) { delete a; return MI_OK; }
+
+extern "C" int mi_addr_set_ami_patch(mi_addr_t a, int32_t patch, int32_t nbr_patch, const int32_t* start, const int32_t* address, const double* weights,
+                                     const uint8_t* low_weight)
+{
+    if (!a || patch < 0 || patch >= a->L.nPatches || nbr_patch < 0 || nbr_patch >= a->L.nPatches)
+        return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: bad argument");
+    if (a->patchIsLocal[(size_t)patch]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: the patch must be created without neighbour cells (ext region), once");
+    if ((start || address || weights) && !(start && address && weights)) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: start, address and weights go together");
+    HIPCHK(hipSetDevice(a->ctx->device));
+    const std::vector<int32_t>& mine = a->patchFaceCellsHost[(size_t)patch];
+    const std::vector<int32_t>& theirs = a->patchFaceCellsHost[(size_t)nbr_patch];
+    const int32_t n = (int32_t)mine.size(), nn = (int32_t)theirs.size();
+    std::vector<int32_t> st((size_t)n + 1, 0), ce, own;
+    std::vector<double> w;
+    if (!start) { // one face to one face with unit weight: a cyclic patch that needs its transformation factor
+        if (n != nn) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: one-to-one coupling needs patches of equal size");
+        ce.resize((size_t)n); w.assign((size_t)n, 1.0);
+        for (int32_t i = 0; i < n; ++i) { st[(size_t)i + 1] = i + 1; ce[i] = a->L.c2e[(size_t)theirs[i]]; }
+    } else {
+        if (start[0] != 0) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: start[0] must be 0");
+        for (int32_t i = 0; i < n; ++i) if (start[i + 1] < start[i]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: start must be non-decreasing");
+        const int32_t na = start[n];
+        ce.resize((size_t)na); w.assign(weights, weights + na);
+        for (int32_t k = 0; k < na; ++k) {
+            if (address[k] < 0 || address[k] >= nn) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: address outside the neighbour patch");
+            ce[k] = a->L.c2e[(size_t)theirs[(size_t)address[k]]];
+        }
+        st.assign(start, start + n + 1);
+    }
+    mi_addr_s::AmiPatch* q = new mi_addr_s::AmiPatch();
+    q->patch = patch; q->nbrPatch = nbr_patch; q->n = n; q->extOff = a->L.patchOffset[(size_t)patch];
+    if (low_weight) {
+        own.assign((size_t)n, -1);
+        for (int32_t i = 0; i < n; ++i) if (low_weight[i]) { own[i] = a->L.c2e[(size_t)mine[i]]; q->hasLow = true; }
+    }
+    hipStream_t s = a->ctx->stream;
+    int r = q->start.upload(st, s);
+    if (r == MI_OK && !ce.empty()) r = q->cellE.upload(ce, s);
+    if (r == MI_OK && !w.empty()) r = q->w.upload(w, s);
+    if (r == MI_OK && q->hasLow) r = q->ownE.upload(own, s);
+    if (r != MI_OK) { delete q; return r; }
+    HIPCHK(hipStreamSynchronize(s));
+    a->ami.push_back(q);
+    a->patchIsLocal[(size_t)patch] = 2; // no exchange: the values come from this rank's own cells
+    a->nLocalPatches++;
+    return MI_OK;
+}
+
+extern "C" int mi_matrix_set_patch_transform(mi_matrix_t m, int32_t patch, double factor)
+{
+    if (!m || patch < 0 || patch >= m->addr->L.nPatches) return fail(MI_ERR_ARG, "mi_matrix_set_patch_transform: bad argument");
+    if (m->addr->patchIsLocal[(size_t)patch] == 1 && factor != 1.0)
+        return fail(MI_ERR_UNSUPPORTED, "mi_matrix_set_patch_transform: a transformed cyclic patch is declared through mi_addr_set_ami_patch (one-to-one, unit weights)");
+    if (m->patchFactor.empty()) m->patchFactor.assign((size_t)m->addr->L.nPatches, 1.0);
+    m->patchFactor[(size_t)patch] = factor;
+    return MI_OK;
+}
 extern "C" int32_t mi_addr_n_cells(mi_addr_t a) { return a ? a->L.nCells : 0; }
 extern "C" int32_t mi_addr_n_faces(mi_addr_t a) { return a ? a->L.nFaces : 0; }
 extern "C" int32_t mi_addr_n_tiles(mi_addr_t a) { return a ? a->L.nTiles : 0; }
@@ -461,7 +534,7 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
     // (asymmetric matrices, AINV) only two fit, and 1024 threads keep the CU at 32 waves (measured:
     // asymmetric Amul 254 -> 211 us on the 216^3 box)
     int bs = m->addr->ctx->amulBS;
-    if (bs == 0) bs = (lds > 53 * 1024) ? 1024 : 512;
+    if (bs == 0) bs = (lds > 53 * 1024) ? 1024 : (m->addr->L.maxCells <= 256 ? 256 : 512); // small tiles (small matrices): four 64-row slices at most
     if (nTiles <= 0) return MI_OK;
 #define MI_LAUNCH(BS)                                                                                                   \
     {                                                                                                                   \
@@ -547,6 +620,54 @@ int ensure_rD(mi_matrix_s* m)
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// cyclicAMI neighbour values (cyclicAMIFvPatchField.C:195-224, cyclicAMIGAMGInterfaceField.C:97-130): the partner patch's
+// internal values, transformed (transformCoupleField: *= factor), then interpolated with the AMI weights --
+// AMIInterpolationF.H:62-105 with multiplyWeightedOp<plusEqOp>: out += w*f in address order, one fma per term under nvcc's
+// default contraction.  A face below the low-weight threshold takes its own cell's value (the `pif` default).
+__global__ void k_ami_fill(const double* __restrict__ x, const int32_t* __restrict__ start, const int32_t* __restrict__ cellE,
+                           const double* __restrict__ w, const int32_t* __restrict__ ownE, double factor, double* __restrict__ ext, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (ownE && ownE[i] >= 0) { ext[i] = x[ownE[i]]; return; }
+    double acc = 0.0;
+    for (int k = start[i]; k < start[i + 1]; ++k) { const double t = factor * x[cellE[k]]; acc = fma(w[k], t, acc); }
+    ext[i] = acc;
+}
+__global__ void k_scale_range(double* __restrict__ v, double factor, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= factor;
+}
+double patch_factor(const mi_matrix_s* m, int32_t p) { return m->patchFactor.empty() ? 1.0 : m->patchFactor[(size_t)p]; }
+// x: engine-order vector; fills the ext values of every cyclicAMI patch from x's owned part
+int ami_fill(const mi_matrix_s* m, const double* x)
+{
+    mi_addr_s* a = m->addr;
+    double* ext = const_cast<double*>(x) + a->L.nCells;
+    for (const mi_addr_s::AmiPatch* q : a->ami) {
+        if (q->n == 0) continue;
+        k_ami_fill<<<(q->n + 255) / 256, 256, 0, a->ctx->stream>>>(x, q->start.p, q->cellE.p, q->w.p, q->hasLow ? q->ownE.p : nullptr, patch_factor(m, q->patch),
+                                                                    ext + q->extOff, q->n);
+    }
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+// received processor-patch values of a transformed (processorCyclic) patch: processorGAMGInterfaceField.C:213,230
+int scale_received(const mi_matrix_s* m, const double* x)
+{
+    if (m->patchFactor.empty()) return MI_OK;
+    mi_addr_s* a = m->addr;
+    for (int32_t p = 0; p < a->L.nPatches; ++p) {
+        const double f = m->patchFactor[(size_t)p];
+        const int n = a->L.patchOffset[(size_t)p + 1] - a->L.patchOffset[p];
+        if (f == 1.0 || n == 0 || a->patchIsLocal[(size_t)p]) continue;
+        k_scale_range<<<(n + 255) / 256, 256, 0, a->ctx->stream>>>(const_cast<double*>(x) + a->L.nCells + a->L.patchOffset[p], f, n);
+    }
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
 // Tile operator over all tiles.  With a communicator attached the neighbour values of the processor patches
 // are exchanged here (init/updateMatrixInterfaces, lduMatrixUpdateMatrixInterfaces.C:30-276): pack, send/recv
 // on the halo stream into x's ext region, interior tiles meanwhile, boundary tiles after the wait.  Without
@@ -556,13 +677,15 @@ int tile_op(mi_matrix_s* m, bool trans, const double* x, const double* b, const 
             double* dotPartial = nullptr, double* dotPartial2 = nullptr)
 {
     constexpr bool readsNbr = (OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_JACOBI);
-    if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial, dotPartial2);
     mi_addr_s* a = m->addr;
+    if (readsNbr && !a->ami.empty()) MICHK(ami_fill(m, x));
+    if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial, dotPartial2);
     if (m->sendBuf.n < (size_t)a->L.nExt) MICHK(m->sendBuf.alloc((size_t)a->L.nExt));
     MICHK(mi_halo_pack_engine(a, x, m->sendBuf.p));
     MICHK(comm_exchange_start(m, m->sendBuf.p, const_cast<double*>(x)));
     MICHK(launch_tile<OP>(m, trans, x, b, rD, y, omega, 1, dotPartial, dotPartial2));
     MICHK(comm_exchange_wait(m));
+    MICHK(scale_received(m, x));
     return launch_tile<OP>(m, trans, x, b, rD, y, omega, 2, dotPartial ? dotPartial + a->nInterior : nullptr, dotPartial2 ? dotPartial2 + a->nInterior : nullptr);
 }
 
@@ -1208,6 +1331,8 @@ extern "C" int mi_dpcg_set_buffers(mi_matrix_t m, double* psi_e, double* src_e, 
     if (!m || !psi_e || !src_e || !pA_e || !wA_e || !rA_e || !scal8 || !ctl) return fail(MI_ERR_ARG, "mi_dpcg_set_buffers: bad argument");
     if (precond != MI_PRECOND_DIAGONAL && precond != MI_PRECOND_NONE) return fail(MI_ERR_ARG, "distributed PCG supports the diagonal / none preconditioners");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
+    if (!m->addr->ami.empty() || !m->patchFactor.empty())
+        return fail(MI_ERR_UNSUPPORTED, "the phase-split distributed PCG does not interpolate cyclicAMI / transformed patches: use mi_pcg_solve on the attached matrix");
     mi_ctx_s* c = m->addr->ctx;
     HIPCHK(hipSetDevice(c->device));
     m->dp.psi = psi_e; m->dp.src = src_e; m->dp.pA = pA_e; m->dp.wA = wA_e; m->dp.rA = rA_e; m->dp.scal = scal8; m->dp.send = send_buf; m->dp.precond = precond;
@@ -1657,7 +1782,7 @@ extern "C" int mi_debug_occupancy(mi_matrix_t m, int32_t* blocks_per_cu, int32_t
     HIPCHK(hipSetDevice(a->ctx->device));
     int32_t o1, o2, o3, o4;
     const size_t lds = lds_bytes(a->L, m->asym, false, &o1, &o2, &o3, &o4);
-    const int bs = a->ctx->amulBS ? a->ctx->amulBS : ((lds > 53 * 1024) ? 1024 : 512);
+    const int bs = a->ctx->amulBS ? a->ctx->amulBS : ((lds > 53 * 1024) ? 1024 : (a->L.maxCells <= 256 ? 256 : 512));
     int nb = 0;
 #define MI_OCC(BS) { if (a->compact) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, BS, true>, BS, lds)); \
                      else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)tile_kernel<OP_AMUL, false, false, BS, false>, BS, lds)); }

@@ -41,6 +41,7 @@ class SolverControls(C.Structure):
 
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
+    "mi_addr_set_ami_patch", "mi_matrix_set_patch_transform",
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
@@ -236,6 +237,17 @@ class Addressing:
     def is_ordered(self) -> bool:
         return bool(lib().mi_addr_is_ordered(self.h))
 
+    def set_ami_patch(self, patch: int, nbr_patch: int, start=None, address=None, weights=None, low_weight=None):
+        """patch becomes a cyclicAMI patch coupled to nbr_patch (mi_addr_set_ami_patch); start None: one face to one face with
+        unit weights (a cyclic patch that carries a transformation factor)"""
+        ip = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        st, ad = ip(start), ip(address)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        lw = None if low_weight is None else np.ascontiguousarray(low_weight, dtype=np.uint8)
+        cp = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+        _chk(lib().mi_addr_set_ami_patch(self.h, C.c_int32(patch), C.c_int32(nbr_patch), cp(st, C.c_int32), cp(ad, C.c_int32),
+                                         cp(w, C.c_double), cp(lw, C.c_uint8)))
+
     def patch_offsets(self) -> np.ndarray:
         out = np.empty(len(self._patches) + 1, dtype=np.int32)
         _chk(lib().mi_addr_patch_offsets(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))))
@@ -331,6 +343,10 @@ class Matrix:
 
     def set_interface_coeffs(self, patch: int, bou, inte=None):
         _chk(lib().mi_matrix_set_interface_coeffs(self.h, C.c_int32(patch), _ptr(bou), _ptr(inte)))
+
+    def set_patch_transform(self, patch: int, factor: float):
+        """transformCoupleField factor of a coupled patch (mi_matrix_set_patch_transform)"""
+        _chk(lib().mi_matrix_set_patch_transform(self.h, C.c_int32(patch), C.c_double(factor)))
 
     def set_ext(self, ext):
         _chk(lib().mi_matrix_set_ext(self.h, _ptr(ext)))

@@ -58,6 +58,12 @@ class Interface:
     face_cells: np.ndarray  # int32 [Pf]
     bou_coeffs: np.ndarray  # float64 [Pf]  interfaceBouCoeffs
     int_coeffs: np.ndarray  # float64 [Pf]  interfaceIntCoeffs
+    # cyclicAMI (cyclicAMIFvPatchField): weights into the faces of the neighbour interface; None = one face to one face
+    ami_start: Optional[np.ndarray] = None   # int32 [Pf+1]
+    ami_addr: Optional[np.ndarray] = None    # int32 [ami_start[-1]] face index in the neighbour interface
+    ami_w: Optional[np.ndarray] = None       # float64
+    ami_low: Optional[np.ndarray] = None     # uint8 [Pf]: weight sum under lowWeightCorrection -> the face's own cell value
+    transform: float = 1.0                   # transformCoupleField factor (rotational cyclic, component solves)
 
 
 @dataclass
@@ -259,6 +265,65 @@ def add_cyclic_y(case: LduCase, kappa_scale: float = 1.0, asym_shift: float = 0.
     out.interfaces = [
         Interface(nbr_domain=0, nbr_patch=1, face_cells=ymin, bou_coeffs=-kappa, int_coeffs=-(kappa - sign * asym_shift * h)),
         Interface(nbr_domain=0, nbr_patch=0, face_cells=ymax, bou_coeffs=-(kappa - sign * asym_shift * h), int_coeffs=-kappa),
+    ]
+    return out
+
+
+def add_cyclic_ami_y(case: LduCase, shift: float = 0.37, low_weight_every: int = 0, transform: float = 1.0, seed: int = 71) -> LduCase:
+    """Couple the y-min and y-max boundary patches of the box through a NON-CONFORMAL interface (cyclicAMI): the y-max patch
+    is the y-min patch refined 1:2 in x and shifted by `shift` cells, so a y-min face overlaps up to three y-max faces and the
+    two sides have different sizes (nx*nz against 2*nx*nz: the y-max cells carry two patch faces each).  Weights are the
+    overlap fractions (area-normalised, AMIInterpolation::normaliseWeights), with a little seeded noise so that they are not
+    exactly representable; low_weight_every > 0 marks every n-th face of each side as a low-weight face."""
+    import copy
+    nx, ny, nz = case.dims
+    c = np.arange(case.n_cells, dtype=np.int64)
+    j = (c // nx) % ny
+    ymin = np.nonzero(j == 0)[0].astype(np.int32)                      # face f -> cell (i, 0, k), f = k*nx + i
+    ymax_cells = np.nonzero(j == ny - 1)[0].astype(np.int32)
+    ymax = np.repeat(ymax_cells, 2).astype(np.int32)                   # two half-width faces per cell: f = 2*(k*nx + i) + half
+    h = 1.0 / nx
+    sign = 1.0 if case.lower is None else -1.0
+
+    def overlaps(x0, x1, width, count):
+        """cells [m*width, (m+1)*width) of a periodic row of `count` cells overlapped by [x0, x1): (index, length) list"""
+        out = []
+        m = int(np.floor(x0 / width))
+        while m * width < x1 - 1e-14:
+            lo, hi = max(x0, m * width), min(x1, (m + 1) * width)
+            if hi - lo > 1e-14:
+                out.append((m % count, hi - lo))
+            m += 1
+        return out
+
+    # source side (y-min, width 1) sees the shifted target row (width 0.5); target side sees the source row
+    s_start, s_addr, s_w = [0], [], []
+    for k in range(nz):
+        for i in range(nx):
+            ov = overlaps(i + shift, i + 1 + shift, 0.5, 2 * nx)
+            for (m, ln) in ov:
+                s_addr.append(2 * k * nx + m); s_w.append(ln / 1.0)
+            s_start.append(len(s_addr))
+    t_start, t_addr, t_w = [0], [], []
+    for k in range(nz):
+        for m in range(2 * nx):
+            ov = overlaps(m * 0.5 - shift, (m + 1) * 0.5 - shift, 1.0, nx)
+            for (i, ln) in ov:
+                t_addr.append(k * nx + i); t_w.append(ln / 0.5)
+            t_start.append(len(t_addr))
+    s_w = np.array(s_w) * (1.0 + 1e-3 * (splitmix_uniform(seed, len(s_w)) - 0.5))
+    t_w = np.array(t_w) * (1.0 + 1e-3 * (splitmix_uniform(seed + 1, len(t_w)) - 0.5))
+    kap_s = sign * h * (0.8 + 0.4 * splitmix_uniform(seed + 2, ymin.shape[0]))
+    kap_t = sign * 0.5 * h * (0.8 + 0.4 * splitmix_uniform(seed + 3, ymax.shape[0]))
+    out = copy.copy(case)
+    out.diag = case.diag.copy()
+    np.subtract.at(out.diag, ymin, kap_s)
+    np.subtract.at(out.diag, ymax, kap_t)
+    low = lambda n: None if low_weight_every <= 0 else (np.arange(n) % low_weight_every == low_weight_every - 1).astype(np.uint8)
+    ic = 1.0 if case.lower is None else 0.9               # interfaceIntCoeffs (Tmul) differ from interfaceBouCoeffs only for asymmetric matrices
+    out.interfaces = [
+        Interface(0, 1, ymin, -kap_s, -kap_s * ic, np.array(s_start, np.int32), np.array(s_addr, np.int32), s_w, low(ymin.shape[0]), transform),
+        Interface(0, 0, ymax, -kap_t, -kap_t * ic, np.array(t_start, np.int32), np.array(t_addr, np.int32), t_w, low(ymax.shape[0]), transform),
     ]
     return out
 

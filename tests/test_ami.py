@@ -1,0 +1,218 @@
+"""cyclicAMI interfaces and transformed coupled patches: neighbour values interpolated with the AMI
+weights of the patch's side, transformCoupleField factor applied first, low-weight faces on their own cell's value.
+
+CPU: the oracle's interpolation against the REFERENCE's AMIInterpolationF.H functors compiled in place (oracle/_ref), and
+against a plain numpy reading.  GPU: every operator bit for bit, whole solvers, against the oracle on a non-conformal
+box interface whose two sides have different face counts (cyclicAMIFvPatchField.C:195-224, cyclicAMIGAMGInterfaceField.C:97-130)."""
+import numpy as np
+import pytest
+
+
+def naive_amul(pkg, orc, case, x):
+    """numpy reading of the interface update on top of the interface-free product"""
+    import copy
+    c0 = copy.copy(case); c0.interfaces = []
+    y = orc.System([c0]).amul(x)
+    for itf in case.interfaces:
+        ot = case.interfaces[itf.nbr_patch]
+        f = itf.transform * x[ot.face_cells]
+        for i in range(itf.face_cells.shape[0]):
+            if itf.ami_low is not None and itf.ami_low[i]:
+                pn = x[itf.face_cells[i]]
+            else:
+                sl = slice(itf.ami_start[i], itf.ami_start[i + 1])
+                pn = float(np.dot(itf.ami_w[sl], f[itf.ami_addr[sl]]))
+            y[itf.face_cells[i]] -= itf.bou_coeffs[i] * pn
+    return y
+
+
+def test_oracle_ami_interpolation_is_the_references_functor(pkg, orc):
+    if not orc.ref_ami_available():
+        pytest.skip("oracle/_ref/libref_ami.so not built (needs /root/reference)")
+    syn = pkg.synthetic
+    case = syn.add_cyclic_ami_y(syn.box_case(7, 5, 4), shift=0.41)
+    x = syn.splitmix_uniform(4, case.n_cells) - 0.5
+    # the oracle's pnf through a unit-coefficient interface on a zero matrix: Amul = -pnf scattered onto faceCells
+    for p, itf in enumerate(case.interfaces):
+        ot = case.interfaces[itf.nbr_patch]
+        ref = orc.ref_ami_interpolate(itf.ami_start, itf.ami_addr, itf.ami_w, x[ot.face_cells])
+        mine = np.array([np.nan] * itf.face_cells.shape[0])
+        for i in range(mine.shape[0]):                       # the oracle's chain, restated: out = fma(w, f, out) in address order
+            acc = 0.0
+            for k in range(itf.ami_start[i], itf.ami_start[i + 1]):
+                acc = float(np.float64(np.longdouble(itf.ami_w[k]) * np.longdouble(x[ot.face_cells[itf.ami_addr[k]]]) + np.longdouble(acc)))
+            mine[i] = acc
+        # long-double fma emulation is exact to 64 bits of mantissa: may differ from a true fma in rare double roundings
+        assert np.max(np.abs(ref - mine)) <= 2e-16 * np.max(np.abs(ref))
+        # low-weight correction: faces under the threshold return the default value, the others the sum
+        ws = np.add.reduceat(itf.ami_w, itf.ami_start[:-1])
+        thr = np.sort(ws)[ws.shape[0] // 3]
+        dflt = x[itf.face_cells]
+        ref_low = orc.ref_ami_interpolate(itf.ami_start, itf.ami_addr, itf.ami_w, x[ot.face_cells], thr, ws, dflt)
+        low = ws < thr
+        assert low.any() and not low.all()
+        assert np.array_equal(ref_low[low], dflt[low]) and np.array_equal(ref_low[~low], ref[~low])
+    # and the oracle's operator IS that chain: compare bitwise through a system whose only entries are the interface's
+    import copy
+    z = copy.copy(case)
+    z.diag = np.zeros(case.n_cells); z.upper = np.zeros(case.n_faces); z.lower = None
+    z.interfaces = [copy.copy(i) for i in case.interfaces]
+    for itf in z.interfaces:
+        itf.bou_coeffs = np.ones_like(itf.bou_coeffs); itf.int_coeffs = np.ones_like(itf.int_coeffs)
+    # one face per cell on side 0: Amul[faceCells[i]] = -pnf[i] exactly
+    y = orc.System([z]).amul(x)
+    itf, ot = z.interfaces[0], z.interfaces[1]
+    ref = orc.ref_ami_interpolate(itf.ami_start, itf.ami_addr, itf.ami_w, x[ot.face_cells])
+    assert np.array_equal(y[itf.face_cells], -ref)
+
+
+def test_oracle_ami_operator_against_numpy_and_unit_weights_reduce_to_cyclic(pkg, orc):
+    syn = pkg.synthetic
+    for sym in (True, False):
+        case = syn.add_cyclic_ami_y(syn.box_case(6, 5, 4, symmetric=sym), low_weight_every=5, transform=-0.75)
+        x = syn.splitmix_uniform(1, case.n_cells) - 0.5
+        y = orc.System([case]).amul(x)
+        assert np.max(np.abs(y - naive_amul(pkg, orc, case, x))) < 1e-15 * np.max(np.abs(y)) * 10
+    # one-to-one addressing with unit weights and factor 1 is the plain cyclic interface, bit for bit
+    import copy
+    cyc = syn.add_cyclic_y(syn.box_case(6, 5, 4))
+    ami = copy.copy(cyc); ami.interfaces = [copy.copy(i) for i in cyc.interfaces]
+    for itf in ami.interfaces:
+        n = itf.face_cells.shape[0]
+        itf.ami_start, itf.ami_addr, itf.ami_w = np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.ones(n)
+    x = syn.splitmix_uniform(2, cyc.n_cells) - 0.5
+    assert np.array_equal(orc.System([ami]).amul(x), orc.System([cyc]).amul(x))
+    assert np.array_equal(orc.System([ami]).jacobi_smooth(x, cyc.source, 2), orc.System([cyc]).jacobi_smooth(x, cyc.source, 2))
+
+
+# ---- GPU -----------------------------------------------------------------------------------------------------------------
+
+def _engine(pkg, ctx, case, ordered=False):
+    import torch
+    eng = pkg.engine
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    fcs = [i.face_cells for i in case.interfaces]
+    kw = {}
+    if ordered:
+        a0 = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, fcs)
+        case = pkg.synthetic.renumber(case, a0.cell_perm())
+        fcs = [i.face_cells for i in case.interfaces]
+        kw = dict(ordered=True, tile_cell_start=a0.tile_starts())
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, fcs, **kw)      # no neighbour cells: ext region
+    for p, itf in enumerate(case.interfaces):
+        if itf.ami_start is not None:
+            addr.set_ami_patch(p, itf.nbr_patch, itf.ami_start, itf.ami_addr, itf.ami_w, itf.ami_low)
+        else:
+            addr.set_ami_patch(p, itf.nbr_patch)
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    for p, itf in enumerate(case.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), dev(itf.int_coeffs))
+        if itf.transform != 1.0:
+            mat.set_patch_transform(p, itf.transform)
+    return case, addr, mat
+
+
+def _hist(perf, ref):
+    assert perf["nIterations"] == ref["nIterations"] and perf["converged"] == ref["converged"]
+    h, hr = perf["history"], ref["history"]
+    assert h.shape == hr.shape and np.max(np.abs(h - hr)) < 1e-10 * hr[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plain", "low_weight", "transformed", "ordered"])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_engine_cyclic_ami_bit_exact_and_solvers(pkg, orc, symmetric, variant):
+    import torch
+    syn, eng = pkg.synthetic, pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    host = lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1]
+    base = syn.box_case(18, 12, 10, symmetric=symmetric)
+    case = syn.add_cyclic_ami_y(base, shift=0.37, low_weight_every=7 if variant == "low_weight" else 0,
+                                transform=0.6 if variant == "transformed" else 1.0)
+    case, addr, mat = _engine(pkg, ctx, case, ordered=(variant == "ordered"))
+    assert addr.n_ext == sum(i.face_cells.shape[0] for i in case.interfaces)
+    S = orc.System([case])
+    n = case.n_cells
+    x = syn.splitmix_uniform(3, n) - 0.5
+    out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+    mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
+    mat.sumA(out); assert np.array_equal(host(out), S.sumA())
+    mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
+    mat.H(dev(x), out); assert np.array_equal(host(out), S.H(x))
+    for sweeps in (1, 2, 3):
+        psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), sweeps)
+        assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, sweeps))
+    # patchNeighbourField: the interpolated (and transformed) partner values, what enters result -= coeffs*pnf
+    nbr = torch.empty(addr.n_ext, dtype=torch.float64, device="cuda:0")
+    mat.patch_neighbour_field(dev(x), nbr)
+    got, off = host(nbr), 0
+    for itf in case.interfaces:
+        ot = case.interfaces[itf.nbr_patch]
+        m = itf.face_cells.shape[0]
+        for i in (0, m // 2, m - 1):
+            if itf.ami_low is not None and itf.ami_low[i]:
+                assert got[off + i] == x[itf.face_cells[i]]
+            else:
+                sl = slice(itf.ami_start[i], itf.ami_start[i + 1])
+                want = float(np.dot(itf.ami_w[sl], itf.transform * x[ot.face_cells[itf.ami_addr[sl]]]))
+                assert abs(got[off + i] - want) < 1e-14
+        off += m
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    src = dev(case.source)
+    if symmetric and variant != "transformed":   # (the transformed case goes through the bi-conjugate solvers below)
+        for pre in ("diagonal", "AINV"):
+            psi.zero_()
+            perf = mat.pcg(psi, src, pre, tolerance=1e-9, maxIter=500)
+            ref_psi, ref = S.pcg(np.zeros(n), case.source, pre, tolerance=1e-9, maxIter=500)
+            _hist(perf, ref)
+            assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+    else:
+        perf = mat.pbicg(psi, src, "DILU" if not symmetric else "diagonal", tolerance=1e-10, maxIter=400)
+        ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV" if not symmetric else "diagonal", tolerance=1e-10, maxIter=400)
+        _hist(perf, ref)
+        assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+        psi.zero_()
+        perf = mat.pbicgstab(psi, src, "diagonal", tolerance=1e-10, maxIter=400)
+        ref_psi, ref = S.pbicgstab(np.zeros(n), case.source, "diagonal", tolerance=1e-10, maxIter=400)
+        _hist(perf, ref)
+    psi.zero_()
+    perf = mat.smooth_solve(psi, src, n_sweeps=2, tolerance=1e-3, maxIter=60)
+    ref_psi, ref = S.smooth_solve(np.zeros(n), case.source, n_sweeps=2, tolerance=1e-3, maxIter=60)
+    _hist(perf, ref)
+    with pytest.raises(eng.MiError):                       # no AMI agglomeration in this build: stated, not silently wrong
+        eng.Gamg(addr, orc.box_face_weights(base), 10)
+
+
+@pytest.mark.gpu
+def test_engine_one_to_one_patch_with_unit_weights_is_the_cyclic_patch(pkg, orc):
+    """mi_addr_set_ami_patch without tables = a cyclic patch that can carry a transformation factor: with factor 1 the same
+    bits as the cyclic patch created with neighbour cells; with a factor, the oracle's transformed interface"""
+    import copy, torch
+    syn, eng = pkg.synthetic, pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    host = lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1]
+    cyc = syn.add_cyclic_y(syn.box_case(18, 12, 10))
+    x = syn.splitmix_uniform(9, cyc.n_cells) - 0.5
+    out = torch.empty(cyc.n_cells, dtype=torch.float64, device="cuda:0")
+    for factor in (1.0, 0.5, -1.0):
+        case = copy.copy(cyc); case.interfaces = [copy.copy(i) for i in cyc.interfaces]
+        for itf in case.interfaces:
+            itf.transform = factor
+        _, addr, mat = _engine(pkg, ctx, case)
+        S = orc.System([case])
+        mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+        psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 2)
+        assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 2))
+        if factor == 1.0:
+            assert np.array_equal(host(out), orc.System([cyc]).amul(x))
+    # a plain cyclic patch refuses a factor (it has no place to apply it): the error says how to declare it
+    fcs = [i.face_cells for i in cyc.interfaces]
+    nbrs = [cyc.interfaces[i.nbr_patch].face_cells for i in cyc.interfaces]
+    mat = eng.Matrix(eng.Addressing(ctx, cyc.n_cells, cyc.lower_addr, cyc.upper_addr, fcs, nbrs))
+    mat.set_patch_transform(0, 1.0)
+    with pytest.raises(eng.MiError):
+        mat.set_patch_transform(0, -1.0)

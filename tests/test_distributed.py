@@ -158,37 +158,43 @@ def test_distributed_pcg_real_engine_ragged_graph_random_partition(pkg, orc, tmp
 
 
 # ---- the engine's OWN (C++) loops with several ranks: communicators over the caller's transport (mi_comm_create_external) ----
-def _native_worker(rank, world, port, spec, out_dir):
+def _native_worker(rank, world, port, spec, out_dir, rccl=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    d = rank if rccl else 0                                   # RCCL: one device per rank; gloo transport: the ranks share device 0
+    torch.cuda.set_device(d)
+    if rccl:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", d))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as graft
     pkg = graft.load_package()
     from importlib import import_module
     par = import_module(graft.PKG_NAME + ".parallel")
-    torch.cuda.set_device(0)
-    ctx = pkg.engine.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx = pkg.engine.Context(d, torch.cuda.current_stream().cuda_stream)
     subs, weights = _native_case(pkg, spec, world)
     sub = subs[rank]
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
-    dm = par.DistributedMatrix(ctx, sub, "cuda:0", comms=par.make_host_comms(ctx))
+    dname = f"cuda:{d}"
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dname)
+    dm = par.DistributedMatrix(ctx, sub, dname, comms=par.make_comms(ctx) if rccl else par.make_host_comms(ctx))
     res = dict(cells=sub.global_cells, n_global=dm.n_global)
     x = pkg.synthetic.splitmix_uniform(3, dm.n_global)[sub.global_cells] - 0.5
-    out = torch.empty(sub.n_cells, dtype=torch.float64, device="cuda:0")
+    out = torch.empty(sub.n_cells, dtype=torch.float64, device=dname)
     dm.mat.amul(dev(x), out); torch.cuda.synchronize(); res["amul"] = out.cpu().numpy()
     for name, solver, kw in spec["solves"]:
         kw = dict(kw)
         if solver == "GAMG":
             kw["face_weights"] = weights[rank]
-        psi = torch.zeros(sub.n_cells, dtype=torch.float64, device="cuda:0")
+        psi = torch.zeros(sub.n_cells, dtype=torch.float64, device=dname)
         perf = dm.solve(solver, psi, dev(sub.source), **kw)
         torch.cuda.synchronize()
         res[name + "_psi"] = psi.cpu().numpy(); res[name + "_hist"] = perf["history"]; res[name + "_nit"] = perf["nIterations"]
     if any(s[1] == "GAMG" for s in spec["solves"]):
         res["gamg_levels"] = dm._gamg.n_levels
-    assert not dm.comms[0].errors, dm.comms[0].errors
+    assert rccl or not dm.comms[0].errors, dm.comms[0].errors
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -233,6 +239,22 @@ def test_native_attached_solvers_on_several_engine_ranks(pkg, orc, tmp_path, nam
     the multi-domain oracle on the same decomposition."""
     spec = NATIVE_SPECS[name]
     mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path)), nprocs=world, join=True)
+    _check_native(pkg, orc, spec, world, str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("box_2", 2), ("box_4_asym", 4)])
+def test_native_attached_solvers_over_rccl_one_device_per_rank(pkg, orc, tmp_path, name, world):
+    """the same loops over RCCL proper (mi_comm_create on ncclUniqueIds, one device per rank, xGMI between them): runs where
+    the box has that many GPUs -- the first multi-GPU lease executes it -- and skips on a single-GPU box"""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, {torch.cuda.device_count()} visible")
+    spec = NATIVE_SPECS[name]
+    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), True), nprocs=world, join=True)
+    _check_native(pkg, orc, spec, world, str(tmp_path))
+
+
+def _check_native(pkg, orc, spec, world, tmp_path):
     subs, weights = _native_case(pkg, spec, world)
     S = orc.System(subs)
     n = sum(s.n_cells for s in subs)
@@ -261,5 +283,5 @@ def test_native_attached_solvers_on_several_engine_ranks(pkg, orc, tmp_path, nam
         # the ranks' coarsest blocks differ in size, so their block offsets in the global coarsest system are distinct
         sizes = [H.level(d, H.n_levels - 2)["n_coarse"] for d in range(world)]
         assert all(v > 0 for v in sizes) and len(set(np.cumsum(sizes).tolist())) == world
-        if name != "box_2":
+        if world > 2 or spec["kind"] == "graph":
             assert len(set(sizes)) > 1 or world > 2
