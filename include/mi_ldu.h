@@ -122,11 +122,18 @@ int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
  * the sum by the face's own cell value, the default the reference passes (`pif`).  The two sides may differ in size.  Every
  * operator and solver that reads coupled-patch neighbour values interpolates them before its tile pass; no exchange.
  * start/address/weights all NULL: one face to one face with unit weight -- a cyclic (or processorCyclic-on-one-rank) patch
- * that needs its transformation factor (cyclicLduInterfaceField.C:45-62).  Not agglomerated for GAMG in this build
- * (AMIInterpolation::agglomerate, AMIInterpolation.C:279-540): mi_gamg_create returns MI_ERR_UNSUPPORTED on such a mesh. */
+ * that needs its transformation factor (cyclicLduInterfaceField.C:45-62).
+ * GAMG (mi_gamg_create on such an addressing; mergeLevels 1): every level carries the agglomerated AMI -- one coarse patch
+ * face per distinct local coarse cell in order of first appearance (cyclicAMIGAMGInterface.C:47-165), addresses and
+ * weights agglomerated with the face areas of mi_addr_set_ami_face_areas and renormalised (AMIInterpolation::agglomerate,
+ * AMIInterpolation.C:279-540; no low-weight correction on coarse levels, :751).  The coarsest level is solved iteratively:
+ * mi_gamg_solve wants directSolveCoarsest = 0 there, as the reference's direct coarsest solver casts every interface to a
+ * cyclic one (LUscalarMatrix.C:246-251) and cannot run such a case either.                                               */
 int mi_addr_set_ami_patch(mi_addr_t addr, int32_t patch, int32_t nbr_patch, const int32_t *start_host_or_null,
                           const int32_t *address_host_or_null, const double *weights_host_or_null,
                           const uint8_t *low_weight_host_or_null);
+/* face areas |Sf| of a cyclicAMI patch's faces (AMIInterpolation::srcMagSf / tgtMagSf), read by the GAMG agglomeration only */
+int mi_addr_set_ami_face_areas(mi_addr_t addr, int32_t patch, const double *mag_sf_host);
 /* ORDERED addressing -- the caller's numbering is kept: engine order == caller order, mi_addr_cell_perm is the identity and the
  * caller-order operators (mi_amul, mi_tmul, mi_residual, mi_H, mi_sumA, mi_precondition, mi_jacobi_smooth) run straight on the
  * caller's arrays, with no permutation passes (only an n_cells copy of the input where an operator reads coupled-patch

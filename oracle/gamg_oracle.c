@@ -25,6 +25,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,6 +33,8 @@
 
 /* from ldu_oracle.c */
 orc_system *orc_sys_create(int nDomains);
+void orc_sys_set_iface_ami(orc_system *s, int d, int p, const label *start, const label *addr, const scalar *w, const unsigned char *low);
+void orc_sys_set_iface_transform(orc_system *s, int d, int p, scalar factor);
 int orc_sys_add_interface(orc_system *s, int d, label nbrDomain, label nbrPatch, label nFaces, const label *faceCells,
                           const scalar *bouCoeffs, const scalar *intCoeffs);
 void orc_sys_set_domain(orc_system *s, int d, label nCells, label nFaces, const label *lower, const label *upper,
@@ -490,7 +493,53 @@ typedef struct {
     label nFine, nCoarse;      /* patch faces on the fine / coarse side of the level */
     label *faceRestrict;       /* [nFine] -> coarse interface face */
     label *faceCells;          /* [nCoarse] coarse cell on this side */
+    /* cyclicAMI: the agglomerated AMI of the coarse side (AMIInterpolation.C:279-540), NULL otherwise */
+    label *amiStart, *amiAddr; /* [nCoarse+1], [amiStart[nCoarse]] coarse face of the neighbour patch */
+    scalar *amiW, *amiMagSf;   /* weights (normalised per coarse face), agglomerated face areas [nCoarse] */
 } gamg_patch;
+
+/* AMIInterpolation::agglomerate (AMIInterpolation.C:279-540, the branch without a distribution map) for one side:
+ * fine faces in order, their addresses in order; an address whose coarse target is already in the coarse face's list adds
+ * fineArea*weight onto it, a new one is appended; then normaliseWeights(conformal = true): every list divided by its sum
+ * (AMIInterpolation.C:199-247).  Host arithmetic in the reference: a product, then an addition.                       */
+static void ami_agglomerate(label nFineSrc, const label *fStart, const label *fAddr, const scalar *fW, const scalar *fMagSf,
+                            const label *srcRestrict, const label *tgtRestrict, label nCoarseSrc, gamg_patch *P)
+{
+    label **el = (label **)calloc((size_t)(nCoarseSrc ? nCoarseSrc : 1), sizeof(label *));
+    scalar **wl = (scalar **)calloc((size_t)(nCoarseSrc ? nCoarseSrc : 1), sizeof(scalar *));
+    label *cnt = (label *)calloc((size_t)(nCoarseSrc ? nCoarseSrc : 1), sizeof(label));
+    P->amiMagSf = (scalar *)calloc((size_t)(nCoarseSrc ? nCoarseSrc : 1), sizeof(scalar));
+    for (label i = 0; i < nFineSrc; i++) P->amiMagSf[srcRestrict[i]] += fMagSf[i];
+    label total = 0;
+    for (label i = 0; i < nFineSrc; i++) {
+        const label I = srcRestrict[i];
+        const scalar fineArea = fMagSf[i];
+        for (label k = fStart[i]; k < fStart[i + 1]; k++) {
+            const label K = tgtRestrict[fAddr[k]];
+            label j;
+            for (j = 0; j < cnt[I]; j++) if (el[I][j] == K) break;
+            const scalar t = fineArea * fW[k];
+            if (j == cnt[I]) {
+                el[I] = (label *)realloc(el[I], sizeof(label) * (size_t)(cnt[I] + 1));
+                wl[I] = (scalar *)realloc(wl[I], sizeof(scalar) * (size_t)(cnt[I] + 1));
+                el[I][j] = K; wl[I][j] = t; cnt[I]++; total++;
+            } else wl[I][j] += t;
+        }
+    }
+    P->amiStart = (label *)malloc(sizeof(label) * (size_t)(nCoarseSrc + 1));
+    P->amiAddr = (label *)malloc(sizeof(label) * (size_t)(total ? total : 1));
+    P->amiW = (scalar *)malloc(sizeof(scalar) * (size_t)(total ? total : 1));
+    label at = 0;
+    for (label I = 0; I < nCoarseSrc; I++) {
+        P->amiStart[I] = at;
+        scalar sum = 0;
+        for (label j = 0; j < cnt[I]; j++) sum += wl[I][j];
+        for (label j = 0; j < cnt[I]; j++) { P->amiAddr[at] = el[I][j]; P->amiW[at] = wl[I][j] / sum; at++; }
+        free(el[I]); free(wl[I]);
+    }
+    P->amiStart[nCoarseSrc] = at;
+    free(el); free(wl); free(cnt);
+}
 
 typedef struct {
     int nDomains, nLevels, forwardOut;
@@ -519,6 +568,10 @@ gamg_sys_hier *orc_gamg_build_sys_merged(const orc_system *S, const scalar *face
     label *nFine = (label *)calloc((size_t)D, sizeof(label)), *nF = (label *)calloc((size_t)D, sizeof(label));
     label ***pfc = (label ***)calloc((size_t)D, sizeof(*pfc)); /* current fine faceCells [d][p] */
     label **pn = (label **)calloc((size_t)D, sizeof(*pn));     /* their sizes */
+    /* cyclicAMI patches: AMI tables of the current fine level (borrowed from the system on the finest level, from the
+     * previous level's gamg_patch afterwards) */
+    const label ***fAs = (const label ***)calloc((size_t)D, sizeof(*fAs)), ***fAa = (const label ***)calloc((size_t)D, sizeof(*fAa));
+    const scalar ***fAw = (const scalar ***)calloc((size_t)D, sizeof(*fAw)), ***fAm = (const scalar ***)calloc((size_t)D, sizeof(*fAm));
     int64_t woff = 0;
     for (int d = 0; d < D; d++) {
         const orc_domain *m = &S->dom[d];
@@ -530,10 +583,17 @@ gamg_sys_hier *orc_gamg_build_sys_merged(const orc_system *S, const scalar *face
         lo[d] = m->lower; up[d] = m->upper; nFine[d] = m->nCells; nF[d] = m->nFaces;
         pfc[d] = (label **)calloc((size_t)(m->nIfaces ? m->nIfaces : 1), sizeof(label *));
         pn[d] = (label *)calloc((size_t)(m->nIfaces ? m->nIfaces : 1), sizeof(label));
+        const size_t np1 = (size_t)(m->nIfaces ? m->nIfaces : 1);
+        fAs[d] = (const label **)calloc(np1, sizeof(label *)); fAa[d] = (const label **)calloc(np1, sizeof(label *));
+        fAw[d] = (const scalar **)calloc(np1, sizeof(scalar *)); fAm[d] = (const scalar **)calloc(np1, sizeof(scalar *));
         for (int p = 0; p < m->nIfaces; p++) {
             pn[d][p] = m->ifaces[p].nFaces;
             pfc[d][p] = (label *)malloc(sizeof(label) * (size_t)(pn[d][p] ? pn[d][p] : 1));
             memcpy(pfc[d][p], m->ifaces[p].faceCells, sizeof(label) * (size_t)pn[d][p]);
+            if (m->ifaces[p].amiStart) {
+                if (!m->ifaces[p].amiMagSf || mergeLevels != 1) { fprintf(stderr, "orc_gamg_build_sys: cyclicAMI interfaces need face areas (orc_sys_set_iface_magsf) and mergeLevels 1\n"); abort(); }
+                fAs[d][p] = m->ifaces[p].amiStart; fAa[d][p] = m->ifaces[p].amiAddr; fAw[d][p] = m->ifaces[p].amiW; fAm[d][p] = m->ifaces[p].amiMagSf;
+            }
         }
     }
     int forward = forwardInit, nPairLevels = 0;
@@ -570,6 +630,19 @@ gamg_sys_hier *orc_gamg_build_sys_merged(const orc_system *S, const scalar *face
                 P->faceCells = (label *)malloc(sizeof(label) * (size_t)(n ? n : 1));
                 label *nbr = (label *)malloc(sizeof(label) * (size_t)(n ? n : 1));
                 label nc = 0;
+                if (fAs[d][p]) {
+                    /* cyclicAMIGAMGInterface.C:66-110: one coarse face per distinct LOCAL coarse cell, first appearance */
+                    for (label i = 0; i < n; i++) {
+                        const label mine = H->lev[d][l].restrictMap[pfc[d][p][i]];
+                        label k;
+                        for (k = 0; k < nc; k++) if (P->faceCells[k] == mine) break;
+                        if (k == nc) { P->faceCells[nc] = mine; nc++; }
+                        P->faceRestrict[i] = k;
+                    }
+                    P->nCoarse = nc;
+                    free(nbr);
+                    continue;
+                }
                 for (label i = 0; i < n; i++) {
                     const label mine = H->lev[d][l].restrictMap[pfc[d][p][i]];
                     const label theirs = H->lev[nd][l].restrictMap[pfc[nd][np][i]];
@@ -580,6 +653,23 @@ gamg_sys_hier *orc_gamg_build_sys_merged(const orc_system *S, const scalar *face
                 }
                 P->nCoarse = nc;
                 free(nbr);
+            }
+        }
+        /* the AMI of the coarse side, from both sides' face agglomeration (cyclicAMIGAMGInterface.C:113-160 builds the
+         * neighbour's the way the neighbour does; here the neighbour's own is at hand) */
+        for (int d = 0; d < D; d++) {
+            const orc_domain *m = &S->dom[d];
+            for (int p = 0; p < m->nIfaces; p++) if (fAs[d][p]) {
+                const int nd = m->ifaces[p].nbrDomain, np = m->ifaces[p].nbrPatch;
+                gamg_patch *P = &H->patch[d][l][p];
+                ami_agglomerate(pn[d][p], fAs[d][p], fAa[d][p], fAw[d][p], fAm[d][p], P->faceRestrict, H->patch[nd][l][np].faceRestrict, P->nCoarse, P);
+            }
+        }
+        for (int d = 0; d < D; d++) {
+            const orc_domain *m = &S->dom[d];
+            for (int p = 0; p < m->nIfaces; p++) if (fAs[d][p]) {
+                const gamg_patch *P = &H->patch[d][l][p];
+                fAs[d][p] = P->amiStart; fAa[d][p] = P->amiAddr; fAw[d][p] = P->amiW; fAm[d][p] = P->amiMagSf;
             }
         }
         for (int d = 0; d < D; d++) {
@@ -612,9 +702,9 @@ gamg_sys_hier *orc_gamg_build_sys_merged(const orc_system *S, const scalar *face
     for (int d = 0; d < D; d++) {
         free(w[d]);
         for (int p = 0; p < S->dom[d].nIfaces; p++) free(pfc[d][p]);
-        free(pfc[d]); free(pn[d]);
+        free(pfc[d]); free(pn[d]); free(fAs[d]); free(fAa[d]); free(fAw[d]); free(fAm[d]);
     }
-    free(w); free(lo); free(up); free(nFine); free(nF); free(pfc); free(pn);
+    free(w); free(lo); free(up); free(nFine); free(nF); free(pfc); free(pn); free(fAs); free(fAa); free(fAw); free(fAm);
     return H;
 }
 
@@ -643,7 +733,10 @@ void orc_gamg_sys_free(gamg_sys_hier *H)
         for (int l = 0; l < H->nLevels; l++) {
             gamg_level *L = &H->lev[d][l];
             free(L->restrictMap); free(L->faceRestrict); free(L->faceFlip); free(L->cLower); free(L->cUpper);
-            for (int p = 0; p < H->nPatches[d]; p++) { free(H->patch[d][l][p].faceRestrict); free(H->patch[d][l][p].faceCells); }
+            for (int p = 0; p < H->nPatches[d]; p++) {
+                gamg_patch *P = &H->patch[d][l][p];
+                free(P->faceRestrict); free(P->faceCells); free(P->amiStart); free(P->amiAddr); free(P->amiW); free(P->amiMagSf);
+            }
             free(H->patch[d][l]);
         }
         free(H->lev[d]); free(H->patch[d]);
@@ -675,6 +768,8 @@ static orc_system *coarse_system(const gamg_sys_hier *H, int l, const orc_system
             scalar *ci = (scalar *)calloc((size_t)(P->nCoarse ? P->nCoarse : 1), sizeof(scalar));
             for (label i = 0; i < P->nFine; i++) { cb[P->faceRestrict[i]] += fm->ifaces[p].bouCoeffs[i]; ci[P->faceRestrict[i]] += fm->ifaces[p].intCoeffs[i]; }
             orc_sys_add_interface(C, d, fm->ifaces[p].nbrDomain, fm->ifaces[p].nbrPatch, P->nCoarse, P->faceCells, cb, ci);
+            if (P->amiStart) orc_sys_set_iface_ami(C, d, p, P->amiStart, P->amiAddr, P->amiW, NULL); /* no low-weight correction on coarse levels (AMIInterpolation.C:751) */
+            orc_sys_set_iface_transform(C, d, p, fm->ifaces[p].factor);                               /* doTransform_/rank_ are the fine interface's (cyclicAMIGAMGInterfaceField.C:63-68) */
             free(cb); free(ci);
         }
     }

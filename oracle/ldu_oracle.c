@@ -142,7 +142,7 @@ int orc_sys_add_interface(orc_system *s, int d, label nbrDomain, label nbrPatch,
     p->faceCells = (label *)dupmem(faceCells, sizeof(label) * (size_t)nFaces);
     p->bouCoeffs = (scalar *)dupmem(bouCoeffs, sizeof(scalar) * (size_t)nFaces);
     p->intCoeffs = (scalar *)dupmem(intCoeffs, sizeof(scalar) * (size_t)nFaces);
-    p->amiStart = p->amiAddr = NULL; p->amiW = NULL; p->amiLow = NULL; p->factor = 1.0;
+    p->amiStart = p->amiAddr = NULL; p->amiW = NULL; p->amiLow = NULL; p->amiMagSf = NULL; p->factor = 1.0;
     return m->nIfaces++;
 }
 
@@ -155,6 +155,12 @@ void orc_sys_set_iface_ami(orc_system *s, int d, int p, const label *start, cons
     q->amiAddr = (label *)dupmem(addr, sizeof(label) * (size_t)(na ? na : 1));
     q->amiW = (scalar *)dupmem(w, sizeof(scalar) * (size_t)(na ? na : 1));
     q->amiLow = low ? (unsigned char *)dupmem(low, (size_t)(n ? n : 1)) : NULL;
+}
+void orc_sys_set_iface_magsf(orc_system *s, int d, int p, const scalar *magSf)
+{
+    orc_iface *q = &s->dom[d].ifaces[p];
+    free(q->amiMagSf);
+    q->amiMagSf = (scalar *)dupmem(magSf, sizeof(scalar) * (size_t)(q->nFaces ? q->nFaces : 1));
 }
 /* transformCoupleField factor of interface p (cyclicLduInterfaceField.C:45-62, processorGAMGInterfaceField.C:213) */
 void orc_sys_set_iface_transform(orc_system *s, int d, int p, scalar factor) { s->dom[d].ifaces[p].factor = factor; }
@@ -172,7 +178,7 @@ void orc_sys_destroy(orc_system *s)
         if (!m->symmetric) free(m->lowerC);
         for (i = 0; i < m->nIfaces; i++) {
             free(m->ifaces[i].faceCells); free(m->ifaces[i].bouCoeffs); free(m->ifaces[i].intCoeffs);
-            free(m->ifaces[i].amiStart); free(m->ifaces[i].amiAddr); free(m->ifaces[i].amiW); free(m->ifaces[i].amiLow);
+            free(m->ifaces[i].amiStart); free(m->ifaces[i].amiAddr); free(m->ifaces[i].amiW); free(m->ifaces[i].amiLow); free(m->ifaces[i].amiMagSf);
         }
         free(m->ifaces);
     }

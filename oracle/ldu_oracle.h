@@ -18,6 +18,7 @@ typedef struct {
     label *amiStart, *amiAddr;
     scalar *amiW;
     unsigned char *amiLow;
+    scalar *amiMagSf;  /* [nFaces] face areas of this side (srcMagSf / tgtMagSf): only the GAMG agglomeration of the AMI reads them */
     scalar factor;     /* transformCoupleField: pow(diag(forwardT).component(cmpt), rank); 1 = no transformation */
 } orc_iface;
 

@@ -92,6 +92,8 @@ class System:
                     low = None if itf.ami_low is None else np.ascontiguousarray(itf.ami_low, dtype=np.uint8)
                     L.orc_sys_set_iface_ami(self.h, d, p, _p(_i(itf.ami_start), C.c_int32), _p(_i(itf.ami_addr), C.c_int32),
                                             _p(_d(itf.ami_w), C.c_double), _p(low, C.c_uint8))
+                if getattr(itf, "ami_magsf", None) is not None:
+                    L.orc_sys_set_iface_magsf(self.h, d, p, _p(_d(itf.ami_magsf), C.c_double))
                 if getattr(itf, "transform", 1.0) != 1.0:
                     L.orc_sys_set_iface_transform(self.h, d, p, C.c_double(itf.transform))
         self.n = int(L.orc_sys_size(self.h))

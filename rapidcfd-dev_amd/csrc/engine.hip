@@ -113,7 +113,11 @@ struct mi_addr_s {
     int64_t nEntries = 0, nHaloTot = 0;
     // cyclicAMI patches (mi_addr_set_ami_patch): declared like processor patches (ext region), their neighbour values are
     // interpolated locally from the partner patch's cells before every operator that reads them
-    struct AmiPatch { int32_t patch = 0, nbrPatch = 0, n = 0, extOff = 0; DevBuf<int32_t> start, cellE, ownE; DevBuf<double> w; bool hasLow = false; };
+    struct AmiPatch {
+        int32_t patch = 0, nbrPatch = 0, n = 0, extOff = 0;
+        DevBuf<int32_t> start, cellE, ownE; DevBuf<double> w; bool hasLow = false;
+        std::vector<int32_t> hStart, hAddr; std::vector<double> hW, hMagSf; // host copies: the GAMG builder agglomerates them
+    };
     std::vector<AmiPatch*> ami;
     ~mi_addr_s() { for (AmiPatch* q : ami) delete q; }
     bool identity = false; // engine order == caller order (ordered addressing, or a mesh whose numbering happens to be tile-contiguous)
@@ -391,6 +395,8 @@ extern "C" int mi_addr_set_ami_patch(mi_addr_t a, int32_t patch, int32_t nbr_pat
     }
     mi_addr_s::AmiPatch* q = new mi_addr_s::AmiPatch();
     q->patch = patch; q->nbrPatch = nbr_patch; q->n = n; q->extOff = a->L.patchOffset[(size_t)patch];
+    q->hStart = st; q->hW = w;
+    if (start) q->hAddr.assign(address, address + start[n]); else { q->hAddr.resize((size_t)n); for (int32_t i = 0; i < n; ++i) q->hAddr[i] = i; }
     if (low_weight) {
         own.assign((size_t)n, -1);
         for (int32_t i = 0; i < n; ++i) if (low_weight[i]) { own[i] = a->L.c2e[(size_t)mine[i]]; q->hasLow = true; }
@@ -406,6 +412,13 @@ extern "C" int mi_addr_set_ami_patch(mi_addr_t a, int32_t patch, int32_t nbr_pat
     a->patchIsLocal[(size_t)patch] = 2; // no exchange: the values come from this rank's own cells
     a->nLocalPatches++;
     return MI_OK;
+}
+
+extern "C" int mi_addr_set_ami_face_areas(mi_addr_t a, int32_t patch, const double* mag_sf)
+{
+    if (!a || !mag_sf) return fail(MI_ERR_ARG, "mi_addr_set_ami_face_areas: bad argument");
+    for (mi_addr_s::AmiPatch* q : a->ami) if (q->patch == patch) { q->hMagSf.assign(mag_sf, mag_sf + q->n); return MI_OK; }
+    return fail(MI_ERR_ARG, "mi_addr_set_ami_face_areas: not a cyclicAMI patch");
 }
 
 extern "C" int mi_matrix_set_patch_transform(mi_matrix_t m, int32_t patch, double factor)

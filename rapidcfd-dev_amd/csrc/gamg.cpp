@@ -132,7 +132,14 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
     const int32_t *lo = lower, *up = upper;
     const int32_t nPatches = cpl ? cpl->nPatches : 0;
     std::vector<std::vector<int32_t>> pfc, pnb; // patch faceCells / local neighbour cells of the current fine level
-    if (cpl) { pfc = cpl->faceCells; pnb = cpl->nbrCells; }
+    std::vector<GamgCoupling::Ami> pami;        // AMI tables of the current fine level (cyclicAMI patches)
+    if (cpl) { pfc = cpl->faceCells; pnb = cpl->nbrCells; pami = cpl->ami; pami.resize((size_t)nPatches); }
+    for (int32_t p = 0; p < nPatches; ++p) if (cpl->isLocal[p] == 2) {
+        if (mergeLevels != 1) return "cyclicAMI patches are agglomerated with mergeLevels 1 only";
+        const GamgCoupling::Ami& A = pami[(size_t)p];
+        if (A.nbrPatch < 0 || A.nbrPatch >= nPatches || A.start.size() != pfc[p].size() + 1 || A.magSf.size() != pfc[p].size())
+            return "cyclicAMI patch without complete AMI tables / face areas (mi_addr_set_ami_face_areas)";
+    }
     int nPairLevels = 0;
     while ((int)H.levels.size() < maxLevels - 1) {
         GamgLevelHost L;
@@ -153,6 +160,7 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
             for (int32_t p = 0; p < nPatches; ++p) {
                 mine[p].resize(pfc[p].size());
                 for (size_t i = 0; i < pfc[p].size(); ++i) mine[p][i] = L.restrictMap[pfc[p][i]];
+                if (cpl->isLocal[p] == 2) continue; // cyclicAMI: no face-to-face partner
                 if (cpl->isLocal[p]) {
                     theirs[p].resize(pnb[p].size());
                     for (size_t i = 0; i < pnb[p].size(); ++i) theirs[p][i] = L.restrictMap[pnb[p][i]];
@@ -168,7 +176,24 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                 }
             }
             L.patches.resize((size_t)nPatches);
+            for (int32_t p = 0; p < nPatches; ++p) if (cpl->isLocal[p] == 2) { // keyed by the local coarse cell alone, first appearance
+                GamgPatchHost& P = L.patches[p];
+                std::unordered_map<int32_t, int32_t> cellToFace;
+                P.faceRestrict.resize(mine[p].size());
+                for (size_t i = 0; i < mine[p].size(); ++i) {
+                    auto it = cellToFace.find(mine[p][i]);
+                    if (it == cellToFace.end()) {
+                        const int32_t k = (int32_t)P.faceCells.size();
+                        cellToFace.emplace(mine[p][i], k);
+                        P.faceCells.push_back(mine[p][i]);
+                        P.faceRestrict[i] = k;
+                    } else P.faceRestrict[i] = it->second;
+                }
+                segment((int32_t)P.faceCells.size(), P.faceRestrict, P.childStart, P.child);
+                pfc[p] = P.faceCells;
+            }
             for (int32_t p = 0; p < nPatches; ++p) {
+                if (cpl->isLocal[p] == 2) continue;
                 GamgPatchHost& P = L.patches[p];
                 std::unordered_map<uint64_t, int32_t> pairToFace;
                 pairToFace.reserve(mine[p].size() * 2);
@@ -187,6 +212,44 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                 pfc[p] = P.faceCells;
                 if (cpl->isLocal[p]) pnb[p] = P.nbrCells;
             }
+            // the coarse AMI of every cyclicAMI patch: fine faces in order, their addresses in order; an address whose coarse
+            // target is already listed adds fineArea*weight, a new one is appended; then every list is divided by its sum
+            // (normaliseWeights with conformal = true).  Host arithmetic of the reference: product, then addition.
+            std::vector<GamgCoupling::Ami> next((size_t)nPatches);
+            for (int32_t p = 0; p < nPatches; ++p) if (cpl->isLocal[p] == 2) {
+                const GamgCoupling::Ami& F = pami[(size_t)p];
+                GamgPatchHost& P = L.patches[p];
+                const std::vector<int32_t>& srcR = P.faceRestrict;
+                const std::vector<int32_t>& tgtR = L.patches[(size_t)F.nbrPatch].faceRestrict;
+                const size_t nc = P.faceCells.size();
+                std::vector<std::vector<int32_t>> el(nc);
+                std::vector<std::vector<double>> wl(nc);
+                P.amiMagSf.assign(nc, 0.0);
+                for (size_t i = 0; i < srcR.size(); ++i) P.amiMagSf[(size_t)srcR[i]] += F.magSf[i];
+                for (size_t i = 0; i < srcR.size(); ++i) {
+                    std::vector<int32_t>& e = el[(size_t)srcR[i]];
+                    std::vector<double>& ww = wl[(size_t)srcR[i]];
+                    const double fineArea = F.magSf[i];
+                    for (int32_t k = F.start[i]; k < F.start[i + 1]; ++k) {
+                        const int32_t K = tgtR[(size_t)F.addr[(size_t)k]];
+                        const double t = fineArea * F.w[(size_t)k];
+                        size_t j = 0;
+                        while (j < e.size() && e[j] != K) ++j;
+                        if (j == e.size()) { e.push_back(K); ww.push_back(t); }
+                        else ww[j] += t;
+                    }
+                }
+                P.amiStart.assign(nc + 1, 0);
+                for (size_t I = 0; I < nc; ++I) {
+                    double sum = 0.0;
+                    for (double v : wl[I]) sum += v;
+                    for (size_t j = 0; j < el[I].size(); ++j) { P.amiAddr.push_back(el[I][j]); P.amiW.push_back(wl[I][j] / sum); }
+                    P.amiStart[I + 1] = (int32_t)P.amiAddr.size();
+                }
+                GamgCoupling::Ami& N = next[(size_t)p];
+                N.nbrPatch = F.nbrPatch; N.start = P.amiStart; N.addr = P.amiAddr; N.w = P.amiW; N.magSf = P.amiMagSf;
+            }
+            for (int32_t p = 0; p < nPatches; ++p) if (cpl->isLocal[p] == 2) pami[(size_t)p] = std::move(next[(size_t)p]);
         }
         if (nPairLevels % mergeLevels) {
             // GAMGAgglomeration::combineLevels (GAMGAgglomerateLduAddressing.C:606-760): fold this pair step into the

@@ -22,6 +22,10 @@ struct GamgPatchHost {
     std::vector<int32_t> nbrCells;      // [nCoarseIfaceFaces] coarse cell on the other side (its owner's numbering)
     std::vector<int32_t> faceRestrict;  // [nFineIfaceFaces] -> coarse interface face
     std::vector<int32_t> childStart, child; // fine patch faces of every coarse interface face, ascending
+    // cyclicAMI patch (cyclicAMIGAMGInterface.C:47-165): one coarse face per distinct LOCAL coarse cell; the AMI of the coarse
+    // side is the fine one agglomerated over both sides' face maps (AMIInterpolation::agglomerate, AMIInterpolation.C:279-540)
+    std::vector<int32_t> amiStart, amiAddr; // [nCoarse+1], coarse face of the neighbour patch
+    std::vector<double> amiW, amiMagSf;     // weights normalised per coarse face; agglomerated face areas
 };
 
 struct GamgLevelHost {
@@ -46,7 +50,9 @@ struct GamgCoupling {
     int32_t nPatches = 0;
     std::vector<std::vector<int32_t>> faceCells;   // finest level, per patch
     std::vector<std::vector<int32_t>> nbrCells;    // finest level, per patch; empty vector = processor patch
-    std::vector<char> isLocal;                     // per patch
+    std::vector<char> isLocal;                     // per patch: 0 processor, 1 cyclic (nbrCells), 2 cyclicAMI (ami tables)
+    struct Ami { int32_t nbrPatch = -1; std::vector<int32_t> start, addr; std::vector<double> w, magSf; };
+    std::vector<Ami> ami;                          // per patch (nbrPatch < 0: not an AMI patch); finest level
     bool (*allAnd)(void* user, bool v) = nullptr;
     // in: send[p] = local coarse ids of patch p's cells (processor patches only); out: recv[p] same length
     bool (*nbrRestrict)(void* user, int level, const std::vector<std::vector<int32_t>>& send, std::vector<std::vector<int32_t>>& recv) = nullptr;

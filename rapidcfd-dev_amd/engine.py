@@ -41,7 +41,7 @@ class SolverControls(C.Structure):
 
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
-    "mi_addr_set_ami_patch", "mi_matrix_set_patch_transform",
+    "mi_addr_set_ami_patch", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
@@ -247,6 +247,11 @@ class Addressing:
         cp = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if a is not None else None
         _chk(lib().mi_addr_set_ami_patch(self.h, C.c_int32(patch), C.c_int32(nbr_patch), cp(st, C.c_int32), cp(ad, C.c_int32),
                                          cp(w, C.c_double), cp(lw, C.c_uint8)))
+
+    def set_ami_face_areas(self, patch: int, mag_sf):
+        """face areas of a cyclicAMI patch (srcMagSf / tgtMagSf): the GAMG hierarchy agglomerates the AMI with them"""
+        a = np.ascontiguousarray(mag_sf, dtype=np.float64)
+        _chk(lib().mi_addr_set_ami_face_areas(self.h, C.c_int32(patch), a.ctypes.data_as(C.POINTER(C.c_double))))
 
     def patch_offsets(self) -> np.ndarray:
         out = np.empty(len(self._patches) + 1, dtype=np.int32)

@@ -63,6 +63,7 @@ class Interface:
     ami_addr: Optional[np.ndarray] = None    # int32 [ami_start[-1]] face index in the neighbour interface
     ami_w: Optional[np.ndarray] = None       # float64
     ami_low: Optional[np.ndarray] = None     # uint8 [Pf]: weight sum under lowWeightCorrection -> the face's own cell value
+    ami_magsf: Optional[np.ndarray] = None   # float64 [Pf] face areas of this side (GAMG agglomerates the AMI with them)
     transform: float = 1.0                   # transformCoupleField factor (rotational cyclic, component solves)
 
 
@@ -325,6 +326,8 @@ def add_cyclic_ami_y(case: LduCase, shift: float = 0.37, low_weight_every: int =
         Interface(0, 1, ymin, -kap_s, -kap_s * ic, np.array(s_start, np.int32), np.array(s_addr, np.int32), s_w, low(ymin.shape[0]), transform),
         Interface(0, 0, ymax, -kap_t, -kap_t * ic, np.array(t_start, np.int32), np.array(t_addr, np.int32), t_w, low(ymax.shape[0]), transform),
     ]
+    out.interfaces[0].ami_magsf = h * h * (1.0 + 0.05 * splitmix_uniform(seed + 4, ymin.shape[0]))
+    out.interfaces[1].ami_magsf = 0.5 * h * h * (1.0 + 0.05 * splitmix_uniform(seed + 5, ymax.shape[0]))
     return out
 
 

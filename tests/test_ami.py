@@ -104,6 +104,8 @@ def _engine(pkg, ctx, case, ordered=False):
             addr.set_ami_patch(p, itf.nbr_patch, itf.ami_start, itf.ami_addr, itf.ami_w, itf.ami_low)
         else:
             addr.set_ami_patch(p, itf.nbr_patch)
+        if itf.ami_magsf is not None:
+            addr.set_ami_face_areas(p, itf.ami_magsf)
     mat = eng.Matrix(addr)
     mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
     for p, itf in enumerate(case.interfaces):
@@ -170,20 +172,20 @@ def test_engine_cyclic_ami_bit_exact_and_solvers(pkg, orc, symmetric, variant):
             _hist(perf, ref)
             assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
     else:
-        perf = mat.pbicg(psi, src, "DILU" if not symmetric else "diagonal", tolerance=1e-10, maxIter=400)
-        ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV" if not symmetric else "diagonal", tolerance=1e-10, maxIter=400)
+        # (tolerance 1e-8: bi-conjugate residuals wander, and at 1e-10 the two histories -- equal to 1e-10 of the initial
+        #  residual -- can sit on either side of the threshold in the last iteration)
+        perf = mat.pbicg(psi, src, "DILU" if not symmetric else "diagonal", tolerance=1e-8, maxIter=400)
+        ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV" if not symmetric else "diagonal", tolerance=1e-8, maxIter=400)
         _hist(perf, ref)
-        assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+        assert np.max(np.abs(host(psi) - ref_psi)) < 1e-7 * np.max(np.abs(ref_psi))
         psi.zero_()
-        perf = mat.pbicgstab(psi, src, "diagonal", tolerance=1e-10, maxIter=400)
-        ref_psi, ref = S.pbicgstab(np.zeros(n), case.source, "diagonal", tolerance=1e-10, maxIter=400)
+        perf = mat.pbicgstab(psi, src, "diagonal", tolerance=1e-8, maxIter=400)
+        ref_psi, ref = S.pbicgstab(np.zeros(n), case.source, "diagonal", tolerance=1e-8, maxIter=400)
         _hist(perf, ref)
     psi.zero_()
     perf = mat.smooth_solve(psi, src, n_sweeps=2, tolerance=1e-3, maxIter=60)
     ref_psi, ref = S.smooth_solve(np.zeros(n), case.source, n_sweeps=2, tolerance=1e-3, maxIter=60)
     _hist(perf, ref)
-    with pytest.raises(eng.MiError):                       # no AMI agglomeration in this build: stated, not silently wrong
-        eng.Gamg(addr, orc.box_face_weights(base), 10)
 
 
 @pytest.mark.gpu
@@ -216,3 +218,35 @@ def test_engine_one_to_one_patch_with_unit_weights_is_the_cyclic_patch(pkg, orc)
     mat.set_patch_transform(0, 1.0)
     with pytest.raises(eng.MiError):
         mat.set_patch_transform(0, -1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plain", "transformed"])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_engine_gamg_with_agglomerated_ami(pkg, orc, symmetric, variant):
+    """GAMG on a mesh with a cyclicAMI pair: every level carries the agglomerated AMI (cyclicAMIGAMGInterface.C:47-165,
+    AMIInterpolation::agglomerate), the coarsest level is solved by ICCG / BICCG (the reference's direct coarsest solver
+    only knows cyclic interfaces).  Cycle-by-cycle residuals against the oracle's hierarchy."""
+    import torch
+    syn, eng = pkg.synthetic, pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    host = lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1]
+    base = syn.box_case(20, 16, 12, symmetric=symmetric)
+    case = syn.add_cyclic_ami_y(base, shift=0.37, transform=0.6 if variant == "transformed" else 1.0)
+    case, addr, mat = _engine(pkg, ctx, case)
+    w = orc.box_face_weights(base)
+    S = orc.System([case])
+    H = orc.GamgSysHierarchy(S, [w], 10)
+    G = eng.Gamg(addr, w, 10)
+    assert G.n_levels == H.n_levels and H.n_levels >= 4
+    n = case.n_cells
+    kw = dict(tolerance=1e-9, maxIter=60, directSolveCoarsest=False)
+    ref_psi, ref = H.solve(np.zeros(n), case.source, **kw)
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    perf = G.solve(mat, psi, dev(case.source), **kw)
+    assert ref["converged"]
+    _hist(perf, ref)
+    assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+    with pytest.raises(eng.MiError):                       # as in the reference: no direct coarsest solver with cyclicAMI interfaces
+        G.solve(mat, psi, dev(case.source), tolerance=1e-9, maxIter=5, directSolveCoarsest=True)
