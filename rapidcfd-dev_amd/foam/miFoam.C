@@ -83,7 +83,9 @@ lduAddressing::lduAddressing(label nCells, const labelList& lower, const labelLi
         if (i.type == "cyclic" && (i.neighbPatchID < 0 || i.neighbPatchID >= (label)interfaces_.size() ||
                                     interfaces_[i.neighbPatchID].faceCells.size() != i.faceCells.size()))
             FatalErrorIn("lduAddressing::lduAddressing", "cyclic patch without a matching neighbour patch");
-        if (i.type != "cyclic" && i.type != "processor" && i.type != "coupled") FatalErrorIn("lduAddressing::lduAddressing", "Unknown interface type " + i.type);
+        if (i.type == "cyclicAMI" && (i.neighbPatchID < 0 || i.neighbPatchID >= (label)interfaces_.size() || i.amiStart.size() != i.faceCells.size() + 1))
+            FatalErrorIn("lduAddressing::lduAddressing", "cyclicAMI patch without a neighbour patch / AMI addressing");
+        if (i.type != "cyclic" && i.type != "processor" && i.type != "coupled" && i.type != "cyclicAMI") FatalErrorIn("lduAddressing::lduAddressing", "Unknown interface type " + i.type);
     }
 }
 lduAddressing::~lduAddressing() { if (gamg_) mi_gamg_destroy(gamg_); if (addr_) mi_addr_destroy(addr_); }
@@ -93,10 +95,20 @@ mi_addr_t lduAddressing::handle() const
         std::vector<label> sizes; std::vector<const label*> ptrs, nbrs;
         for (std::size_t p = 0; p < patchAddr_.size(); ++p) {
             sizes.push_back((label)patchAddr_[p].size()); ptrs.push_back(patchAddr_[p].data());
-            nbrs.push_back(interfaces_[p].type == "cyclic" ? patchAddr_[(std::size_t)interfaces_[p].neighbPatchID].data() : nullptr);
+            const bool plainCyclic = interfaces_[p].type == "cyclic" && !interfaces_[p].transforms;
+            nbrs.push_back(plainCyclic ? patchAddr_[(std::size_t)interfaces_[p].neighbPatchID].data() : nullptr);
         }
         miCheck(mi_addr_create_coupled(miEngine::New().ctx, size_, (label)lower_.size(), lower_.data(), upper_.data(), (label)sizes.size(),
                                        sizes.data(), ptrs.data(), nbrs.data(), &addr_), "lduAddressing::handle()");
+        for (std::size_t p = 0; p < interfaces_.size(); ++p) {
+            const lduInterface& i = interfaces_[p];
+            if (i.type == "cyclicAMI") {
+                miCheck(mi_addr_set_ami_patch(addr_, (label)p, i.neighbPatchID, i.amiStart.data(), i.amiAddress.data(), i.amiWeights.data(),
+                                              i.amiLowWeight.empty() ? nullptr : i.amiLowWeight.data()), "cyclicAMILduInterface");
+                if (!i.amiMagSf.empty()) miCheck(mi_addr_set_ami_face_areas(addr_, (label)p, i.amiMagSf.data()), "cyclicAMILduInterface");
+            } else if (i.type == "cyclic" && i.transforms)
+                miCheck(mi_addr_set_ami_patch(addr_, (label)p, i.neighbPatchID, nullptr, nullptr, nullptr, nullptr), "cyclicLduInterface (transformed)");
+        }
     }
     return addr_;
 }
@@ -150,6 +162,10 @@ void lduMatrix::sync(const FieldFieldScalar* bou, const FieldFieldScalar* inte, 
     for (label p = 0; p < nP; ++p) {
         const label n = (label)lduAddr_.patchAddr(p).size();
         miCheck(mi_matrix_set_interface_coeffs(mat_, p, (*bou)[p].data(), inte && (label)inte->size() == nP ? (*inte)[p].data() : nullptr), "lduMatrix::sync");
+        if ((*ifs)[p]->doTransform() || transformSet_) { // transformCoupleField(pnf, cmpt) of this solve's component
+            miCheck(mi_matrix_set_patch_transform(mat_, p, (*ifs)[p]->transformFactor(cmpt_)), "lduMatrix::sync");
+            transformSet_ = true;
+        }
         if (callerExt && n) miCopyD2D(ext.data() + off, (*ifs)[p]->patchNeighbourField.data(), sizeof(scalar) * n);
         off += n;
     }
@@ -165,12 +181,13 @@ void lduMatrix::sync(const FieldFieldScalar* bou, const FieldFieldScalar* inte, 
     }
     mi_ctx_synchronize(miEngine::New().ctx);
 }
-void lduMatrix::Amul(scalargpuField& Apsi, const scalargpuField& psi, const FieldFieldScalar& b, const lduInterfaceFieldPtrsList& ifs, direction) const
+void lduMatrix::Amul(scalargpuField& Apsi, const scalargpuField& psi, const FieldFieldScalar& b, const lduInterfaceFieldPtrsList& ifs, direction cmpt) const
 {
-    sync(&b, nullptr, &ifs); miCheck(mi_amul(mat_, psi.data(), Apsi.data()), "lduMatrix::Amul");
+    cmpt_ = cmpt; sync(&b, nullptr, &ifs); miCheck(mi_amul(mat_, psi.data(), Apsi.data()), "lduMatrix::Amul");
 }
-void lduMatrix::Tmul(scalargpuField& Tpsi, const scalargpuField& psi, const FieldFieldScalar& i, const lduInterfaceFieldPtrsList& ifs, direction) const
+void lduMatrix::Tmul(scalargpuField& Tpsi, const scalargpuField& psi, const FieldFieldScalar& i, const lduInterfaceFieldPtrsList& ifs, direction cmpt) const
 {
+    cmpt_ = cmpt;
     // Tmul uses interfaceIntCoeffs (lduMatrixATmul.C:264-342): pass them in both slots so the engine's lower side holds them
     sync(&i, &i, &ifs); miCheck(mi_tmul(mat_, psi.data(), Tpsi.data()), "lduMatrix::Tmul");
     dirty_ = true;
@@ -196,9 +213,9 @@ void lduMatrix::patchNeighbourField(FieldFieldScalar& nbr, const scalargpuField&
     }
 }
 void lduMatrix::residual(scalargpuField& rA, const scalargpuField& psi, const scalargpuField& source, const FieldFieldScalar& b,
-                         const lduInterfaceFieldPtrsList& ifs, direction) const
+                         const lduInterfaceFieldPtrsList& ifs, direction cmpt) const
 {
-    sync(&b, nullptr, &ifs); miCheck(mi_residual(mat_, psi.data(), source.data(), rA.data()), "lduMatrix::residual");
+    cmpt_ = cmpt; sync(&b, nullptr, &ifs); miCheck(mi_residual(mat_, psi.data(), source.data(), rA.data()), "lduMatrix::residual");
 }
 void lduMatrix::negSumDiag() { miCheck(mi_row_face_op(lduAddr_.handle(), 1, lowerPtr_ ? lowerPtr_->data() : nullptr, upper_.data(), diag_.data()), "lduMatrix::negSumDiag"); dirty_ = true; }
 void lduMatrix::sumDiag() { miCheck(mi_row_face_op(lduAddr_.handle(), 0, lowerPtr_ ? lowerPtr_->data() : nullptr, upper_.data(), diag_.data()), "lduMatrix::sumDiag"); dirty_ = true; }
@@ -306,13 +323,13 @@ class PCG : public lduMatrix::solver
 {
 public:
     using lduMatrix::solver::solver;
-    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction cmpt) const override
     {
         requireUncoupled(interfaces_, "PCG::solve");
         const word pre = lduMatrix::preconditioner::getName(controlDict_);
         const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
         mi_solver_perf r;
-        miCheck(mi_pcg_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
+        miCheck(mi_pcg_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_, cmpt), psi.data(), source.data(), &c,
                              lduMatrix::preconditioner::kindFor(controlDict_, matrix_.symmetric()), &r, nullptr, 0), "PCG::solve");
         return perfOf(pre + "PCG", fieldName_, r); // PCG.C:75-80
     }
@@ -321,13 +338,13 @@ class PBiCG : public lduMatrix::solver
 {
 public:
     using lduMatrix::solver::solver;
-    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction cmpt) const override
     {
         requireUncoupled(interfaces_, "PBiCG::solve");
         const word pre = lduMatrix::preconditioner::getName(controlDict_);
         const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
         mi_solver_perf r;
-        miCheck(mi_pbicg_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
+        miCheck(mi_pbicg_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_, cmpt), psi.data(), source.data(), &c,
                                lduMatrix::preconditioner::kindFor(controlDict_, matrix_.symmetric()), &r, nullptr, 0), "PBiCG::solve");
         return perfOf(pre + "PBiCG", fieldName_, r);
     }
@@ -336,7 +353,7 @@ class PBiCGStab : public lduMatrix::solver
 {
 public:
     using lduMatrix::solver::solver;
-    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction cmpt) const override
     {
         requireUncoupled(interfaces_, "PBiCGStab::solve");
         const word pre = lduMatrix::preconditioner::getName(controlDict_);
@@ -344,7 +361,7 @@ public:
         mi_solver_perf r;
         // keep the reference's `psi += omega*yA` (PBiCGStab.C:263-270) unless the case asks for the textbook update
         const int quirk = controlDict_.lookupOrDefault<label>("textbookOmegaUpdate", 0) ? 0 : 1;
-        miCheck(mi_pbicgstab_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
+        miCheck(mi_pbicgstab_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_, cmpt), psi.data(), source.data(), &c,
                                    lduMatrix::preconditioner::kindFor(controlDict_, matrix_.symmetric()), quirk, &r, nullptr, 0), "PBiCGStab::solve");
         return perfOf(pre + "PBiCGStab", fieldName_, r);
     }
@@ -353,7 +370,7 @@ class smoothSolver : public lduMatrix::solver
 {
 public:
     using lduMatrix::solver::solver;
-    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction cmpt) const override
     {
         requireUncoupled(interfaces_, "smoothSolver::solve");
         const word sm = controlDict_.lookup("smoother");
@@ -361,7 +378,7 @@ public:
             FatalErrorIn("lduMatrix::smoother::New", "Unknown smoother " + sm + "\n\nValid smoothers are :\n(GaussSeidel Jacobi)");
         const mi_solver_controls c = controlsOf(tolerance_, relTol_, maxIter_, minIter_);
         mi_solver_perf r;
-        miCheck(mi_smooth_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c,
+        miCheck(mi_smooth_solve(matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_, cmpt), psi.data(), source.data(), &c,
                                 controlDict_.lookupOrDefault<scalar>("omega", 0.9), controlDict_.lookupOrDefault<label>("nSweeps", 1),
                                 &r, nullptr, 0), "smoothSolver::solve");
         return perfOf("smoothSolver", fieldName_, r);
@@ -371,7 +388,7 @@ class GAMGSolver : public lduMatrix::solver
 {
 public:
     using lduMatrix::solver::solver;
-    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction) const override
+    solverPerformance solve(scalargpuField& psi, const scalargpuField& source, const direction cmpt) const override
     {
         requireUncoupled(interfaces_, "GAMGSolver::solve");
         const word agg = controlDict_.lookupOrDefault<word>("agglomerator", "faceAreaPair");
@@ -412,7 +429,7 @@ public:
             c.reserved = 0;
         }
         mi_solver_perf r;
-        miCheck(mi_gamg_solve(g, matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_), psi.data(), source.data(), &c, &r, nullptr, 0), "GAMGSolver::solve");
+        miCheck(mi_gamg_solve(g, matrix_.handle(interfaceBouCoeffs_, interfaceIntCoeffs_, interfaces_, cmpt), psi.data(), source.data(), &c, &r, nullptr, 0), "GAMGSolver::solve");
         return perfOf("GAMG", fieldName_, r);
     }
     static const scalarField* faceWeights_;

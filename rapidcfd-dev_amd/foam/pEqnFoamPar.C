@@ -4,6 +4,9 @@
 // coefficients, lduMatrix::solver::New(...)->solve(psi, source).
 //
 //   pEqnFoamPar nx ny nz cyclic       one process; the box is periodic in y through a cyclic patch pair
+//   pEqnFoamPar nx ny nz cyclicAMI    the same pair coupled through a cyclicAMI interface: every face sees its opposite face
+//                                     with weight 0.75 and that face's x-neighbour with 0.25 (a quarter-cell shift);
+//                                     GAMG agglomerates the AMI, coarsest level by ICCG (directSolveCoarsest off)
 //   pEqnFoamPar nx ny nz processor    one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment, as torchrun or
 //                                     mpirun wrappers set them; MI_COMM_ID_FILE = path all ranks can see): z-slab
 //                                     decomposition with processor patches between the slabs; the y-periodicity is posed
@@ -35,7 +38,8 @@ int main(int argc, char** argv)
         const int nx = argc > 1 ? atoi(argv[1]) : 16, ny = argc > 2 ? atoi(argv[2]) : 16, nz = argc > 3 ? atoi(argv[3]) : 16;
         const std::string mode = argc > 4 ? argv[4] : "cyclic";
         const bool par = mode == "processor";
-        if (!par && mode != "cyclic") { fprintf(stderr, "usage: pEqnFoamPar nx ny nz cyclic|processor\n"); return 2; }
+        const bool ami = mode == "cyclicAMI";
+        if (!par && !ami && mode != "cyclic") { fprintf(stderr, "usage: pEqnFoamPar nx ny nz cyclic|cyclicAMI|processor\n"); return 2; }
         const int rank = par && getenv("RANK") ? atoi(getenv("RANK")) : 0;
         const int world = par && getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
         if (par) {
@@ -64,8 +68,18 @@ int main(int argc, char** argv)
             ifs[1].faceCells.push_back(i + nx * ((ny - 1) + ny * kl));
         }
         for (int p = 0; p < 2; ++p) {
-            ifs[p].type = par ? "processor" : "cyclic"; ifs[p].neighbPatchID = 1 - p; ifs[p].neighbProcNo = par ? rank : -1;
+            ifs[p].type = par ? "processor" : ami ? "cyclicAMI" : "cyclic"; ifs[p].neighbPatchID = 1 - p; ifs[p].neighbProcNo = par ? rank : -1;
             bou[p] = scalarField(ifs[p].faceCells.size(), -h);            // coupling kappa = h: boundaryCoeffs = -kappa
+            if (ami) {  // AMIInterpolation::srcAddress / srcWeights (p = 0, the owner) and tgtAddress / tgtWeights (p = 1), flattened
+                const int shift = p == 0 ? 1 : nx - 1;
+                ifs[p].amiStart.push_back(0);
+                for (int kl = 0; kl < nzl; ++kl) for (int i = 0; i < nx; ++i) {
+                    ifs[p].amiAddress.push_back(i + nx * kl); ifs[p].amiWeights.push_back(0.75);
+                    ifs[p].amiAddress.push_back((i + shift) % nx + nx * kl); ifs[p].amiWeights.push_back(0.25);
+                    ifs[p].amiStart.push_back((label)ifs[p].amiAddress.size());
+                    ifs[p].amiMagSf.push_back(h * h * (1.0 + 0.05 * splitmixUniform(555 + (uint64_t)p, (uint64_t)(i + nx * kl))));
+                }
+            }
         }
         if (par && rank > 0) {          // cut below: the owner of a cut face is the cell of the lower slab
             lduInterface I; I.type = "processor"; I.neighbProcNo = rank - 1; scalarField b;
@@ -101,6 +115,7 @@ int main(int argc, char** argv)
         for (std::size_t p = 0; p < ifs.size(); ++p) {
             bouCoeffs.push_back(scalargpuField(bou[p])); intCoeffs.push_back(scalargpuField(bou[p]));
             if (ifs[p].type == "cyclic") interfaces.push_back(new cyclicLduInterfaceField(ifs[p].faceCells, ifs[p].neighbPatchID));
+            else if (ifs[p].type == "cyclicAMI") interfaces.push_back(new cyclicAMILduInterfaceField(ifs[p].faceCells, ifs[p].neighbPatchID));
             else interfaces.push_back(new processorLduInterfaceField(ifs[p].faceCells, rank, ifs[p].neighbProcNo, ifs[p].neighbPatchID));
         }
         scalargpuField source(src);
@@ -113,7 +128,8 @@ int main(int argc, char** argv)
             dictionary{{"solver", "PCG"}, {"preconditioner", "diagonal"}, {"tolerance", "1e-08"}, {"relTol", "0"}},
             dictionary{{"solver", "PCG"}, {"preconditioner", "DIC"}, {"tolerance", "1e-08"}, {"relTol", "0"}},
             dictionary{{"solver", "GAMG"}, {"smoother", "GaussSeidel"}, {"agglomerator", "faceAreaPair"}, {"nCellsInCoarsestLevel", "10"},
-                       {"mergeLevels", "1"}, {"tolerance", "1e-08"}, {"relTol", "0"}, {"cacheAgglomeration", "true"}},
+                       {"mergeLevels", "1"}, {"tolerance", "1e-08"}, {"relTol", "0"}, {"cacheAgglomeration", "true"},
+                       {"directSolveCoarsest", ami ? "false" : "true"}},
             dictionary{{"solver", "smoothSolver"}, {"smoother", "GaussSeidel"}, {"nSweeps", "2"}, {"tolerance", "1e-03"}, {"maxIter", "400"}},
             dictionary{{"solver", "PBiCGStab"}, {"preconditioner", "diagonal"}, {"tolerance", "0"}, {"relTol", "0"}, {"maxIter", "12"}},
         };

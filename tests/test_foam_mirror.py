@@ -145,8 +145,25 @@ def _periodic_case(pkg, dims):
     return syn.LduCase(n, lo.astype(np.int32), up.astype(np.int32), diag, upper, None, src, dims=dims, interfaces=ifs)
 
 
+def _as_ami(pkg, case, dims):
+    """pEqnFoamPar's cyclicAMI mode: every face sees its opposite face (0.75) and that face's x-neighbour (0.25)"""
+    syn = pkg.synthetic
+    nx, ny, nz = dims
+    h = 1.0 / nx
+    for p, itf in enumerate(case.interfaces):
+        shift = 1 if p == 0 else nx - 1
+        q = np.arange(nx * nz)
+        i, k = q % nx, q // nx
+        addr = np.stack([i + nx * k, (i + shift) % nx + nx * k], axis=1).reshape(-1)
+        itf.ami_start = (2 * np.arange(nx * nz + 1)).astype(np.int32)
+        itf.ami_addr = addr.astype(np.int32)
+        itf.ami_w = np.tile([0.75, 0.25], nx * nz)
+        itf.ami_magsf = h * h * (1.0 + 0.05 * syn.splitmix_uniform(555 + p, nx * nz))
+    return case
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["cyclic", "processor"])
+@pytest.mark.parametrize("mode", ["cyclic", "processor", "cyclicAMI"])
 def test_pEqnFoamPar_matches_oracle(pkg, orc, mode, tmp_path):
     """lduMatrix::solver::New(...)->solve on a matrix with cyclic patches / on a (1-rank) decomposed case whose halo goes
     through RCCL (Pstream::init -> mi_matrix_attach_comm, mi_gamg_create_coupled), against the oracle's system."""
@@ -156,12 +173,14 @@ def test_pEqnFoamPar_matches_oracle(pkg, orc, mode, tmp_path):
     assert out.returncode == 0, out.stderr
     got = [(m.group(1), m.group(2), float(m.group(3)), float(m.group(4)), int(m.group(5))) for m in map(LINE.match, out.stdout.splitlines()) if m]
     case = _periodic_case(pkg, dims)
+    if mode == "cyclicAMI":
+        case = _as_ami(pkg, case, dims)
     S = orc.System([case])
     z, src = np.zeros(case.n_cells), case.source
     exp = []
     _, p = S.pcg(z, src, "diagonal", tolerance=1e-8); exp.append(("diagonalPCG", p))
     _, p = S.pcg(z, src, "AINV", tolerance=1e-8); exp.append(("AINVPCG", p))
-    _, p = orc.GamgSysHierarchy(S, [orc.box_face_weights(case)], 10).solve(z, src, tolerance=1e-8); exp.append(("GAMG", p))
+    _, p = orc.GamgSysHierarchy(S, [orc.box_face_weights(case)], 10).solve(z, src, tolerance=1e-8, directSolveCoarsest=(mode != "cyclicAMI")); exp.append(("GAMG", p))
     _, p = S.smooth_solve(z, src, n_sweeps=2, tolerance=1e-3, maxIter=400); exp.append(("smoothSolver", p))
     _, p = S.pbicgstab(z, src, "diagonal", tolerance=0.0, maxIter=12, replicate_quirk=True); exp.append(("diagonalPBiCGStab", p))
     assert len(got) == len(exp), out.stdout + out.stderr
