@@ -379,6 +379,7 @@ def main():
             "cells": N, "faces": F, "parallelism": f"domain-decomposition {parts_for(world)}" if world > 1 else "single GPU",
             "pcg_algorithmic_GBps": (160 * N + 16 * F) * its / 1e9,
             "host_enqueue_us_per_step": host_enqueue_us, "host_loop": host_loop,
+            "allreduce": (getattr(solver, "allreduce", "rccl") if world > 1 else "none (one rank)"),
             "timing": f"median of {R} repeats of the timed region of {K} steps (barrier + synchronize on both sides of each repeat, max over ranks)",
             "repeat_ms_per_step": [1e3 * t / K for t in rep_s], "repeat_amul_us_in_loop": [1e3 * a / K for a in rep_amul_ms],
             "amul_alone_us_rotating_buffers": amul_alone_us,

@@ -518,6 +518,20 @@ int mi_comm_allreduce_sum(mi_comm_t comm, double *buf_dev, int64_t n);
  * mi_pcg_solve / mi_pbicg_solve / mi_pbicgstab_solve / mi_smooth_solve solve the GLOBAL system; all ranks call
  * them together, like the MPI ranks of the reference.  (mi_pcg_solve: diagonal/none run the device-resident
  * phase pipeline, AINV a host-stepped loop.)  GAMG on such a matrix: mi_gamg_create_coupled.                 */
+/* ONE-SHOT PEER ALL-REDUCE ("RCCL ncclAllReduce fallback / one-shot P2P all-to-all on the fully connected
+ * node"; replaces the latency of src/Pstream/mpi/allReduceTemplates.C:195-208 for the 1-3 scalars of a Krylov iteration).
+ * Opt-in, on any communicator (RCCL or external): every rank calls mi_comm_peer_window (allocates a window of device memory
+ * -- fine-grained when the runtime exports that over IPC -- and returns its 64-byte hipIpcMemHandle), ships the handle to
+ * all ranks with whatever transport it has, and calls mi_comm_peer_connect with the handles of ALL ranks in rank order;
+ * after a barrier of the caller's, every all-reduce of <= 8 doubles on this communicator is one single-workgroup kernel
+ * per rank: store the values + an epoch flag into the own slot of every rank's window, poll the own window until all
+ * slots carry the epoch, add them in rank order (the same bits on every rank).  Larger all-reduces keep the
+ * communicator's ordinary path.  mi_comm_peer_status: 0, or 1 once a wait has run out of polls (a rank that never
+ * arrived: the sums are void); fine_grained_out says which memory the window got.  Exercised between processes that
+ * share one device (tests/test_distributed.py); between devices it needs the fine-grained window -- unmeasured here. */
+int mi_comm_peer_window(mi_comm_t comm, void *ipc_handle_out_64_bytes, int32_t len);
+int mi_comm_peer_connect(mi_comm_t comm, const void *handles_rank_order, int32_t n_handles);
+int mi_comm_peer_status(mi_comm_t comm, int32_t *status_out, int32_t *fine_grained_out_or_null);
 int mi_matrix_attach_comm(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,
                           const int32_t *patch_nbr_patch_or_null, int64_t n_global_cells);
 int mi_matrix_detach_comm(mi_matrix_t m);

@@ -42,6 +42,7 @@ class SolverControls(C.Structure):
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
     "mi_addr_set_ami_patch", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
+    "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status",
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
@@ -296,6 +297,22 @@ class Comm:
 
     def allreduce_sum(self, t):
         _chk(lib().mi_comm_allreduce_sum(self.h, _ptr(t), C.c_int64(t.numel())))
+
+    # one-shot peer all-reduce (opt-in): window() on every rank, ship the 64 bytes to all ranks, peer_connect(all handles)
+    def peer_window(self) -> bytes:
+        buf = (C.c_char * 64)()
+        _chk(lib().mi_comm_peer_window(self.h, buf, C.c_int32(64)))
+        return bytes(buf)
+
+    def peer_connect(self, handles):
+        blob = b"".join(handles)
+        assert len(blob) == 64 * self.n_ranks
+        _chk(lib().mi_comm_peer_connect(self.h, C.c_char_p(blob), C.c_int32(self.n_ranks)))
+
+    def peer_status(self):
+        st, fg = C.c_int32(0), C.c_int32(0)
+        _chk(lib().mi_comm_peer_status(self.h, C.byref(st), C.byref(fg)))
+        return int(st.value), bool(fg.value)
 
     def close(self):
         if self.h:

@@ -140,6 +140,11 @@ class DistributedPCG:
                 flag = torch.tensor([ok], dtype=torch.int32, device=device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
+            self.allreduce = "rccl"
+            if ok and self.world > 1 and os.environ.get("MI_ALLREDUCE", "rccl") == "peer":
+                # opt-in: the scalars of an iteration through the peer windows (mi_comm_peer_*) instead of ncclAllReduce
+                enable_peer_allreduce(self.comms[0])
+                self.allreduce = "peer windows"
             if not ok:
                 self.comms = None
                 self.driver = "torch"
@@ -315,6 +320,19 @@ def make_host_comms(ctx):
 
     c = eng.ExternalComm(ctx, world, rank, allreduce, exchange)
     return c, c
+
+
+def enable_peer_allreduce(comm):
+    """Switch the small all-reduces of ``comm`` (<= 8 doubles: the scalars of the Krylov loops, GAMG's scale factors) to the
+    one-shot peer-window form (mi_comm_peer_window / mi_comm_peer_connect): every rank exports its window, the 64-byte handles
+    travel through torch.distributed, every rank maps its peers' windows.  All ranks call together."""
+    world = dist.get_world_size()
+    mine = comm.peer_window()
+    handles = [None] * world
+    dist.all_gather_object(handles, mine)
+    comm.peer_connect(handles)
+    dist.barrier()                                  # nobody writes into a window that is not mapped yet
+    return comm
 
 
 class DistributedMatrix:

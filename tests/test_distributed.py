@@ -158,7 +158,7 @@ def test_distributed_pcg_real_engine_ragged_graph_random_partition(pkg, orc, tmp
 
 
 # ---- the engine's OWN (C++) loops with several ranks: communicators over the caller's transport (mi_comm_create_external) ----
-def _native_worker(rank, world, port, spec, out_dir, rccl=False):
+def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -179,7 +179,10 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False):
     sub = subs[rank]
     dname = f"cuda:{d}"
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dname)
-    dm = par.DistributedMatrix(ctx, sub, dname, comms=par.make_comms(ctx) if rccl else par.make_host_comms(ctx))
+    comms = par.make_comms(ctx) if rccl else par.make_host_comms(ctx)
+    if peer:
+        par.enable_peer_allreduce(comms[0])
+    dm = par.DistributedMatrix(ctx, sub, dname, comms=comms)
     res = dict(cells=sub.global_cells, n_global=dm.n_global)
     x = pkg.synthetic.splitmix_uniform(3, dm.n_global)[sub.global_cells] - 0.5
     out = torch.empty(sub.n_cells, dtype=torch.float64, device=dname)
@@ -195,6 +198,10 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False):
     if any(s[1] == "GAMG" for s in spec["solves"]):
         res["gamg_levels"] = dm._gamg.n_levels
     assert rccl or not dm.comms[0].errors, dm.comms[0].errors
+    if peer:
+        st, fine = comms[0].peer_status()
+        assert st == 0, "a peer all-reduce ran out of polls"
+        res["peer_fine_grained"] = fine
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -251,6 +258,18 @@ def test_native_attached_solvers_over_rccl_one_device_per_rank(pkg, orc, tmp_pat
         pytest.skip(f"needs {world} GPUs, {torch.cuda.device_count()} visible")
     spec = NATIVE_SPECS[name]
     mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), True), nprocs=world, join=True)
+    _check_native(pkg, orc, spec, world, str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("box_2", 2), ("box_4_asym", 4)])
+def test_native_solvers_with_the_one_shot_peer_allreduce(pkg, orc, tmp_path, name, world):
+    """the same loops with every small all-reduce (the scalars of PCG / PBiCG / PBiCGStab, GAMG's scale factors and stop flag)
+    going through the peer windows (mi_comm_peer_window / mi_comm_peer_connect): each rank writes its values + an epoch flag
+    into every rank's window and adds the nRanks contributions in rank order.  Here the ranks are processes that share the
+    GPU and map each other's windows over hipIpc; halo exchange and the large all-reduces stay on the gloo transport."""
+    spec = NATIVE_SPECS[name]
+    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, True), nprocs=world, join=True)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 

@@ -637,3 +637,39 @@ def test_ordered_addressing_with_coupled_patches(pkg, orc, ctx):
     mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
     psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(rc.source), 2)
     assert np.array_equal(host(psi), S.jacobi_smooth(x, rc.source, 2))
+
+
+def test_engine_against_the_reference_source_run_on_the_host(pkg, orc, ctx):
+    """The bound between the ENGINE and the reference's own lduMatrixATmul.C (compiled where it lies, run on the host over a
+    sequential thrust: tests/golden/golden_ref_atmul.npz, made by tests/golden/make_golden_ref.py), stated where the GPU runs:
+      * sumA and H1 -- sums of coefficients in the reference's row order -- are the reference's BITS;
+      * Amul / Tmul / residual are within 2 ulp of the row magnitude sum_j |a_ij x_j| of them.  The reference's functor rounds
+        its three staged products per side before adding them (matrixMultiplyFunctor<fast,3>), engine and oracle fold every
+        term with one fma (what nvcc's contraction makes of the unstaged loop): the same terms in the same order, at most one
+        rounding apart per staged term;
+      * and the engine IS the oracle's reading, bit for bit (test_spmv_family_bit_exact), so the two statements chain."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_atmul.npz"))
+    eps = np.finfo(float).eps
+    worst = 0.0
+    for name, case in make_golden_ref.atmul_cases(pkg, orc).items():
+        addr, mat = make(pkg, ctx, case)
+        n = case.n_cells
+        x = pkg.synthetic.splitmix_uniform(5, n) - 0.5
+        b = pkg.synthetic.splitmix_uniform(6, n) - 0.5
+        lower = case.upper if case.lower is None else case.lower
+        row_mag = np.abs(case.diag * x)
+        np.add.at(row_mag, case.lower_addr, np.abs(case.upper * x[case.upper_addr])); np.add.at(row_mag, case.upper_addr, np.abs(lower * x[case.lower_addr]))
+        out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+        mat.sumA(out); assert np.array_equal(host(out), G[f"{name}/sumA"]), name
+        mat.H1(out); assert np.array_equal(host(out), G[f"{name}/H1/fs0"]), name
+        for fs in (0, 1, 2):
+            mat.amul(dev(x), out); d = np.max(np.abs(host(out) - G[f"{name}/amul/fs{fs}"]) / row_mag); worst = max(worst, d)
+            assert d < 2 * eps, (name, fs, d / eps)
+            mat.tmul(dev(x), out); d = np.max(np.abs(host(out) - G[f"{name}/tmul/fs{fs}"]) / row_mag)
+            assert d < 2 * eps, (name, fs, d / eps)
+        mat.residual(dev(x), dev(b), out)
+        assert np.max(np.abs(host(out) - G[f"{name}/residual/fs0"]) / (row_mag + np.abs(b))) < 2 * eps, name
+    assert worst > 0.0      # (the two readings do differ somewhere: the bound is not vacuous)
