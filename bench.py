@@ -136,7 +136,9 @@ def bench_gamg(args, eng, syn, ctx, dev, json_fd):
         perf = G.solve(mat, psi, src, tolerance=0.0, maxIter=K)
         torch.cuda.synchronize()
         rep_s.append(time.perf_counter() - t0)
-        assert perf["nIterations"] == K and np.all(np.diff(perf["history"]) < 0), perf
+        h = perf["history"]
+        above = h > 1e-12                     # (past ~70 cycles the residual sits at the rounding floor; the cycles cost the same)
+        assert perf["nIterations"] == K and np.all(np.diff(h)[above[1:]] < 0), perf
     elapsed = float(np.median(rep_s))
     levels = [(G.level_sizes(l)["n_coarse"], G.level_sizes(l)["n_coarse_faces"]) for l in range(G.n_levels)]
     ctl = dict(nPostSweeps=2, postSweepsLevelMultiplier=1, maxPostSweeps=4, nFinestSweeps=2)
@@ -258,6 +260,7 @@ def main():
     rep_s, rep_amul_ms, amul_alone_us = [], [], None
     host_enqueue_us = None
     host_loop = "single-GPU device-resident pipeline (mi_pcg_iterate)"
+    allreduce_kind = "none (one rank)"
     weak = None
     if single:
         t0 = time.perf_counter()
@@ -304,6 +307,7 @@ def main():
         sub = syn.box_subdomain((nx, ny, nz), parts_for(world), rank)   # == decompose_box(box_case(...))[rank], built directly
         solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
         host_loop = {"native": "C++ loop over RCCL (mi_dpcg_comm_iterate)", "torch": "torch.distributed loop (parallel.py)"}[solver.driver]
+        allreduce_kind = getattr(solver, "allreduce", "torch.distributed") if world > 1 else "none (one rank)"
         solver.begin(tolerance=0.0, max_iter=W + R * K + 8)
         solver.iterate(W)
         for _ in range(R):
@@ -379,7 +383,7 @@ def main():
             "cells": N, "faces": F, "parallelism": f"domain-decomposition {parts_for(world)}" if world > 1 else "single GPU",
             "pcg_algorithmic_GBps": (160 * N + 16 * F) * its / 1e9,
             "host_enqueue_us_per_step": host_enqueue_us, "host_loop": host_loop,
-            "allreduce": (getattr(solver, "allreduce", "rccl") if world > 1 else "none (one rank)"),
+            "allreduce": allreduce_kind,
             "timing": f"median of {R} repeats of the timed region of {K} steps (barrier + synchronize on both sides of each repeat, max over ranks)",
             "repeat_ms_per_step": [1e3 * t / K for t in rep_s], "repeat_amul_us_in_loop": [1e3 * a / K for a in rep_amul_ms],
             "amul_alone_us_rotating_buffers": amul_alone_us,

@@ -127,6 +127,7 @@ class DistributedPCG:
         self._s01, self._s2, self._s3, self._s4 = o.scal[0:2], o.scal[2:3], o.scal[3:4], o.scal[4:5]
         self._p2p = {}
         self.comms = None
+        self.allreduce = "torch.distributed"
         if self.driver == "native":
             # both loops drive the same HIP phases over RCCL; if the C++ side cannot set its communicators up on ANY
             # rank (e.g. librccl cannot be bound), all ranks agree to use the torch.distributed loop instead
@@ -148,6 +149,7 @@ class DistributedPCG:
             if not ok:
                 self.comms = None
                 self.driver = "torch"
+                self.allreduce = "torch.distributed"
                 if len(set(self.nbrs)) != len(self.nbrs):
                     raise ValueError("one processor patch per neighbour rank is supported by the torch.distributed loop")
 
