@@ -41,6 +41,20 @@ def test_single_gpu_line():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
 
 
+def test_gamg_mode_line():
+    """`--solver gamg` (BASELINE config 3): one JSON line, V-cycles/s, a roofline over the whole cycle; a run long enough to
+    reach the rounding floor of the residual (the default K does at full size) must not trip the bench's own checks"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--solver", "gamg", "--steps", "90", "--warmup", "3", "--dims", "40", "32", "24"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["unit"] == "V-cycles/s" and d["steps"] == 90 and d["n_gpus"] == 1 and d["value"] > 0
+    assert abs(d["ms_per_step"] * d["value"] - 1e3) < 1e-6 * 1e3
+    assert d["config"]["solver"] == "GAMG" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+
+
 @pytest.mark.parametrize("n", [2, 4])
 def test_multi_rank_rehearsal_over_gloo(n):
     env = dict(os.environ, MI_BENCH_BACKEND="gloo")
