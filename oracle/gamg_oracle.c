@@ -727,6 +727,19 @@ label orc_gamg_sys_patch(const gamg_sys_hier *H, int d, int l, int p, label *fac
     if (faceCells) memcpy(faceCells, P->faceCells, sizeof(label) * (size_t)P->nCoarse);
     return P->nCoarse;
 }
+/* the agglomerated AMI of a cyclicAMI patch on the coarse side of level l: returns the number of addresses (-1: not an AMI
+ * patch); start [nCoarse+1], addr / w [count], magSf [nCoarse] are filled when given */
+label orc_gamg_sys_patch_ami(const gamg_sys_hier *H, int d, int l, int p, label *start, label *addr, scalar *w, scalar *magSf)
+{
+    const gamg_patch *P = &H->patch[d][l][p];
+    if (!P->amiStart) return -1;
+    const label na = P->amiStart[P->nCoarse];
+    if (start) memcpy(start, P->amiStart, sizeof(label) * (size_t)(P->nCoarse + 1));
+    if (addr) memcpy(addr, P->amiAddr, sizeof(label) * (size_t)na);
+    if (w) memcpy(w, P->amiW, sizeof(scalar) * (size_t)na);
+    if (magSf) memcpy(magSf, P->amiMagSf, sizeof(scalar) * (size_t)P->nCoarse);
+    return na;
+}
 void orc_gamg_sys_free(gamg_sys_hier *H)
 {
     for (int d = 0; d < H->nDomains; d++) {

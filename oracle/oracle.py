@@ -348,6 +348,16 @@ class GamgSysHierarchy:
         nc = int(lib().orc_gamg_sys_patch(self.h, d, l, p, _p(fr, C.c_int32), _p(fc, C.c_int32)))
         return dict(face_restrict=fr, face_cells=fc[:nc].copy())
 
+    def patch_ami(self, d, l, p, n_coarse_faces):
+        """agglomerated AMI of cyclicAMI patch p on the coarse side of level l (None for other patches)"""
+        na = int(lib().orc_gamg_sys_patch_ami(self.h, d, l, p, None, None, None, None))
+        if na < 0:
+            return None
+        st, ad = np.empty(n_coarse_faces + 1, np.int32), np.empty(max(na, 1), np.int32)
+        w, ms = np.empty(max(na, 1)), np.empty(max(n_coarse_faces, 1))
+        lib().orc_gamg_sys_patch_ami(self.h, d, l, p, _p(st, C.c_int32), _p(ad, C.c_int32), _p(w, C.c_double), _p(ms, C.c_double))
+        return dict(start=st, addr=ad[:na].copy(), w=w[:na].copy(), magsf=ms[:n_coarse_faces].copy())
+
     def solve(self, psi, source, **kw):
         ctl = gamg_controls(**kw)
         x = _d(psi).copy()

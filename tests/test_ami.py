@@ -253,3 +253,63 @@ def test_engine_gamg_with_agglomerated_ami(pkg, orc, symmetric, variant):
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
     with pytest.raises(eng.MiError):                       # as in the reference: no direct coarsest solver with cyclicAMI interfaces
         G.solve(mat, psi, dev(case.source), tolerance=1e-9, maxIter=5, directSolveCoarsest=True)
+
+
+def test_oracle_ami_agglomeration_follows_the_reference_loop(pkg, orc):
+    """AMIInterpolation::agglomerate + normaliseWeights (AMIInterpolation.C:199-247,279-540) and the face agglomeration of
+    cyclicAMIGAMGInterface.C:66-110, restated here in plain Python straight from the reference's loops, against the oracle's C
+    (oracle/gamg_oracle.c: ami_agglomerate) on every level of a hierarchy: same coarse faces, same addresses in the same order,
+    the same weights bit for bit (host arithmetic: a product, an addition, one division per weight)."""
+    syn = pkg.synthetic
+    base = syn.box_case(12, 10, 8)
+    case = syn.add_cyclic_ami_y(base, shift=0.37)
+    S = orc.System([case])
+    H = orc.GamgSysHierarchy(S, [orc.box_face_weights(base)], 10)
+    assert H.n_levels >= 3
+    fine = [dict(start=i.ami_start, addr=i.ami_addr, w=i.ami_w, magsf=i.ami_magsf, cells=i.face_cells) for i in case.interfaces]
+    for l in range(H.n_levels):
+        rmap = H.level(0, l)["restrict"]
+        # cyclicAMIGAMGInterface.C:66-110: coarse face per distinct local coarse cell, order of first appearance
+        face_restrict, coarse_cells = [], []
+        for f in fine:
+            seen, fr, cc = {}, [], []
+            for c in f["cells"]:
+                m = int(rmap[c])
+                if m not in seen:
+                    seen[m] = len(cc); cc.append(m)
+                fr.append(seen[m])
+            face_restrict.append(np.array(fr)); coarse_cells.append(np.array(cc, np.int32))
+        coarse = []
+        for p, f in enumerate(fine):
+            src_r, tgt_r = face_restrict[p], face_restrict[1 - p]
+            nc = coarse_cells[p].shape[0]
+            mag = np.zeros(nc)
+            for i in range(src_r.shape[0]):                       # "Agglomerate face areas"
+                mag[src_r[i]] += f["magsf"][i]
+            elems, weights = [[] for _ in range(nc)], [[] for _ in range(nc)]
+            for i in range(src_r.shape[0]):                       # "Agglomerate weights and indices" (no distribution map)
+                fine_area = f["magsf"][i]
+                I = src_r[i]
+                for k in range(f["start"][i], f["start"][i + 1]):
+                    K = int(tgt_r[f["addr"][k]])
+                    if K in elems[I]:
+                        weights[I][elems[I].index(K)] += fine_area * f["w"][k]
+                    else:
+                        elems[I].append(K); weights[I].append(fine_area * f["w"][k])
+            start, addr, w = [0], [], []
+            for I in range(nc):                                   # normaliseWeights, conformal: denom = sum(w)
+                s = 0.0
+                for v in weights[I]:
+                    s += v
+                addr += elems[I]; w += [v / s for v in weights[I]]
+                start.append(len(addr))
+            coarse.append(dict(start=np.array(start, np.int32), addr=np.array(addr, np.int32), w=np.array(w), magsf=mag, cells=coarse_cells[p]))
+        for p in range(2):
+            got_patch = H.patch(0, l, p, fine[p]["cells"].shape[0])
+            assert np.array_equal(got_patch["face_restrict"], face_restrict[p]) and np.array_equal(got_patch["face_cells"], coarse_cells[p])
+            got = H.patch_ami(0, l, p, coarse_cells[p].shape[0])
+            assert np.array_equal(got["start"], coarse[p]["start"]) and np.array_equal(got["addr"], coarse[p]["addr"])
+            assert np.array_equal(got["w"], coarse[p]["w"]) and np.array_equal(got["magsf"], coarse[p]["magsf"])
+            ws = np.add.reduceat(got["w"], got["start"][:-1])
+            assert np.max(np.abs(ws - 1.0)) < 1e-14               # every coarse face's weights sum to one
+        fine = coarse

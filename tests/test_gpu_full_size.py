@@ -8,6 +8,7 @@ reduction trees differ most from the oracle's long-double sums and where a tile-
     normalised initial residual (north_star: "residuals matching to 1e-10 rel at 10 M cells"), the first ten iterations
     1e-10 relative per iteration, identical iteration counts (PCG.C:133-204);
   * diagonal PCG to tolerance 1e-6: the SAME number of iterations as the oracle and the 1e-10 bar over the whole history;
+  * PBiCG + DILU and PBiCGStab + DILU (config 5's momentum solvers) for 40 fixed iterations on the asymmetric 216^3 matrix;
   * GAMG (nCellsInCoarsestLevel 100, the config-3 solve) against orc.GamgHierarchy cycle by cycle (GAMGSolverSolve.C:59-160);
   * the box cut 2 x 2 x 2 (the 8-GPU partition of SURVEY.md 8e) through the distributed PCG phases on one GPU.
 
@@ -115,6 +116,30 @@ def test_pcg_to_convergence_same_iteration_count_at_10M_cells(pkg, big):
     ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-6, maxIter=5000)
     assert ref["converged"] and ref["nIterations"] > 500
     check_hist(perf, ref)
+    assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+@pytest.mark.parametrize("solver", ["PBiCG", "PBiCGStab"])
+def test_asymmetric_krylov_history_at_10M_cells(pkg, orc, ctx, solver):
+    """BASELINE config 5's momentum solve (PBiCG + DILU; PBiCGStab as the reference writes it) at 216^3: 40 fixed iterations
+    of the device-resident loops against the oracle, every entry within 1e-10 of the normalised initial residual
+    (PBiCG.C:67-246, PBiCGStab.C:67-300)"""
+    case = pkg.synthetic.box_case(N, N, N, symmetric=False)
+    addr = pkg.engine.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    mat = pkg.engine.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), dev(case.lower))
+    S = orc.System([case])
+    psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+    kw = dict(tolerance=0.0, maxIter=40)
+    if solver == "PBiCG":
+        perf = mat.pbicg(psi, dev(case.source), "DILU", **kw)
+        ref_psi, ref = S.pbicg(np.zeros(case.n_cells), case.source, "AINV", **kw)
+    else:
+        perf = mat.pbicgstab(psi, dev(case.source), "DILU", **kw)
+        ref_psi, ref = S.pbicgstab(np.zeros(case.n_cells), case.source, "AINV", **kw)
+    assert perf["nIterations"] == ref["nIterations"]
+    h, hr = perf["history"], ref["history"]
+    assert h.shape == hr.shape and np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
 
 
