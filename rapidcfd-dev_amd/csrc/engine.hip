@@ -86,6 +86,7 @@ struct mi_ctx_s {
     int nCU = 0;
     bool coarseLevelBuild = false; // set by the GAMG hierarchy builder around its level addressings (tile size choice)
     int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
+    int deferPsi = 1;  // MI_PCG_DEFER_PSI: psi += alpha pA rides in the next k_pcg_update_p (one vector read less per iteration; A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
     int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1; // MI_* switches, read once per context
@@ -216,6 +217,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->attachEvents = env_int("MI_EVENT_ATTACH", 1);
     c->persist = env_int("MI_TILE_PERSIST", 0);
     c->xcdRows = env_int("MI_XCD_ROWS", 1);
+    c->deferPsi = env_int("MI_PCG_DEFER_PSI", 1);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
@@ -1152,6 +1154,8 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
     if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
     if (m->tilePartial.n < (size_t)a->L.nTiles) MICHK(m->tilePartial.alloc((size_t)a->L.nTiles));
     const bool fuse = c->fuseFinal && precond != MI_PRECOND_AINV;
+    const int defer = (c->deferPsi && !fuse) ? 1 : 0; // (the fused convergence test has no per-iteration k_pcg_final to record the added psi term)
+    double* psiD = defer ? psi : nullptr;
     struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
     for (int k = 0; k < count; ++k) {
         const int it = it0 < 0 ? -1 : it0 + k; // it0 < 0: the iteration counter lives on the device (graph replay)
@@ -1160,11 +1164,11 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
             MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0, m->tilePartial.p));
             k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P1);
             MICHK(globalize(m, P1));
-            k_pcg_update_p<0><<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, nullptr, nullptr, pA, n); // AINV path keeps k_pcg_final (P1 is rewritten before it)
+            k_pcg_update_p<0><<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, nullptr, nullptr, pA, n, nullptr, nullptr, 0, psiD); // AINV path keeps k_pcg_final (P1 is rewritten before it)
         } else if (precond == MI_PRECOND_DIAGONAL) {
-            k_pcg_update_p<1><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, m->rD.p, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen);
+            k_pcg_update_p<1><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, m->rD.p, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen, psiD);
         } else {
-            k_pcg_update_p<2><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, nullptr, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen);
+            k_pcg_update_p<2><<<RG, RB, 0, s>>>(c->state.p, it, P1, nullptr, nullptr, rA, pA, n, fuse ? P3 : nullptr, m->hist.p, m->histLen, psiD);
         }
         const bool rec = evStride > 0 && (k % evStride) == 0;
         const size_t ev = rec ? (size_t)2 * (size_t)(k / evStride) : 0;
@@ -1180,17 +1184,30 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
         k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P2);
         MICHK(globalize(m, P2));
         if (precond == MI_PRECOND_AINV)
-            k_pcg_update_psi_r<0><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
+            k_pcg_update_psi_r<0><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1, defer);
         else if (precond == MI_PRECOND_DIAGONAL)
-            k_pcg_update_psi_r<1><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, m->rD.p, psi, rA, n, P3, P1);
+            k_pcg_update_psi_r<1><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, m->rD.p, psi, rA, n, P3, P1, defer);
         else
-            k_pcg_update_psi_r<2><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1);
+            k_pcg_update_psi_r<2><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1, defer);
         MICHK(globalize(m, P3, precond == MI_PRECOND_AINV ? nullptr : P1));   // sum|rA| (+ the next iteration's wA.rA from the same pass)
         // diagonal / none: the convergence test of this iteration is fused into the next k_pcg_update_p
         if (!fuse) k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it, P3, m->hist.p, m->histLen);
     }
     // test of the last enqueued iteration (idempotent: the next batch's first kernel repeats it)
     if (count > 0 && fuse) k_pcg_final<false><<<1, RB, 0, s>>>(c->state.p, it0 < 0 ? -1 : it0 + count - 1, P3, m->hist.p, m->histLen);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+// end of a pcg_enqueue-driven solve: the psi term the last iteration still owes (deferred psi update)
+int pcg_flush(mi_matrix_s* m)
+{
+    mi_ctx_s* c = m->addr->ctx;
+    if (!c->deferPsi) return MI_OK;
+    double *psi, *pA;
+    MICHK(m->vec(3, &psi)); MICHK(m->vec(5, &pA));
+    k_pcg_flush_psi<<<RG, RB, 0, c->stream>>>(c->state.p, pA, psi, m->addr->L.nCells);
+    k_pcg_flush_mark<<<1, 1, 0, c->stream>>>(c->state.p);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -1260,6 +1277,7 @@ extern "C" int mi_pcg_end(mi_matrix_t m, double* psi_out, mi_solver_perf* perf, 
     HIPCHK(hipSetDevice(a->ctx->device));
     double* psi;
     MICHK(m->vec(3, &psi));
+    MICHK(pcg_flush(m));
     if (psi_out) k_scatter_perm<<<RG, RB, 0, a->ctx->stream>>>(psi, a->perm(), psi_out, a->L.nCells);
     HIPCHK(hipGetLastError());
     MICHK(fetch_state(a->ctx));

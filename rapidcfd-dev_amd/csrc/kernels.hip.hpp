@@ -635,7 +635,13 @@ struct PcgState {
     double tolerance, relTol;
     int32_t maxIter, minIter;
     int32_t nIterations, done, converged, singular;
-    int32_t it, pad_;  // device-side iteration counter: kernels launched with it < 0 (graph replays) read it here
+    int32_t it;        // device-side iteration counter: kernels launched with it < 0 (graph replays) read it here
+    // deferred psi update (PCG): k_pcg_update_psi_r(it) leaves `psi += alpha pA` to the next k_pcg_update_p, which reads pA
+    // anyway (one vector read less per iteration, same values).  rItP1 = it + 1 once the residual update of iteration it has
+    // run (k_pcg_update_psi_r, block 0); pApplyItP1 = it once the psi term of iteration it - 1 has been added -- recorded by
+    // the single-workgroup kernel that FOLLOWS the adding pass (k_pcg_final of the same iteration, k_pcg_flush_mark at the end
+    // of a solve), never by the adding pass itself, whose blocks read it.
+    int32_t rItP1, pApplyItP1, pad_;
 };
 
 constexpr double SP_SMALL = 1e-20, SP_VSMALL = 1e-300, SP_GREAT = 1e20; // SolverPerformance.H:269-275
@@ -695,29 +701,55 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
                                                      const double* __restrict__ wA, const double* __restrict__ rD,
                                                      const double* __restrict__ rA, double* __restrict__ pA, int64_t n,
                                                      const double* __restrict__ partial3 = nullptr, double* __restrict__ hist = nullptr,
-                                                     int histLen = 0)
+                                                     int histLen = 0, double* __restrict__ psi = nullptr) // psi != nullptr: deferred psi update
 {
-    if (st->done) return;
-    if (it < 0) it = st->it; // graph replay: the counter lives on the device (advanced by k_pcg_final)
+    const int itk = it < 0 ? st->it : it; // graph replay: the counter lives on the device (advanced by k_pcg_final)
+    // the psi term of iteration itk - 1 is still owed when its residual update ran (and, the solve having ended there or not,
+    // must be added exactly once: here, or by k_pcg_flush_psi when no further k_pcg_update_p follows)
+    // (pApplyItP1 is written by k_pcg_final / k_pcg_flush_mark only -- kernels that run strictly between two of these -- so
+    //  every block of this launch reads the same value whenever it starts)
+    const bool owed = psi != nullptr && itk > 0 && st->rItP1 == itk && st->pApplyItP1 != itk;
+    auto add_owed = [&]() {
+        const double alpha = st->alpha;
+        chunk_loop(n, [&](int64_t i) { const double2 p = ld2(pA, i); double2 x = ld2(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2(psi, i, x); },
+                   [&](int64_t i) { psi[i] = fma(alpha, pA[i], psi[i]); });
+    };
+    if (st->done) { if (owed) add_owed(); return; }
+    it = itk;
     __shared__ double red[RB / 64];
-    if (partial3 && it > 0 && !pcg_test_previous<DIST>(st, it - 1, partial3, hist, histLen, red)) return;
+    if (partial3 && it > 0 && !pcg_test_previous<DIST>(st, it - 1, partial3, hist, histLen, red)) { if (owed) add_owed(); return; }
     const double wArA = DIST ? partial1[0] : sum_partials(partial1, red); // DIST: global sum from the allreduce
     const double beta = (it == 0) ? 0.0 : wArA / st->wArA[(it & 1) ^ 1];
     const bool first = (it == 0);
+    const double alpha = owed ? st->alpha : 0.0;
     chunk_loop(n, [&](int64_t i) {
             double2 w;
             if (PMODE == 0) w = ld2(wA, i);
             else if (PMODE == 1) { const double2 d = ld2_rd(rD, i), r = ld2(rA, i); w = make_double2(d.x * r.x, d.y * r.y); }
             else w = ld2(rA, i);
             if (first) st2(pA, i, w);
-            else { const double2 p = ld2(pA, i); st2(pA, i, make_double2(fma(beta, p.x, w.x), fma(beta, p.y, w.y))); }
+            else {
+                const double2 p = ld2(pA, i);
+                if (owed) { double2 x = ld2(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2(psi, i, x); }
+                st2(pA, i, make_double2(fma(beta, p.x, w.x), fma(beta, p.y, w.y)));
+            }
         },
         [&](int64_t i) {
             const double w = (PMODE == 0) ? wA[i] : (PMODE == 1) ? rD[i] * rA[i] : rA[i];
+            if (owed) psi[i] = fma(alpha, pA[i], psi[i]);
             pA[i] = first ? w : fma(beta, pA[i], w);
         });
     if (blockIdx.x == 0 && threadIdx.x == 0) st->wArA[it & 1] = wArA;
 }
+// end of a solve: the psi term of the last iteration whose residual update ran, unless a k_pcg_update_p already added it
+__global__ __launch_bounds__(RB) void k_pcg_flush_psi(const PcgState* __restrict__ st, const double* __restrict__ pA, double* __restrict__ psi, int64_t n)
+{
+    if (st->rItP1 <= 0 || st->pApplyItP1 == st->rItP1) return;
+    const double alpha = st->alpha;
+    chunk_loop(n, [&](int64_t i) { const double2 p = ld2(pA, i); double2 x = ld2(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2(psi, i, x); },
+               [&](int64_t i) { psi[i] = fma(alpha, pA[i], psi[i]); });
+}
+__global__ void k_pcg_flush_mark(PcgState* __restrict__ st) { st->pApplyItP1 = st->rItP1; }
 
 // wApA = sum(partial2); singular? ; alpha; psi += alpha pA; rA -= alpha wA; partial3 = sum|rA|  [PCG.C:166-195]
 // PMODE 1/2 additionally produce partial1 = sum (M^-1 rA)*rA for the NEXT iteration's wArA
@@ -727,7 +759,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
                                                          const double* __restrict__ pA, const double* __restrict__ wA,
                                                          const double* __restrict__ rD,
                                                          double* __restrict__ psi, double* __restrict__ rA, int64_t n,
-                                                         double* __restrict__ partial3, double* __restrict__ partial1)
+                                                         double* __restrict__ partial3, double* __restrict__ partial1, int deferPsi = 0)
 {
     if (st->done) return;
     if (it < 0) it = st->it;
@@ -741,15 +773,16 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
     const double alpha = st->wArA[it & 1] / wApA;
     double acc0 = 0, acc1 = 0, d0 = 0, d1 = 0;
     chunk_loop(n, [&](int64_t i) {
-            const double2 p = ld2(pA, i), w = ld2(wA, i); double2 x = ld2(psi, i), r = ld2(rA, i);
-            x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y);
+            const double2 w = ld2(wA, i); double2 r = ld2(rA, i);
+            if (!deferPsi) { const double2 p = ld2(pA, i); double2 x = ld2(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2(psi, i, x); }
             r.x = fma(-alpha, w.x, r.x); r.y = fma(-alpha, w.y, r.y);
-            st2(psi, i, x); st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y);
+            st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y);
             if (PMODE == 1) { const double2 d = ld2_rd(rD, i); d0 = fma(d.x * r.x, r.x, d0); d1 = fma(d.y * r.y, r.y, d1); }
             else if (PMODE == 2) { d0 = fma(r.x, r.x, d0); d1 = fma(r.y, r.y, d1); }
         },
         [&](int64_t i) {
-            psi[i] = fma(alpha, pA[i], psi[i]); const double r = fma(-alpha, wA[i], rA[i]); rA[i] = r; acc0 += fabs(r);
+            if (!deferPsi) psi[i] = fma(alpha, pA[i], psi[i]);
+            const double r = fma(-alpha, wA[i], rA[i]); rA[i] = r; acc0 += fabs(r);
             if (PMODE == 1) d0 = fma(rD[i] * r, r, d0); else if (PMODE == 2) d0 = fma(r, r, d0);
         });
     const double t = block_sum<RB>(acc0 + acc1, red);
@@ -758,7 +791,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
         const double u = block_sum<RB>(d0 + d1, red);
         if (threadIdx.x == 0) partial1[blockIdx.x] = u;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->alpha = alpha; st->wApA = wApA; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->alpha = alpha; st->wApA = wApA; if (deferPsi) st->rItP1 = it + 1; }
 }
 
 // ---------------------------------------------------------------------------
@@ -942,8 +975,11 @@ template <bool DIST = false>
 __global__ __launch_bounds__(RB) void k_pcg_final(PcgState* __restrict__ st, int it, const double* __restrict__ partial3,
                                                   double* __restrict__ hist, int histLen)
 {
-    if (st->done) return;
     if (it < 0) it = st->it;
+    // the k_pcg_update_p of this iteration (it ran before this kernel, converged or not) has added the psi term iteration
+    // it - 1 owed (rItP1 is it + 1 by now if this iteration's residual update ran, it if it was gated or singular)
+    if (threadIdx.x == 0 && st->rItP1 >= it) st->pApplyItP1 = it;
+    if (st->done) return;
     __shared__ double red[RB / 64];
     const bool sing = partial3[0] < 0.0; // sum|r| partials are never negative
     const double s = DIST ? partial3[0] : sum_partials(partial3, red);
