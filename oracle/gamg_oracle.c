@@ -831,8 +831,10 @@ void orc_gamg_solve_sys(const gamg_sys_hier *H, const orc_system *S, scalar *psi
     /* coarsest level: the global matrix, dense LU */
     const orc_system *Ac = A[nL];
     const int nc = (int)Ac->nTotal;
-    orc_lu *LU = orc_gamg_sys_coarsest_lu(Ac);
-    scalar *dense = LU->dense; int *piv = LU->piv;
+    /* (only when it is used: with directSolveCoarsest off the coarsest level is solved by ICCG / BICCG below, and a system with
+     *  cyclicAMI interfaces has no such dense form in the reference -- LUscalarMatrix.C:246-251 casts every interface to a cyclic one) */
+    orc_lu *LU = ctl->directSolveCoarsest ? orc_gamg_sys_coarsest_lu(Ac) : NULL;
+    scalar *dense = LU ? LU->dense : NULL; int *piv = LU ? LU->piv : NULL;
 
     const int64_t n0 = S->nTotal;
     scalar **corr = (scalar **)calloc((size_t)nL, sizeof(*corr));
@@ -925,6 +927,7 @@ orc_lu *orc_gamg_sys_coarsest_lu(const orc_system *Ac)
             const orc_iface *me = &m->ifaces[p];
             const orc_domain *nb = &Ac->dom[me->nbrDomain];
             const orc_iface *ot = &nb->ifaces[me->nbrPatch];
+            if (me->amiStart) { fprintf(stderr, "orc_gamg_sys_coarsest_lu: cyclicAMI interfaces have no direct coarsest solve (LUscalarMatrix.C:246-251): directSolveCoarsest 0\n"); abort(); }
             for (label k = 0; k < me->nFaces; k++)
                 L->dense[(size_t)(o + me->faceCells[k]) * nc + (size_t)(nb->offset + ot->faceCells[k])] -= me->bouCoeffs[k];
         }
@@ -933,4 +936,4 @@ orc_lu *orc_gamg_sys_coarsest_lu(const orc_system *Ac)
     return L;
 }
 void orc_lu_solve(const orc_lu *L, scalar *b) { lu_solve(L->n, L->dense, L->piv, b); }
-void orc_lu_free(orc_lu *L) { free(L->dense); free(L->piv); free(L); }
+void orc_lu_free(orc_lu *L) { if (!L) return; free(L->dense); free(L->piv); free(L); }

@@ -159,6 +159,42 @@ def build_v3(pkg, orc):
     return out
 
 
+def v4_cases(pkg):
+    syn = pkg.synthetic
+    return {"ami_sym": syn.add_cyclic_ami_y(syn.box_case(14, 10, 8), shift=0.37, low_weight_every=9),
+            "ami_asym_T": syn.add_cyclic_ami_y(syn.box_case(12, 10, 8, symmetric=False), shift=0.61, transform=0.8)}
+
+
+def build_v4(pkg, orc):
+    """fourth fixture set (round 2): cyclicAMI interfaces -- operators, Jacobi, Krylov histories, the agglomerated AMI of the
+    first GAMG level and the GAMG history (iterative coarsest solve) -- on a non-conformal interface with low-weight faces and
+    with a transformation factor"""
+    syn = pkg.synthetic
+    out = {}
+    for tag, case in v4_cases(pkg).items():
+        S = orc.System([case])
+        n = case.n_cells
+        x = syn.splitmix_uniform(404, n) - 0.5
+        step = max(1, n // 257)
+        out[f"{tag}/amul"] = S.amul(x)[::step]; out[f"{tag}/tmul"] = S.tmul(x)[::step]
+        out[f"{tag}/residual"] = S.residual(x, case.source)[::step]
+        out[f"{tag}/jacobi2"] = S.jacobi_smooth(x, case.source, 2)[::step]
+        z = np.zeros(n)
+        if case.lower is None:
+            out[f"{tag}/pcg_dic"] = S.pcg(z, case.source, "AINV", tolerance=1e-9, maxIter=300)[1]["history"]
+        else:
+            out[f"{tag}/pbicg_dilu"] = S.pbicg(z, case.source, "AINV", tolerance=1e-8, maxIter=300)[1]["history"]
+        import copy
+        base = copy.copy(case); base.interfaces = []
+        H = orc.GamgSysHierarchy(S, [orc.box_face_weights(base)], 10)
+        out[f"{tag}/gamg"] = H.solve(z, case.source, tolerance=1e-9, maxIter=80, directSolveCoarsest=False)[1]["history"]
+        for p, itf in enumerate(case.interfaces):
+            P = H.patch(0, 0, p, itf.face_cells.shape[0])
+            A = H.patch_ami(0, 0, p, P["face_cells"].shape[0])
+            out[f"{tag}/level0_patch{p}_start"] = A["start"]; out[f"{tag}/level0_patch{p}_addr"] = A["addr"]; out[f"{tag}/level0_patch{p}_w"] = A["w"]
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
@@ -168,5 +204,7 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(here, "golden_v1.npz"), **build(pkg, orc))
     if "--v2" in sys.argv or not os.path.exists(os.path.join(here, "golden_v2.npz")):   # frozen as well
         np.savez_compressed(os.path.join(here, "golden_v2.npz"), **build_v2(pkg, orc))
-    np.savez_compressed(os.path.join(here, "golden_v3.npz"), **build_v3(pkg, orc))
+    if "--v3" in sys.argv or not os.path.exists(os.path.join(here, "golden_v3.npz")):   # frozen
+        np.savez_compressed(os.path.join(here, "golden_v3.npz"), **build_v3(pkg, orc))
+    np.savez_compressed(os.path.join(here, "golden_v4.npz"), **build_v4(pkg, orc))
     print("written")
