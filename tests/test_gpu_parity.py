@@ -673,3 +673,45 @@ def test_engine_against_the_reference_source_run_on_the_host(pkg, orc, ctx):
         mat.residual(dev(x), dev(b), out)
         assert np.max(np.abs(host(out) - G[f"{name}/residual/fs0"]) / (row_mag + np.abs(b))) < 2 * eps, name
     assert worst > 0.0      # (the two readings do differ somewhere: the bound is not vacuous)
+
+
+def test_no_device_memory_is_lost_over_create_solve_destroy_cycles(pkg, orc):
+    """a solver application creates and destroys matrices, hierarchies and patches for every equation of every time step:
+    after a few warm-up cycles (allocator pools, lazily built tables) the free device memory must stop moving"""
+    import copy
+    eng, syn = pkg.engine, pkg.synthetic
+    ctxl = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    case = syn.add_cyclic_ami_y(syn.box_case(24, 20, 16), shift=0.37)
+    base = copy.copy(case); base.interfaces = []
+    w = orc.box_face_weights(base)
+
+    def cycle():
+        addr = eng.Addressing(ctxl, case.n_cells, case.lower_addr, case.upper_addr, [i.face_cells for i in case.interfaces])
+        for p, itf in enumerate(case.interfaces):
+            addr.set_ami_patch(p, itf.nbr_patch, itf.ami_start, itf.ami_addr, itf.ami_w, itf.ami_low)
+            addr.set_ami_face_areas(p, itf.ami_magsf)
+        mat = eng.Matrix(addr)
+        mat.set_coeffs(dev(case.diag), dev(case.upper), None)
+        for p, itf in enumerate(case.interfaces):
+            mat.set_interface_coeffs(p, dev(itf.bou_coeffs), dev(itf.int_coeffs))
+        psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+        mat.pcg(psi, dev(case.source), "AINV", tolerance=1e-6, maxIter=50)
+        G = eng.Gamg(addr, w, 10)
+        G.solve(mat, psi, dev(case.source), tolerance=1e-6, maxIter=5, directSolveCoarsest=False)
+        asm = eng.Assembly(addr)
+        d = torch.empty(case.n_cells, dtype=torch.float64, device="cuda:0"); u = torch.empty(case.n_faces, dtype=torch.float64, device="cuda:0")
+        asm.fvm_laplacian(dev(np.ones(case.n_faces)), dev(np.ones(case.n_faces)), u, d)
+        P = eng.Patch(ctxl, case.n_cells, case.interfaces[0].face_cells)
+        P.close(); G.close(); mat.close(); addr.close()
+        del psi, d, u
+        torch.cuda.synchronize()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(12):
+        cycle()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)       # nothing accumulates (a leaked 24x20x16 layout alone is several MB per cycle)
