@@ -318,6 +318,10 @@ int mi_gamg_create(mi_addr_t fine_addr, const double *face_weights_host, int32_t
  * patch cells on every level, every level matrix exchanges its own halo, the scale factors are all-reduced
  * (GAMGSolverScale.C:104-107) and the coarsest level is the GLOBAL system (LUscalarMatrix.C:57-150) whose dense
  * inverse every rank holds the rows of.  All ranks call create/solve together.                                  */
+/* agglomerator "dummy" (GAMGAgglomerations/dummyAgglomeration/dummyAgglomeration.C:45-90; the reference's debugging
+ * agglomerator): n_levels levels whose restrict addressing is the identity -- every level is the fine mesh again, the
+ * coarsest (= fine) system is solved directly, so it is for small meshes (<= 4096 cells with directSolveCoarsest). */
+int mi_gamg_create_dummy(mi_addr_t fine_addr, int32_t n_levels, mi_gamg_t *out);
 int mi_gamg_create_coupled(mi_addr_t fine_addr, const double *face_weights_host,
                            int32_t n_cells_in_coarsest_level, int32_t merge_levels, int forward_init, mi_comm_t reduce_or_null,
                            mi_comm_t halo_or_null, const int32_t *patch_rank,

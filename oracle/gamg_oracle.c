@@ -213,6 +213,28 @@ gamg_hier *orc_gamg_build_merged(label nCells, label nFaces, const label *lower,
     return H;
 }
 
+/* dummyAgglomeration (GAMGAgglomerations/dummyAgglomeration/dummyAgglomeration.C:45-90): nLevels levels whose restrict
+ * addressing is the identity, agglomerateLduAddressing run on each */
+gamg_hier *orc_gamg_build_dummy(label nCells, label nFaces, const label *lower, const label *upper, int nLevels)
+{
+    gamg_hier *H = (gamg_hier *)calloc(1, sizeof(gamg_hier));
+    H->lev = (gamg_level *)calloc((size_t)(nLevels + 1), sizeof(gamg_level));
+    label nF = nFaces;
+    const label *lo = lower, *up = upper;
+    for (int l = 0; l < nLevels; l++) {
+        gamg_level *L = &H->lev[l];
+        L->nFine = nCells; L->nFineFaces = nF;
+        L->restrictMap = (label *)malloc(sizeof(label) * (size_t)nCells);
+        for (label i = 0; i < nCells; i++) L->restrictMap[i] = i;
+        L->nCoarse = nCells;
+        coarse_addressing(L, lo, up);
+        nF = L->nCoarseFaces; lo = L->cLower; up = L->cUpper;
+        H->nLevels++;
+    }
+    H->forwardOut = 1;
+    return H;
+}
+
 int orc_gamg_n_levels(const gamg_hier *H) { return H->nLevels; }
 int orc_gamg_forward_out(const gamg_hier *H) { return H->forwardOut; }
 void orc_gamg_level_sizes(const gamg_hier *H, int l, label *out4)

@@ -248,15 +248,21 @@ def box_face_weights(case):
 
 
 class GamgHierarchy:
-    def __init__(self, case, face_weights, n_cells_in_coarsest_level=10, forward=True, merge_levels=1):
+    def __init__(self, case, face_weights, n_cells_in_coarsest_level=10, forward=True, merge_levels=1, dummy_levels=0):
+        """dummy_levels n > 0: the reference's dummyAgglomeration (n identity levels) instead of the pair agglomeration"""
         L = lib()
         L.orc_gamg_build_merged.restype = C.c_void_p
+        L.orc_gamg_build_dummy.restype = C.c_void_p
         self.case = case
-        lo, up, w = _i(case.lower_addr), _i(case.upper_addr), _d(face_weights)
+        lo, up = _i(case.lower_addr), _i(case.upper_addr)
         self._keep = (lo, up)
-        self.h = C.c_void_p(L.orc_gamg_build_merged(C.c_int32(case.n_cells), C.c_int32(case.n_faces), _p(lo, C.c_int32),
-                                                    _p(up, C.c_int32), _p(w, C.c_double), C.c_int32(n_cells_in_coarsest_level),
-                                                    int(forward), int(merge_levels)))
+        if dummy_levels > 0:
+            self.h = C.c_void_p(L.orc_gamg_build_dummy(C.c_int32(case.n_cells), C.c_int32(case.n_faces), _p(lo, C.c_int32), _p(up, C.c_int32), int(dummy_levels)))
+        else:
+            w = _d(face_weights)
+            self.h = C.c_void_p(L.orc_gamg_build_merged(C.c_int32(case.n_cells), C.c_int32(case.n_faces), _p(lo, C.c_int32),
+                                                        _p(up, C.c_int32), _p(w, C.c_double), C.c_int32(n_cells_in_coarsest_level),
+                                                        int(forward), int(merge_levels)))
         self.n_levels = int(L.orc_gamg_n_levels(self.h))
         self.forward_out = bool(L.orc_gamg_forward_out(self.h))
 

@@ -121,13 +121,14 @@ void segment(int32_t nTargets, const std::vector<int32_t>& target, std::vector<i
 
 std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* lower, const int32_t* upper,
                                  const double* faceWeights, int32_t nCellsInCoarsestLevel, bool forwardInit,
-                                 GamgHierarchyHost& H, const GamgCoupling* cpl, int32_t mergeLevels)
+                                 GamgHierarchyHost& H, const GamgCoupling* cpl, int32_t mergeLevels, int32_t dummyLevels)
 {
-    if (nCells <= 0 || !faceWeights || mergeLevels < 1) return "bad argument";
+    if (nCells <= 0 || (!faceWeights && dummyLevels <= 0) || mergeLevels < 1 || dummyLevels < 0) return "bad argument";
+    if (dummyLevels > 0 && mergeLevels != 1) return "the dummy agglomeration has no mergeLevels";
     H.levels.clear();
     bool forward = forwardInit;
     const int maxLevels = 50;
-    std::vector<double> w(faceWeights, faceWeights + nFaces);
+    std::vector<double> w = faceWeights ? std::vector<double>(faceWeights, faceWeights + nFaces) : std::vector<double>((size_t)nFaces, 0.0);
     int32_t nFine = nCells, nF = nFaces;
     const int32_t *lo = lower, *up = upper;
     const int32_t nPatches = cpl ? cpl->nPatches : 0;
@@ -144,9 +145,17 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
     while ((int)H.levels.size() < maxLevels - 1) {
         GamgLevelHost L;
         L.nFine = nFine; L.nFineFaces = nF;
+        bool cont;
+        if (dummyLevels > 0) { // dummyAgglomeration.C:60-85: identity restrict addressing, nLevels of them
+            L.restrictMap.resize((size_t)nFine);
+            for (int32_t i = 0; i < nFine; ++i) L.restrictMap[i] = i;
+            L.nCoarse = nFine;
+            cont = (int32_t)H.levels.size() < dummyLevels;
+        } else {
         L.nCoarse = match_pairs(nFine, nF, lo, up, w, forward, L.restrictMap);
         forward = !forward;
-        bool cont = !(L.nCoarse < nCellsInCoarsestLevel || L.nCoarse == nFine); // continueAgglomerating
+        cont = !(L.nCoarse < nCellsInCoarsestLevel || L.nCoarse == nFine); // continueAgglomerating
+        }
         if (cpl && cpl->allAnd) cont = cpl->allAnd(cpl->user, cont);              // ... on all processors
         if (!cont) break;
         build_coarse_faces(L, lo, up);

@@ -67,7 +67,10 @@ struct GamgHierarchyHost {
 // faceWeights: [nFaces] (faceAreaPair: |Sf/sqrt|Sf| o (1,1.01,1.02)|; algebraicPair: |upper|)
 std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* lower, const int32_t* upper,
                                  const double* faceWeights, int32_t nCellsInCoarsestLevel, bool forwardInit,
-                                 GamgHierarchyHost& out, const GamgCoupling* coupling = nullptr, int32_t mergeLevels = 1);
+                                 GamgHierarchyHost& out, const GamgCoupling* coupling = nullptr, int32_t mergeLevels = 1,
+                                 int32_t dummyLevels = 0);
+// dummyLevels n > 0: dummyAgglomeration (GAMGAgglomerations/dummyAgglomeration/dummyAgglomeration.C:45-90) -- n levels whose
+// restrict addressing is the identity (every level is the fine mesh again); face weights and nCellsInCoarsestLevel are unused.
 // mergeLevels m > 1: every created level is m consecutive pair steps folded into one by
 // GAMGAgglomeration::combineLevels (GAMGAgglomerateLduAddressing.C:606-760), including its face-flip rule (the flip
 // of the LAST pair step is kept, the earlier ones are dropped -- the reference's behaviour, reproduced as is).

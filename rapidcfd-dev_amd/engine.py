@@ -42,7 +42,7 @@ class SolverControls(C.Structure):
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
     "mi_addr_set_ami_patch", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
-    "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status",
+    "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy",
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
@@ -541,11 +541,18 @@ class Gamg:
     """GAMG hierarchy + solver (lduMatrix::solver 'GAMG', agglomerator faceAreaPair/algebraicPair)."""
 
     def __init__(self, addr: Addressing, face_weights, n_cells_in_coarsest_level: int = 10, forward: bool = True,
-                 comms=None, patch_rank=None, patch_nbr_patch=None, merge_levels: int = 1):
-        """comms = (reduce, halo) Comm pair of a decomposed case (the matrix must be attached to the same pair)"""
+                 comms=None, patch_rank=None, patch_nbr_patch=None, merge_levels: int = 1, dummy_levels: int = 0):
+        """comms = (reduce, halo) Comm pair of a decomposed case (the matrix must be attached to the same pair);
+        dummy_levels n > 0: the reference's dummyAgglomeration (n identity levels), face_weights unused"""
         self.addr = addr
-        w = np.ascontiguousarray(face_weights, dtype=np.float64)
         self.h = C.c_void_p()
+        if dummy_levels > 0:
+            _chk(lib().mi_gamg_create_dummy(addr.h, C.c_int32(dummy_levels), C.byref(self.h)))
+            self._keep = None
+            self.n_levels = int(lib().mi_gamg_n_levels(self.h))
+            self.forward_out = bool(lib().mi_gamg_forward_out(self.h))
+            return
+        w = np.ascontiguousarray(face_weights, dtype=np.float64)
         I32 = C.POINTER(C.c_int32)
         pr = None if patch_rank is None else np.ascontiguousarray(patch_rank, dtype=np.int32)
         pn = None if patch_nbr_patch is None else np.ascontiguousarray(patch_nbr_patch, dtype=np.int32)

@@ -112,6 +112,12 @@ mi_addr_t lduAddressing::handle() const
     }
     return addr_;
 }
+mi_gamg_t lduAddressing::dummyAgglomeration(label nLevels) const
+{   // agglomerator dummy (dummyAgglomeration.C:45-90): cached like the pair agglomerations, keyed by -nLevels
+    if (gamg_ && gamgCoarsest_ != -nLevels) { mi_gamg_destroy(gamg_); gamg_ = nullptr; }
+    if (!gamg_) { miCheck(mi_gamg_create_dummy(handle(), nLevels, &gamg_), "dummyAgglomeration::dummyAgglomeration"); gamgCoarsest_ = -nLevels; gamgMerge_ = 1; }
+    return gamg_;
+}
 mi_gamg_t lduAddressing::agglomeration(const scalarField& w, label nCoarsest, label mergeLevels) const
 {
     if (gamg_ && (gamgCoarsest_ != nCoarsest || gamgMerge_ != mergeLevels)) { mi_gamg_destroy(gamg_); gamg_ = nullptr; }
@@ -394,7 +400,8 @@ public:
         const word agg = controlDict_.lookupOrDefault<word>("agglomerator", "faceAreaPair");
         const label nCoarsest = controlDict_.lookupOrDefault<label>("nCellsInCoarsestLevel", -1);
         if (nCoarsest < 0) FatalErrorIn("GAMGAgglomeration::GAMGAgglomeration", "keyword nCellsInCoarsestLevel is undefined in dictionary"); // GAMGAgglomeration.C:96-99
-        if (!controlDict_.found("mergeLevels")) FatalErrorIn("pairGAMGAgglomeration::pairGAMGAgglomeration", "keyword mergeLevels is undefined in dictionary");
+        if (agg != "dummy" && !controlDict_.found("mergeLevels")) FatalErrorIn("pairGAMGAgglomeration::pairGAMGAgglomeration", "keyword mergeLevels is undefined in dictionary");
+        if (agg == "dummy" && !controlDict_.found("nLevels")) FatalErrorIn("dummyAgglomeration::dummyAgglomeration", "keyword nLevels is undefined in dictionary"); // dummyAgglomeration.C:52
         {   // GAMGSolver.C:75: interpolateCorrection (default false).  The reference's interpolate() overload that every level
             // with a coarser level calls starts with notImplemented() (GAMGSolverInterpolate.C:180), i.e. it aborts: same here.
             const word ic = controlDict_.lookupOrDefault<word>("interpolateCorrection", "false");
@@ -410,8 +417,9 @@ public:
             const word key = "faceAreaPairWeights";  // supplied by the mesh layer (faceAreaPairGAMGAgglomeration.C:54-81)
             if (!faceWeights_) FatalErrorIn("faceAreaPairGAMGAgglomeration", "no face-area weights registered for this mesh (" + key + ")");
             w = *faceWeights_;
-        } else FatalErrorIn("GAMGAgglomeration::New", "Unknown GAMGAgglomeration type " + agg);
-        mi_gamg_t g = matrix_.lduAddr().agglomeration(w, nCoarsest, mergeLevels);
+        } else if (agg != "dummy") FatalErrorIn("GAMGAgglomeration::New", "Unknown GAMGAgglomeration type " + agg);
+        mi_gamg_t g = agg == "dummy" ? matrix_.lduAddr().dummyAgglomeration(controlDict_.lookupOrDefault<label>("nLevels", 1))
+                                     : matrix_.lduAddr().agglomeration(w, nCoarsest, mergeLevels);
         mi_gamg_controls c;
         c.tolerance = tolerance_; c.relTol = relTol_; c.maxIter = maxIter_; c.minIter = minIter_;
         c.nPreSweeps = controlDict_.lookupOrDefault<label>("nPreSweeps", 0);

@@ -604,3 +604,34 @@ def test_merged_levels_galerkin_and_the_flip_rule(pkg, orc):
             Af = Ac if sym else G                                               # next level from the true Galerkin operator would differ: stop after comparing
             if not sym:
                 break
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_dummy_agglomeration_levels_are_the_fine_mesh(pkg, orc, symmetric):
+    """agglomerator dummy (dummyAgglomeration.C:45-90): nLevels identity levels.  Level sizes equal the fine mesh, the level
+    matrices are the fine matrix (Galerkin sum over one child), and the V-cycle history follows the oracle's."""
+    import torch
+    eng, syn = pkg.engine, pkg.synthetic
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to("cuda:0")
+    case = syn.box_case(9, 8, 7, symmetric=symmetric)
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    G = eng.Gamg(addr, None, dummy_levels=3)
+    H = orc.GamgHierarchy(case, None, dummy_levels=3)
+    assert G.n_levels == H.n_levels == 3
+    for l in range(3):
+        s = G.level_sizes(l)
+        assert s["n_fine"] == s["n_coarse"] == case.n_cells and s["n_coarse_faces"] == case.n_faces
+    n = case.n_cells
+    kw = dict(tolerance=1e-9, maxIter=30)
+    ref_psi, ref = H.solve(np.zeros(n), case.source, **kw)
+    psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    perf = G.solve(mat, psi, dev(case.source), **kw)
+    assert perf["nIterations"] == ref["nIterations"] and ref["converged"]
+    h, hr = perf["history"], ref["history"]
+    assert h.shape == hr.shape and np.max(np.abs(h - hr)) < 1e-10 * hr[0]
+    torch.cuda.synchronize()
+    assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
