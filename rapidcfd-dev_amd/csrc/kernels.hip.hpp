@@ -28,9 +28,6 @@ static_assert(RG == 1024, "the fold kernels (k_fold_partials / k_fold_final: one
 #ifndef MI_RB
 #define MI_RB 512   // 1024 x 512 threads = 32 waves per CU: +2 % PCG iterations/s over 256 (profiles/r02_b_cache_policy_ab.md)
 #endif
-#ifndef MI_VEC_NT
-#define MI_VEC_NT 0
-#endif
 constexpr int RB = MI_RB;     // threads per block of the streaming kernels
 
 // ---------------------------------------------------------------------------
@@ -358,11 +355,9 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
 // Register budget: 512- and 1024-thread workgroups are launched where four / two of them are meant to share a CU (32 waves,
 // 8 per SIMD): that needs <= 64 VGPRs per lane, which the compiler is told here (without it the symmetric Amul takes 66 and
 // the symmetric Jacobi sweep 75, and a CU holds three workgroups instead of four).
-#ifndef MI_TILE_WAVES
-#define MI_TILE_WAVES 8
-#endif
+// (the opt-in compact asymmetric form would spill two registers under that budget and is left alone)
 template <int OP, bool ASYM, bool TRANS, int BS, bool C16>
-__global__ __launch_bounds__(BS, (BS >= 512 && MI_TILE_WAVES > 0 && !(C16 && ASYM)) ? MI_TILE_WAVES : 1) void tile_kernel(const TileArgs a)
+__global__ __launch_bounds__(BS, (BS >= 512 && !(C16 && ASYM)) ? 8 : 1) void tile_kernel(const TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (a.done && *a.done) return;
@@ -494,63 +489,25 @@ __device__ __forceinline__ void chunk_loop(int64_t n, F2 body2, F1 body1)
     if (((ck.hi - ck.lo) & 1) && threadIdx.x == 0) body1(ck.hi - 1);
 }
 typedef double mi_dvec2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 ld2(const double* p, int64_t i)
-{
-#if MI_VEC_NT
-    const mi_dvec2 v = __builtin_nontemporal_load(reinterpret_cast<const mi_dvec2*>(p + i));
-    return make_double2(v.x, v.y);
-#else
-    return *reinterpret_cast<const double2*>(p + i);
-#endif
-}
-#ifndef MI_RD_NT
-#define MI_RD_NT 0
-#endif
+// 16-byte accesses of the streaming kernels.  Ordinary cache policy: non-temporal accesses on EVERY vector were measured
+// (no gain, profiles/r02_b_cache_policy_ab.md); the two streams that are dead after one touch have their own helpers below.
+__device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return *reinterpret_cast<const double2*>(p + i); }
 // rD (reciprocal diagonal) is read twice per PCG iteration and never written inside a solve
-__device__ __forceinline__ double2 ld2_rd(const double* p, int64_t i)
-{
-#if MI_RD_NT
-    const mi_dvec2 v = __builtin_nontemporal_load(reinterpret_cast<const mi_dvec2*>(p + i));
-    return make_double2(v.x, v.y);
-#else
-    return ld2(p, i);
-#endif
-}
-__device__ __forceinline__ void st2(double* p, int64_t i, double2 v)
-{
-#if MI_VEC_NT
-    mi_dvec2 w; w.x = v.x; w.y = v.y;
-    __builtin_nontemporal_store(w, reinterpret_cast<mi_dvec2*>(p + i));
-#else
-    *reinterpret_cast<double2*>(p + i) = v;
-#endif
-}
+__device__ __forceinline__ double2 ld2_rd(const double* p, int64_t i) { return ld2(p, i); }
+__device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { *reinterpret_cast<double2*>(p + i) = v; }
 
-// psi is touched once per PCG iteration (read-modify-write in k_pcg_update_p): streamed, so that its dirty lines leave with
-// the pass that wrote them instead of being written back under the Amul that follows (MI_PSI_NT=0: ordinary accesses)
-#ifndef MI_PSI_NT
-#define MI_PSI_NT 1
-#endif
-#ifndef MI_WA_NT
-#define MI_WA_NT 1 // the Amul result is dead after k_pcg_update_psi_r has read it (3 401 -> 3 433 it/s, within the noise of the A/B)
-#endif
-__device__ __forceinline__ double2 ld2_psi(const double* p, int64_t i)
+// psi is touched once per Krylov iteration (read-modify-write) and the Amul result wA is dead once the residual update has
+// read it: both are STREAMED (non-temporal), so that psi's dirty lines leave with the pass that wrote them instead of being
+// written back under the Amul that follows (Amul inside the PCG loop 159 -> 151 us, 3 265 -> 3 365 it/s on one box).
+__device__ __forceinline__ double2 ld2_stream(const double* p, int64_t i)
 {
-#if MI_PSI_NT
     const mi_dvec2 v = __builtin_nontemporal_load(reinterpret_cast<const mi_dvec2*>(p + i));
     return make_double2(v.x, v.y);
-#else
-    return ld2(p, i);
-#endif
 }
-__device__ __forceinline__ void st2_psi(double* p, int64_t i, double2 v)
+__device__ __forceinline__ void st2_stream(double* p, int64_t i, double2 v)
 {
-#if MI_PSI_NT
     mi_dvec2 w; w.x = v.x; w.y = v.y;
     __builtin_nontemporal_store(w, reinterpret_cast<mi_dvec2*>(p + i));
-#else
-    st2(p, i, v);
-#endif
 }
 
 enum { RED_SUM = 0, RED_PROD = 1, RED_MAG = 2 };
@@ -744,7 +701,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
     const bool owed = psi != nullptr && itk > 0 && st->rItP1 == itk && st->pApplyItP1 != itk;
     auto add_owed = [&]() {
         const double alpha = st->alpha;
-        chunk_loop(n, [&](int64_t i) { const double2 p = ld2(pA, i); double2 x = ld2_psi(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2_psi(psi, i, x); },
+        chunk_loop(n, [&](int64_t i) { const double2 p = ld2(pA, i); double2 x = ld2_stream(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2_stream(psi, i, x); },
                    [&](int64_t i) { psi[i] = fma(alpha, pA[i], psi[i]); });
     };
     if (st->done) { if (owed) add_owed(); return; }
@@ -763,7 +720,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
             if (first) st2(pA, i, w);
             else {
                 const double2 p = ld2(pA, i);
-                if (owed) { double2 x = ld2_psi(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2_psi(psi, i, x); }
+                if (owed) { double2 x = ld2_stream(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2_stream(psi, i, x); }
                 st2(pA, i, make_double2(fma(beta, p.x, w.x), fma(beta, p.y, w.y)));
             }
         },
@@ -806,11 +763,7 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
     const double alpha = st->wArA[it & 1] / wApA;
     double acc0 = 0, acc1 = 0, d0 = 0, d1 = 0;
     chunk_loop(n, [&](int64_t i) {
-#if MI_WA_NT
-            const double2 w = ld2_psi(wA, i);
-#else
-            const double2 w = ld2(wA, i);
-#endif
+            const double2 w = ld2_stream(wA, i);
             double2 r = ld2(rA, i);
             if (!deferPsi) { const double2 p = ld2(pA, i); double2 x = ld2(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2(psi, i, x); }
             r.x = fma(-alpha, w.x, r.x); r.y = fma(-alpha, w.y, r.y);
@@ -890,11 +843,11 @@ __global__ __launch_bounds__(RB) void k_bicg_update_psi_r(PcgState* __restrict__
     const double alpha = st->wArA[it & 1] / wApT;
     double acc0 = 0, acc1 = 0;
     chunk_loop(n, [&](int64_t i) {
-            const double2 p = ld2(pA, i), w = ld2(wA, i), v = ld2(wT, i); double2 x = ld2_psi(psi, i), r = ld2(rA, i), t = ld2(rT, i);
+            const double2 p = ld2(pA, i), w = ld2(wA, i), v = ld2(wT, i); double2 x = ld2_stream(psi, i), r = ld2(rA, i), t = ld2(rT, i);
             x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y);
             r.x = fma(-alpha, w.x, r.x); r.y = fma(-alpha, w.y, r.y);
             t.x = fma(-alpha, v.x, t.x); t.y = fma(-alpha, v.y, t.y);
-            st2_psi(psi, i, x); st2(rA, i, r); st2(rT, i, t); acc0 += fabs(r.x); acc1 += fabs(r.y); },
+            st2_stream(psi, i, x); st2(rA, i, r); st2(rT, i, t); acc0 += fabs(r.x); acc1 += fabs(r.y); },
         [&](int64_t i) { psi[i] = fma(alpha, pA[i], psi[i]); const double r = fma(-alpha, wA[i], rA[i]); rA[i] = r;
             rT[i] = fma(-alpha, wT[i], rT[i]); acc0 += fabs(r); });
     const double s = block_sum<RB>(acc0 + acc1, red);
@@ -998,10 +951,10 @@ __global__ __launch_bounds__(RB) void k_stab_update(PcgState* __restrict__ st, c
     const double omega = tAsA / tAtA, alpha = st->alpha;
     double acc0 = 0, acc1 = 0;
     chunk_loop(n, [&](int64_t i) {
-            const double2 y = ld2(yA, i), z = ld2(q, i), sv = ld2(sA, i), t = ld2(tA, i); double2 x = ld2_psi(psi, i);
+            const double2 y = ld2(yA, i), z = ld2(q, i), sv = ld2(sA, i), t = ld2(tA, i); double2 x = ld2_stream(psi, i);
             x.x = fma(omega, z.x, fma(alpha, y.x, x.x)); x.y = fma(omega, z.y, fma(alpha, y.y, x.y));
             const double2 r = make_double2(fma(-omega, t.x, sv.x), fma(-omega, t.y, sv.y));
-            st2_psi(psi, i, x); st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y); },
+            st2_stream(psi, i, x); st2(rA, i, r); acc0 += fabs(r.x); acc1 += fabs(r.y); },
         [&](int64_t i) { psi[i] = fma(omega, q[i], fma(alpha, yA[i], psi[i])); const double r = fma(-omega, tA[i], sA[i]); rA[i] = r; acc0 += fabs(r); });
     const double t = block_sum<RB>(acc0 + acc1, red);
     if (threadIdx.x == 0) partial3[blockIdx.x] = t;
