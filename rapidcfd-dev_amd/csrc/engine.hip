@@ -317,6 +317,7 @@ static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, cons
         prm.tileCells = std::min(1024, std::max(128, target));
     }
     prm.slotCap = env_int("MI_TILE_SLOTS", 4094);
+    prm.reorder = env_int("MI_TILE_REORDER", -1); // -1: Cuthill-McKee pre-ordering when the numbering has no locality (tiling.hpp)
     prm.compact = env_int("MI_ENTRY16", 0) != 0; // opt-in: half the entry bytes, measured 2-4 % slower (profiles/r01_n_compact_entries_ab.md)
     prm.keepOrder = ordered; prm.givenTileStart = tile_cell_start; prm.nGivenTiles = n_tiles;
     const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L, patch_nbr_cells);
@@ -1873,6 +1874,7 @@ extern "C" int mi_layout_build_host(int32_t n_cells, int32_t n_faces, const int3
     TileParams prm;
     if (tile_cells > 0) prm.tileCells = tile_cells;
     if (slot_cap > 0) prm.slotCap = slot_cap;
+    prm.reorder = env_int("MI_TILE_REORDER", -1);
     const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, *L, patch_nbr_cells);
     if (!err.empty()) { delete L; return fail(MI_ERR_LIMIT, "mi_layout_build_host: " + err); }
     *out = L;

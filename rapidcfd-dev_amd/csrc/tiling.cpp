@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 #include <atomic>
 #include <cstdlib>
 #include <numeric>
@@ -123,6 +124,40 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, int32_t nc, Graph
     });
 }
 
+// Reverse Cuthill-McKee ordering of the cell graph (new -> old): components started from their lowest-degree cell, neighbours
+// appended in order of increasing degree (ties by cell index: deterministic).  Host, sequential, only for meshes whose
+// numbering has no locality.
+void cuthill_mckee(int32_t n, const std::vector<int32_t>& ownStart, const std::vector<int32_t>& neiStart, const std::vector<int32_t>& ownFaces,
+                   const std::vector<int32_t>& neiFaces, const int32_t* lower, const int32_t* upper, std::vector<int32_t>& order)
+{
+    std::vector<int32_t> deg((size_t)n);
+    int32_t maxDeg = 0;
+    for (int32_t c = 0; c < n; ++c) { deg[c] = (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]); maxDeg = std::max(maxDeg, deg[c]); }
+    std::vector<int32_t> byDeg((size_t)n); // cells by (degree, index): counting sort
+    {
+        std::vector<int32_t> cnt((size_t)maxDeg + 2, 0);
+        for (int32_t c = 0; c < n; ++c) cnt[(size_t)deg[c] + 1]++;
+        for (int32_t d = 0; d <= maxDeg; ++d) cnt[(size_t)d + 1] += cnt[d];
+        for (int32_t c = 0; c < n; ++c) byDeg[(size_t)cnt[deg[c]]++] = c;
+    }
+    std::vector<char> seen((size_t)n, 0);
+    order.clear(); order.reserve((size_t)n);
+    std::vector<int32_t> nb;
+    for (int32_t s = 0; s < n; ++s) {
+        const int32_t start = byDeg[s];
+        if (seen[start]) continue;
+        seen[start] = 1; order.push_back(start);
+        for (size_t head = order.size() - 1; head < order.size(); ++head) {
+            const int32_t v = order[head];
+            nb.clear();
+            for (int32_t j = ownStart[v]; j < ownStart[(size_t)v + 1]; ++j) { const int32_t u = upper[ownFaces[j]]; if (!seen[u]) { seen[u] = 1; nb.push_back(u); } }
+            for (int32_t j = neiStart[v]; j < neiStart[(size_t)v + 1]; ++j) { const int32_t u = lower[neiFaces[j]]; if (!seen[u]) { seen[u] = 1; nb.push_back(u); } }
+            std::sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+            order.insert(order.end(), nb.begin(), nb.end());
+        }
+    }
+    std::reverse(order.begin(), order.end());
+}
 } // namespace
 
 std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* lower,
@@ -191,6 +226,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     std::vector<int32_t> part((size_t)nCells);
     std::iota(part.begin(), part.end(), 0);
     int32_t nClusters = nCells;
+    std::vector<int32_t> cmOrder, cmRank; // Cuthill-McKee ordering (new -> old) and its inverse, when the clustering runs on it
     if (prm.keepOrder) {
         // ordered layout: tiles are ranges of the caller's numbering (given, or cut greedily under the caps)
         if (prm.givenTileStart) {
@@ -223,24 +259,48 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
             nClusters = t + 1;
         }
     } else {
+        // numbering without locality?  then the clustering (which visits vertices in index order) runs on a Cuthill-McKee
+        // ordering: vertex v of the graph = cell cmOrder[v]
+        bool reorder = prm.reorder > 0;
+        if (prm.reorder < 0 && nCells > 2 * prm.tileCells && nFaces > 0) {
+            double sum = 0;
+            for (int32_t f = 0; f < nFaces; ++f) sum += (double)(upper[f] - lower[f]);
+            reorder = sum / nFaces > 4.0 * std::pow((double)nCells, 2.0 / 3.0);
+        }
+        if (reorder) {
+            cuthill_mckee(nCells, ownStart, neiStart, ownFaces, neiFaces, lower, upper, cmOrder);
+            cmRank.resize((size_t)nCells);
+            for (int32_t v = 0; v < nCells; ++v) cmRank[(size_t)cmOrder[v]] = v;
+            MI_T("Cuthill-McKee");
+        }
         Graph g;
         g.n = nCells;
         g.xadj.assign((size_t)nCells + 1, 0);
-        for (int32_t c = 0; c < nCells; ++c)
-            g.xadj[(size_t)c + 1] = g.xadj[c] + (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]);
+        for (int32_t v = 0; v < nCells; ++v) {
+            const int32_t c = reorder ? cmOrder[v] : v;
+            g.xadj[(size_t)v + 1] = g.xadj[v] + (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]);
+        }
         g.adj.resize((size_t)2 * nFaces); g.ew.resize((size_t)2 * nFaces);
         g.vw.assign(nCells, 1); g.vint.assign(nCells, 0); g.vinc.resize(nCells);
         std::atomic<bool> tooMany{false};
         parallel_blocks(nCells, 65536, [&](int64_t b, int64_t e, int) {
-            for (int32_t c = (int32_t)b; c < (int32_t)e; ++c) {
-                int64_t k = g.xadj[c];
+            for (int32_t v = (int32_t)b; v < (int32_t)e; ++v) {
+                const int32_t c = reorder ? cmOrder[v] : v;
+                int64_t k = g.xadj[v];
                 for (int32_t j = ownStart[c]; j < ownStart[(size_t)c + 1]; ++j) { g.ew[(size_t)k] = 1; g.adj[(size_t)k++] = upper[ownFaces[j]]; }
                 for (int32_t j = neiStart[c]; j < neiStart[(size_t)c + 1]; ++j) { g.ew[(size_t)k] = 1; g.adj[(size_t)k++] = lower[neiFaces[j]]; }
-                g.vinc[c] = (int32_t)(g.xadj[(size_t)c + 1] - g.xadj[c]) + (pfStart[(size_t)c + 1] - pfStart[c]);
-                if (g.vinc[c] > prm.slotCap) tooMany = true;
+                if (reorder) { // as the row of a mesh numbered that way would read: larger-numbered neighbours ascending, then the smaller ones
+                    int32_t* a0 = g.adj.data() + g.xadj[v]; int32_t* a1 = g.adj.data() + g.xadj[(size_t)v + 1];
+                    for (int32_t* q = a0; q < a1; ++q) *q = cmRank[(size_t)*q];
+                    int32_t* mid = std::partition(a0, a1, [&](int32_t u) { return u > v; });
+                    std::sort(a0, mid); std::sort(mid, a1);
+                }
+                g.vinc[v] = (int32_t)(g.xadj[(size_t)v + 1] - g.xadj[v]) + (pfStart[(size_t)c + 1] - pfStart[c]);
+                if (g.vinc[v] > prm.slotCap) tooMany = true;
             }
         });
         if (tooMany) return "a single cell has more faces than a tile can hold";
+        if (reorder) for (int32_t c = 0; c < nCells; ++c) part[c] = cmRank[(size_t)c];
         // multi-edges (two faces between the same cell pair) are legal in LDU addressing; merge them
         std::vector<int32_t> cmap;
         for (int level = 0; level < 64; ++level) {
@@ -261,8 +321,11 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     // ---- order tiles by their smallest caller cell, cells inside a tile ascending ----
     const int32_t nT = nClusters;
     L.nTiles = nT;
+    const bool byRank = !cmRank.empty(); // tiles and the cells inside them follow the ordering the clustering ran on
     {
         std::vector<int32_t> tileMin((size_t)nT, INT32_MAX);
+        if (byRank) for (int32_t v = nCells - 1; v >= 0; --v) tileMin[part[cmOrder[v]]] = v;
+        else
         for (int32_t c = nCells - 1; c >= 0; --c) tileMin[part[c]] = c;
         std::vector<int32_t> order((size_t)nT);
         std::iota(order.begin(), order.end(), 0);
@@ -277,7 +340,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     L.e2c.resize(nCells); L.c2e.resize(nCells);
     {
         std::vector<int32_t> cur(L.tileCellStart.begin(), L.tileCellStart.end() - 1);
-        for (int32_t c = 0; c < nCells; ++c) { const int32_t e = cur[part[c]]++; L.e2c[e] = c; L.c2e[c] = e; }
+        for (int32_t v = 0; v < nCells; ++v) { const int32_t c = byRank ? cmOrder[v] : v; const int32_t e = cur[part[c]]++; L.e2c[e] = c; L.c2e[c] = e; }
     }
 
     MI_T("renumbering");

@@ -66,6 +66,11 @@ struct TileParams {
     bool keepOrder = false;
     const int32_t* givenTileStart = nullptr;
     int32_t nGivenTiles = 0;
+    // The clustering visits cells in index order, so its quality follows the locality of the caller's numbering: a mesh
+    // numbered at random gets tiles of ~550 cells instead of 1024 and a 2.4x slower Amul.  reorder: -1 = when the mean
+    // |upperAddr - lowerAddr| says the numbering has no locality (> 4 N^(2/3)), the clustering runs on a Cuthill-McKee
+    // ordering of the cell graph instead (same tiles as for the well-numbered mesh); 0 = never; 1 = always.
+    int32_t reorder = -1;
 };
 
 // returns empty string on success, else an error message
