@@ -715,3 +715,48 @@ def test_no_device_memory_is_lost_over_create_solve_destroy_cycles(pkg, orc):
     torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, (free0, free1)       # nothing accumulates (a leaked 24x20x16 layout alone is several MB per cycle)
+
+
+def test_randomly_numbered_mesh_through_every_path(pkg, orc, ctx):
+    """a box whose cells were renumbered at random (no locality at all: the clustering takes its Cuthill-McKee path): the
+    operators bit for bit, PCG / PBiCG / GAMG histories, and the assembly row passes on the caller's (random) numbering"""
+    syn, eng = pkg.synthetic, pkg.engine
+    rng = np.random.default_rng(3)
+    for symmetric in (True, False):
+        base = syn.box_case(24, 20, 16, symmetric=symmetric)
+        case = syn.renumber(base, rng.permutation(base.n_cells).astype(np.int32))
+        addr, mat = make(pkg, ctx, case)
+        ref_addr = eng.Addressing(ctx, base.n_cells, base.lower_addr, base.upper_addr)
+        assert addr.n_tiles == ref_addr.n_tiles and addr.stats()["slots"] == ref_addr.stats()["slots"]   # the bricks of the well-numbered box
+        S = orc.System([case])
+        n = case.n_cells
+        x = syn.splitmix_uniform(5, n) - 0.5
+        out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+        mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+        mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
+        mat.precondition("AINV", dev(x), out); assert np.array_equal(host(out), S.precondition("AINV", x))
+        psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 2); assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 2))
+        psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        if symmetric:
+            perf = mat.pcg(psi, dev(case.source), "AINV", tolerance=1e-9, maxIter=300)
+            ref_psi, ref = S.pcg(np.zeros(n), case.source, "AINV", tolerance=1e-9, maxIter=300)
+        else:
+            perf = mat.pbicg(psi, dev(case.source), "DILU", tolerance=1e-8, maxIter=300)
+            ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV", tolerance=1e-8, maxIter=300)
+        _check_hist(perf, ref)
+        w = 0.5 + syn.splitmix_uniform(77, case.n_faces)
+        H = orc.GamgHierarchy(case, w, 20)
+        G = eng.Gamg(addr, w, 20)
+        assert G.n_levels == H.n_levels
+        ref_psi, ref = H.solve(np.zeros(n), case.source, tolerance=1e-8, maxIter=60)
+        psi.zero_()
+        perf = G.solve(mat, psi, dev(case.source), tolerance=1e-8, maxIter=60)
+        assert perf["nIterations"] == ref["nIterations"]
+        assert np.max(np.abs(perf["history"] - ref["history"])) < HIST_RTOL * ref["history"][0]
+        asm = eng.Assembly(addr)
+        nf = case.n_faces
+        delta, gam = 1.0 + syn.splitmix_uniform(7, nf), 0.5 + syn.splitmix_uniform(8, nf)
+        uo, do = torch.empty(nf, dtype=torch.float64, device="cuda:0"), torch.empty(n, dtype=torch.float64, device="cuda:0")
+        asm.fvm_laplacian(dev(delta), dev(gam), uo, do)
+        ru, rd = orc.fvm_laplacian(n, case.lower_addr, case.upper_addr, delta, gam)
+        assert np.array_equal(host(uo), ru) and np.array_equal(host(do), rd)
