@@ -430,6 +430,7 @@ extern "C" int mi_matrix_set_patch_transform(mi_matrix_t m, int32_t patch, doubl
     if (m->addr->patchIsLocal[(size_t)patch] == 1 && factor != 1.0)
         return fail(MI_ERR_UNSUPPORTED, "mi_matrix_set_patch_transform: a transformed cyclic patch is declared through mi_addr_set_ami_patch (one-to-one, unit weights)");
     if (m->patchFactor.empty()) m->patchFactor.assign((size_t)m->addr->L.nPatches, 1.0);
+    if (m->patchFactor[(size_t)patch] != factor) ++m->epoch; // a GAMG hierarchy keeps the factors with its level matrices: rebuild them
     m->patchFactor[(size_t)patch] = factor;
     return MI_OK;
 }
