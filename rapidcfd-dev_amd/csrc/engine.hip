@@ -86,6 +86,7 @@ struct mi_ctx_s {
     int nCU = 0;
     bool coarseLevelBuild = false; // set by the GAMG hierarchy builder around its level addressings (tile size choice)
     int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
+    int fusePerm = 1;  // MI_FUSE_PERM: caller-order operators gather / scatter through e2c inside the tile kernel (A/B hook)
     int deferPsi = 1;  // MI_PCG_DEFER_PSI: psi += alpha pA rides in the next k_pcg_update_p (one vector read less per iteration; A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
@@ -110,6 +111,7 @@ struct mi_addr_s {
     int32_t nInterior = 0, nBoundary = 0, nLocalPatches = 0;
     std::vector<char> patchIsLocal; // [nPatches] cyclic (local) coupled patch: no exchange
     DevBuf<int32_t> ifaceNbrCaller; // [nExt] caller cell across every LOCAL interface face, -1 for remote faces (lazy)
+    DevBuf<int32_t> haloSrc;        // [nHaloTot] caller cell of every halo entry, or -1-k for ext value k (lazy; caller-order tile launches)
     std::vector<std::vector<int32_t>> patchFaceCellsHost, patchNbrCellsHost; // caller order (GAMG interface agglomeration)
     int64_t nEntries = 0, nHaloTot = 0;
     // cyclicAMI patches (mi_addr_set_ami_patch): declared like processor patches (ext region), their neighbour values are
@@ -145,6 +147,7 @@ struct mi_matrix_s {
     hipGraphExec_t pcgGraph = nullptr;
     struct { int precond = -1, batch = 0, histLen = 0; const void* hist = nullptr; const void* psi = nullptr; } pcgGraphKey;
     bool gateDone = false; // tile launches of a device-resident solver loop read PcgState::done and exit past convergence
+    const double *callerX = nullptr, *callerB = nullptr; double* callerY = nullptr; // set around ONE tile launch: x, b, y are the caller's arrays (permutation folded into the kernel)
     hipEvent_t kevStart = nullptr, kevStop = nullptr; // when set: attached to the next tile-kernel launch (hipExtLaunchKernel)
     struct mi_dpcg_comm_s* dpc = nullptr; // attached RCCL communicators + exchange plan (comm.inc)
     DevBuf<double> sendBuf, dscal;         // halo send buffer / scalar block of engine-driven distributed solves
@@ -218,6 +221,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->persist = env_int("MI_TILE_PERSIST", 0);
     c->xcdRows = env_int("MI_XCD_ROWS", 1);
     c->deferPsi = env_int("MI_PCG_DEFER_PSI", 1);
+    c->fusePerm = env_int("MI_FUSE_PERM", 1);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
@@ -598,6 +602,7 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     t.entries = a->entries.p; t.entries16 = a->entries16.p; t.sliceEntryStart16 = a->sliceEntryStart16.p; t.slotBase = reinterpret_cast<const uint32_t*>(a->slotBase.p); t.tileSbStart = a->tileSbStart.p;
     t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
     t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega; t.dotPartial = dotPartial; t.dotPartial2 = dotPartial2; t.flags = a->ctx->tileFlags;
+
     const size_t lds = lds_bytes(a->L, m->asym, OP == OP_AINV, &t.offLow, &t.offX, &t.offRD, &t.offSB);
     if (lds > 159 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 159 KiB of LDS");
     int nTiles = a->L.nTiles;
@@ -606,6 +611,29 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     else if (which == 2) { t.tileList = a->boundaryTiles.p; nTiles = a->nBoundary; }
     t.nPos = nTiles;
     t.done = m->gateDone ? &a->ctx->state.p->done : nullptr;
+    if (m->callerY) { // caller-order launch (caller_op): the engine vector x only supplies its ext tail
+        if constexpr (OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_SUMA || OP == OP_H1) {
+            t.perm = a->e2c.p; t.haloSrc = a->haloSrc.p; t.xExt = x ? x + a->L.nCells : nullptr;
+            t.x = m->callerX; t.b = m->callerB; t.y = m->callerY;
+            mi_ctx_s* cx = a->ctx;
+            hipStream_t s = cx->stream;
+            const bool big = lds > 53 * 1024;
+#define MI_LAUNCH_PERM(ASYM, TRANS)                                                                                      \
+            {                                                                                                           \
+                const void* fn = big ? (const void*)tile_kernel_perm<OP, ASYM, TRANS, 1024> : (const void*)tile_kernel_perm<OP, ASYM, TRANS, 512>; \
+                if (!cx->ldsAttrSet.count(fn)) { HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); cx->ldsAttrSet.insert(fn); } \
+                if (big) tile_kernel_perm<OP, ASYM, TRANS, 1024><<<nTiles, 1024, lds, s>>>(t);                           \
+                else tile_kernel_perm<OP, ASYM, TRANS, 512><<<nTiles, 512, lds, s>>>(t);                                 \
+            }
+            if (nTiles > 0) {
+                if (m->asym) { if (trans) MI_LAUNCH_PERM(true, true) else MI_LAUNCH_PERM(true, false) }
+                else MI_LAUNCH_PERM(false, false)
+            }
+#undef MI_LAUNCH_PERM
+            HIPCHK(hipGetLastError());
+            return MI_OK;
+        } else return fail(MI_ERR_STATE, "caller-order tile launch of an operator without a caller-order form");
+    }
     if (a->compact) {
         if (m->asym) {
             if (trans) return launch_tile_bs<OP, true, true, true>(m, t, nTiles, lds);
@@ -785,6 +813,23 @@ int caller_op(mi_matrix_s* m, bool trans, const double* x, const double* b, doub
         const double* xin = x;
         if (x && a->L.nExt > 0) { MICHK(m->vec(0, &v0)); HIPCHK(hipMemcpyAsync(v0, x, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s)); xin = v0; }
         return tile_op<OP>(m, trans, xin, b, nullptr, y, 0.0);
+    }
+    constexpr bool fusable = (OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_SUMA || OP == OP_H1);
+    if (fusable && a->ctx->fusePerm && !comm_remote(m) && a->ami.empty() && !a->compact) {
+        // the permutation folded into the tile kernel: it gathers x[e2c] while staging and stores y[e2c] -- no separate passes.
+        // (The ext tail, if the mesh has coupled patches whose values the caller placed with mi_matrix_set_ext, lives in work 0.)
+        MICHK(m->vec(0, &v0));
+        if (a->haloSrc.n != a->haloCell.n) {
+            std::vector<int32_t> hc(a->haloCell.n), src(a->haloCell.n);
+            HIPCHK(hipMemcpy(hc.data(), a->haloCell.p, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost));
+            for (size_t h = 0; h < hc.size(); ++h) src[h] = hc[h] < a->L.nCells ? a->L.e2c[(size_t)hc[h]] : -1 - (hc[h] - a->L.nCells);
+            MICHK(a->haloSrc.upload(src, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        m->callerX = x; m->callerB = b; m->callerY = y;
+        const int rc = launch_tile<OP>(m, trans, v0, nullptr, nullptr, nullptr, 0.0, 0);
+        m->callerX = nullptr; m->callerB = nullptr; m->callerY = nullptr;
+        return rc;
     }
     MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1));
     if (x) k_gather_perm<<<RG, RB, 0, s>>>(x, a->perm(), v0, a->L.nCells);

@@ -105,6 +105,12 @@ struct TileArgs {
     const double* diag;
     const double* up;
     const double* low;
+    // caller-order launch (tile_kernel_perm: mi_amul / mi_tmul / mi_residual / mi_H / mi_sumA / mi_H1 on an addressing that
+    // permutes): x, b and y are the CALLER's arrays; perm = e2c (engine cell -> caller cell), haloSrc[h] = caller cell of halo
+    // entry h, or -1-k for ext value k of xExt.  Unused by tile_kernel (engine-order vectors: every solver loop).
+    const int32_t* perm = nullptr;
+    const int32_t* haloSrc = nullptr;
+    const double* xExt = nullptr;
     const double* x;  // psi (Amul, residual, H, Jacobi) or r (AINV)
     const double* b;  // source (residual, Jacobi)
     const double* rD; // AINV
@@ -181,7 +187,7 @@ __device__ __forceinline__ void stage_dma8(const double* __restrict__ src, doubl
 }
 
 // one tile: position p of the launch (p indexes tileList / dotPartial)
-template <int OP, bool ASYM, bool TRANS, int BS, bool C16>
+template <int OP, bool ASYM, bool TRANS, int BS, bool C16, bool PERM = false>
 __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double* __restrict__ smem)
 {
     double* cU = smem;
@@ -197,6 +203,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     const int ifs0 = (OP == OP_JACOBI || OP == OP_AINV || OP == OP_H || OP == OP_H1 || (C16 && ASYM)) ? a.tileIfaceSlot0[t] : 0; // first interface slot of the tile
     uint16_t* sb = reinterpret_cast<uint16_t*>(smem + a.offSB);
     constexpr bool NEEDX = (OP != OP_SUMA && OP != OP_H1);
+    static_assert(!PERM || OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_SUMA || OP == OP_H1, "caller-order form: ops with a caller-order entry point only");
 
     // ---- stage: coefficients (16-byte coalesced), psi, halo -------------------
     // All global loads of a phase are issued before the first LDS store (4-deep
@@ -213,8 +220,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
         if (ASYM) stage_dma16<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
     }
     if (NEEDX) {
+        if (PERM) { // the permutation of the caller-order entry points, folded into the staging
+            stage_gather<BS>(a.x, a.perm + c0, xs, nc, tid);
+            for (int k = tid; k < nh; k += BS) { const int src = a.haloSrc[h0 + k]; xs[nc + k] = src >= 0 ? a.x[src] : a.xExt[-1 - src]; }
+        } else {
         stage_dma8<BS>(a.x + c0, xs, nc, tid);
         stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
+        }
         if (OP == OP_AINV) {
             stage_dma8<BS>(a.rD + c0, rDs, nc, tid);
             stage_gather<BS>(a.rD, a.haloCell + h0, rDs + nc, nh, tid);
@@ -276,12 +288,13 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
         const int i = s * 64 + lane;
         const bool live = i < nc;
         const int gi = c0 + (live ? i : 0);
+        const int go = PERM ? a.perm[gi] : gi; // index into the caller's arrays (b, y)
         const double xi = (NEEDX && live) ? xs[i] : 0.0;
         double acc, accI = 0.0;
         if (OP == OP_JACOBI) accI = a.b[gi];
         if (OP == OP_AMUL) acc = ((a.flags & 8) ? __builtin_nontemporal_load(a.diag + gi) : a.diag[gi]) * xi;
         else if (OP == OP_SUMA) acc = a.diag[gi];
-        else if (OP == OP_RESIDUAL) acc = a.b[gi] - a.diag[gi] * xi;
+        else if (OP == OP_RESIDUAL) acc = a.b[go] - a.diag[gi] * xi;
         else acc = 0.0;
         auto apply = [&](const int o, const int sl, const bool lowerSide) {
             double c;
@@ -327,8 +340,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
                 const double rD = 1.0 / a.diag[gi];
                 const double extra = (1 - a.omega) * xi + a.omega * rD * accI;
                 a.y[gi] = extra - a.omega * rD * acc;
-            } else if (a.flags & 4) __builtin_nontemporal_store(acc, a.y + gi);
-            else a.y[gi] = acc;
+            } else if (a.flags & 4) __builtin_nontemporal_store(acc, a.y + go);
+            else a.y[go] = acc;
             if (OP == OP_AMUL) { dot = fma(acc, xi, dot); if (a.dotPartial2) dot2 = fma(a.b[gi], xi, dot2); }
             if (OP == OP_RESIDUAL) dot += fabs(acc);
         }
@@ -374,6 +387,17 @@ __global__ __launch_bounds__(BS, (BS >= 512 && !(C16 && ASYM)) ? 8 : 1) void til
         tile_body<OP, ASYM, TRANS, BS, C16>(a, p, smem);
         __syncthreads(); // every wave is done with the LDS image before the next tile is staged
     }
+}
+
+// the same tile pass on the CALLER's arrays: x gathered through e2c while it is staged, y (and b) addressed through e2c in the
+// row loop -- the two permutation passes of the caller-order entry points folded into the kernel.  Separate instantiation, so
+// that the engine-order kernel above keeps its registers (a run-time switch cost it two spills).
+template <int OP, bool ASYM, bool TRANS, int BS>
+__global__ __launch_bounds__(BS) void tile_kernel_perm(const TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, per = gridDim.x >> 3;
+    tile_body<OP, ASYM, TRANS, BS, false, true>(a, (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b, smem);
 }
 
 // fold n per-workgroup partials into the RG slots the consumers reduce (fixed order)
