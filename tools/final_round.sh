@@ -10,3 +10,4 @@ echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 timeout 400 python tools/bench_assembly.py > gpurun_out/bench_assembly.log 2>&1
 timeout 600 python tools/bench_kernels.py > gpurun_out/bench_kernels.log 2>&1
 grep -E "passed|failed" gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log; cat gpurun_out/bench.json | cut -c1-600; cat gpurun_out/bench_gamg.json | cut -c1-300
+timeout 600 python tools/bench_dropin.py > gpurun_out/dropin.log 2>&1
