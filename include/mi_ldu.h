@@ -207,7 +207,10 @@ int mi_vec_from_engine(mi_addr_t addr, const double *x_engine_dev, double *x_cal
  *      sumA :345-395, residual :397-496, H1 :533-554, H lduMatrixOperations.C:130-154,
  *      faceH lduMatrixTemplates.C:110-148) ----
  * Interface (halo) terms use ext values previously placed with mi_set_ext (single
- * process: none).                                                                 */
+ * process: none).  On an addressing that permutes (mi_addr_create) these run the tile pass straight on the caller's arrays:
+ * x is gathered through the cell permutation while a tile is staged, y (and source) are addressed through it in the row
+ * loop -- no separate permutation passes (mi_amul 173 us against 146 in engine order on the 216^3 box); with ordered
+ * addressing there is no permutation at all.                                                                            */
 int mi_amul(mi_matrix_t m, const double *psi_dev, double *Apsi_dev);
 int mi_tmul(mi_matrix_t m, const double *psi_dev, double *Tpsi_dev);
 int mi_sumA(mi_matrix_t m, double *sumA_dev);
