@@ -340,3 +340,27 @@ def test_layout_does_not_depend_on_the_callers_numbering(pkg, orc, monkeypatch, 
     else:
         got = interpret_amul(L, case, x)
     assert np.max(np.abs(got - ref)) <= 4e-16 * np.max(np.abs(ref)) * 8
+
+
+def test_forced_reordering_on_disconnected_and_isolated_cells(pkg, orc, monkeypatch):
+    """the Cuthill-McKee pre-ordering on the awkward inputs: several components, cells without any face, a single cell"""
+    syn, eng = pkg.synthetic, pkg.engine
+    monkeypatch.setenv("MI_TILE_REORDER", "1")
+    # two boxes that do not touch + three isolated cells at the end
+    a, b = syn.box_case(7, 5, 3), syn.box_case(4, 4, 4, symmetric=False)
+    n = a.n_cells + b.n_cells + 3
+    lo = np.concatenate([a.lower_addr, b.lower_addr + a.n_cells]).astype(np.int32)
+    up = np.concatenate([a.upper_addr, b.upper_addr + a.n_cells]).astype(np.int32)
+    upper = np.concatenate([a.upper, b.upper]); lower = np.concatenate([a.upper, b.lower])
+    diag = np.concatenate([a.diag, b.diag, [2.0, 3.0, 4.0]])
+    case = syn.LduCase(n, lo, up, diag, upper, lower, np.zeros(n))
+    rng = np.random.default_rng(5)
+    case = syn.renumber(case, rng.permutation(n).astype(np.int32))
+    for tile_cells in (16, 1024):
+        L = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr, tile_cells=tile_cells)
+        assert np.array_equal(np.sort(L["e2c"]), np.arange(n))
+        x = syn.splitmix_uniform(3, n) - 0.5
+        ref = orc.System([case]).amul(x)
+        assert np.max(np.abs(interpret_amul(L, case, x) - ref)) <= 4e-16 * np.max(np.abs(ref)) * 8
+    L = eng.host_layout(1, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert L["tileCellStart"].tolist() == [0, 1]
