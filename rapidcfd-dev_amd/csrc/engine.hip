@@ -887,6 +887,16 @@ extern "C" int mi_faceH(mi_matrix_t m, const double* psi, double* faceH)
     return MI_OK;
 }
 
+namespace {
+// diagonal preconditioner on the caller's arrays of a permuting addressing: wA[c] = rD[c2e(c)] * rA[c], written as one pass
+// over the engine cells (rD is stored in engine order) instead of gather + multiply + scatter
+__global__ __launch_bounds__(256) void k_mul_perm(double* __restrict__ w, const double* __restrict__ rD, const double* __restrict__ r,
+                                                  const int32_t* __restrict__ e2c, int n)
+{
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) { const int c = e2c[e]; w[c] = rD[e] * r[c]; }
+}
+} // namespace
+
 extern "C" int mi_precondition(mi_matrix_t m, int kind, int transpose, const double* rA, double* wA)
 {
     if (!m || !rA || !wA) return fail(MI_ERR_ARG, "mi_precondition: bad argument");
@@ -901,6 +911,15 @@ extern "C" int mi_precondition(mi_matrix_t m, int kind, int transpose, const dou
         MICHK(ensure_rD(m));
         if (kind == MI_PRECOND_DIAGONAL && aligned16(rA) && aligned16(wA)) { k_mul<<<RG, RB, 0, s>>>(wA, m->rD.p, rA, a->L.nCells); HIPCHK(hipGetLastError()); return MI_OK; }
         if (kind == MI_PRECOND_AINV) return launch_tile<OP_AINV>(m, transpose != 0, rA, nullptr, m->rD.p, wA, 0.0, 0);
+    }
+    if (!a->identity && wA != rA && a->ctx->fusePerm) { // no permutation passes for the two preconditioners that are pointwise
+        if (kind == MI_PRECOND_NONE) { HIPCHK(hipMemcpyAsync(wA, rA, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s)); return MI_OK; }
+        if (kind == MI_PRECOND_DIAGONAL) {
+            MICHK(ensure_rD(m));
+            k_mul_perm<<<4096, 256, 0, s>>>(wA, m->rD.p, rA, a->e2c.p, a->L.nCells);
+            HIPCHK(hipGetLastError());
+            return MI_OK;
+        }
     }
     MICHK(m->vec(0, &v0)); MICHK(m->vec(1, &v1));
     k_gather_perm<<<RG, RB, 0, s>>>(rA, a->perm(), v0, a->L.nCells);
