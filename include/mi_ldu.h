@@ -455,6 +455,13 @@ int mi_gamg_host_build_domains(int32_t n_domains, const int32_t *n_cells, const 
                                const int32_t *const *patch_nbr_domain, const int32_t *const *patch_nbr_patch,
                                int32_t n_cells_in_coarsest_level, int32_t merge_levels, int forward_init,
                                void **hierarchies_out);
+/* one domain whose coupled patches are all cyclicAMI (arguments as mi_addr_set_ami_patch / mi_addr_set_ami_face_areas take
+ * them, per patch); mi_gamg_host_patch_array then also answers "amiStart" / "amiAddr" (int32) and "amiW" / "amiMagSf" (double) */
+int mi_gamg_host_build_ami(int32_t n_cells, int32_t n_faces, const int32_t *lower_addr_host, const int32_t *upper_addr_host,
+                           const double *face_weights_host, int32_t n_cells_in_coarsest_level, int32_t n_patches,
+                           const int32_t *patch_sizes, const int32_t *const *patch_face_cells_host, const int32_t *patch_nbr_patch,
+                           const int32_t *const *ami_start_host, const int32_t *const *ami_addr_host, const double *const *ami_w_host,
+                           const double *const *ami_mag_sf_host, void **hierarchy_out);
 int mi_gamg_host_patch_array(void *hierarchy, int32_t level, int32_t patch, const char *name, const void **data,
                              int64_t *len);
 int32_t mi_gamg_host_n_levels(void *hierarchy);

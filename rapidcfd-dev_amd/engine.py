@@ -42,7 +42,7 @@ class SolverControls(C.Structure):
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
     "mi_addr_set_ami_patch", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
-    "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy",
+    "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy", "mi_gamg_host_build_ami",
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
@@ -643,6 +643,46 @@ def gamg_host_hierarchy_domains(domains, face_weights_per_domain, n_cells_in_coa
         for d in range(D):
             lib().mi_gamg_host_free(C.c_void_p(out[d]))
     return res
+
+
+def gamg_host_hierarchy_ami(case, face_weights, n_cells_in_coarsest_level=10):
+    """Host-only build of the GAMG hierarchy of ONE domain whose interfaces are all cyclicAMI (LduCase with ami_* fields);
+    returns [level] dicts incl. "patches": [{faceRestrict, faceCells, amiStart, amiAddr, amiW, amiMagSf}] (CPU tests)."""
+    I32P, F64P = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    keep = []
+    def i32(a):
+        a = np.ascontiguousarray(a, dtype=np.int32); keep.append(a); return a.ctypes.data_as(I32P)
+    def f64(a):
+        a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); return a.ctypes.data_as(F64P)
+    P = len(case.interfaces)
+    sizes = i32([len(i.face_cells) for i in case.interfaces]); nbr = i32([i.nbr_patch for i in case.interfaces])
+    fc = (I32P * P)(*[i32(i.face_cells) for i in case.interfaces])
+    st = (I32P * P)(*[i32(i.ami_start) for i in case.interfaces]); ad = (I32P * P)(*[i32(i.ami_addr) for i in case.interfaces])
+    ww = (F64P * P)(*[f64(i.ami_w) for i in case.interfaces]); ms = (F64P * P)(*[f64(i.ami_magsf) for i in case.interfaces])
+    h = C.c_void_p()
+    _chk(lib().mi_gamg_host_build_ami(C.c_int32(case.n_cells), C.c_int32(case.n_faces), i32(case.lower_addr), i32(case.upper_addr), f64(face_weights),
+                                      C.c_int32(n_cells_in_coarsest_level), C.c_int32(P), sizes, fc, nbr, st, ad, ww, ms, C.byref(h)))
+    levels = []
+    try:
+        for lvl in range(int(lib().mi_gamg_host_n_levels(h))):
+            lv = {}
+            for name in ("restrictMap",):
+                data, ln, es = C.c_void_p(), C.c_int64(), C.c_int32()
+                _chk(lib().mi_gamg_host_array(h, C.c_int32(lvl), name.encode(), C.byref(data), C.byref(ln), C.byref(es)))
+                lv[name] = np.frombuffer((C.c_char * (ln.value * 4)).from_address(data.value), dtype=np.int32).copy()
+            lv["patches"] = []
+            for p in range(P):
+                pd = {}
+                for name, dt in (("faceRestrict", np.int32), ("faceCells", np.int32), ("amiStart", np.int32), ("amiAddr", np.int32), ("amiW", np.float64), ("amiMagSf", np.float64)):
+                    data, ln = C.c_void_p(), C.c_int64()
+                    _chk(lib().mi_gamg_host_patch_array(h, C.c_int32(lvl), C.c_int32(p), name.encode(), C.byref(data), C.byref(ln)))
+                    nb = ln.value * np.dtype(dt).itemsize
+                    pd[name] = np.frombuffer((C.c_char * nb).from_address(data.value), dtype=dt).copy() if ln.value else np.zeros(0, dt)
+                lv["patches"].append(pd)
+            levels.append(lv)
+    finally:
+        lib().mi_gamg_host_free(h)
+    return levels
 
 
 def gamg_host_hierarchy(n_cells, lower_addr, upper_addr, face_weights, n_cells_in_coarsest_level=10, forward=True, merge_levels=1):

@@ -313,3 +313,28 @@ def test_oracle_ami_agglomeration_follows_the_reference_loop(pkg, orc):
             ws = np.add.reduceat(got["w"], got["start"][:-1])
             assert np.max(np.abs(ws - 1.0)) < 1e-14               # every coarse face's weights sum to one
         fine = coarse
+
+
+def test_engine_host_builder_agglomerates_the_ami_like_the_oracle(pkg, orc):
+    """the ENGINE's host-side hierarchy builder (csrc/gamg.cpp, no device needed) against the oracle's, level by level: the same
+    coarse patch faces, the same addresses in the same order, the same weights and face areas bit for bit"""
+    import copy
+    syn, eng = pkg.synthetic, pkg.engine
+    for sym, shift in ((True, 0.37), (False, 0.61)):
+        base = syn.box_case(14, 10, 8, symmetric=sym)
+        case = syn.add_cyclic_ami_y(base, shift=shift)
+        w = orc.box_face_weights(base)
+        H = orc.GamgSysHierarchy(orc.System([case]), [w], 10)
+        L = eng.gamg_host_hierarchy_ami(case, w, 10)
+        assert len(L) == H.n_levels >= 3
+        n_fine = [i.face_cells.shape[0] for i in case.interfaces]
+        for l in range(H.n_levels):
+            assert np.array_equal(L[l]["restrictMap"], H.level(0, l)["restrict"])
+            for p in range(2):
+                ref = H.patch(0, l, p, n_fine[p])
+                got = L[l]["patches"][p]
+                assert np.array_equal(got["faceRestrict"], ref["face_restrict"]) and np.array_equal(got["faceCells"], ref["face_cells"])
+                A = H.patch_ami(0, l, p, ref["face_cells"].shape[0])
+                assert np.array_equal(got["amiStart"], A["start"]) and np.array_equal(got["amiAddr"], A["addr"])
+                assert np.array_equal(got["amiW"], A["w"]) and np.array_equal(got["amiMagSf"], A["magsf"])
+            n_fine = [L[l]["patches"][p]["faceCells"].shape[0] for p in range(2)]
