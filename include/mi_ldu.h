@@ -546,6 +546,45 @@ int mi_comm_allreduce_sum(mi_comm_t comm, double *buf_dev, int64_t n);
 int mi_comm_peer_window(mi_comm_t comm, void *ipc_handle_out_64_bytes, int32_t len);
 int mi_comm_peer_connect(mi_comm_t comm, const void *handles_rank_order, int32_t n_handles);
 int mi_comm_peer_status(mi_comm_t comm, int32_t *status_out, int32_t *fine_grained_out_or_null);
+/* The same set-up without help from the launcher, plus what makes it safe to be the DEFAULT (round 3):
+ *   mi_comm_peer_auto     collective.  Allocates the window, all-gathers the IPC handles over the communicator's own transport
+ *                         (RCCL or the external callbacks; the bytes travel as 16-bit integers through one all-reduce), maps the
+ *                         peers, runs the coherence self-test and lets the ranks agree: *enabled_out = 1 on every rank, or 0 on
+ *                         every rank (then nothing changes: RCCL / the external transport stay in charge).  It never fails because
+ *                         windows are unavailable -- no IPC, a window that is not fine-grained while a peer sits on another device
+ *                         (mi_comm_peer_connect refuses that with MI_ERR_UNSUPPORTED), a wait that runs out -- only on a broken
+ *                         base transport.
+ *   mi_comm_peer_selftest rounds all-reduces of known values against every peer with a short poll limit; *ok_out = 1 when every
+ *                         sum is right.  All ranks together, after every rank has connected.
+ *   mi_comm_peer_enable   switch the windows on / off after the ranks have agreed on the self-test's outcome.
+ * A communicator in peer mode also moves the HALO of every matrix attached to it afterwards through windows
+ * (mi_matrix_peer_halo_auto below), and the phase loop of the distributed PCG becomes three launches per iteration with no
+ * collective call.  A wait that runs out of polls (a rank that died) raises a status word; the solver loops check it at their
+ * host synchronisations and return MI_ERR_DEVICE (they used to carry on with void sums).                                      */
+int mi_comm_peer_auto(mi_comm_t comm, int32_t *enabled_out);
+int mi_comm_peer_selftest(mi_comm_t comm, int32_t rounds, int32_t *ok_out);
+int mi_comm_peer_enable(mi_comm_t comm, int32_t on);
+/* HALO WINDOWS (replaces lduMatrixUpdateMatrixInterfaces.C:30-276 / processorFvPatchScalarField.C:36-170 -- pack, host-staged
+ * MPI_Isend/Irecv, unpack -- and this engine's own ncclSend/ncclRecv group): every attached matrix owns a window of
+ * fine-grained device memory ([2 parities][n_ext] values + an epoch flag per patch and parity) that its neighbour ranks map
+ * over hipIpc.  An exchange is then: one launch that gathers the patch-internal values and STORES them into the neighbours'
+ * windows (k_halo_push; flags behind a system-scope release), the interior tiles meanwhile, one small launch that waits for the
+ * own flags and copies the window into the operand's ext region (k_halo_pull; transformCoupleField factors of processorCyclic
+ * patches applied there), the boundary tiles.  No second stream, no events, no collective call.  mi_matrix_attach_comm sets the
+ * windows up by itself (collectively: every rank attaches its matching matrix at that point, GAMG level matrices included)
+ * when the reduce communicator is in peer mode (MI_PEER_HALO=0 keeps the send/recv path); mi_matrix_peer_halo_auto does it
+ * explicitly.  The set-up ends with a self-test against the communicator's ordinary exchange and an agreement of the ranks;
+ * *enabled_out = 0 leaves the matrix on send/recv.  mi_matrix_peer_halo_status: whether windows are in use and whether a wait
+ * has run out of polls.
+ * With halo windows AND a peer-mode reduce communicator, mi_dpcg_comm_iterate (and mi_pcg_solve on the attached matrix,
+ * diagonal / none) runs the FUSED iteration: k_dpcg_update_p (p-update + convergence test of the previous iteration + deferred
+ * psi update; every block packs the patch cells of its own chunk into the neighbours' windows, the last block raises the
+ * flags), tile_kernel_dist (all tiles in one launch, interior first; a boundary tile polls the flags and reads the window
+ * directly; the last workgroup folds wA.pA and all-reduces it through the windows), k_dpcg_update_psi_r (the last block reduces
+ * sum|rA| and the next wA.rA and all-reduces both): 3 launches, 0 collective calls per iteration (MI_DPCG_FUSED=0: the phase
+ * loop).  The sums are formed in the order the separate reduction kernels use: same bits as the phase loop.                     */
+int mi_matrix_peer_halo_auto(mi_matrix_t m, int32_t *enabled_out);
+int mi_matrix_peer_halo_status(mi_matrix_t m, int32_t *enabled_out, int32_t *status_out_or_null);
 int mi_matrix_attach_comm(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,
                           const int32_t *patch_nbr_patch_or_null, int64_t n_global_cells);
 int mi_matrix_detach_comm(mi_matrix_t m);

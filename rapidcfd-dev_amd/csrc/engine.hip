@@ -173,6 +173,11 @@ int64_t comm_n_global(const mi_matrix_s* m);                     // global cell 
 int comm_exchange_start(mi_matrix_s* m, const double* send, double* vec);
 int comm_exchange_wait(mi_matrix_s* m);
 int comm_allreduce(mi_matrix_s* m, double* dev, size_t n);
+bool peer_halo_ready(const mi_matrix_s* m);                      // halo windows mapped by the neighbours (peer.inc)
+int peer_exchange_push(mi_matrix_s* m, const double* x);         // x's patch values into the neighbours' windows
+int peer_exchange_pull(mi_matrix_s* m, double* x);               // wait, then window -> x's ext region (patch factors applied)
+int peer_check(mi_matrix_s* m);                                  // MI_ERR_DEVICE when a window wait ran out of polls
+int dpcg_flush_if_fused(mi_matrix_s* m);
 int pcg_solve_attached(mi_matrix_s* m, double* psi_io, const double* source, const mi_solver_controls* ctl, int precond,
                        mi_solver_perf* perf, double* hist_host, int32_t hist_len);
 
@@ -725,6 +730,12 @@ int tile_op(mi_matrix_s* m, bool trans, const double* x, const double* b, const 
     mi_addr_s* a = m->addr;
     if (readsNbr && !a->ami.empty()) MICHK(ami_fill(m, x));
     if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial, dotPartial2);
+    if (peer_halo_ready(m)) { // stores into the neighbours' windows instead of send/recv calls: two small launches, no second stream
+        MICHK(peer_exchange_push(m, x));
+        MICHK(launch_tile<OP>(m, trans, x, b, rD, y, omega, 1, dotPartial, dotPartial2));
+        MICHK(peer_exchange_pull(m, const_cast<double*>(x)));
+        return launch_tile<OP>(m, trans, x, b, rD, y, omega, 2, dotPartial ? dotPartial + a->nInterior : nullptr, dotPartial2 ? dotPartial2 + a->nInterior : nullptr);
+    }
     if (m->sendBuf.n < (size_t)a->L.nExt) MICHK(m->sendBuf.alloc((size_t)a->L.nExt));
     MICHK(mi_halo_pack_engine(a, x, m->sendBuf.p));
     MICHK(comm_exchange_start(m, m->sendBuf.p, const_cast<double*>(x)));
@@ -910,7 +921,9 @@ extern "C" int mi_precondition(mi_matrix_t m, int kind, int transpose, const dou
         if (kind != MI_PRECOND_DIAGONAL && kind != MI_PRECOND_AINV) return fail(MI_ERR_ARG, "unknown preconditioner kind");
         MICHK(ensure_rD(m));
         if (kind == MI_PRECOND_DIAGONAL && aligned16(rA) && aligned16(wA)) { k_mul<<<RG, RB, 0, s>>>(wA, m->rD.p, rA, a->L.nCells); HIPCHK(hipGetLastError()); return MI_OK; }
-        if (kind == MI_PRECOND_AINV) return launch_tile<OP_AINV>(m, transpose != 0, rA, nullptr, m->rD.p, wA, 0.0, 0);
+        // (the AINV tile pass stages x[haloCell] for every halo entry, ext entries included -- their values are never used, but
+        //  the caller's rA ends at n_cells: with an ext region the input goes through work vector 0 below, as caller_op does)
+        if (kind == MI_PRECOND_AINV && a->L.nExt == 0) return launch_tile<OP_AINV>(m, transpose != 0, rA, nullptr, m->rD.p, wA, 0.0, 0);
     }
     if (!a->identity && wA != rA && a->ctx->fusePerm) { // no permutation passes for the two preconditioners that are pointwise
         if (kind == MI_PRECOND_NONE) { HIPCHK(hipMemcpyAsync(wA, rA, sizeof(double) * (size_t)a->L.nCells, hipMemcpyDeviceToDevice, s)); return MI_OK; }
@@ -1115,6 +1128,7 @@ int reduce_sync(mi_matrix_s* m, const double* a, const double* b, double* out)
     if (comm_attached(m)) MICHK(comm_allreduce(m, c->scalars.p, 1)); // Foam::reduce(..., sumOp<scalar>())
     HIPCHK(hipMemcpyAsync(c->hostScal, c->scalars.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (comm_attached(m)) MICHK(peer_check(m));   // a window wait that ran out of polls voids the sum
     *out = c->hostScal[0];
     return MI_OK;
 }
@@ -1515,7 +1529,9 @@ extern "C" int mi_dpcg_status(mi_matrix_t m, mi_solver_perf* perf, int32_t* done
     if (!m || !perf) return fail(MI_ERR_ARG, "mi_dpcg_status: bad argument");
     mi_ctx_s* c = m->addr->ctx;
     HIPCHK(hipSetDevice(c->device));
+    MICHK(dpcg_flush_if_fused(m));   // the fused loop defers psi += alpha pA to the next p-update: add what the last iteration owes
     MICHK(fetch_state(c));
+    MICHK(peer_check(m));
     fill_perf(*c->hostState, perf);
     if (done) *done = c->hostState->done;
     MICHK(copy_hist(m, hist_host, hist_len, c->hostState->nIterations));
@@ -1623,6 +1639,7 @@ int pbicg_solve_device(mi_matrix_s* m, double* psi_io, const double* source, con
         MICHK(bicg_enqueue(m, it, nb, precond, psi, pA, wA, rA, pT, wT, rT));
         it += nb;
         MICHK(fetch_state(c));
+        MICHK(peer_check(m));
         nb = nb * 2 > batch ? batch : nb * 2;
     }
     k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->perm(), psi_io, a->L.nCells);
@@ -1747,6 +1764,7 @@ int pbicgstab_solve_device(mi_matrix_s* m, double* psi_io, const double* source,
         MICHK(stab_enqueue(m, it, nb, precond, replicate_quirk != 0, psi, pA, yA, rA, AyA, sA, zA, tA, rA0));
         it += nb;
         MICHK(fetch_state(c));
+        MICHK(peer_check(m));
         nb = nb * 2 > batch ? batch : nb * 2;
     }
     k_scatter_perm<<<RG, RB, 0, s>>>(psi, a->perm(), psi_io, a->L.nCells);
@@ -1992,6 +2010,7 @@ mi_matrix_s::~mi_matrix_s()
         if (dpc->commStream) (void)hipStreamDestroy(dpc->commStream);
         if (dpc->evPack) (void)hipEventDestroy(dpc->evPack);
         if (dpc->evHalo) (void)hipEventDestroy(dpc->evHalo);
+        delete dpc->ph;
         delete dpc;
     }
 }

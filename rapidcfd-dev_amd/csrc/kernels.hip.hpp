@@ -111,6 +111,7 @@ struct TileArgs {
     const int32_t* perm = nullptr;
     const int32_t* haloSrc = nullptr;
     const double* xExt = nullptr;
+    int32_t nCells = 0; // EXTWIN launches (peer.inc: tile_kernel_dist): halo entries >= nCells read xExt[entry - nCells], the rank's halo WINDOW
     const double* x;  // psi (Amul, residual, H, Jacobi) or r (AINV)
     const double* b;  // source (residual, Jacobi)
     const double* rD; // AINV
@@ -187,7 +188,7 @@ __device__ __forceinline__ void stage_dma8(const double* __restrict__ src, doubl
 }
 
 // one tile: position p of the launch (p indexes tileList / dotPartial)
-template <int OP, bool ASYM, bool TRANS, int BS, bool C16, bool PERM = false>
+template <int OP, bool ASYM, bool TRANS, int BS, bool C16, bool PERM = false, bool EXTWIN = false>
 __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double* __restrict__ smem)
 {
     double* cU = smem;
@@ -225,6 +226,12 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
             for (int k = tid; k < nh; k += BS) { const int src = a.haloSrc[h0 + k]; xs[nc + k] = src >= 0 ? a.x[src] : a.xExt[-1 - src]; }
         } else {
         stage_dma8<BS>(a.x + c0, xs, nc, tid);
+        if (EXTWIN) { // neighbour ranks' values come straight from this rank's halo window (written by the peers, system scope)
+            for (int k = tid; k < nh; k += BS) {
+                const int idx = a.haloCell[h0 + k];
+                xs[nc + k] = idx < a.nCells ? a.x[idx] : __hip_atomic_load(a.xExt + (idx - a.nCells), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else
         stage_gather<BS>(a.x, a.haloCell + h0, xs + nc, nh, tid);
         }
         if (OP == OP_AINV) {
@@ -710,12 +717,14 @@ __device__ __forceinline__ bool pcg_test_previous(PcgState* __restrict__ st, int
     return cont;
 }
 
-template <int PMODE, bool DIST = false>
-__global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
-                                                     const double* __restrict__ wA, const double* __restrict__ rD,
-                                                     const double* __restrict__ rA, double* __restrict__ pA, int64_t n,
-                                                     const double* __restrict__ partial3 = nullptr, double* __restrict__ hist = nullptr,
-                                                     int histLen = 0, double* __restrict__ psi = nullptr) // psi != nullptr: deferred psi update
+// the pass as a device function (returns false when the launch had nothing to update: solve finished): the single-GPU kernel
+// below and the fused distributed kernel (peer.inc: + halo pack into the neighbours' windows) are both this body
+template <int PMODE, bool DIST>
+__device__ __forceinline__ bool pcg_update_p_body(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
+                                                  const double* __restrict__ wA, const double* __restrict__ rD,
+                                                  const double* __restrict__ rA, double* __restrict__ pA, int64_t n,
+                                                  const double* __restrict__ partial3, double* __restrict__ hist,
+                                                  int histLen, double* __restrict__ psi, double* red) // psi != nullptr: deferred psi update
 {
     const int itk = it < 0 ? st->it : it; // graph replay: the counter lives on the device (advanced by k_pcg_final)
     // the psi term of iteration itk - 1 is still owed when its residual update ran (and, the solve having ended there or not,
@@ -728,10 +737,9 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
         chunk_loop(n, [&](int64_t i) { const double2 p = ld2(pA, i); double2 x = ld2_stream(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2_stream(psi, i, x); },
                    [&](int64_t i) { psi[i] = fma(alpha, pA[i], psi[i]); });
     };
-    if (st->done) { if (owed) add_owed(); return; }
+    if (st->done) { if (owed) add_owed(); return false; }
     it = itk;
-    __shared__ double red[RB / 64];
-    if (partial3 && it > 0 && !pcg_test_previous<DIST>(st, it - 1, partial3, hist, histLen, red)) { if (owed) add_owed(); return; }
+    if (partial3 && it > 0 && !pcg_test_previous<DIST>(st, it - 1, partial3, hist, histLen, red)) { if (owed) add_owed(); return false; }
     const double wArA = DIST ? partial1[0] : sum_partials(partial1, red); // DIST: global sum from the allreduce
     const double beta = (it == 0) ? 0.0 : wArA / st->wArA[(it & 1) ^ 1];
     const bool first = (it == 0);
@@ -754,6 +762,17 @@ __global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, 
             pA[i] = first ? w : fma(beta, pA[i], w);
         });
     if (blockIdx.x == 0 && threadIdx.x == 0) st->wArA[it & 1] = wArA;
+    return true;
+}
+template <int PMODE, bool DIST = false>
+__global__ __launch_bounds__(RB) void k_pcg_update_p(PcgState* __restrict__ st, int it, const double* __restrict__ partial1,
+                                                     const double* __restrict__ wA, const double* __restrict__ rD,
+                                                     const double* __restrict__ rA, double* __restrict__ pA, int64_t n,
+                                                     const double* __restrict__ partial3 = nullptr, double* __restrict__ hist = nullptr,
+                                                     int histLen = 0, double* __restrict__ psi = nullptr) // psi != nullptr: deferred psi update
+{
+    __shared__ double red[RB / 64];
+    (void)pcg_update_p_body<PMODE, DIST>(st, it, partial1, wA, rD, rA, pA, n, partial3, hist, histLen, psi, red);
 }
 // end of a solve: the psi term of the last iteration whose residual update ran, unless a k_pcg_update_p already added it
 __global__ __launch_bounds__(RB) void k_pcg_flush_psi(const PcgState* __restrict__ st, const double* __restrict__ pA, double* __restrict__ psi, int64_t n)
@@ -768,21 +787,22 @@ __global__ void k_pcg_flush_mark(PcgState* __restrict__ st) { st->pApplyItP1 = s
 // wApA = sum(partial2); singular? ; alpha; psi += alpha pA; rA -= alpha wA; partial3 = sum|rA|  [PCG.C:166-195]
 // PMODE 1/2 additionally produce partial1 = sum (M^-1 rA)*rA for the NEXT iteration's wArA
 // (precondition + gSumProd of PCG.C:139-142 fused into this pass).
-template <int PMODE, bool DIST = false>
-__global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
-                                                         const double* __restrict__ pA, const double* __restrict__ wA,
-                                                         const double* __restrict__ rD,
-                                                         double* __restrict__ psi, double* __restrict__ rA, int64_t n,
-                                                         double* __restrict__ partial3, double* __restrict__ partial1, int deferPsi = 0)
+// (device body: returns false when the solve has finished -- nothing was written; true also on the singular exit, whose
+//  partial3 markers still have to reach k_pcg_final / the other ranks)
+template <int PMODE, bool DIST>
+__device__ __forceinline__ bool pcg_update_psi_r_body(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
+                                                      const double* __restrict__ pA, const double* __restrict__ wA,
+                                                      const double* __restrict__ rD,
+                                                      double* __restrict__ psi, double* __restrict__ rA, int64_t n,
+                                                      double* __restrict__ partial3, double* __restrict__ partial1, int deferPsi, double* red)
 {
-    if (st->done) return;
+    if (st->done) return false;
     if (it < 0) it = st->it;
-    __shared__ double red[RB / 64];
     const double wApA = DIST ? partial2[0] : sum_partials(partial2, red);
     if (fabs(wApA) / st->normFactor < SP_VSMALL) { // checkSingularity, SolverPerformance.C:32-44
         // every block takes this branch; only later kernels read done/singular
         if (threadIdx.x == 0) partial3[blockIdx.x] = -1.0; // marks "singular" for k_pcg_final
-        return;
+        return true;
     }
     const double alpha = st->wArA[it & 1] / wApA;
     double acc0 = 0, acc1 = 0, d0 = 0, d1 = 0;
@@ -807,6 +827,17 @@ __global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ 
         if (threadIdx.x == 0) partial1[blockIdx.x] = u;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->alpha = alpha; st->wApA = wApA; if (deferPsi) st->rItP1 = it + 1; }
+    return true;
+}
+template <int PMODE, bool DIST = false>
+__global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
+                                                         const double* __restrict__ pA, const double* __restrict__ wA,
+                                                         const double* __restrict__ rD,
+                                                         double* __restrict__ psi, double* __restrict__ rA, int64_t n,
+                                                         double* __restrict__ partial3, double* __restrict__ partial1, int deferPsi = 0)
+{
+    __shared__ double red[RB / 64];
+    (void)pcg_update_psi_r_body<PMODE, DIST>(st, it, partial2, pA, wA, rD, psi, rA, n, partial3, partial1, deferPsi, red);
 }
 
 // ---------------------------------------------------------------------------

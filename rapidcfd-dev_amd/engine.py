@@ -43,6 +43,7 @@ class SolverControls(C.Structure):
 SYMBOLS = [
     "mi_addr_set_ami_patch", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
     "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy", "mi_gamg_host_build_ami",
+    "mi_comm_peer_auto", "mi_comm_peer_selftest", "mi_comm_peer_enable", "mi_matrix_peer_halo_auto", "mi_matrix_peer_halo_status",
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
@@ -314,6 +315,21 @@ class Comm:
         _chk(lib().mi_comm_peer_status(self.h, C.byref(st), C.byref(fg)))
         return int(st.value), bool(fg.value)
 
+    def peer_auto(self) -> bool:
+        """collective: windows + handle exchange over the communicator's own transport + self-test + agreement (mi_comm_peer_auto);
+        True on every rank when the scalars (and the halo of matrices attached afterwards) travel through peer windows"""
+        on = C.c_int32(0)
+        _chk(lib().mi_comm_peer_auto(self.h, C.byref(on)))
+        return bool(on.value)
+
+    def peer_selftest(self, rounds: int = 16) -> bool:
+        ok = C.c_int32(0)
+        _chk(lib().mi_comm_peer_selftest(self.h, C.c_int32(rounds), C.byref(ok)))
+        return bool(ok.value)
+
+    def peer_enable(self, on: bool):
+        _chk(lib().mi_comm_peer_enable(self.h, C.c_int32(1 if on else 0)))
+
     def close(self):
         if self.h:
             lib().mi_comm_destroy(self.h)
@@ -502,6 +518,18 @@ class Matrix:
     def detach_comm(self):
         _chk(lib().mi_matrix_detach_comm(self.h))
         self._comms = None
+
+    def peer_halo_auto(self) -> bool:
+        """collective: halo windows of this attached matrix (mi_matrix_peer_halo_auto); True when every rank has them"""
+        on = C.c_int32(0)
+        _chk(lib().mi_matrix_peer_halo_auto(self.h, C.byref(on)))
+        return bool(on.value)
+
+    def peer_halo_status(self):
+        """(windows in use, a wait ran out of polls)"""
+        on, st = C.c_int32(0), C.c_int32(0)
+        _chk(lib().mi_matrix_peer_halo_status(self.h, C.byref(on), C.byref(st)))
+        return bool(on.value), int(st.value)
 
     def dpcg_comm_begin(self, reduce: "Comm", halo: "Comm", patch_rank, patch_nbr_patch=None, n_global=0):
         pr = np.ascontiguousarray(patch_rank, dtype=np.int32)

@@ -142,10 +142,8 @@ class DistributedPCG:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
             self.allreduce = "rccl"
-            if ok and self.world > 1 and os.environ.get("MI_ALLREDUCE", "rccl") == "peer":
-                # opt-in: the scalars of an iteration through the peer windows (mi_comm_peer_*) instead of ncclAllReduce
-                enable_peer_allreduce(self.comms[0])
-                self.allreduce = "peer windows"
+            if ok and getattr(self.comms[0], "peer_mode", False):
+                self.allreduce = "peer windows (one-shot stores into the peers' memory; self-tested at set-up)"
             if not ok:
                 self.comms = None
                 self.driver = "torch"
@@ -273,10 +271,17 @@ def make_comms(ctx, device=None):
         dist.broadcast_object_list(ids, src=0)
     reduce_c = eng.Comm(ctx, world, rank, ids[0][0])
     halo_c = reduce_c if os.environ.get("MI_DPCG_ONE_COMM", "0") == "1" else eng.Comm(ctx, world, rank, ids[0][1])
+    # Peer windows are the default between several ranks: mi_comm_peer_auto sets them up over the communicator's own
+    # transport, self-tests their coherence and lets the ranks agree; when any rank cannot, every rank keeps RCCL.
+    # MI_ALLREDUCE=rccl keeps RCCL; MI_ALLREDUCE=peer also switches a 1-rank communicator over (measurements).
+    want = os.environ.get("MI_ALLREDUCE", "auto")
+    reduce_c.peer_mode = False
+    if want == "peer" or (want == "auto" and world > 1):
+        reduce_c.peer_mode = reduce_c.peer_auto()
     return reduce_c, halo_c
 
 
-def make_host_comms(ctx):
+def make_host_comms(ctx, peer: bool = False):
     """(reduce, halo) communicators over torch.distributed's HOST transport (gloo): the engine's external-transport hook
     (mi_comm_create_external) fed with device<->host copies + gloo collectives -- the shape of the reference's own path
     (host-staged MPI, processorFvPatchScalarField.C:77-84) and of a Pstream-backed shim.  Used where RCCL cannot connect the
@@ -321,6 +326,9 @@ def make_host_comms(ctx):
             h2d(ptr, selfbox[tag] if peer == rank else t)
 
     c = eng.ExternalComm(ctx, world, rank, allreduce, exchange)
+    c.peer_mode = False
+    if peer:
+        c.peer_mode = c.peer_auto()      # windows between the processes (they share a GPU here); the set-up talks over gloo
     return c, c
 
 

@@ -179,8 +179,10 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
     sub = subs[rank]
     dname = f"cuda:{d}"
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dname)
-    comms = par.make_comms(ctx) if rccl else par.make_host_comms(ctx)
-    if peer:
+    comms = par.make_comms(ctx) if rccl else par.make_host_comms(ctx, peer=(peer == "auto"))
+    if peer == "auto":
+        assert comms[0].peer_mode, "mi_comm_peer_auto did not come up between processes sharing one GPU"
+    elif peer:
         par.enable_peer_allreduce(comms[0])
     dm = par.DistributedMatrix(ctx, sub, dname, comms=comms)
     res = dict(cells=sub.global_cells, n_global=dm.n_global)
@@ -202,6 +204,7 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
         st, fine = comms[0].peer_status()
         assert st == 0, "a peer all-reduce ran out of polls"
         res["peer_fine_grained"] = fine
+        assert dm.mat.peer_halo_status() == (True, 0), "the halo of the attached matrix did not go through windows"
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -270,6 +273,18 @@ def test_native_solvers_with_the_one_shot_peer_allreduce(pkg, orc, tmp_path, nam
     GPU and map each other's windows over hipIpc; halo exchange and the large all-reduces stay on the gloo transport."""
     spec = NATIVE_SPECS[name]
     mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, True), nprocs=world, join=True)
+    _check_native(pkg, orc, spec, world, str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("box_2", 2), ("graph_3", 3), ("box_4_asym", 4)])
+def test_native_solvers_entirely_over_peer_windows(pkg, orc, tmp_path, name, world):
+    """Round 3: mi_comm_peer_auto (windows, handle exchange over the communicator's own transport, coherence self-test, agreement)
+    and, on top of it, the HALO of every attached matrix -- GAMG level matrices included -- through windows (k_halo_push /
+    k_halo_pull) and the fused three-launch distributed PCG iteration, between 2, 3 and 4 processes that map each other's
+    windows over hipIpc.  Only what does not fit the windows (all-reduces > 8 doubles, the hierarchy build) still uses gloo."""
+    spec = NATIVE_SPECS[name]
+    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, "auto"), nprocs=world, join=True)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 

@@ -635,3 +635,56 @@ def test_dummy_agglomeration_levels_are_the_fine_mesh(pkg, orc, symmetric):
     assert h.shape == hr.shape and np.max(np.abs(h - hr)) < 1e-10 * hr[0]
     torch.cuda.synchronize()
     assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(nFinestSweeps=3), dict(nPreSweeps=1, nPostSweeps=1), dict(scaleCorrection=1)])
+def test_cycle_graph_replay_equals_eager_cycles(pkg, orc, kw, monkeypatch):
+    """The captured V-cycle (hipGraph, MI_GAMG_GRAPH) replays with the reference's DEFAULT sweep schedule as well -- 2, 3, 4, 4 ...
+    post sweeps: odd counts used to switch the replay off -- and with odd finest / pre sweep counts; every cycle's
+    residual equals the eagerly enqueued cycle's bit for bit, and both follow the oracle."""
+    import torch
+    eng = pkg.engine
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    case = pkg.synthetic.box_case(24, 20, 16, symmetric=True); w = orc.box_face_weights(case)
+    args = dict(tolerance=1e-10, maxIter=40); args.update(kw)
+    hist = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("MI_GAMG_GRAPH", graph)
+        ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+        mat = eng.Matrix(addr); mat.set_coeffs(dev(case.diag), dev(case.upper), None)
+        G = eng.Gamg(addr, w, 10)
+        assert G.n_levels >= 4                      # levels 1.. have 3 and 4 post sweeps with the defaults
+        psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+        perf = G.solve(mat, psi, dev(case.source), **args)
+        hist[graph] = (perf["history"], psi.cpu().numpy())
+    assert np.array_equal(hist["1"][0], hist["0"][0]) and np.array_equal(hist["1"][1], hist["0"][1])
+    _, ref = orc.GamgHierarchy(case, w, 10).solve(np.zeros(case.n_cells), case.source, **args)
+    assert hist["1"][0].shape == ref["history"].shape and np.max(np.abs(hist["1"][0] - ref["history"])) < 1e-10 * ref["history"][0]
+
+
+@pytest.mark.gpu
+def test_cycle_graph_is_not_replayed_across_a_symmetric_to_asymmetric_rebind(pkg, orc):
+    """the cached V-cycle graph captured tile kernels of the SYMMETRIC matrix; re-binding the same matrix
+    handle with asymmetric coefficients (same hierarchy, same vectors, explicit scaleCorrection so that nothing else in the key
+    changes) must not replay them -- the second solve has to be the asymmetric system's, cycle by cycle."""
+    import torch
+    eng = pkg.engine
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    sym = pkg.synthetic.box_case(24, 20, 16, symmetric=True)
+    asym = pkg.synthetic.box_case(24, 20, 16, symmetric=False)
+    w = orc.box_face_weights(sym)
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    addr = eng.Addressing(ctx, sym.n_cells, sym.lower_addr, sym.upper_addr)
+    mat = eng.Matrix(addr)
+    G = eng.Gamg(addr, w, 10)
+    args = dict(tolerance=1e-10, maxIter=30, scaleCorrection=0, nPostSweeps=2, postSweepsLevelMultiplier=0)   # even sweeps everywhere
+    for case in (sym, asym, sym):
+        mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+        psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+        perf = G.solve(mat, psi, dev(case.source), **args)
+        ref_psi, ref = orc.GamgHierarchy(case, w, 10).solve(np.zeros(case.n_cells), case.source, **args)
+        assert perf["nIterations"] == ref["nIterations"] and perf["nIterations"] >= 3
+        assert np.max(np.abs(perf["history"] - ref["history"])) < 1e-10 * ref["history"][0]
+        assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))

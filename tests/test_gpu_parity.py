@@ -466,6 +466,82 @@ def test_native_rccl_loop_self_exchange(pkg, orc, ctx):
     assert torch.equal(t.cpu(), torch.arange(5, dtype=torch.float64))
 
 
+def test_fused_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, ctx, monkeypatch):
+    """Round 3: the THREE-launch distributed PCG iteration (k_dpcg_update_p with the halo pack into the neighbours' windows,
+    tile_kernel_dist with boundary tiles polling the flags + the fused wA.pA all-reduce, k_dpcg_update_psi_r with the fused
+    two-scalar all-reduce; peer.inc) on a 1-rank communicator whose processor patches point at the rank itself: every store
+    goes through the windows, every flag is waited for.  Same iteration counts and history as the serial oracle, and the SAME
+    BITS as the phase loop over RCCL (the sums are formed in the same order)."""
+    syn, par = pkg.synthetic, pkg.parallel
+    case = syn.add_cyclic_y(syn.box_case(40, 32, 24, symmetric=True))        # 30 tiles: interior and boundary ones
+    S = orc.System([case])
+    out = {}
+    for mode in ("peer", "rccl"):
+        monkeypatch.setenv("MI_ALLREDUCE", mode)
+        for precond in ("diagonal", "none"):
+            solver = par.DistributedPCG(ctx, case, "cuda:0", precond=precond, n_global=case.n_cells)
+            assert solver.driver == "native"
+            st = solver.solve(tolerance=1e-9, max_iter=500)
+            used, bad = solver.ops.mat.peer_halo_status()
+            assert used == (mode == "peer") and bad == 0
+            assert solver.comms[0].peer_mode == (mode == "peer")
+            ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=1e-9, maxIter=500)
+            _check_hist(st, ref)
+            got = solver.ops.solution()
+            assert np.max(np.abs(got - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+            out[mode, precond] = (st["history"], got)
+            if mode == "peer":
+                assert solver.comms[0].peer_status()[0] == 0
+    for precond in ("diagonal", "none"):
+        assert np.array_equal(out["peer", precond][0], out["rccl", precond][0])
+        assert np.array_equal(out["peer", precond][1], out["rccl", precond][1])
+
+
+def test_attached_operators_over_halo_windows(pkg, orc, ctx):
+    """every attached operator and solver with the halo in peer windows (k_halo_push / k_halo_pull instead of ncclSend/ncclRecv)
+    and the scalars in the all-reduce windows, symmetric and asymmetric, incl. GAMG whose level matrices get windows of their
+    own; 1-rank communicator, patches to self; bit-exact operators, histories to 1e-10"""
+    syn, eng = pkg.synthetic, pkg.engine
+    for symmetric in (True, False):
+        case = syn.add_cyclic_y(syn.box_case(18, 12, 10, symmetric=symmetric), asym_shift=0.0 if symmetric else 0.25)
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, [i.face_cells for i in case.interfaces])
+        mat = eng.Matrix(addr)
+        mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+        for p, itf in enumerate(case.interfaces):
+            mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if symmetric else dev(itf.int_coeffs))
+        comm = eng.Comm(ctx, 1, 0, eng.Comm.unique_id())
+        assert comm.peer_auto()
+        mat.attach_comm(comm, comm, [0, 0], [1, 0], n_global=case.n_cells)
+        assert mat.peer_halo_status() == (True, 0)
+        S = orc.System([case])
+        n = case.n_cells
+        x = syn.splitmix_uniform(3, n) - 0.5
+        out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+        mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+        mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
+        mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
+        psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 3)
+        assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 3))
+
+        def run(fn_eng, fn_orc, **kw):
+            psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+            perf = fn_eng(psi, dev(case.source), **kw)
+            ref_psi, ref = fn_orc(np.zeros(n), case.source, **kw)
+            _check_hist(perf, ref)
+            assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+
+        if symmetric:
+            run(mat.pcg, S.pcg, precond="diagonal", tolerance=1e-9, maxIter=500)      # the fused three-launch iteration
+            run(mat.pcg, S.pcg, precond="AINV", tolerance=1e-9, maxIter=500)
+        else:
+            run(mat.pbicg, S.pbicg, precond="AINV", tolerance=1e-10, maxIter=300)
+            run(mat.pbicgstab, S.pbicgstab, precond="diagonal", tolerance=1e-10, maxIter=300)
+        run(mat.smooth_solve, S.smooth_solve, n_sweeps=2, tolerance=1e-4, maxIter=400)
+        assert mat.peer_halo_status() == (True, 0) and comm.peer_status()[0] == 0
+        mat.detach_comm()
+        comm.close()
+
+
 @pytest.mark.parametrize("symmetric", [True, False])
 def test_attached_comm_operators_and_solvers(pkg, orc, ctx, symmetric):
     """mi_matrix_attach_comm on a 1-rank RCCL communicator.  The y-periodic box is posed with PROCESSOR patches whose
