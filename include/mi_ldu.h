@@ -577,12 +577,16 @@ int mi_comm_peer_enable(mi_comm_t comm, int32_t on);
  * *enabled_out = 0 leaves the matrix on send/recv.  mi_matrix_peer_halo_status: whether windows are in use and whether a wait
  * has run out of polls.
  * With halo windows AND a peer-mode reduce communicator, mi_dpcg_comm_iterate (and mi_pcg_solve on the attached matrix,
- * diagonal / none) runs the FUSED iteration: k_dpcg_update_p (p-update + convergence test of the previous iteration + deferred
- * psi update; every block packs the patch cells of its own chunk into the neighbours' windows, the last block raises the
- * flags), tile_kernel_dist (all tiles in one launch, interior first; a boundary tile polls the flags and reads the window
- * directly; the last workgroup folds wA.pA and all-reduces it through the windows), k_dpcg_update_psi_r (the last block reduces
- * sum|rA| and the next wA.rA and all-reduces both): 3 launches, 0 collective calls per iteration (MI_DPCG_FUSED=0: the phase
- * loop).  The sums are formed in the order the separate reduction kernels use: same bits as the phase loop.                     */
+ * diagonal / none) runs WITHOUT any collective call: k_dpcg_update_p (p-update + convergence test of the previous iteration +
+ * deferred psi update; every block packs the patch cells of its own chunk into the neighbours' windows), tile_kernel_dist (all
+ * tiles in one launch, interior first; block 0 raises the neighbours' flags, a boundary tile polls its own and reads the window
+ * directly), a one-workgroup kernel that folds wA.pA and all-reduces it through the windows, k_dpcg_update_psi_r, a one-workgroup
+ * kernel for sum|rA| and the next wA.rA: five launches, 51 us per iteration at 108^3 cells per rank against 81 us for the phase
+ * loop over RCCL on the same box (profiles/r03_a_*; MI_DPCG_FUSED=0: the phase loop, 3 | 4: the all-reduces inside the passes,
+ * measured slower).  The sums are formed in the order the separate reduction kernels use: same bits as the phase loop.
+ * Not on this path: cyclicAMI / transformed patches (mi_dpcg_set_buffers refuses them: the boundary tiles read the window
+ * without the interpolation / factor; mi_pcg_solve on such a matrix takes the tile-operator pipeline, whose k_halo_pull
+ * applies the factors) and AINV (its preconditioner is itself a tile pass with a halo of its own).                              */
 int mi_matrix_peer_halo_auto(mi_matrix_t m, int32_t *enabled_out);
 int mi_matrix_peer_halo_status(mi_matrix_t m, int32_t *enabled_out, int32_t *status_out_or_null);
 int mi_matrix_attach_comm(mi_matrix_t m, mi_comm_t reduce, mi_comm_t halo, const int32_t *patch_rank,

@@ -9,3 +9,10 @@ through ``__graft_entry__.load_package()`` which registers it as
 """
 from . import synthetic  # noqa: F401
 from . import engine  # noqa: F401
+
+
+def __getattr__(name):  # ``pkg.parallel`` pulls in torch.distributed: imported on first use
+    if name == "parallel":
+        from importlib import import_module
+        return import_module(__name__ + ".parallel")
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -3,7 +3,7 @@ periodic in y and the two y-patches are posed as PROCESSOR patches whose neighbo
 and all-reduce of the N > 1 code path is really issued (to self).  Compares the phase loop over RCCL (7 kernels + 2
 ncclAllReduce + 1 send/recv group per iteration) with the fused three-launch iteration over peer windows (peer.inc).
 
-    python tools/bench_selfcomm.py [--dims 108 108 108] [--iters 400] [--mode peer|rccl|both] [--out file.json]
+    python tools/bench_selfcomm.py [--dims 108 108 108] [--iters 400] [--mode both | rccl,peer3,peer4,peer5,peer4_t512] [--out file.json]
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,8 +28,14 @@ stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
 ctx = eng.Context(0, stream.cuda_stream)
 case = syn.add_cyclic_y(syn.box_case(*args.dims))
 res = {"dims": args.dims, "cells": case.n_cells, "ext_values": int(sum(len(i.face_cells) for i in case.interfaces))}
-for mode in (["rccl", "peer"] if args.mode == "both" else [args.mode]):
-    os.environ["MI_ALLREDUCE"] = mode
+modes = ["rccl", "peer3", "peer4", "peer5", "peer4_t512"] if args.mode == "both" else args.mode.split(",")
+for mode in modes:
+    os.environ["MI_ALLREDUCE"] = "rccl" if mode == "rccl" else "peer"
+    # peer3: every all-reduce inside the passes; peer4 (the default between devices): the two-scalar one inside the p-update,
+    # wA.pA in a one-workgroup kernel; peer5: both in one-workgroup kernels (ranks that share a device)
+    os.environ["MI_DPCG_FUSED"] = mode[4] if mode.startswith("peer") and len(mode) > 4 and mode[4] in "345" else "1"
+    if "_t" in mode: os.environ["MI_TILE_CELLS"] = mode.split("_t")[1]       # e.g. peer5_t640: 640-cell tiles
+    else: os.environ.pop("MI_TILE_CELLS", None)
     s = par.DistributedPCG(ctx, case, dev, precond="diagonal", n_global=case.n_cells)
     K = args.iters
     s.begin(tolerance=0.0, max_iter=5 * K + 64)
@@ -47,7 +53,7 @@ for mode in (["rccl", "peer"] if args.mode == "both" else [args.mode]):
     used, bad = s.ops.mat.peer_halo_status()
     res[mode] = {"us_per_iteration": sorted(r[0] for r in reps)[len(reps) // 2], "host_enqueue_us_per_iteration": sorted(r[1] for r in reps)[len(reps) // 2],
                  "all_repeats_us": [r[0] for r in reps], "amul_us": 1e3 * a_ms / 64, "halo_windows": used, "wait_timeouts": bad,
-                 "allreduce": s.allreduce, "launches_per_iteration": 3 if used else "7 kernels + 2 ncclAllReduce + 1 ncclGroup(send, recv)"}
+                 "allreduce": s.allreduce, "launches_per_iteration": int(os.environ["MI_DPCG_FUSED"]) if used and os.environ["MI_DPCG_FUSED"] in "345" else 4 if used else "7 kernels + 2 ncclAllReduce + 1 ncclGroup(send, recv)"}
     print(mode, json.dumps(res[mode]), flush=True)
     del s
 print(json.dumps(res))
