@@ -604,6 +604,21 @@ int mi_dpcg_comm_iterate(mi_matrix_t m, int32_t n_iters, int32_t record_amul_eve
 int mi_event_record(mi_matrix_t m, int32_t idx);
 int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, float *ms_out);
 
+/* fvMatrix<vector>::solveSegregated (src/finiteVolume/fvMatrices/fvMatrix/fvMatrixSolve.C:103-225) as ONE call: nrhs <= 3
+ * right-hand sides against the same matrix (the components of a momentum equation).  Every component runs the reference's
+ * PBiCG loop (PBiCG.C:67-246) with its own scalars, convergence test and iteration count -- the same fma chains and reduction
+ * trees as mi_pbicg_solve, hence the same bits per component -- while each pass over the matrix serves all components:
+ * tile_kernel_multi stages a tile's upper / lower once for the 2 x nrhs operand vectors of a step (A pA_c and A^T pT_c; the
+ * DILU pair precondition / preconditionT), sumA and 1/diag are computed once per coefficient binding, the host polls all
+ * components with one copy.  diag_dev: nrhs device pointers to the components' DIAGONALS (caller order) -- solveSegregated adds
+ * the boundary contribution per component, addBoundaryDiag(diag, cmpt), so the components share upper / lower but not
+ * necessarily the diagonal -- or NULL: the bound diagonal for all.  psi_dev / source_dev: nrhs device pointers; perf_out: nrhs records;
+ * residual_history_host: nrhs rows of history_len doubles (or NULL).  On a matrix with communicators attached the components
+ * are solved one after the other (each tile operator exchanges the halo of ITS operand).
+ * mi_pbicg_solve itself uses the one-component form of the same kernel: A pA and A^T pT in one pass (MI_PBICG_PAIR=0: two).   */
+int mi_pbicg_solve_multi(mi_matrix_t m, int32_t nrhs, const double *const *diag_dev_or_null, double *const *psi_dev, const double *const *source_dev,
+                         const mi_solver_controls *controls, int precond, mi_solver_perf *perf_out,
+                         double *residual_history_host, int32_t history_len);
 int mi_pbicg_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
                    const mi_solver_controls *controls, int precond,
                    mi_solver_perf *perf_out, double *residual_history_host, int32_t history_len);

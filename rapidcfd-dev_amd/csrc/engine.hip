@@ -89,6 +89,7 @@ struct mi_ctx_s {
     int fusePerm = 1;  // MI_FUSE_PERM: caller-order operators gather / scatter through e2c inside the tile kernel (A/B hook)
     int deferPsi = 1;  // MI_PCG_DEFER_PSI: psi += alpha pA rides in the next k_pcg_update_p (one vector read less per iteration; A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
+    int pairAT = 1;    // MI_PBICG_PAIR: PBiCG's A p / A^T pT (and the DILU pair) in one pass over the coefficients (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
     int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1; // MI_* switches, read once per context
     std::set<const void*> ldsAttrSet;                         // kernels whose dynamic-LDS limit has been raised on THIS device
@@ -138,6 +139,7 @@ struct mi_matrix_s {
     uint64_t epoch = 0; // bumped whenever coefficients are (re)bound: lets a GAMG hierarchy keep its level matrices between solves
     std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
     DevBuf<double> hist, tilePartial;
+    DevBuf<PcgState> mstate; DevBuf<double> mpartial, mhist, mtilePartial; PcgState* mhostState = nullptr;   // multi-right-hand-side solves (multi.inc): one state / partial block / history per component
     int histLen = 0;
     // running PCG session (mi_pcg_begin/iterate/end)
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
@@ -228,6 +230,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->deferPsi = env_int("MI_PCG_DEFER_PSI", 1);
     c->fusePerm = env_int("MI_FUSE_PERM", 1);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
+    c->pairAT = env_int("MI_PBICG_PAIR", 1);
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
     c->pcgBatch = env_int("MI_PCG_BATCH", 16); c->pcgGraph = env_int("MI_PCG_GRAPH", -1); c->pbicgHostStepped = env_int("MI_PBICG_HOST_STEPPED", 0);
@@ -1581,6 +1584,9 @@ int host_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* p
 } // namespace
 
 namespace {
+// y0 = Op x0, y1 = Op^T x1 in ONE pass over the coefficients (multi.inc: tile_kernel_multi with one component), Op = A or the
+// AINV apply; gate: &PcgState::done of the running solve or nullptr
+int tile_pair(mi_matrix_s* m, bool ainv, const double* x0, const double* x1, double* y0, double* y1, const int32_t* gate, double* dotPartial, bool* fused);
 // enqueue PBiCG iteration bodies it0 .. it0+count-1 (no host sync): precondition both residuals (+ fused sum wA.rT),
 // update pA/pT, Amul, Tmul, sum wA.pT, update psi/rA/rT (+ sum|rA|), convergence test
 int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, double* pA, double* wA, double* rA,
@@ -1592,19 +1598,31 @@ int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, d
     const int64_t n = a->L.nCells;
     double* P1 = c->partial.p; double* P2 = c->partial.p + RG; double* P3 = c->partial.p + 2 * RG;
     if (precond != MI_PRECOND_NONE) MICHK(ensure_rD(m));
+    if (m->tilePartial.n < (size_t)a->L.nTiles) MICHK(m->tilePartial.alloc((size_t)a->L.nTiles));
     struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
     for (int it = it0; it < it0 + count; ++it) {
+        const bool paired = !comm_attached(m) && c->pairAT;   // the plain and the transposed pass share one staging of the coefficients
         if (precond == MI_PRECOND_AINV) {
+            bool fusedDot = false;   // sum wA.rT out of the preconditioner pass (per-tile partials, folded like the Amul's in PCG)
+            if (paired) MICHK(tile_pair(m, true, rA, rT, wA, wT, &c->state.p->done, m->tilePartial.p, &fusedDot));
+            else {
             MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0));
             MICHK(launch_tile<OP_AINV>(m, true, rT, nullptr, m->rD.p, wT, 0.0, 0));
-            k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rT, n, P1);
+            }
+            if (fusedDot) k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P1);
+            else k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, rT, n, P1);
         } else if (precond == MI_PRECOND_DIAGONAL) k_bicg_precond_dot<true><<<RG, RB, 0, s>>>(c->state.p, m->rD.p, rA, rT, wA, wT, n, P1);
         else k_bicg_precond_dot<false><<<RG, RB, 0, s>>>(c->state.p, nullptr, rA, rT, wA, wT, n, P1);
         MICHK(globalize(m, P1));
         k_bicg_update_p<<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, wT, pA, pT, n);
+        bool fusedDot2 = false;      // sum wA.pT out of the Amul / Tmul pass
+        if (paired) MICHK(tile_pair(m, false, pA, pT, wA, wT, &c->state.p->done, m->tilePartial.p, &fusedDot2));
+        else {
         MICHK(tile_op<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0));   // halo exchange inside when attached
         MICHK(tile_op<OP_AMUL>(m, true, pT, nullptr, nullptr, wT, 0.0));
-        k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, pT, n, P2);
+        }
+        if (fusedDot2) k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P2);
+        else k_reduce<RED_PROD><<<RG, RB, 0, s>>>(wA, pT, n, P2);
         MICHK(globalize(m, P2));
         k_bicg_update_psi_r<<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, wT, psi, rA, rT, n, P3);
         MICHK(globalize(m, P3));
@@ -1997,6 +2015,7 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
     return MI_OK;
 }
 
+#include "multi.inc"
 #include "comm.inc"
 #include "gamg_engine.inc"
 #include "assembly.inc"
@@ -2004,6 +2023,7 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
 mi_matrix_s::~mi_matrix_s()
 {
     if (pcgGraph) (void)hipGraphExecDestroy(pcgGraph);
+    if (mhostState) (void)hipHostFree(mhostState);
     for (auto* w : work) delete w;
     for (auto e : evPool) (void)hipEventDestroy(e);
     if (dpc) {

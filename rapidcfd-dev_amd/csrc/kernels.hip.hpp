@@ -407,6 +407,168 @@ __global__ __launch_bounds__(BS) void tile_kernel_perm(const TileArgs a)
     tile_body<OP, ASYM, TRANS, BS, false, true>(a, (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b, smem);
 }
 
+// ---------------------------------------------------------------------------
+// multi-vector tile pass (round 3): ONE staging of a tile's coefficients serves 2*NRHS operand vectors -- NRHS of them through
+// the matrix as bound, NRHS through its transpose.  That is PBiCG's pair  wA = A pA, wT = A^T pT  (PBiCG.C:177-181) and its
+// preconditioner pair  precondition(wA, rA), preconditionT(wT, rT)  (PBiCG.C:149-153) in one pass, and for NRHS = 3 the three
+// components of fvMatrix<vector>::solveSegregated (fvMatrixSolve.C:148-206), which the reference solves one after the other,
+// each re-reading the same upper / lower / addressing: bytes per row 52.6 (both triangles) + 24 (row entries) + 28.8 per
+// operand instead of (52.6 + 24 + 28.8) per operand.  Per operand the fma chain is the single-vector kernel's, term by term,
+// so every output bit equals the single-vector pass (and the oracle).  Asymmetric matrices (the bi-conjugate solvers' case;
+// a symmetric matrix passes its upper array for both triangles).
+// ---------------------------------------------------------------------------
+template <int NRHS>
+struct MultiVec {
+    const double* x[2 * NRHS];     // operands: [0, NRHS) plain, [NRHS, 2 NRHS) through the transpose
+    double* y[2 * NRHS];           // (OP_SUMA: y[c], c < NRHS, receives sumA of component c)
+    const int32_t* done[NRHS];     // &PcgState::done of component c (or nullptr): a finished component costs nothing
+    // fvMatrix<vector>::solveSegregated adds the boundary contribution to the diagonal PER COMPONENT (addBoundaryDiag(diag, cmpt),
+    // fvMatrixSolve.C:171-176): the components share upper / lower but may differ in the diagonal
+    const double* diag[NRHS];      // engine order
+    const double* rD[NRHS];        // 1 / diag (AINV); SRD: all equal, staged once
+    // fused into the pass (all optional): per-workgroup partials of sum_i y[c][i] * x[NRHS + c][i] -- PBiCG's wA.rT (PBiCG.C:155,
+    // out of the preconditioner pass) and wA.pT (PBiCG.C:183, out of the Amul/Tmul pass); and for the solver prologue
+    // y2[v] = b[c] - y[v] (rA = source - A psi, rT = source - A^T psi, PBiCG.C:110-128) with y[v] itself optional
+    double* dotPartial[NRHS];
+    const double* b[NRHS];
+    double* y2[2 * NRHS];
+};
+
+template <int OP, int NRHS, bool SRD, int BS>
+__global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const MultiVec<NRHS> V)
+{
+    static_assert(OP == OP_AMUL || OP == OP_AINV || OP == OP_SUMA, "multi-vector form: Amul/Tmul pairs, AINV / AINV^T pairs, sumA per diagonal");
+    constexpr int NV = (OP == OP_SUMA) ? NRHS : 2 * NRHS;
+    constexpr int NRD = SRD ? 1 : NRHS;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    bool act[NRHS];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < NRHS; ++c) { act[c] = !(V.done[c] && *V.done[c]); any = any || act[c]; }
+    if (!any) return;
+    const int b = blockIdx.x, per = gridDim.x >> 3;
+    const int t = (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;     // XCD-aware, as tile_kernel
+    double* cU = smem;
+    double* cL = smem + a.offLow;
+    double* xs = smem + a.offX;             // NV arrays of xlen doubles
+    double* rDs = smem + a.offRD;           // NRD arrays of xlen doubles
+    const int xlen = a.offSB;               // (re-used field: doubles per staged operand)
+    const int tid = threadIdx.x;
+    const int c0 = a.tileCellStart[t], nc = a.tileCellStart[t + 1] - c0;
+    const int s0 = a.tileSlotStart[t], ns = a.tileSlotStart[t + 1] - s0;
+    const int h0 = a.tileHaloStart[t], nh = a.tileHaloStart[t + 1] - h0;
+    const int ifs0 = (OP == OP_AINV) ? a.tileIfaceSlot0[t] : 0;
+    stage_dma16<BS, true>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid >> 6, tid & 63);
+    stage_dma16<BS, true>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
+    if (OP != OP_SUMA) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!act[v % NRHS]) continue;
+            stage_dma8<BS>(V.x[v] + c0, xs + v * xlen, nc, tid);
+            stage_gather<BS>(V.x[v], a.haloCell + h0, xs + v * xlen + nc, nh, tid);
+        }
+    }
+    if (OP == OP_AINV) {
+#pragma unroll
+        for (int c = 0; c < NRD; ++c) {
+            stage_dma8<BS>(V.rD[c] + c0, rDs + c * xlen, nc, tid);
+            stage_gather<BS>(V.rD[c], a.haloCell + h0, rDs + c * xlen + nc, nh, tid);
+        }
+    }
+    const int sl0 = a.tileSliceStart[t], nsl = a.tileSliceStart[t + 1] - sl0;
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = BS / 64;
+    constexpr int PRE = 8;
+    const uint32_t padEnt = (uint32_t)(ns - 1) << 16;   // last slot of the segment is always 0.0
+    uint32_t ecur[PRE];
+    int wcur = 0, e0cur = 0;
+    auto fetch = [&](int s, uint32_t (&e)[PRE], int& e0, int& width) {
+        e0 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s]);
+        const int e1 = __builtin_amdgcn_readfirstlane(a.sliceEntryStart[sl0 + s + 1]);
+        width = (e1 - e0) >> 6;
+        const uint32_t* ent = a.entries + e0 + lane;
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) e[j] = (j < width) ? ent[j * 64] : padEnt;
+    };
+    if (wave < nsl) fetch(wave, ecur, e0cur, wcur);
+    else {
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) ecur[j] = padEnt;
+    }
+    __syncthreads();
+    double dot[NRHS];
+#pragma unroll
+    for (int c = 0; c < NRHS; ++c) dot[c] = 0.0;
+    for (int s = wave; s < nsl; s += NW) {
+        uint32_t enext[PRE];
+        int wnext = 0, e0next = 0;
+        if (s + NW < nsl) fetch(s + NW, enext, e0next, wnext);
+        else {
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) enext[j] = padEnt;
+        }
+        const int i = s * 64 + lane;
+        const bool live = i < nc;
+        const int gi = c0 + (live ? i : 0);
+        double xi[NV], acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            xi[v] = (OP != OP_SUMA && live && act[v % NRHS]) ? xs[v * xlen + i] : 0.0;
+            if (OP == OP_AMUL) acc[v] = V.diag[v % NRHS][gi] * xi[v];
+            else if (OP == OP_SUMA) acc[v] = V.diag[v][gi];
+            else acc[v] = 0.0;
+        }
+        auto accumulate = [&](uint32_t en) {
+            const int o = en & 0xFFFFu, sl = (en >> 16) & 0x7FFFu;
+            const bool lowerSide = (en >> 31) != 0u;
+            const double cu = cU[sl], cl = cL[sl];
+            const double cPlain = lowerSide ? cl : cu, cTrans = lowerSide ? cu : cl;   // TRANS swaps which triangle a side uses
+            if (OP == OP_AINV) {
+                if (sl < ifs0) { // faces only (AINVPreconditioner.C)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const double rd = rDs[(SRD ? 0 : (v % NRHS)) * xlen + o];
+                        acc[v] = fma((v < NRHS ? cPlain : cTrans) * rd, xs[v * xlen + o], acc[v]);
+                    }
+                }
+            } else if (OP == OP_SUMA) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += cPlain;
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] = fma(v < NRHS ? cPlain : cTrans, xs[v * xlen + o], acc[v]);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) if (j < wcur) accumulate(ecur[j]);
+        if (wcur > PRE) {
+            const uint32_t* ent = a.entries + e0cur + lane;
+            for (int j = PRE; j < wcur; ++j) accumulate(ent[j * 64]);
+        }
+        if (live) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (!act[v % NRHS]) continue;
+                const double out = (OP == OP_AINV) ? rDs[(SRD ? 0 : (v % NRHS)) * xlen + i] * (xi[v] - acc[v]) : acc[v];
+                if (V.y[v]) V.y[v][gi] = out;
+                if (OP == OP_AMUL && V.y2[v]) V.y2[v][gi] = V.b[v % NRHS][gi] - out;
+                if (OP != OP_SUMA && v < NRHS) dot[v] = fma(out, xi[(NRHS + v) % NV], dot[v]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) ecur[j] = enext[j];
+        wcur = wnext; e0cur = e0next;
+    }
+    if (OP != OP_SUMA && V.dotPartial[0]) {
+        __shared__ double red[BS / 64];
+#pragma unroll
+        for (int c = 0; c < NRHS; ++c) {
+            const double tsum = block_sum<BS>(dot[c], red);
+            if (tid == 0 && act[c]) V.dotPartial[c][b] = tsum;
+        }
+    }
+}
+
 // fold n per-workgroup partials into the RG slots the consumers reduce (fixed order)
 __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict__ in, int n, double* __restrict__ out)
 {
@@ -415,6 +577,15 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
     out[threadIdx.x] = v;
 }
 
+// the same for up to three arrays in one launch (block c: in[c] -> out[c])
+struct Fold3 { const double* in[3]; double* out[3]; };
+__global__ __launch_bounds__(1024) void k_fold_partials3(const Fold3 f, int n)
+{
+    const double* in = f.in[blockIdx.x];
+    double v = 0.0;
+    for (int k = threadIdx.x; k < n; k += 1024) v += in[k];
+    f.out[blockIdx.x][threadIdx.x] = v;
+}
 // the same for two arrays in one launch (block 0: inA -> outA, block 1: inB -> outB)
 __global__ __launch_bounds__(1024) void k_fold_partials2(const double* __restrict__ inA, const double* __restrict__ inB, int n,
                                                          double* __restrict__ outA, double* __restrict__ outB)
@@ -634,6 +805,22 @@ __global__ __launch_bounds__(RB) void k_normfactor(const double* __restrict__ Ap
                                                    const double* __restrict__ sumA, double avg, int64_t n, double* __restrict__ partial)
 {
     __shared__ double red[RB / 64];
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 A = ld2(Apsi, i), b = ld2(src, i), s = ld2(sumA, i);
+          const double t0 = avg * s.x, t1 = avg * s.y;
+          acc0 += fabs(A.x - t0) + fabs(b.x - t0); acc1 += fabs(A.y - t1) + fabs(b.y - t1); },
+        [&](int64_t i) { const double t0 = avg * sumA[i]; acc0 += fabs(Apsi[i] - t0) + fabs(src[i] - t0); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// the same with gAverage(psi) = sum(psi) / n formed on the device from the reduced sum (no host read in the solver prologue)
+__global__ __launch_bounds__(RB) void k_normfactor_dev(const double* __restrict__ Apsi, const double* __restrict__ src,
+                                                       const double* __restrict__ sumA, const double* __restrict__ sumPsi, double nGlobal,
+                                                       int64_t n, double* __restrict__ partial)
+{
+    __shared__ double red[RB / 64];
+    const double avg = sumPsi[0] / nGlobal;
     double acc0 = 0, acc1 = 0;
     chunk_loop(n, [&](int64_t i) { const double2 A = ld2(Apsi, i), b = ld2(src, i), s = ld2(sumA, i);
           const double t0 = avg * s.x, t1 = avg * s.y;

@@ -43,7 +43,7 @@ class SolverControls(C.Structure):
 SYMBOLS = [
     "mi_addr_set_ami_patch", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
     "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy", "mi_gamg_host_build_ami",
-    "mi_comm_peer_auto", "mi_comm_peer_selftest", "mi_comm_peer_enable", "mi_matrix_peer_halo_auto", "mi_matrix_peer_halo_status",
+    "mi_pbicg_solve_multi", "mi_comm_peer_auto", "mi_comm_peer_selftest", "mi_comm_peer_enable", "mi_matrix_peer_halo_auto", "mi_matrix_peer_halo_status",
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
@@ -450,6 +450,27 @@ class Matrix:
 
     def pbicg(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0):
         return self._solve("mi_pbicg_solve", psi, source, (C.c_int(PRECOND[precond]),), tolerance, relTol, maxIter, minIter)
+
+    def pbicg_multi(self, psis, sources, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0, diags=None):
+        """the components of a vector equation in one solve (mi_pbicg_solve_multi): list of per-component results;
+        diags: per-component diagonals (addBoundaryDiag(diag, cmpt)) or None = the bound diagonal for all"""
+        n = len(psis)
+        assert 1 <= n <= 3 and len(sources) == n
+        ctl = SolverControls(tolerance, relTol, maxIter, minIter)
+        perf = (SolverPerf * n)()
+        hist_len = maxIter + 2
+        hist = np.full((n, hist_len), np.nan)
+        P = (C.c_void_p * n)(*[_ptr(t) for t in psis])
+        S = (C.c_void_p * n)(*[_ptr(t) for t in sources])
+        D = None if diags is None else (C.c_void_p * n)(*[_ptr(t) for t in diags])
+        _chk(lib().mi_pbicg_solve_multi(self.h, C.c_int32(n), D, P, S, C.byref(ctl), C.c_int(PRECOND[precond]), perf,
+                                        hist.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(hist_len)))
+        out = []
+        for k in range(n):
+            d = {f: getattr(perf[k], f) for f, _ in SolverPerf._fields_ if f != "reserved"}
+            d["history"] = hist[k][~np.isnan(hist[k])].copy()
+            out.append(d)
+        return out
 
     def pbicgstab(self, psi, source, precond="diagonal", tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0,
                   replicate_quirk=True):

@@ -549,6 +549,32 @@ solverPerformance fvVectorMatrix::solve(vectorgpuField& psi, const dictionary& s
     for (direction d = 0; d < 3; ++d) source.component(d) = source_.component(d);
     addBoundarySource(source);
     FieldFieldScalar noCoeffs; lduInterfaceFieldPtrsList noInterfaces;
+    // MI355X form of the component loop: PBiCG on the three components as ONE solve (mi_pbicg_solve_multi) -- every pass over
+    // upper / lower serves all components, each component keeps its own diagonal (addBoundaryDiag(diag, cmpt)), scalars,
+    // convergence test and solverPerformance line; same numbers as the loop below (`segregatedLoop yes;` selects that)
+    if (asymmetric() && solverControls.lookup("solver") == "PBiCG" && solverControls.lookupOrDefault<word>("segregatedLoop", "no") != "yes") {
+        std::vector<scalargpuField> dc;
+        dc.reserve(3);
+        const double* dptr[3]; double* pptr[3]; const double* sptr[3];
+        for (direction cmpt = 0; cmpt < 3; ++cmpt) {
+            dc.emplace_back(saveDiag);
+            addBoundaryDiag(dc.back(), cmpt);
+        }
+        for (direction cmpt = 0; cmpt < 3; ++cmpt) { dptr[cmpt] = dc[cmpt].data(); pptr[cmpt] = psi.component(cmpt).data(); sptr[cmpt] = source.component(cmpt).data(); }
+        const mi_solver_controls c = controlsOf(solverControls.lookupOrDefault<scalar>("tolerance", 1e-6), solverControls.lookupOrDefault<scalar>("relTol", 0),
+                                                solverControls.lookupOrDefault<label>("maxIter", 1000), solverControls.lookupOrDefault<label>("minIter", 0));
+        mi_solver_perf r[3];
+        miCheck(mi_pbicg_solve_multi(handle(noCoeffs, noCoeffs, noInterfaces, 0), 3, dptr, pptr, sptr, &c,
+                                     lduMatrix::preconditioner::kindFor(solverControls, false), r, nullptr, 0), "fvMatrix<Type>::solveSegregated");
+        const word pre = lduMatrix::preconditioner::getName(solverControls);
+        for (direction cmpt = 0; cmpt < 3; ++cmpt) {
+            solverPerformance solverPerf = perfOf(pre + "PBiCG", psiName_ + componentNames[cmpt], r[cmpt]);
+            solverPerf.print(Info);
+            solverPerformance m = max(solverPerfVec, solverPerf);
+            solverPerfVec = solverPerformance(solverPerf.solverName(), psiName_, m.initialResidual(), m.finalResidual(), m.nIterations(), m.converged(), m.singular());
+        }
+        return solverPerfVec;
+    }
     for (direction cmpt = 0; cmpt < 3; ++cmpt) {
         addBoundaryDiag(diag(), cmpt);
         solverPerformance solverPerf = lduMatrix::solver::New(psiName_ + componentNames[cmpt], *this, noCoeffs, noCoeffs, noInterfaces, solverControls)

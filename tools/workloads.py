@@ -1,0 +1,167 @@
+"""The BASELINE workloads beyond config 2 as callable measurements (bench.py appends them to its JSON line as
+`config.supplements`; tools/bench_timestep.py and tools/bench_gamg.py print them on their own):
+
+  gamg_supplement      config 3: GAMG pressure solve on the 10 M-cell box (V-cycles/s, fraction of the HBM roofline on the
+                       ALGORITHMIC bytes of the reference's unfused cycle, cycles to 1e-6)
+  timestep_supplement  configs 4 / 5 per rank: one PISO-like time step -- full fvMatrix assembly, PBiCG + DILU momentum
+                       (three components), GAMG pressure, flux / gradient correction -- every stage through the C ABI
+"""
+import os
+import time
+
+import numpy as np
+
+
+def box_direction(case):
+    nx = case.dims[0]
+    d = case.upper_addr.astype(np.int64) - case.lower_addr
+    return np.where(d == 1, 0, np.where(d == nx, 1, 2))
+
+
+def box_pair_weights(case):
+    return (1.0 / case.dims[0]) * np.array([1.0, 1.01, 1.02])[box_direction(case)]   # faceAreaPair weights of the box
+
+
+def gamg_cycle_bytes(levels, n0, f0, ctl):
+    """ALGORITHMIC bytes of one V-cycle + finest residual, summed over the levels with the SURVEY.md 8(d) formulas and the
+    reference's UNFUSED op sequence (GAMGSolverSolve.C:181-474), symmetric matrix: Jacobi sweep 32N+16F; Amul 24N+16F;
+    restrict or prolong between levels (8+4)N_fine + 8N_coarse; correction scaling = Amul + two dot products (2 x 16N) + the
+    scaling pass (field, Acf, source, D -> field: 40N); finest: psi += corr (24N), residual = Amul + subtract (24N) + sumMag (8N).
+    levels: [(cells, faces)] of the coarse levels 0..L-1; n0, f0 the finest level."""
+    nL = len(levels)
+    size = [(n0, f0)] + list(levels)                       # size[k]: finest is k = 0, coarse level l is k = l + 1
+    tot = 0.0
+    for k in range(nL):                                    # restrict k -> k+1 on the way down, prolong on the way up
+        tot += 2 * ((8 + 4) * size[k][0] + 8 * size[k + 1][0])
+    for l in range(nL - 1):                                # every coarse level but the coarsest: [scale] + post sweeps
+        n, f = levels[l]
+        sweeps = min(ctl["nPostSweeps"] + ctl["postSweepsLevelMultiplier"] * l, ctl["maxPostSweeps"])
+        tot += sweeps * (32 * n + 16 * f)
+        if l < nL - 2:
+            tot += (24 * n + 16 * f) + 32 * n + 40 * n
+    tot += (24 * n0 + 16 * f0) + 32 * n0 + 40 * n0 + 24 * n0                       # finest: scale + psi update
+    tot += ctl["nFinestSweeps"] * (32 * n0 + 16 * f0)
+    tot += (24 * n0 + 16 * f0) + 24 * n0 + 8 * n0                                   # finest residual
+    nc = levels[-1][0]
+    tot += 8 * nc * nc + 16 * nc                                                    # coarsest: dense inverse times source
+    return tot
+
+
+def gamg_supplement(eng, case, addr, mat, dev, cycles=20, repeats=3, hbm_peak_gbs=8000.0):
+    """BASELINE config 3 on an existing addressing / matrix of the box: V-cycles/s inside mi_gamg_solve (tolerance 0)"""
+    import torch
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    N, F = case.n_cells, case.n_faces
+    t0 = time.perf_counter()
+    G = eng.Gamg(addr, box_pair_weights(case), 100)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    src = t(case.source)
+    psi = torch.zeros(N, dtype=torch.float64, device=dev)
+    G.solve(mat, psi, src, tolerance=0.0, maxIter=3)           # warm-up: level matrices, scratch, the cycle graph
+    rep = []
+    for _ in range(repeats):
+        psi.zero_(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        perf = G.solve(mat, psi, src, tolerance=0.0, maxIter=cycles)
+        torch.cuda.synchronize()
+        rep.append(time.perf_counter() - t0)
+        assert perf["nIterations"] == cycles, perf
+    el = float(np.median(rep))
+    levels = [(G.level_sizes(l)["n_coarse"], G.level_sizes(l)["n_coarse_faces"]) for l in range(G.n_levels)]
+    ctl = dict(nPostSweeps=2, postSweepsLevelMultiplier=1, maxPostSweeps=4, nFinestSweeps=2)
+    alg = gamg_cycle_bytes(levels, N, F, ctl)
+    psi.zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    pc = G.solve(mat, psi, src, tolerance=1e-6, maxIter=200); torch.cuda.synchronize(); t_conv = time.perf_counter() - t0
+    out = {"workload": "BASELINE config 3: GAMG pressure solve on the same box (faceAreaPair agglomeration, "
+                       f"{G.n_levels} levels down to {levels[-1][0]} cells, GaussSeidel(=Jacobi) smoother, correction scaling, direct coarsest solve)",
+           "v_cycles_per_s": cycles / el, "ms_per_v_cycle": 1e3 * el / cycles, "algorithmic_bytes_per_cycle": alg,
+           "roofline_frac": alg / (el / cycles) / 1e9 / hbm_peak_gbs, "hierarchy_build_s": t_build,
+           "solve_to_1e-6": {"cycles": int(pc["nIterations"]), "seconds": t_conv},
+           "timing": f"median of {repeats} mi_gamg_solve calls of {cycles} V-cycles (tolerance 0; the solve's prologue is inside the clock)"}
+    return out, G
+
+
+def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batched=None):
+    """One PISO-like time step on the box (configs 4 / 5 per rank): stage times by HIP events, wall time per step.
+    batched: solve the three momentum components with ONE multi-right-hand-side PBiCG (mi_pbicg_solve_multi) -- default: when
+    the engine has it (MI_TIMESTEP_SEGREGATED=1 forces three single solves)."""
+    import torch
+    N, F = case.n_cells, case.n_faces
+    nx = case.dims[0]
+    h = 1.0 / nx
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    E = lambda n: torch.empty(n, dtype=torch.float64, device=dev)
+    asm = eng.Assembly(addr)
+    dirn = box_direction(case)
+    Sf = [t(h * h * (dirn == d)) for d in range(3)]
+    magSf, delta, vol = t(np.full(F, h * h)), t(np.full(F, 1.0 / h)), t(np.full(N, h ** 3))
+    phi = t(0.3 * h * h * (dirn == 0) * (1.0 + 0.2 * (syn.splitmix_uniform(3, F) - 0.5)))
+    nuMagSf = t(np.full(F, 1e-3 * h * h))
+    U = [t(0.1 * (syn.splitmix_uniform(10 + d, N) - 0.5)) for d in range(3)]
+    p = t(np.zeros(N))
+    UM, PM = eng.Matrix(addr), eng.Matrix(addr)
+    G = gamg if gamg is not None else eng.Gamg(addr, box_pair_weights(case), 100)
+    xmin = np.nonzero(np.arange(N) % nx == 0)[0]
+    patch = eng.Patch(ctx, N, xmin)
+    icU, icP = t(np.full(xmin.shape[0], 2.0 * 1e-3 * h)), t(np.full(xmin.shape[0], -2.0 * h))
+    wts, cl, cu, cd, lu, ld = E(F), E(F), E(F), E(N), E(F), E(N)
+    dd, ds = E(N), [E(N) for _ in range(3)]
+    ul, uu, ud = E(F), E(F), E(N)
+    rAU, rAUf, pu, pd, psrc = E(N), E(F), E(F), E(N), E(N)
+    fh, grad = E(F), [E(N) for _ in range(3)]
+    if batched is None:
+        batched = hasattr(UM, "pbicg_multi") and not os.environ.get("MI_TIMESTEP_SEGREGATED")
+    ev = {}
+
+    class stage:
+        def __init__(self, name): self.name = name
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True); self.b = torch.cuda.Event(enable_timing=True); self.a.record()
+        def __exit__(self, *x):
+            self.b.record(); ev.setdefault(self.name, []).append((self.a, self.b))
+
+    def step():
+        with stage("momentum: upwind weights + fvm::div + fvm::laplacian"):
+            asm.upwind_weights(phi, wts); asm.fvm_div(wts, phi, cl, cu, cd); asm.fvm_laplacian(delta, nuMagSf, lu, ld)
+        with stage("momentum: fvm::ddt x3 + UEqn = ddt + div - laplacian + boundary diag"):
+            for d in range(3): asm.fvm_ddt_euler(1.0 / 1e-3, 1.0, vol, U[d], dd, ds[d])
+            asm.axpby(1.0, cl, -1.0, lu, ul); asm.axpby(1.0, cu, -1.0, lu, uu)
+            asm.axpby(1.0, dd, 1.0, cd, ud); asm.axpby(1.0, ud, -1.0, ld, ud)
+            patch.add(icU, ud, 0)
+        with stage("momentum: relax(0.7) + bind coefficients"):
+            asm.relax(0.7, ud, ul, uu, ds[0], U[0])
+            UM.set_coeffs(ud, uu, ul)
+        with stage("momentum: PBiCG + DILU, 3 components (relTol 0.1)" + (" -- one batched solve" if batched else "")):
+            if batched:
+                its = [q["nIterations"] for q in UM.pbicg_multi(U, ds, "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)]
+            else:
+                its = [UM.pbicg(U[d], ds[d], "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)["nIterations"] for d in range(3)]
+        with stage("pressure: rAU, interpolate, fvm::laplacian(rAUf), bind, div(phi) source"):
+            torch.reciprocal(ud, out=rAU); rAU.mul_(vol)
+            asm.face_interpolate(wts, rAU, rAUf); rAUf.mul_(magSf)
+            asm.fvm_laplacian(delta, rAUf, pu, pd); patch.add(icP, pd, 0)
+            PM.set_coeffs(pd, pu, None)
+            asm.surface_integrate(phi, None, psrc)
+        with stage("pressure: GAMG (relTol 0.05)"):
+            p.zero_()                   # same work every step: V-cycles from a zero start (a restart from the old p takes fewer)
+            cyc = G.solve(PM, p, psrc, tolerance=1e-12, relTol=0.05, maxIter=50)["nIterations"]
+        with stage("corrector: flux (faceH), fvc::grad(p), U -= rAU grad p"):
+            PM.faceH(p, fh); phi.sub_(fh * 0.0)
+            asm.face_interpolate(wts, p, rAUf); asm.gauss_grad(Sf, rAUf, vol, grad)
+            for d in range(3): asm.axpby(1.0, U[d], -1e-3, grad[d], U[d])
+        return its, cyc
+
+    step(); torch.cuda.synchronize(); ev.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        its, cyc = step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    return {"workload": f"BASELINE configs 4/5, per-rank share: one PISO-like time step on the {case.dims[0]}x{case.dims[1]}x{case.dims[2]} box "
+                        "(fvm::ddt + upwind fvm::div - fvm::laplacian, relax, PBiCG + DILU x 3 components, pressure assembly, GAMG, flux + Gauss gradient correction), "
+                        "every stage through the C ABI",
+            "ms_per_time_step": 1e3 * wall, "pbicg_iterations_per_component": [int(v) for v in its], "gamg_cycles": int(cyc),
+            "momentum_solve": "one batched 3-right-hand-side PBiCG" if batched else "three segregated PBiCG solves",
+            "stages_ms": {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()},
+            "timing": f"mean of {steps} steps after one warm-up step; stages by HIP events on the engine's stream"}
