@@ -147,6 +147,26 @@ int mi_addr_create_ordered(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const
                            int32_t n_patches, const int32_t *patch_sizes, const int32_t *const *patch_face_cells_host,
                            const int32_t *const *patch_nbr_cells_host_or_null, int32_t n_tiles, const int32_t *tile_cell_start_host_or_null,
                            mi_addr_t *out);
+/* RENUMBER AT BIND (round 3): the two steps above as ONE call for a mesh that was never renumberMesh-ed -- the shim adopts the
+ * engine's cell order for the life of the mesh.  Builds the clustered layout of the mesh as given, renumbers the cells into the
+ * engine order and the faces into the upper-triangular order of that numbering (faces whose owner and neighbour swap are
+ * flipped), and returns the ORDERED addressing of the renumbered mesh together with what polyMesh::renumber / mapPolyMesh need:
+ *   cell_new_to_old [n_cells]   new cell i = old cell map[i]                 (the cellMap of renumberMesh's manual method)
+ *   face_new_to_old [n_faces]   new internal face f = old face map[f]
+ *   face_flipped    [n_faces]   1: its owner / neighbour (hence upper / lower, and the sign of a flux) swapped
+ *   lower_out / upper_out       the addressing of the renumbered mesh (any of the five outputs may be NULL)
+ * Fields are permuted ONCE when they are read (new[i] = old[cell_new_to_old[i]]) and back when they are written; from then on
+ * every operator of this ABI runs on the caller's arrays without permutation passes (mi_amul 0.62-0.70 of the HBM roofline
+ * instead of 0.52 through the permuting addressing).  Patch face cells (and local partner cells) are renumbered inside; their
+ * face order is kept.  mi_layout_adopt_host: the host part alone (no device; tests).                                           */
+int mi_addr_create_adopted(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t *lower_host, const int32_t *upper_host,
+                           int32_t n_patches, const int32_t *patch_sizes, const int32_t *const *patch_face_cells_host,
+                           const int32_t *const *patch_nbr_cells_host_or_null, int32_t *cell_new_to_old_out, int32_t *face_new_to_old_out,
+                           uint8_t *face_flipped_out, int32_t *lower_out, int32_t *upper_out, mi_addr_t *out);
+int mi_layout_adopt_host(int32_t n_cells, int32_t n_faces, const int32_t *lower_host, const int32_t *upper_host, int32_t n_patches,
+                         const int32_t *patch_sizes, const int32_t *const *patch_face_cells_host, const int32_t *const *patch_nbr_cells_host_or_null,
+                         int32_t *cell_new_to_old_out, int32_t *face_new_to_old_out, uint8_t *face_flipped_out, int32_t *lower_out,
+                         int32_t *upper_out, int32_t *n_tiles_out);
 /* the tiles of a layout as ranges of ENGINE cells: n_tiles + 1 offsets (mi_addr_n_tiles) */
 int mi_addr_tile_starts(mi_addr_t addr, int32_t *tile_cell_start_out_host);
 /* 1 when engine order == caller order (mi_addr_create_ordered, or a numbering that happened to be tile-contiguous) */

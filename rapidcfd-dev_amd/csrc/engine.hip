@@ -300,6 +300,97 @@ extern "C" int mi_addr_create_ordered(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
     return addr_create_impl(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, true, n_tiles, tile_cell_start, out);
 }
 
+// Renumber-at-bind (round 3): the mesh adopts the engine's cell order for its lifetime.  Host part (no device): the clustered layout
+// of the mesh as given -> new-to-old cell map (the engine order) -> faces re-pointed, flipped where owner > neighbour, and sorted
+// into upper-triangular order of the new numbering -- what polyMesh::renumber / renumberMesh.C do with a manual cell map.
+namespace {
+struct AdoptedMesh {
+    std::vector<int32_t> cellMap, faceMap, lower, upper, tileStart;   // new -> old cell / face; addressing of the renumbered mesh
+    std::vector<uint8_t> flipped;                                      // new face f has owner and neighbour swapped w.r.t. old face faceMap[f]
+    std::vector<std::vector<int32_t>> patchFaceCells, patchNbrCells;   // renumbered
+};
+std::string adopt_engine_order(int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches, const int32_t* patch_sizes,
+                               const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells, AdoptedMesh& M)
+{
+    TileLayout L;
+    TileParams prm;
+    prm.tileCells = env_int("MI_TILE_CELLS", 0) > 0 ? env_int("MI_TILE_CELLS", 0) : 1024;
+    prm.slotCap = env_int("MI_TILE_SLOTS", 4094);
+    prm.reorder = env_int("MI_TILE_REORDER", -1);
+    prm.compact = false;
+    const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, L, patch_nbr_cells);
+    if (!err.empty()) return err;
+    M.cellMap = L.e2c; M.tileStart = L.tileCellStart;
+    const std::vector<int32_t>& o2n = L.c2e;
+    std::vector<int32_t> lo((size_t)n_faces), up((size_t)n_faces);
+    std::vector<uint8_t> fl((size_t)n_faces);
+    for (int32_t f = 0; f < n_faces; ++f) {
+        const int32_t a = o2n[(size_t)lower[f]], b = o2n[(size_t)upper[f]];
+        fl[(size_t)f] = a > b; lo[(size_t)f] = a < b ? a : b; up[(size_t)f] = a < b ? b : a;
+    }
+    // owner-sorted, then by neighbour, ties in old face order (two counting-sort passes: stable)
+    std::vector<int32_t> byUp((size_t)n_faces), cnt((size_t)n_cells + 1, 0);
+    for (int32_t f = 0; f < n_faces; ++f) cnt[(size_t)up[(size_t)f] + 1]++;
+    for (int32_t c = 0; c < n_cells; ++c) cnt[(size_t)c + 1] += cnt[(size_t)c];
+    for (int32_t f = 0; f < n_faces; ++f) byUp[(size_t)cnt[(size_t)up[(size_t)f]]++] = f;
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int32_t f = 0; f < n_faces; ++f) cnt[(size_t)lo[(size_t)f] + 1]++;
+    for (int32_t c = 0; c < n_cells; ++c) cnt[(size_t)c + 1] += cnt[(size_t)c];
+    M.faceMap.resize((size_t)n_faces);
+    for (int32_t k = 0; k < n_faces; ++k) { const int32_t f = byUp[(size_t)k]; M.faceMap[(size_t)cnt[(size_t)lo[(size_t)f]]++] = f; }
+    M.lower.resize((size_t)n_faces); M.upper.resize((size_t)n_faces); M.flipped.resize((size_t)n_faces);
+    for (int32_t k = 0; k < n_faces; ++k) { const int32_t f = M.faceMap[(size_t)k]; M.lower[(size_t)k] = lo[(size_t)f]; M.upper[(size_t)k] = up[(size_t)f]; M.flipped[(size_t)k] = fl[(size_t)f]; }
+    M.patchFaceCells.resize((size_t)n_patches); M.patchNbrCells.resize((size_t)n_patches);
+    for (int32_t p = 0; p < n_patches; ++p) {
+        for (int32_t i = 0; i < patch_sizes[p]; ++i) M.patchFaceCells[(size_t)p].push_back(o2n[(size_t)patch_face_cells[p][i]]);
+        if (patch_nbr_cells && patch_nbr_cells[p]) for (int32_t i = 0; i < patch_sizes[p]; ++i) M.patchNbrCells[(size_t)p].push_back(o2n[(size_t)patch_nbr_cells[p][i]]);
+    }
+    return std::string();
+}
+void adopted_maps_out(const AdoptedMesh& M, int32_t* cell_map, int32_t* face_map, uint8_t* flipped, int32_t* lower_out, int32_t* upper_out)
+{
+    if (cell_map) memcpy(cell_map, M.cellMap.data(), sizeof(int32_t) * M.cellMap.size());
+    if (face_map) memcpy(face_map, M.faceMap.data(), sizeof(int32_t) * M.faceMap.size());
+    if (flipped) memcpy(flipped, M.flipped.data(), M.flipped.size());
+    if (lower_out) memcpy(lower_out, M.lower.data(), sizeof(int32_t) * M.lower.size());
+    if (upper_out) memcpy(upper_out, M.upper.data(), sizeof(int32_t) * M.upper.size());
+}
+} // namespace
+
+// host only (CPU tests): the renumbered mesh and its maps
+extern "C" int mi_layout_adopt_host(int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches, const int32_t* patch_sizes,
+                                    const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells, int32_t* cell_new_to_old_out,
+                                    int32_t* face_new_to_old_out, uint8_t* face_flipped_out, int32_t* lower_out, int32_t* upper_out, int32_t* n_tiles_out)
+{
+    if ((n_faces > 0 && (!lower || !upper)) || n_patches < 0) return fail(MI_ERR_ARG, "mi_layout_adopt_host: bad argument");
+    AdoptedMesh M;
+    const std::string err = adopt_engine_order(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, M);
+    if (!err.empty()) return fail(MI_ERR_LIMIT, "mi_layout_adopt_host: " + err);
+    adopted_maps_out(M, cell_new_to_old_out, face_new_to_old_out, face_flipped_out, lower_out, upper_out);
+    if (n_tiles_out) *n_tiles_out = (int32_t)M.tileStart.size() - 1;
+    return MI_OK;
+}
+extern "C" int mi_addr_create_adopted(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches,
+                                      const int32_t* patch_sizes, const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells,
+                                      int32_t* cell_new_to_old_out, int32_t* face_new_to_old_out, uint8_t* face_flipped_out, int32_t* lower_out, int32_t* upper_out,
+                                      mi_addr_t* out)
+{
+    if (!ctx || !out || (n_faces > 0 && (!lower || !upper)) || n_patches < 0) return fail(MI_ERR_ARG, "mi_addr_create_adopted: bad argument");
+    AdoptedMesh M;
+    const std::string err = adopt_engine_order(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, M);
+    if (!err.empty()) return fail(MI_ERR_LIMIT, "mi_addr_create_adopted: " + err);
+    std::vector<const int32_t*> pfc((size_t)n_patches), pnb((size_t)n_patches, nullptr);
+    bool anyNbr = false;
+    for (int32_t p = 0; p < n_patches; ++p) {
+        pfc[(size_t)p] = M.patchFaceCells[(size_t)p].data();
+        if (patch_nbr_cells && patch_nbr_cells[p]) { pnb[(size_t)p] = M.patchNbrCells[(size_t)p].data(); anyNbr = true; }
+    }
+    MICHK(addr_create_impl(ctx, n_cells, n_faces, M.lower.data(), M.upper.data(), n_patches, patch_sizes, pfc.data(), anyNbr ? pnb.data() : nullptr, true,
+                           (int32_t)M.tileStart.size() - 1, M.tileStart.data(), out));
+    adopted_maps_out(M, cell_new_to_old_out, face_new_to_old_out, face_flipped_out, lower_out, upper_out);
+    return MI_OK;
+}
+
 extern "C" int mi_addr_tile_starts(mi_addr_t a, int32_t* tile_cell_start_out)
 {
     if (!a || !tile_cell_start_out) return fail(MI_ERR_ARG, "mi_addr_tile_starts: bad argument");

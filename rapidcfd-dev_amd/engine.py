@@ -43,7 +43,7 @@ class SolverControls(C.Structure):
 SYMBOLS = [
     "mi_addr_set_ami_patch", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
     "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy", "mi_gamg_host_build_ami",
-    "mi_pbicg_solve_multi", "mi_comm_peer_auto", "mi_comm_peer_selftest", "mi_comm_peer_enable", "mi_matrix_peer_halo_auto", "mi_matrix_peer_halo_status",
+    "mi_addr_create_adopted", "mi_layout_adopt_host", "mi_pbicg_solve_multi", "mi_comm_peer_auto", "mi_comm_peer_selftest", "mi_comm_peer_enable", "mi_matrix_peer_halo_auto", "mi_matrix_peer_halo_status",
     "mi_pcg_iterate_sampled",
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
@@ -87,6 +87,26 @@ def gamg_controls(tolerance=1e-6, relTol=0.0, maxIter=1000, minIter=0, nPreSweep
     return GamgControls(tolerance, relTol, maxIter, minIter, nPreSweeps, preSweepsLevelMultiplier, maxPreSweeps,
                         nPostSweeps, postSweepsLevelMultiplier, maxPostSweeps, nFinestSweeps, scaleCorrection, omega,
                         int(bool(directSolveCoarsest)), 0)
+
+
+def adopt_host(n_cells, lower_addr, upper_addr, patch_face_cells=(), patch_nbr_cells=()):
+    """host part of renumber-at-bind (mi_layout_adopt_host): dict with cell_map, face_map, face_flipped, lower, upper, n_tiles"""
+    lo = np.ascontiguousarray(lower_addr, dtype=np.int32); up = np.ascontiguousarray(upper_addr, dtype=np.int32)
+    patches = [np.ascontiguousarray(p, dtype=np.int32) for p in patch_face_cells]
+    npatch = len(patches)
+    I32, U8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    sizes = (C.c_int32 * max(npatch, 1))(*[p.shape[0] for p in patches])
+    ptrs = (I32 * max(npatch, 1))(*[p.ctypes.data_as(I32) for p in patches])
+    nbrs = [None if (k >= len(patch_nbr_cells) or patch_nbr_cells[k] is None) else np.ascontiguousarray(patch_nbr_cells[k], dtype=np.int32) for k in range(npatch)]
+    nptrs = (I32 * max(npatch, 1))(*[q.ctypes.data_as(I32) if q is not None else I32() for q in nbrs])
+    out = dict(cell_map=np.empty(n_cells, dtype=np.int32), face_map=np.empty(lo.shape[0], dtype=np.int32), face_flipped=np.empty(lo.shape[0], dtype=np.uint8),
+               lower=np.empty(lo.shape[0], dtype=np.int32), upper=np.empty(lo.shape[0], dtype=np.int32))
+    nt = C.c_int32(0)
+    _chk(lib().mi_layout_adopt_host(C.c_int32(n_cells), C.c_int32(lo.shape[0]), lo.ctypes.data_as(I32), up.ctypes.data_as(I32), C.c_int32(npatch), sizes, ptrs, nptrs,
+                                    out["cell_map"].ctypes.data_as(I32), out["face_map"].ctypes.data_as(I32), out["face_flipped"].ctypes.data_as(U8),
+                                    out["lower"].ctypes.data_as(I32), out["upper"].ctypes.data_as(I32), C.byref(nt)))
+    out["n_tiles"] = int(nt.value)
+    return out
 
 
 def host_layout(n_cells, lower_addr, upper_addr, patch_face_cells=(), tile_cells=0, slot_cap=0, patch_nbr_cells=()) -> dict:
@@ -195,9 +215,11 @@ class Addressing:
     """lduAddressing: host lowerAddr/upperAddr + coupled-patch faceCells -> tiled engine layout."""
 
     def __init__(self, ctx: Context, n_cells: int, lower_addr, upper_addr, patch_face_cells: Sequence = (),
-                 patch_nbr_cells: Sequence = (), ordered: bool = False, tile_cell_start=None):
+                 patch_nbr_cells: Sequence = (), ordered: bool = False, tile_cell_start=None, adopt: bool = False):
         """patch_nbr_cells[p] (optional): local cells across patch p => cyclic (local) coupling; None => processor patch.
-        ordered: keep the caller's numbering (mi_addr_create_ordered); tile_cell_start: the tiles as cell ranges, or None"""
+        ordered: keep the caller's numbering (mi_addr_create_ordered); tile_cell_start: the tiles as cell ranges, or None.
+        adopt: renumber-at-bind (mi_addr_create_adopted) -- the addressing is that of the mesh RENUMBERED into the engine order;
+        self.cell_map / face_map / face_flipped / lower_addr / upper_addr describe the renumbering (new -> old)"""
         self.ctx = ctx
         lo = np.ascontiguousarray(lower_addr, dtype=np.int32)
         up = np.ascontiguousarray(upper_addr, dtype=np.int32)
@@ -210,7 +232,16 @@ class Addressing:
                       else np.ascontiguousarray(patch_nbr_cells[k], dtype=np.int32) for k in range(npatch)]
         nptrs = (C.POINTER(C.c_int32) * max(npatch, 1))(*[q.ctypes.data_as(C.POINTER(C.c_int32)) if q is not None
                                                            else C.POINTER(C.c_int32)() for q in self._nbrs])
-        if ordered:
+        if adopt:
+            I32, U8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+            self.cell_map = np.empty(n_cells, dtype=np.int32); self.face_map = np.empty(lo.shape[0], dtype=np.int32)
+            self.face_flipped = np.empty(lo.shape[0], dtype=np.uint8)
+            self.lower_addr = np.empty(lo.shape[0], dtype=np.int32); self.upper_addr = np.empty(lo.shape[0], dtype=np.int32)
+            _chk(lib().mi_addr_create_adopted(ctx.h, C.c_int32(n_cells), C.c_int32(lo.shape[0]), lo.ctypes.data_as(I32), up.ctypes.data_as(I32),
+                                              C.c_int32(npatch), sizes, ptrs, nptrs, self.cell_map.ctypes.data_as(I32), self.face_map.ctypes.data_as(I32),
+                                              self.face_flipped.ctypes.data_as(U8), self.lower_addr.ctypes.data_as(I32), self.upper_addr.ctypes.data_as(I32),
+                                              C.byref(self.h)))
+        elif ordered:
             ts = None if tile_cell_start is None else np.ascontiguousarray(tile_cell_start, dtype=np.int32)
             _chk(lib().mi_addr_create_ordered(ctx.h, C.c_int32(n_cells), C.c_int32(lo.shape[0]),
                                               lo.ctypes.data_as(C.POINTER(C.c_int32)), up.ctypes.data_as(C.POINTER(C.c_int32)),

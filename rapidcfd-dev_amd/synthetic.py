@@ -244,6 +244,28 @@ def decompose_box(case: LduCase, parts) -> List[LduCase]:
     return subs
 
 
+def add_cyclic_x(case: LduCase, kappa_scale: float = 1.0) -> LduCase:
+    """The box made periodic in x (a channel's stream-wise cyclic pair, BASELINE config 4): the x-min and x-max cells become
+    a cyclic patch pair, face q of one side coupled with face q of the other (both enumerate (j, k) in the same order);
+    symmetric coefficients as add_cyclic_y.  The x-min Dirichlet contribution of box_case stays in the diagonal."""
+    import copy
+    nx, ny, nz = case.dims
+    c = np.arange(case.n_cells, dtype=np.int64)
+    i = c % nx
+    xmin = np.nonzero(i == 0)[0].astype(np.int32)
+    xmax = np.nonzero(i == nx - 1)[0].astype(np.int32)
+    h = 1.0 / nx
+    sign = 1.0 if case.lower is None else -1.0
+    kappa = sign * h * kappa_scale * np.ones(xmin.shape[0])
+    out = copy.copy(case)
+    out.diag = case.diag.copy()
+    np.subtract.at(out.diag, xmin, kappa)
+    np.subtract.at(out.diag, xmax, kappa)
+    out.interfaces = [Interface(nbr_domain=0, nbr_patch=1, face_cells=xmin, bou_coeffs=-kappa, int_coeffs=-kappa),
+                      Interface(nbr_domain=0, nbr_patch=0, face_cells=xmax, bou_coeffs=-kappa, int_coeffs=-kappa)]
+    return out
+
+
 def add_cyclic_y(case: LduCase, kappa_scale: float = 1.0, asym_shift: float = 0.0) -> LduCase:
     """Make the box periodic in y: the y-min and y-max boundary patches become a cyclic pair
     (cyclicFvPatchField / cyclicLduInterfaceField: the neighbour values are local cells).  Face i of the
@@ -343,10 +365,10 @@ def _global_face_index(c, i, j, k, direction, dims):
     return before + np.where(direction == 0, 0, np.where(direction == 1, has_x, has_x + has_y))
 
 
-def box_subdomain(global_dims, parts, rank: int, *, vary: float = 0.1, seed: int = 12345, rhs_seed: int = 777) -> LduCase:
-    """Sub-domain ``rank`` of decompose_box(box_case(*global_dims), parts) built DIRECTLY (symmetric case): the global
+def box_subdomain(global_dims, parts, rank: int, *, symmetric: bool = True, vary: float = 0.1, seed: int = 12345, rhs_seed: int = 777) -> LduCase:
+    """Sub-domain ``rank`` of decompose_box(box_case(*global_dims, symmetric=symmetric), parts) built DIRECTLY: the global
     case is never formed, so an 8 x 216^3 weak-scaling run costs every rank only its own 10 M cells.  Identical, array
-    for array, to the decomposed global case (tests/test_distributed.py)."""
+    for array, to the decomposed global case (tests/test_distributed.py), pressure-like and momentum-like."""
     nx, ny, nz = global_dims
     px, py, pz = parts
     bx, by, bz = _chunks(nx, px), _chunks(ny, py), _chunks(nz, pz)
@@ -366,10 +388,17 @@ def box_subdomain(global_dims, parts, rank: int, *, vary: float = 0.1, seed: int
         return h * (1.0 + vary * splitmix_at(seed, f))
 
     upper = coef(lo.astype(np.int64), direction.astype(np.int64))
-    diag = -(np.bincount(lo, weights=upper, minlength=n) + np.bincount(up, weights=upper, minlength=n)).astype(np.float64)
-    diag[gi == 0] += -2.0 * h
+    lower = None
+    if symmetric:
+        diag = -(np.bincount(lo, weights=upper, minlength=n) + np.bincount(up, weights=upper, minlength=n)).astype(np.float64)
+        diag[gi == 0] += -2.0 * h
+    else:   # box_case's momentum-like matrix: -nu laplacian + upwind convection (flux 0.3 h^2 in +x) + ddt
+        nu_h = upper
+        upper = -nu_h
+        lower = -nu_h - np.where(direction == 0, 0.3 * h * h, 0.0)
+        diag = -(np.bincount(lo, weights=lower, minlength=n) + np.bincount(up, weights=upper, minlength=n)).astype(np.float64)
     source = (2.0 * splitmix_at(rhs_seed, gc) - 1.0) * h ** 3
-    sub = LduCase(n, lo, up, diag, upper, None, source, dims=(lx, ly, lz), global_cells=gc)
+    sub = LduCase(n, lo, up, diag, upper, lower, source, dims=(lx, ly, lz), global_cells=gc)
     # processor patches, ordered by neighbour rank (as decompose_box orders them); faces by global face id
     def nbr_list(qx, qy, qz):
         out = []
@@ -400,10 +429,23 @@ def box_subdomain(global_dims, parts, rank: int, *, vary: float = 0.1, seed: int
         order = np.argsort(fidx, kind="stable")
         cells, fidx = cells[order], fidx[order]
         cf = h * (1.0 + vary * splitmix_at(seed, fidx))
-        np.subtract.at(sub.diag, cells, cf)
         theirs = nbr_list(ax, ay, az)
-        sub.interfaces.append(Interface(nbr_domain=nb, nbr_patch=theirs.index(rank), face_cells=cells.astype(np.int32),
-                                        bou_coeffs=-cf, int_coeffs=-cf))
+        if symmetric:
+            np.subtract.at(sub.diag, cells, cf)
+            sub.interfaces.append(Interface(nbr_domain=nb, nbr_patch=theirs.index(rank), face_cells=cells.astype(np.int32),
+                                            bou_coeffs=-cf, int_coeffs=-cf))
+        else:
+            up_f = -cf
+            lo_f = -cf - (0.3 * h * h if d == 0 else 0.0)
+            # this block holds the owner of the cut face (neighbour on the + side): row coefficient upper, diag -= lower;
+            # else it holds the neighbour: row coefficient lower, diag -= upper (negSumDiag on the undivided mesh)
+            mine_c, other_c = (up_f, lo_f) if plus else (lo_f, up_f)
+            np.subtract.at(sub.diag, cells, other_c)
+            sub.interfaces.append(Interface(nbr_domain=nb, nbr_patch=theirs.index(rank), face_cells=cells.astype(np.int32),
+                                            bou_coeffs=-mine_c, int_coeffs=-other_c))
+    if not symmetric:
+        sub.diag[gi == 0] += 2.0 * h
+        sub.diag += h ** 3 / 1e-3   # V/deltaT
     return sub
 
 

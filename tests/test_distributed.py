@@ -68,18 +68,21 @@ def test_direct_subdomain_equals_decomposed_global_case(pkg):
     # bench.py builds every rank's sub-domain directly (an 8 x 216^3 run never forms the 80 M-cell global case):
     # same addressing, coefficients, source, interface order and pairing as decompose_box(box_case(...))
     syn = pkg.synthetic
-    for dims, parts in (((9, 7, 5), (2, 2, 2)), ((8, 6, 5), (1, 2, 2)), ((7, 5, 6), (1, 1, 2)), ((10, 9, 4), (3, 2, 1))):
-        subs = syn.decompose_box(syn.box_case(*dims), parts)
-        for r, ref in enumerate(subs):
-            got = syn.box_subdomain(dims, parts, r)
-            assert got.n_cells == ref.n_cells and got.dims == ref.dims
-            for name in ("lower_addr", "upper_addr", "upper", "source", "global_cells"):
-                assert np.array_equal(getattr(got, name), getattr(ref, name)), (dims, parts, r, name)
-            assert np.max(np.abs(got.diag - ref.diag)) < 1e-15
-            assert len(got.interfaces) == len(ref.interfaces)
-            for a, b in zip(got.interfaces, ref.interfaces):
-                assert (a.nbr_domain, a.nbr_patch) == (b.nbr_domain, b.nbr_patch)
-                assert np.array_equal(a.face_cells, b.face_cells) and np.array_equal(a.bou_coeffs, b.bou_coeffs)
+    for symmetric in (True, False):     # pressure-like and momentum-like (config 5's PBiCG runs on the latter)
+        for dims, parts in (((9, 7, 5), (2, 2, 2)), ((8, 6, 5), (1, 2, 2)), ((7, 5, 6), (1, 1, 2)), ((10, 9, 4), (3, 2, 1))):
+            subs = syn.decompose_box(syn.box_case(*dims, symmetric=symmetric), parts)
+            for r, ref in enumerate(subs):
+                got = syn.box_subdomain(dims, parts, r, symmetric=symmetric)
+                assert got.n_cells == ref.n_cells and got.dims == ref.dims
+                for name in ("lower_addr", "upper_addr", "upper", "source", "global_cells") + (() if symmetric else ("lower",)):
+                    assert np.array_equal(getattr(got, name), getattr(ref, name)), (dims, parts, r, name)
+                assert (got.lower is None) == symmetric
+                assert np.max(np.abs(got.diag - ref.diag)) < 1e-12 * np.max(np.abs(ref.diag))
+                assert len(got.interfaces) == len(ref.interfaces)
+                for a, b in zip(got.interfaces, ref.interfaces):
+                    assert (a.nbr_domain, a.nbr_patch) == (b.nbr_domain, b.nbr_patch)
+                    assert np.array_equal(a.face_cells, b.face_cells) and np.array_equal(a.bou_coeffs, b.bou_coeffs)
+                    assert np.array_equal(a.int_coeffs, b.int_coeffs)
 
 
 # ---- the same N>1 path with the REAL engine: several ranks share the one GPU of the box, torch.distributed over gloo ----

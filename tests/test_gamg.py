@@ -688,3 +688,38 @@ def test_cycle_graph_is_not_replayed_across_a_symmetric_to_asymmetric_rebind(pkg
         assert perf["nIterations"] == ref["nIterations"] and perf["nIterations"] >= 3
         assert np.max(np.abs(perf["history"] - ref["history"])) < 1e-10 * ref["history"][0]
         assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,ncoarsest", [("box_sym", 10), ("box_sym", 60), ("box_asym", 120), ("graph_sym", 60)])
+def test_register_resident_coarsest_inverse_equals_the_host_elimination(pkg, orc, name, ncoarsest, monkeypatch):
+    """Round 3: the dense inverse of the coarsest level is formed in the REGISTERS of one workgroup (k_dense_invert_reg, in-place
+    Gauss-Jordan with partial pivoting, up to 192 coarsest cells: the default there).  Element by element it performs the host
+    elimination's operations (gamg.cpp invert_dense), so a solve gives the SAME BITS whichever path built the inverse -- and the
+    global-memory kernel of larger systems agrees to rounding."""
+    import torch
+    eng = pkg.engine
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    if name == "graph_sym":
+        case = random_graph_case(pkg, 2500); w = graph_weights(pkg, case)
+    else:
+        case = pkg.synthetic.box_case(24, 20, 16, symmetric=(name == "box_sym")); w = orc.box_face_weights(case)
+    args = dict(tolerance=1e-10, maxIter=60)
+    out = {}
+    for mode, env in (("registers", {}), ("host", {"MI_GAMG_DEVICE_INVERT": "0"}), ("global", {"MI_GAMG_DEVICE_INVERT": "1", "MI_GAMG_REG_INVERT": "0"})):
+        for k in ("MI_GAMG_DEVICE_INVERT", "MI_GAMG_REG_INVERT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+        mat = eng.Matrix(addr); mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+        G = eng.Gamg(addr, w, ncoarsest)
+        psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+        perf = G.solve(mat, psi, dev(case.source), **args)
+        out[mode] = (perf["history"], psi.cpu().numpy(), G.level_sizes(G.n_levels - 1)["n_coarse"])
+    assert out["registers"][2] <= 192
+    assert np.array_equal(out["registers"][0], out["host"][0]) and np.array_equal(out["registers"][1], out["host"][1])
+    assert out["global"][0].shape == out["host"][0].shape and np.max(np.abs(out["global"][0] - out["host"][0])) < 1e-10 * out["host"][0][0]
+    _, ref = orc.GamgHierarchy(case, w, ncoarsest).solve(np.zeros(case.n_cells), case.source, **args)
+    assert out["registers"][0].shape == ref["history"].shape and np.max(np.abs(out["registers"][0] - ref["history"])) < 1e-10 * ref["history"][0]

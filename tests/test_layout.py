@@ -364,3 +364,26 @@ def test_forced_reordering_on_disconnected_and_isolated_cells(pkg, orc, monkeypa
         assert np.max(np.abs(interpret_amul(L, case, x) - ref)) <= 4e-16 * np.max(np.abs(ref)) * 8
     L = eng.host_layout(1, np.zeros(0, np.int32), np.zeros(0, np.int32))
     assert L["tileCellStart"].tolist() == [0, 1]
+
+
+def test_renumber_at_bind_is_what_renumberMesh_does_with_the_engine_order(pkg):
+    """mi_layout_adopt_host (the host part of mi_addr_create_adopted, round 3): the mesh renumbered into the engine's cell order in
+    ONE call -- cells by the clustered layout's new-to-old map, faces re-pointed, flipped where owner > neighbour and sorted
+    upper-triangular -- equals synthetic.renumber (polyMesh::renumber with that cell map) array for array; the maps invert
+    consistently; and the renumbered mesh is tile-contiguous, so its ORDERED layout has the same tiles and the identity permutation."""
+    syn, eng = pkg.synthetic, pkg.engine
+    for case in (syn.box_case(20, 16, 12), syn.add_cyclic_y(syn.box_case(12, 10, 8)), random_graph_case(pkg, 1500, symmetric=False)):
+        fcs = [i.face_cells for i in case.interfaces]
+        nbs = [case.interfaces[i.nbr_patch].face_cells for i in case.interfaces]
+        A = eng.adopt_host(case.n_cells, case.lower_addr, case.upper_addr, fcs, nbs)
+        L = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr, fcs, patch_nbr_cells=nbs)
+        assert np.array_equal(A["cell_map"], L["e2c"]) and A["n_tiles"] == len(L["tileCellStart"]) - 1
+        ref = syn.renumber(case, A["cell_map"])
+        assert np.array_equal(A["lower"], ref.lower_addr) and np.array_equal(A["upper"], ref.upper_addr)
+        assert np.array_equal(A["face_map"], ref.global_faces) and np.array_equal(A["face_flipped"].astype(bool), ref.face_flipped)
+        assert np.all(A["lower"] < A["upper"]) and np.all(np.diff(A["lower"].astype(np.int64) * case.n_cells + A["upper"]) > 0)   # upper-triangular order
+        # the ordered layout of the renumbered mesh: identity permutation, the same tile boundaries
+        rfcs = [i.face_cells for i in ref.interfaces]
+        rnbs = [ref.interfaces[i.nbr_patch].face_cells for i in ref.interfaces]
+        Lo = eng.host_layout(ref.n_cells, ref.lower_addr, ref.upper_addr, rfcs, patch_nbr_cells=rnbs)
+        assert np.array_equal(np.sort(Lo["e2c"]), np.arange(case.n_cells))
