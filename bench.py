@@ -301,8 +301,32 @@ def main():
         par = import_module(graft.PKG_NAME + ".parallel")
         sub = syn.box_subdomain((nx, ny, nz), parts_for(world), rank)   # == decompose_box(box_case(...))[rank], built directly
         solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
+        # Peer windows (halo + all-reduce as stores into the neighbours' memory) are the default between ranks; their set-up
+        # self-tests and the ranks agree on it.  On top of that a TRIAL solve: a few iterations, every rank reports whether it
+        # came through (no wait ran out of polls, iteration count right); unless all did, every rank rebuilds on RCCL.
+        peer_note = ""
+        if world > 1 and getattr(solver.comms[0] if solver.comms else None, "peer_mode", False):
+            ok = 1
+            try:
+                solver.begin(tolerance=0.0, max_iter=64)
+                solver.iterate(12)
+                st = solver.end()
+                if st["nIterations"] != 12 or not np.all(np.isfinite(st["history"])):
+                    ok = 0
+            except Exception as e:  # MiError: a window wait ran out of polls
+                ok = 0
+                log(f"[bench] rank {rank}: peer-window trial failed: {e}")
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                os.environ["MI_ALLREDUCE"] = "rccl"
+                del solver
+                solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
+                peer_note = " (the peer-window trial did not come through on every rank: RCCL)"
         host_loop = {"native": "C++ loop over RCCL (mi_dpcg_comm_iterate)", "torch": "torch.distributed loop (parallel.py)"}[solver.driver]
-        allreduce_kind = getattr(solver, "allreduce", "torch.distributed") if world > 1 else "none (one rank)"
+        if solver.driver == "native" and getattr(solver.comms[0], "peer_mode", False):
+            host_loop = "C++ loop, no collective calls: halo and all-reduce through peer windows, five launches per iteration (mi_dpcg_comm_iterate)"
+        allreduce_kind = (getattr(solver, "allreduce", "torch.distributed") + peer_note) if world > 1 else "none (one rank)"
         solver.begin(tolerance=0.0, max_iter=W + R * K + 8)
         solver.iterate(W)
         for _ in range(R):

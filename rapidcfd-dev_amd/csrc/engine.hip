@@ -279,14 +279,14 @@ extern "C" int mi_addr_create(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
 
 static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches,
                             const int32_t* patch_sizes, const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells,
-                            bool ordered, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out);
+                            bool ordered, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out, TileLayout* prebuilt);
 
 extern "C" int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
                                       const int32_t* lower, const int32_t* upper, int32_t n_patches,
                                       const int32_t* patch_sizes, const int32_t* const* patch_face_cells,
                                       const int32_t* const* patch_nbr_cells, mi_addr_t* out)
 {
-    return addr_create_impl(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, false, 0, nullptr, out);
+    return addr_create_impl(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, false, 0, nullptr, out, nullptr);
 }
 
 // ORDERED addressing: the caller's numbering is kept (engine order == caller order, mi_addr_cell_perm is the identity), so the
@@ -297,7 +297,7 @@ extern "C" int mi_addr_create_ordered(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
                                       const int32_t* const* patch_nbr_cells, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out)
 {
     if (tile_cell_start && n_tiles <= 0) return fail(MI_ERR_ARG, "mi_addr_create_ordered: n_tiles must be positive when tile_cell_start is given");
-    return addr_create_impl(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, true, n_tiles, tile_cell_start, out);
+    return addr_create_impl(ctx, n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, true, n_tiles, tile_cell_start, out, nullptr);
 }
 
 // Renumber-at-bind (round 3): the mesh adopts the engine's cell order for its lifetime.  Host part (no device): the clustered layout
@@ -386,7 +386,7 @@ extern "C" int mi_addr_create_adopted(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
         if (patch_nbr_cells && patch_nbr_cells[p]) { pnb[(size_t)p] = M.patchNbrCells[(size_t)p].data(); anyNbr = true; }
     }
     MICHK(addr_create_impl(ctx, n_cells, n_faces, M.lower.data(), M.upper.data(), n_patches, patch_sizes, pfc.data(), anyNbr ? pnb.data() : nullptr, true,
-                           (int32_t)M.tileStart.size() - 1, M.tileStart.data(), out));
+                           (int32_t)M.tileStart.size() - 1, M.tileStart.data(), out, nullptr));
     adopted_maps_out(M, cell_new_to_old_out, face_new_to_old_out, face_flipped_out, lower_out, upper_out);
     return MI_OK;
 }
@@ -399,9 +399,30 @@ extern "C" int mi_addr_tile_starts(mi_addr_t a, int32_t* tile_cell_start_out)
 }
 extern "C" int mi_addr_is_ordered(mi_addr_t a) { return a && a->identity ? 1 : 0; }
 
+// the tile-layout parameters of an addressing of n_cells cells on this context (coarse: a level of a GAMG hierarchy)
+static TileParams addr_tile_params(mi_ctx_t ctx, int32_t n_cells, bool coarse, bool ordered, int32_t n_tiles, const int32_t* tile_cell_start);
+// prebuilt != nullptr: the host layout was built elsewhere (the GAMG builder builds its levels' layouts on other threads while
+// it matches the next level) with addr_tile_params' parameters; it is moved from
 static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches,
                             const int32_t* patch_sizes, const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells,
-                            bool ordered, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out)
+                            bool ordered, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out, TileLayout* prebuilt);
+static TileParams addr_tile_params(mi_ctx_t ctx, int32_t n_cells, bool coarse, bool ordered, int32_t n_tiles, const int32_t* tile_cell_start)
+{
+    TileParams prm;
+    prm.tileCells = env_int("MI_TILE_CELLS", 0);
+    if (prm.tileCells <= 0) {
+        const int target = (coarse && env_int("MI_SMALL_TILES", 1)) ? (int)(((int64_t)n_cells / std::max(1, ctx->nCU) + 63) / 64 * 64) : 1024;
+        prm.tileCells = std::min(1024, std::max(128, target));
+    }
+    prm.slotCap = env_int("MI_TILE_SLOTS", 4094);
+    prm.reorder = env_int("MI_TILE_REORDER", -1);
+    prm.compact = env_int("MI_ENTRY16", 0) != 0;
+    prm.keepOrder = ordered; prm.givenTileStart = tile_cell_start; prm.nGivenTiles = n_tiles;
+    return prm;
+}
+static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches,
+                            const int32_t* patch_sizes, const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells,
+                            bool ordered, int32_t n_tiles, const int32_t* tile_cell_start, mi_addr_t* out, TileLayout* prebuilt)
 {
     if (!ctx || !out || (n_faces > 0 && (!lower || !upper)) || n_patches < 0)
         return fail(MI_ERR_ARG, "mi_addr_create: bad argument");
@@ -423,8 +444,11 @@ static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, cons
     prm.reorder = env_int("MI_TILE_REORDER", -1); // -1: Cuthill-McKee pre-ordering when the numbering has no locality (tiling.hpp)
     prm.compact = env_int("MI_ENTRY16", 0) != 0; // opt-in: half the entry bytes, measured 2-4 % slower (profiles/r01_n_compact_entries_ab.md)
     prm.keepOrder = ordered; prm.givenTileStart = tile_cell_start; prm.nGivenTiles = n_tiles;
+    if (prebuilt) a->L = std::move(*prebuilt);
+    else {
     const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L, patch_nbr_cells);
     if (!err.empty()) { delete a; return fail(MI_ERR_LIMIT, "mi_addr_create: " + err); }
+    }
     a->identity = true;
     for (int32_t e = 0; e < n_cells; ++e) if (a->L.e2c[(size_t)e] != e) { a->identity = false; break; }
     a->nLocalPatches = 0;

@@ -128,6 +128,8 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
     H.levels.clear();
     bool forward = forwardInit;
     const int maxLevels = 50;
+    H.levels.reserve((size_t)maxLevels);          // element addresses stay valid for the onLevel consumers
+    const bool pipelined = (bool)H.onLevel && mergeLevels == 1;
     std::vector<double> w = faceWeights ? std::vector<double>(faceWeights, faceWeights + nFaces) : std::vector<double>((size_t)nFaces, 0.0);
     int32_t nFine = nCells, nF = nFaces;
     const int32_t *lo = lower, *up = upper;
@@ -280,19 +282,23 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                 segment((int32_t)PP.faceCells.size(), PP.faceRestrict, PP.childStart, PP.child);
             }
         } else H.levels.push_back(std::move(L));
+        if (pipelined) H.onLevel((int)H.levels.size() - 1);
         ++nPairLevels;
         GamgLevelHost& B = H.levels.back();
         nFine = B.nCoarse; nF = B.nCoarseFaces; lo = B.cLower.data(); up = B.cUpper.data();
     }
-    for (GamgLevelHost& B : H.levels) { // device tables from the final (possibly combined) maps
-        segment(B.nCoarse, B.restrictMap, B.cellChildStart, B.cellChild);
-        segment(B.nCoarseFaces, B.faceRestrict, B.faceChildStart, B.faceChild);
-        std::vector<int32_t> interior((size_t)B.nFineFaces);
-        for (int32_t f = 0; f < B.nFineFaces; ++f) interior[f] = B.faceRestrict[f] < 0 ? -1 - B.faceRestrict[f] : -1;
-        segment(B.nCoarse, interior, B.diagChildStart, B.diagChild);
-    }
+    if (!pipelined) for (GamgLevelHost& B : H.levels) finish_gamg_level(B); // device tables from the final (possibly combined) maps
     H.forwardOut = forward;
     return std::string();
+}
+
+void finish_gamg_level(GamgLevelHost& B)
+{
+    segment(B.nCoarse, B.restrictMap, B.cellChildStart, B.cellChild);
+    segment(B.nCoarseFaces, B.faceRestrict, B.faceChildStart, B.faceChild);
+    std::vector<int32_t> interior((size_t)B.nFineFaces);
+    for (int32_t f = 0; f < B.nFineFaces; ++f) interior[f] = B.faceRestrict[f] < 0 ? -1 - B.faceRestrict[f] : -1;
+    segment(B.nCoarse, interior, B.diagChildStart, B.diagChild);
 }
 
 // Gauss-Jordan with partial pivoting on [A | I].  Row k of A is zero left of the pivot once the earlier columns are

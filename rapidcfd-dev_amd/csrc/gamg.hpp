@@ -9,6 +9,7 @@
 // the reference's sort/target/targetStart triplets, GAMGAgglomerateLduAddressing.C:37-120).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -62,7 +63,14 @@ struct GamgCoupling {
 struct GamgHierarchyHost {
     std::vector<GamgLevelHost> levels;
     bool forwardOut = true;
+    // Called (when set, mergeLevels == 1) as soon as a level's coarse addressing and patches are final -- BEFORE the pair
+    // matching of the next level starts; levels is reserved up front, so &levels[level] stays valid.  The engine uses it to
+    // build that level's tile layout and children lists on other threads while the sequential matching goes on.
+    // The children lists (cellChild / faceChild / diagChild) of such a level are left to the callee: finish_gamg_level.
+    std::function<void(int level)> onLevel;
 };
+// the segmented children lists of a level from its final maps (what build_gamg_hierarchy does for every level at its end)
+void finish_gamg_level(GamgLevelHost& level);
 
 // faceWeights: [nFaces] (faceAreaPair: |Sf/sqrt|Sf| o (1,1.01,1.02)|; algebraicPair: |upper|)
 std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* lower, const int32_t* upper,

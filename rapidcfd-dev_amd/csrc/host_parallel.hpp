@@ -10,13 +10,13 @@
 namespace mi {
 // Host threads for the one-time layout build: plain std::thread workers pulling blocks of `grain` indices from an atomic
 // counter (no OpenMP runtime to clash with the caller's).  Everything built under it is independent per index, so the
-// layout does not depend on the number of threads (MI_HOST_THREADS; default: the hardware's, at most 32).
+// layout does not depend on the number of threads (MI_HOST_THREADS; default: the hardware's, at most 64).
 inline int host_threads()
 {
     static int n = [] {
         const char* e = getenv("MI_HOST_THREADS");
         int v = (e && *e) ? atoi(e) : (int)std::thread::hardware_concurrency();
-        return v < 1 ? 1 : (v > 32 ? 32 : v);
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
     }();
     return n;
 }

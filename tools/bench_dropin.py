@@ -47,7 +47,7 @@ for precond in ("diagonal", "AINV"):
 t0 = time.perf_counter()
 addr_o = eng.Addressing(ctx, n, case.lower_addr, case.upper_addr, adopt=True)
 out["renumber-at-bind (mi_addr_create_adopted): seconds"] = time.perf_counter() - t0
-assert addr_o.is_ordered()
+assert addr_o.is_ordered
 mat_o = eng.Matrix(addr_o); mat_o.set_coeffs(t(case.diag[addr_o.cell_map]), t(case.upper[addr_o.face_map]), None)
 src_o = t(case.source[addr_o.cell_map])
 for precond in ("diagonal", "AINV"):

@@ -1,0 +1,38 @@
+#!/bin/bash
+# timing build of the engine (MI_TIMING) on the GPU box: where the layout / hierarchy seconds go
+set -e
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -pthread -DMI_TIMING rapidcfd-dev_amd/csrc/engine.hip rapidcfd-dev_amd/csrc/tiling.cpp rapidcfd-dev_amd/csrc/gamg.cpp -o /tmp/libtiming.so
+MI_ENGINE_LIB=/tmp/libtiming.so python - 2> /tmp/timing.err <<'PY'
+import os, sys, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import numpy as np, torch
+import __graft_entry__ as g
+pkg = g.load_package(); eng, syn = pkg.engine, pkg.synthetic
+import workloads
+case = syn.box_case(216, 216, 216)
+ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+for rep in range(2):
+    print(f"== rep {rep}", file=sys.stderr, flush=True)
+    t0 = time.perf_counter(); addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr); t1 = time.perf_counter()
+    print(f"== layout done {t1-t0:.3f}", file=sys.stderr, flush=True)
+    G = eng.Gamg(addr, workloads.box_pair_weights(case), 100); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"== hierarchy done {t2-t1:.3f}", file=sys.stderr, flush=True)
+    del G, addr
+PY
+python - <<'PY'
+import collections, re
+lines = open("/tmp/timing.err").read().splitlines()
+i = max(k for k, l in enumerate(lines) if l.startswith("== rep"))
+agg = collections.OrderedDict(); build = 0
+for l in lines[i:]:
+    if l.startswith("=="): print(l); continue
+    if l.startswith("[gamg]"): print(l); continue
+    m = re.match(r"\[tiling\]\s+(.*?)\s+([0-9.]+) s", l)
+    if not m: continue
+    key = (build, m.group(1).strip()); agg[key] = agg.get(key, 0.0) + float(m.group(2))
+    if m.group(1).strip() == "slots / halos / entries": build += 1
+for b in range(build):
+    tot = {k[1]: v for k, v in agg.items() if k[0] == b}
+    top = sum(v for k, v in tot.items() if k in ("face lists", "clustering", "renumbering", "slots / halos / entries", "Cuthill-McKee"))
+    if top > 0.02: print(f"layout build {b}: total {top:.3f} s :", {k: round(v, 3) for k, v in tot.items()})
+PY
