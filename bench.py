@@ -306,36 +306,65 @@ def main():
         # came through (no wait ran out of polls, iteration count right); unless all did, every rank rebuilds on RCCL.
         peer_note = ""
         if world > 1 and getattr(solver.comms[0] if solver.comms else None, "peer_mode", False):
-            ok = 1
-            try:
-                solver.begin(tolerance=0.0, max_iter=64)
-                solver.iterate(12)
-                st = solver.end()
-                if st["nIterations"] != 12 or not np.all(np.isfinite(st["history"])):
-                    ok = 0
-            except Exception as e:  # MiError: a window wait ran out of polls
-                ok = 0
-                log(f"[bench] rank {rank}: peer-window trial failed: {e}")
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
+            def trial():
+                """12 iterations; (came through on THIS rank, history)"""
+                try:
+                    solver.begin(tolerance=0.0, max_iter=64)
+                    solver.iterate(12)
+                    st = solver.end()
+                    return int(st["nIterations"] == 12 and bool(np.all(np.isfinite(st["history"][:13])))), np.array(st["history"][:13])
+                except Exception as e:  # MiError: a window wait / a grid barrier ran out of polls
+                    log(f"[bench] rank {rank}: peer-window trial failed: {e}")
+                    return 0, None
+
+            def all_ok(ok):
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
+
+            before = ctx.stat(1)
+            ok, h_persist = trial()
+            persistent = ctx.stat(1) > before                      # the sub-domain fits the persistent kernel (csrc/persist.inc)
+            good = all_ok(ok)
+            if persistent:
+                # the same 12 iterations through the five-launch loop: the persistent kernel must reproduce them
+                ctx.set_option("pcg_persist", 0)
+                ok5, h5 = trial() if good else (0, None)
+                same = int(good and ok5 and float(np.max(np.abs(h_persist - h5))) < 1e-10 * float(h5[0]))
+                if all_ok(same):
+                    ctx.set_option("pcg_persist", 1)
+                else:
+                    peer_note = " (the persistent kernel's trial did not reproduce the five-launch loop on every rank: five launches)"
+                    if not good:                                   # windows possibly out of step after a timed-out wait: once more from scratch
+                        del solver
+                        solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
+                        good = all_ok(trial()[0])
+                    else:
+                        good = all_ok(ok5)
+            if not good:
                 os.environ["MI_ALLREDUCE"] = "rccl"
                 del solver
                 solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
                 peer_note = " (the peer-window trial did not come through on every rank: RCCL)"
         host_loop = {"native": "C++ loop over RCCL (mi_dpcg_comm_iterate)", "torch": "torch.distributed loop (parallel.py)"}[solver.driver]
-        if solver.driver == "native" and getattr(solver.comms[0], "peer_mode", False):
-            host_loop = "C++ loop, no collective calls: halo and all-reduce through peer windows, five launches per iteration (mi_dpcg_comm_iterate)"
-        allreduce_kind = (getattr(solver, "allreduce", "torch.distributed") + peer_note) if world > 1 else "none (one rank)"
-        solver.begin(tolerance=0.0, max_iter=W + R * K + 8)
+        solver.begin(tolerance=0.0, max_iter=W + (R + 1) * K + 8)
+        before = ctx.stat(1)
         solver.iterate(W)
+        in_kernel = ctx.stat(1) > before                           # batches run as ONE persistent cooperative kernel each
+        if solver.driver == "native" and getattr(solver.comms[0], "peer_mode", False):
+            host_loop = ("C++ loop, no collective calls: halo and all-reduce through peer windows, " +
+                         ("one persistent cooperative kernel per batch of iterations (csrc/persist.inc)" if in_kernel else "five launches per iteration") +
+                         " (mi_dpcg_comm_iterate)")
+        allreduce_kind = (getattr(solver, "allreduce", "torch.distributed") + peer_note) if world > 1 else "none (one rank)"
         for _ in range(R):
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            a_ms = solver.iterate(K, time_amul=True, event_stride=8)   # sampled: event records cost ~3 us each in this latency-bound loop
+            # sampled Amul events: their records cost ~3 us each in this latency-bound loop; the persistent kernel has no Amul
+            # launch to bracket -- its repeats run bare and the Amul of the same sub-domain is sampled in one more batch below
+            a_ms = solver.iterate(K, time_amul=not in_kernel, event_stride=8)
             host_enqueue_us = 1e6 * solver.last_enqueue_s / K   # host time to enqueue one iteration (incl. collectives)
             torch.cuda.synchronize()
             if world > 1:
@@ -346,8 +375,14 @@ def main():
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 el = float(tmax.item())
             rep_s.append(el); rep_amul_ms.append(a_ms)
+        if in_kernel:
+            a_ms = solver.iterate(K, time_amul=True, event_stride=8)
+            torch.cuda.synchronize()
+            rep_amul_ms = [a_ms] * len(rep_s)
+        else:
+            solver.iterate(K); torch.cuda.synchronize()
         perf = solver.end()
-        assert perf["nIterations"] == W + R * K, perf
+        assert perf["nIterations"] == W + (R + 1) * K, perf
         n_amul_cells, n_amul_faces = sub.n_cells, sub.n_faces + sum(len(i.face_cells) for i in sub.interfaces)
         # supplement (not `value`): the same solver with the per-GPU work held at the N = 1 size (weak scaling;
         # at 8 GPUs this is the 80 M-cell box of BASELINE config 5), so that the latency-bound strong-scaling number

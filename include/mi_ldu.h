@@ -86,6 +86,14 @@ typedef struct {
 int mi_ctx_create(int device, void *hip_stream, mi_ctx_t *out);
 int mi_ctx_destroy(mi_ctx_t ctx);
 int mi_ctx_synchronize(mi_ctx_t ctx);
+/* which solver paths ran on this context (diagnostics, tests): launches of the persistent PCG kernel -- one per batch of
+ * iterations -- on plain (MI_STAT_PERSIST_PCG) / communicator-attached (MI_STAT_PERSIST_DPCG) matrices */
+/* run-time switch of a context; name "pcg_persist" (0 / 1): the persistent PCG kernel for matrices whose tiles fit the
+ * CUs' registers (csrc/persist.inc); the environment variable MI_PCG_PERSIST sets the value a new context starts with */
+int mi_ctx_set_option(mi_ctx_t ctx, const char *name, int32_t value);
+#define MI_STAT_PERSIST_PCG 0
+#define MI_STAT_PERSIST_DPCG 1
+int mi_ctx_stat(mi_ctx_t ctx, int32_t which, int64_t *out);
 const char *mi_last_error(void);
 /* 1 if a usable gfx950 device is visible to this process, else 0 */
 int mi_device_available(void);

@@ -89,6 +89,9 @@ struct mi_ctx_s {
     int fusePerm = 1;  // MI_FUSE_PERM: caller-order operators gather / scatter through e2c inside the tile kernel (A/B hook)
     int deferPsi = 1;  // MI_PCG_DEFER_PSI: psi += alpha pA rides in the next k_pcg_update_p (one vector read less per iteration; A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
+    int pcgPersist = 1; // MI_PCG_PERSIST: 0 never, 1 (default) whenever the tiles fit the CUs' registers (persist.inc)
+    int64_t stats[4] = {0, 0, 0, 0}; // mi_ctx_stat
+    int persistCoop = -1; // cooperative launch of the persistent kernel possible on this device (-1: not asked yet)
     int pairAT = 1;    // MI_PBICG_PAIR: PBiCG's A p / A^T pT (and the DILU pair) in one pass over the coefficients (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
     int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1; // MI_* switches, read once per context
@@ -140,6 +143,7 @@ struct mi_matrix_s {
     std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
     DevBuf<double> hist, tilePartial;
     DevBuf<PcgState> mstate; DevBuf<double> mpartial, mhist, mtilePartial; PcgState* mhostState = nullptr;   // multi-right-hand-side solves (multi.inc): one state / partial block / history per component
+    DevBuf<double> persistScratch;   // per-workgroup partials + the grid barrier of the persistent PCG kernel (persist.inc) PcgState* mhostState = nullptr;   // multi-right-hand-side solves (multi.inc): one state / partial block / history per component
     int histLen = 0;
     // running PCG session (mi_pcg_begin/iterate/end)
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
@@ -231,6 +235,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->fusePerm = env_int("MI_FUSE_PERM", 1);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->pairAT = env_int("MI_PBICG_PAIR", 1);
+    c->pcgPersist = env_int("MI_PCG_PERSIST", 1);
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
     c->pcgBatch = env_int("MI_PCG_BATCH", 16); c->pcgGraph = env_int("MI_PCG_GRAPH", -1); c->pbicgHostStepped = env_int("MI_PBICG_HOST_STEPPED", 0);
@@ -258,6 +263,24 @@ extern "C" int mi_ctx_synchronize(mi_ctx_t c)
 {
     if (!c) return fail(MI_ERR_ARG, "ctx is NULL");
     HIPCHK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+// run-time switches of a context (the environment variables of the same meaning are read once, at mi_ctx_create):
+//   "pcg_persist"  0 / 1: the persistent PCG kernel for matrices that fit the CUs' registers (MI_PCG_PERSIST)
+extern "C" int mi_ctx_set_option(mi_ctx_t c, const char* name, int32_t value)
+{
+    if (!c || !name) return fail(MI_ERR_ARG, "mi_ctx_set_option: bad argument");
+    if (std::string(name) == "pcg_persist") { c->pcgPersist = value; return MI_OK; }
+    return fail(MI_ERR_ARG, "mi_ctx_set_option: unknown option");
+}
+
+// which solver paths ran on this context: MI_STAT_PERSIST_PCG / MI_STAT_PERSIST_DPCG = launches of the persistent PCG kernel
+// (one per batch of iterations) on plain / attached matrices
+extern "C" int mi_ctx_stat(mi_ctx_t c, int32_t which, int64_t* out)
+{
+    if (!c || !out || which < 0 || which >= 4) return fail(MI_ERR_ARG, "mi_ctx_stat: bad argument");
+    *out = c->stats[which];
     return MI_OK;
 }
 
@@ -1298,6 +1321,7 @@ int fetch_state(mi_ctx_s* c)
 {
     HIPCHK(hipMemcpyAsync(c->hostState, c->state.p, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->hostState->fault) return fail(MI_ERR_DEVICE, "persistent PCG kernel: a workgroup never reached a grid barrier (ran out of polls); the results of this solve are not valid");
     return MI_OK;
 }
 
@@ -1336,6 +1360,8 @@ int globalize(mi_matrix_s* m, double* PA, double* PB = nullptr)
     return MI_OK;
 }
 
+bool pcg_persist_usable(const mi_matrix_s* m, int precond);       // persist.inc: the iteration as one persistent cooperative kernel
+int pcg_persist_enqueue(mi_matrix_s* m, int n_iters, int precond);
 // enqueue PCG iteration bodies it0 .. it0+count-1 (no host sync).
 // diagonal / none: 5 launches per iteration -- update_p (precondition fused), Amul (+ fused
 // gSumProd partials), fold, update_psi_r (+ next iteration's wArA partials), final.
@@ -1456,6 +1482,11 @@ extern "C" int mi_pcg_iterate_sampled(mi_matrix_t m, int32_t n_iters, int32_t ev
     if (!m || !m->pcgActive || n_iters < 0 || event_stride < 0) return fail(MI_ERR_STATE, "mi_pcg_iterate: no active PCG session");
     HIPCHK(hipSetDevice(m->addr->ctx->device));
     const int stride = amul_ms_sum ? (event_stride > 0 ? event_stride : 1) : 0;
+    if (!amul_ms_sum && pcg_persist_usable(m, m->pcgPrecond)) { // small matrix: the whole batch is ONE cooperative launch (persist.inc)
+        MICHK(pcg_persist_enqueue(m, n_iters, m->pcgPrecond));
+        m->pcgIt += n_iters;
+        return MI_OK;
+    }
     MICHK(pcg_enqueue(m, m->pcgIt, n_iters, m->pcgPrecond, stride));
     m->pcgIt += n_iters;
     if (amul_ms_sum) {
@@ -1503,7 +1534,7 @@ extern "C" int mi_pcg_solve(mi_matrix_t m, double* psi, const double* source, co
     // captured ONCE into a hipGraph -- the iteration counter lives in PcgState, so the kernel arguments never change --
     // and replayed until the device reports done.  Same kernels, same order: results are bit-identical.
     const int wantGraph = c->pcgGraph;
-    const bool useGraph = (precond == MI_PRECOND_DIAGONAL || precond == MI_PRECOND_NONE) && !c->fuseFinal &&
+    const bool useGraph = !pcg_persist_usable(m, precond) && (precond == MI_PRECOND_DIAGONAL || precond == MI_PRECOND_NONE) && !c->fuseFinal &&
                           (wantGraph == 1 || (wantGraph < 0 && m->addr->L.nCells <= 4000000));
     if (useGraph && !c->hostState->done) {
         double* psiE; MICHK(m->vec(3, &psiE));
@@ -2132,6 +2163,7 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
 
 #include "multi.inc"
 #include "comm.inc"
+#include "persist.inc"
 #include "gamg_engine.inc"
 #include "assembly.inc"
 

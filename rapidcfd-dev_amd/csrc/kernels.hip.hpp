@@ -690,6 +690,16 @@ __device__ __forceinline__ void chunk_loop(int64_t n, F2 body2, F1 body1)
     for (int64_t q = threadIdx.x; q < np; q += RB) body2(ck.lo + 2 * q);
     if (((ck.hi - ck.lo) & 1) && threadIdx.x == 0) body1(ck.hi - 1);
 }
+// the same, unrolled twice only: passes over many streams (k_pcg_update_psi_r: four reads, one write, two sums) fit 64 VGPRs with it
+template <class F2, class F1>
+__device__ __forceinline__ void chunk_loop2(int64_t n, F2 body2, F1 body1)
+{
+    const Chunk ck = my_chunk(n);
+    const int64_t np = (ck.hi - ck.lo) >> 1;
+#pragma unroll 2
+    for (int64_t q = threadIdx.x; q < np; q += RB) body2(ck.lo + 2 * q);
+    if (((ck.hi - ck.lo) & 1) && threadIdx.x == 0) body1(ck.hi - 1);
+}
 typedef double mi_dvec2 __attribute__((ext_vector_type(2)));
 // 16-byte accesses of the streaming kernels.  Ordinary cache policy: non-temporal accesses on EVERY vector were measured
 // (no gain, profiles/r02_b_cache_policy_ab.md); the two streams that are dead after one touch have their own helpers below.
@@ -849,7 +859,8 @@ struct PcgState {
     // run (k_pcg_update_psi_r, block 0); pApplyItP1 = it once the psi term of iteration it - 1 has been added -- recorded by
     // the single-workgroup kernel that FOLLOWS the adding pass (k_pcg_final of the same iteration, k_pcg_flush_mark at the end
     // of a solve), never by the adding pass itself, whose blocks read it.
-    int32_t rItP1, pApplyItP1, pad_;
+    int32_t rItP1, pApplyItP1;
+    int32_t fault;     // a grid barrier of the persistent kernel (persist.inc) ran out of polls: the results are not valid
 };
 
 constexpr double SP_SMALL = 1e-20, SP_VSMALL = 1e-300, SP_GREAT = 1e20; // SolverPerformance.H:269-275
@@ -993,7 +1004,11 @@ __device__ __forceinline__ bool pcg_update_psi_r_body(PcgState* __restrict__ st,
     }
     const double alpha = st->wArA[it & 1] / wApA;
     double acc0 = 0, acc1 = 0, d0 = 0, d1 = 0;
+#if defined(MI_PSIR_UNROLL2)
+    chunk_loop2(n, [&](int64_t i) {
+#else
     chunk_loop(n, [&](int64_t i) {
+#endif
             const double2 w = ld2_stream(wA, i);
             double2 r = ld2(rA, i);
             if (!deferPsi) { const double2 p = ld2(pA, i); double2 x = ld2(psi, i); x.x = fma(alpha, p.x, x.x); x.y = fma(alpha, p.y, x.y); st2(psi, i, x); }
@@ -1017,7 +1032,10 @@ __device__ __forceinline__ bool pcg_update_psi_r_body(PcgState* __restrict__ st,
     return true;
 }
 template <int PMODE, bool DIST = false>
-__global__ __launch_bounds__(RB) void k_pcg_update_psi_r(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
+#ifndef MI_PSIR_WAVES
+#define MI_PSIR_WAVES 1
+#endif
+__global__ __launch_bounds__(RB, MI_PSIR_WAVES) void k_pcg_update_psi_r(PcgState* __restrict__ st, int it, const double* __restrict__ partial2,
                                                          const double* __restrict__ pA, const double* __restrict__ wA,
                                                          const double* __restrict__ rD,
                                                          double* __restrict__ psi, double* __restrict__ rA, int64_t n,

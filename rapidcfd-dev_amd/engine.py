@@ -48,7 +48,7 @@ SYMBOLS = [
     "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
     "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm", "mi_matrix_patch_neighbour_field",
-    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_last_error", "mi_device_available",
+    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_ctx_stat", "mi_ctx_set_option", "mi_last_error", "mi_device_available",
     "mi_addr_create", "mi_addr_create_coupled", "mi_addr_destroy", "mi_addr_n_cells", "mi_addr_n_faces", "mi_addr_n_tiles",
     "mi_addr_n_ext", "mi_addr_cell_perm", "mi_addr_stats", "mi_addr_patch_offsets",
     "mi_matrix_create", "mi_matrix_addr", "mi_matrix_destroy", "mi_matrix_set_coeffs", "mi_matrix_set_interface_coeffs",
@@ -186,6 +186,16 @@ class Context:
 
     def synchronize(self):
         _chk(lib().mi_ctx_synchronize(self.h))
+
+    def set_option(self, name: str, value: int):
+        """mi_ctx_set_option: "pcg_persist" 0 / 1"""
+        _chk(lib().mi_ctx_set_option(self.h, name.encode(), C.c_int32(int(value))))
+
+    def stat(self, which: int) -> int:
+        """mi_ctx_stat: 0 = launches of the persistent PCG kernel on plain matrices, 1 = on communicator-attached ones"""
+        v = C.c_int64(0)
+        _chk(lib().mi_ctx_stat(self.h, C.c_int32(which), C.byref(v)))
+        return int(v.value)
 
     def close(self):
         if self.h:

@@ -518,13 +518,45 @@ def test_multi_rhs_pbicg_equals_the_single_solves_bit_for_bit(pkg, orc, ctx, nam
             assert got[c]["nIterations"] == o["nIterations"] and np.max(np.abs(got[c]["history"] - o["history"])) < HIST_RTOL * o["history"][0]
 
 
-def test_fused_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, ctx, monkeypatch):
+@pytest.mark.parametrize("name", ["box_sym", "box_30tiles", "graph_sym", "one_cell", "two_cells"])
+@pytest.mark.parametrize("precond", ["diagonal", "none"])
+def test_persistent_pcg_kernel_small_matrices(pkg, orc, name, precond, monkeypatch):
+    """csrc/persist.inc: the PCG iteration of a small matrix as ONE cooperative kernel per batch -- every CU's workgroup keeps
+    its rows' rA, pA, psi and the Amul result in registers (1/diag, diag in LDS) across iterations, the three synchronisation
+    points of the reference's loop are grid barriers.  Same iteration counts and histories (1e-10) as the oracle, the maxIter
+    quirk and the convergence rule included; sums are grouped per workgroup, so it equals the five-launch pipeline to rounding."""
+    monkeypatch.setenv("MI_PCG_PERSIST", "1")
+    eng = pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    case = pkg.synthetic.box_case(40, 32, 24) if name == "box_30tiles" else cases(pkg)[name]
+    addr, mat = make(pkg, ctx, case)
+    S = orc.System([case])
+    n = case.n_cells
+    for kw in (dict(tolerance=1e-9, maxIter=600), dict(tolerance=0.0, maxIter=7), dict(tolerance=1e-30, relTol=1e-3, maxIter=600), dict(tolerance=1e30, minIter=3, maxIter=600)):
+        psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        perf = mat.pcg(psi, dev(case.source), precond, **kw)
+        ref_psi, ref = S.pcg(np.zeros(n), case.source, precond, **kw)
+        assert perf["nIterations"] == ref["nIterations"] and perf["converged"] == ref["converged"], (kw, perf["nIterations"], ref["nIterations"])
+        h, hr = perf["history"], ref["history"]
+        assert h.shape == hr.shape and np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
+        assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * max(np.max(np.abs(ref_psi)), 1e-300)
+    # a solve that starts from the previous solution (residual already small) and the session API mixing both pipelines
+    psi2 = psi.clone()
+    perf2 = mat.pcg(psi2, dev(case.source), precond, tolerance=1e-9, maxIter=600)
+    ref_psi2, ref2 = S.pcg(host(psi), case.source, precond, tolerance=1e-9, maxIter=600)
+    assert perf2["nIterations"] == ref2["nIterations"]
+    assert ctx.stat(0) > 0                                   # the persistent kernel really ran
+
+
+def test_fused_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, monkeypatch):
     """Round 3: the THREE-launch distributed PCG iteration (k_dpcg_update_p with the halo pack into the neighbours' windows,
     tile_kernel_dist with boundary tiles polling the flags + the fused wA.pA all-reduce, k_dpcg_update_psi_r with the fused
     two-scalar all-reduce; peer.inc) on a 1-rank communicator whose processor patches point at the rank itself: every store
     goes through the windows, every flag is waited for.  Same iteration counts and history as the serial oracle, and the SAME
     BITS as the phase loop over RCCL (the sums are formed in the same order)."""
     syn, par = pkg.synthetic, pkg.parallel
+    monkeypatch.setenv("MI_PCG_PERSIST", "0")                                # (the persistent kernel has its own test below)
+    ctx = pkg.engine.Context(0, torch.cuda.current_stream().cuda_stream)
     case = syn.add_cyclic_y(syn.box_case(40, 32, 24, symmetric=True))        # 30 tiles: interior and boundary ones
     S = orc.System([case])
     out = {}
@@ -547,6 +579,55 @@ def test_fused_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, ctx, mo
     for precond in ("diagonal", "none"):
         assert np.array_equal(out["peer", precond][0], out["rccl", precond][0])
         assert np.array_equal(out["peer", precond][1], out["rccl", precond][1])
+
+
+@pytest.mark.parametrize("dims", [(40, 32, 24), (70, 64, 60)])
+def test_persistent_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, dims, monkeypatch):
+    """csrc/persist.inc, DIST form: the whole distributed PCG iteration -- p-update, halo stores into the neighbours' windows,
+    flags, Amul with neighbour-rank values gathered from the window, both all-reduces through the communicator's windows,
+    residual update, convergence test -- inside ONE persistent cooperative kernel per batch.  1-rank communicator whose
+    processor patches point at the rank itself (every store goes through the windows, every flag is waited for); iteration
+    counts and histories (1e-10) of the serial oracle; batches of the five-launch loop in between (Amul timing samples)."""
+    syn, par = pkg.synthetic, pkg.parallel
+    monkeypatch.setenv("MI_PCG_PERSIST", "1")
+    monkeypatch.setenv("MI_ALLREDUCE", "peer")
+    ctx = pkg.engine.Context(0, torch.cuda.current_stream().cuda_stream)
+    case = syn.add_cyclic_y(syn.box_case(*dims, symmetric=True))
+    S = orc.System([case])
+    for precond in ("diagonal", "none"):
+        solver = par.DistributedPCG(ctx, case, "cuda:0", precond=precond, n_global=case.n_cells)
+        assert solver.driver == "native"
+        before = ctx.stat(1)
+        st = solver.solve(tolerance=1e-9, max_iter=500)
+        assert ctx.stat(1) > before                              # the persistent kernel really ran
+        assert solver.ops.mat.peer_halo_status() == (True, 0) and solver.comms[0].peer_status()[0] == 0
+        ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=1e-9, maxIter=500)
+        _check_hist(st, ref)
+        assert np.max(np.abs(solver.ops.solution() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+        # mixed batches: persistent, five-launch (Amul timing), persistent
+        solver.begin(tolerance=0.0, max_iter=200)
+        solver.iterate(7); solver.iterate(5, time_amul=True, event_stride=2); solver.iterate(9)
+        st = solver.end()
+        _, ref = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=0.0, maxIter=20)
+        assert st["nIterations"] == 21 and np.max(np.abs(st["history"][:22] - ref["history"][:22])) < HIST_RTOL * ref["history"][0]
+        assert solver.ops.mat.peer_halo_status() == (True, 0)
+    # the attached mi_pcg_solve entry point
+    eng = pkg.engine
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, [i.face_cells for i in case.interfaces])
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None)
+    for p, itf in enumerate(case.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None)
+    comm = eng.Comm(ctx, 1, 0, eng.Comm.unique_id())
+    assert comm.peer_auto()
+    mat.attach_comm(comm, comm, [0, 0], [1, 0], n_global=case.n_cells)
+    before = ctx.stat(1)
+    psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+    perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=1e-9, maxIter=500)
+    ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-9, maxIter=500)
+    _check_hist(perf, ref)
+    assert ctx.stat(1) > before and np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+    mat.detach_comm(); comm.close()
 
 
 def test_attached_operators_over_halo_windows(pkg, orc, ctx):

@@ -25,12 +25,14 @@ par = import_module(graft.PKG_NAME + ".parallel")
 syn, eng = pkg.synthetic, pkg.engine
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
-ctx = eng.Context(0, stream.cuda_stream)
 case = syn.add_cyclic_y(syn.box_case(*args.dims))
 res = {"dims": args.dims, "cells": case.n_cells, "ext_values": int(sum(len(i.face_cells) for i in case.interfaces))}
-modes = ["rccl", "peer3", "peer4", "peer5", "peer4_t512"] if args.mode == "both" else args.mode.split(",")
+modes = ["rccl", "peer5", "persist"] if args.mode == "both" else args.mode.split(",")
 for mode in modes:
     os.environ["MI_ALLREDUCE"] = "rccl" if mode == "rccl" else "peer"
+    # persist: the whole batch of iterations as ONE persistent cooperative kernel (csrc/persist.inc, DIST form)
+    os.environ["MI_PCG_PERSIST"] = "1" if mode.startswith("persist") else "0"
+    ctx = eng.Context(0, stream.cuda_stream)
     # peer3: every all-reduce inside the passes; peer4 (the default between devices): the two-scalar one inside the p-update,
     # wA.pA in a one-workgroup kernel; peer5: both in one-workgroup kernels (ranks that share a device)
     os.environ["MI_DPCG_FUSED"] = mode[4] if mode.startswith("peer") and len(mode) > 4 and mode[4] in "345" else "1"
@@ -53,7 +55,8 @@ for mode in modes:
     used, bad = s.ops.mat.peer_halo_status()
     res[mode] = {"us_per_iteration": sorted(r[0] for r in reps)[len(reps) // 2], "host_enqueue_us_per_iteration": sorted(r[1] for r in reps)[len(reps) // 2],
                  "all_repeats_us": [r[0] for r in reps], "amul_us": 1e3 * a_ms / 64, "halo_windows": used, "wait_timeouts": bad,
-                 "allreduce": s.allreduce, "launches_per_iteration": int(os.environ["MI_DPCG_FUSED"]) if used and os.environ["MI_DPCG_FUSED"] in "345" else 4 if used else "7 kernels + 2 ncclAllReduce + 1 ncclGroup(send, recv)"}
+                 "allreduce": s.allreduce, "persistent_kernel_launches": ctx.stat(1),
+                 "launches_per_iteration": "1 per batch of iterations" if ctx.stat(1) else int(os.environ["MI_DPCG_FUSED"]) if used and os.environ["MI_DPCG_FUSED"] in "345" else 4 if used else "7 kernels + 2 ncclAllReduce + 1 ncclGroup(send, recv)"}
     print(mode, json.dumps(res[mode]), flush=True)
     del s
 print(json.dumps(res))
