@@ -91,6 +91,8 @@ struct mi_ctx_s {
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
     int pcgPersist = 1; // MI_PCG_PERSIST: 0 never, 1 (default) whenever the tiles fit the CUs' registers (persist.inc)
     int64_t stats[4] = {0, 0, 0, 0}; // mi_ctx_stat
+    int persistGrid = 0; // MI_PERSIST_GRID: workgroups of the persistent kernel (0: one per CU); MI_PERSIST_SHARED=1 lets ranks that share a device use it -- tests only: their grids must fit the device TOGETHER
+    int persistShared = 0;
     int persistCoop = -1; // cooperative launch of the persistent kernel possible on this device (-1: not asked yet)
     int pairAT = 1;    // MI_PBICG_PAIR: PBiCG's A p / A^T pT (and the DILU pair) in one pass over the coefficients (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
@@ -236,6 +238,8 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->pairAT = env_int("MI_PBICG_PAIR", 1);
     c->pcgPersist = env_int("MI_PCG_PERSIST", 1);
+    c->persistGrid = env_int("MI_PERSIST_GRID", 0);
+    c->persistShared = env_int("MI_PERSIST_SHARED", 0);
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
     c->pcgBatch = env_int("MI_PCG_BATCH", 16); c->pcgGraph = env_int("MI_PCG_GRAPH", -1); c->pbicgHostStepped = env_int("MI_PBICG_HOST_STEPPED", 0);

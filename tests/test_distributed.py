@@ -167,6 +167,16 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    persist = isinstance(peer, str) and peer.startswith("persist")
+    if persist:
+        # the persistent kernel between processes that SHARE the GPU: every rank's cooperative grid gets a share of the CUs
+        # (all grids must be resident together, or they wait for each other until the polls run out -- bounded, and shortened here)
+        os.environ["MI_PERSIST_SHARED"] = "1"
+        os.environ["MI_PERSIST_GRID"] = peer.split(":")[1]
+        os.environ["MI_PEER_POLLS"] = "3000000"
+        peer = "auto"
+    else:
+        os.environ["MI_PCG_PERSIST"] = "0"
     d = rank if rccl else 0                                   # RCCL: one device per rank; gloo transport: the ranks share device 0
     torch.cuda.set_device(d)
     if rccl:
@@ -208,6 +218,8 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
         assert st == 0, "a peer all-reduce ran out of polls"
         res["peer_fine_grained"] = fine
         assert dm.mat.peer_halo_status() == (True, 0), "the halo of the attached matrix did not go through windows"
+    if persist:
+        assert ctx.stat(1) > 0, "the persistent distributed kernel did not run"
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -248,6 +260,12 @@ NATIVE_SPECS = {
                               solves=[("bicg", "PBiCG", dict(precond="AINV", tolerance=1e-7, maxIter=300)),   # (it stalls near 1e-8 on this operator)
                                       ("stab", "PBiCGStab", dict(precond="diagonal", tolerance=1e-10, maxIter=300)),
                                       ("smooth", "smoothSolver", dict(n_sweeps=2, tolerance=1e-4, maxIter=300))]),
+    # sub-domains for the persistent distributed kernel: two tiles per workgroup at 2 ranks x 96 workgroups, one at 4 x 48
+    # (short solves: the processes' cooperative grids share one GPU and every exchange waits for the other process's kernel)
+    "box_2_persist": dict(kind="box", dims=(96, 64, 48), parts=(2, 1, 1), symmetric=True,
+                          solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=60)), ("pcg0", "PCG", dict(precond="none", tolerance=1e-2, maxIter=600))]),
+    "box_4_persist": dict(kind="box", dims=(64, 64, 48), parts=(2, 2, 1), symmetric=True,
+                          solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=1e-3, maxIter=600)), ("pcg0", "PCG", dict(precond="none", tolerance=0.0, maxIter=25))]),
     "graph_3": dict(kind="graph", n=3000, symmetric=True,
                     solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=1e-9, maxIter=400)), ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=80))]),
 }
@@ -312,6 +330,18 @@ def test_native_solvers_entirely_over_peer_windows(pkg, orc, tmp_path, name, wor
     windows over hipIpc.  Only what does not fit the windows (all-reduces > 8 doubles, the hierarchy build) still uses gloo."""
     spec = NATIVE_SPECS[name]
     mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, "auto"), nprocs=world, join=True)
+    _check_native(pkg, orc, spec, world, str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,grid", [("box_2_persist", 2, 96), ("box_4_persist", 4, 48)])
+def test_persistent_distributed_pcg_between_processes(pkg, orc, tmp_path, name, world, grid):
+    """csrc/persist.inc, DIST form, between REAL ranks: 2 and 4 processes (distinct sub-domains, each other's windows mapped over
+    hipIpc) run the whole PCG iteration -- halo stores into the neighbours' windows, flags, both all-reduces through the
+    replicated window slots, rank-order sums -- inside their persistent cooperative kernels, which share the one GPU of this
+    box (MI_PERSIST_GRID workgroups each).  Iteration counts, histories (1e-10) and solutions against the multi-domain oracle."""
+    spec = NATIVE_SPECS[name]
+    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, f"persist:{grid}"), nprocs=world, join=True)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 
