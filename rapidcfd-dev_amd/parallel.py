@@ -264,6 +264,10 @@ def make_comms(ctx, device=None):
     """(reduce, halo) RCCL communicators of this rank: the unique ids come from rank 0 through torch.distributed."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    if world > 1 and os.environ.get("MI_COMM_TRANSPORT", "rccl") == "host":
+        # rehearsals on a box with fewer GPUs than ranks (RCCL refuses ranks that share a device): the external-transport
+        # hook over torch.distributed's host backend, peer windows on top unless MI_ALLREDUCE=rccl
+        return make_host_comms(ctx, peer=os.environ.get("MI_ALLREDUCE", "auto") != "rccl")
     ids = [None]
     if rank == 0:
         ids = [[eng.Comm.unique_id(), eng.Comm.unique_id()]]

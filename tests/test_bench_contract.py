@@ -76,6 +76,24 @@ def test_multi_rank_rehearsal_over_gloo(n):
     assert d["config"]["weak_scaling_supplement"]["cells_per_gpu"] == 40 * 32 * 24
 
 
+def test_two_rank_rehearsal_with_peer_windows_and_the_persistent_kernel():
+    """the N > 1 path of bench.py as an 8-GPU node takes it -- peer windows, the trial solve that compares the persistent kernel's
+    history with the five-launch loop's, bare timed repeats, one more sampled batch for the Amul duration -- rehearsed with two
+    ranks that share this box's GPU: communicators over the host transport, windows over hipIpc, the two cooperative grids side by
+    side (MI_PERSIST_GRID workgroups each)"""
+    env = dict(os.environ, MI_BENCH_BACKEND="gloo", MI_DPCG_DRIVER="native", MI_COMM_TRANSPORT="host", MI_PERSIST_SHARED="1", MI_PERSIST_GRID="96", MI_PEER_POLLS="3000000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+           "--dims", "96", "64", "48", "--no-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = _check(lines[0], 2)
+    assert "one persistent cooperative kernel per batch" in d["config"]["host_loop"], d["config"]["host_loop"]
+    assert d["config"]["allreduce"].startswith("peer windows"), d["config"]["allreduce"]
+
+
 def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
     """`python bench.py --gpus 2` (no torch.distributed.run around it) must not fall back to one GPU silently: it re-executes
     itself under the launcher.  Rehearsed over gloo (two ranks share this box's GPU); over RCCL it refuses when fewer GPUs than
