@@ -71,6 +71,21 @@ def traffic_from_profile(nx, ny, nz, n_gpus):
     return None, None
 
 
+def gamg_traffic_from_profile(nx, ny, nz):
+    """HBM bytes per V-cycle from the committed PMC passes (profiles/traffic_latest.json "gamg": the difference of a 25- and a
+    5-cycle solve, tools/gpu_r03_g.sh); quoted only for this workload and while the sources it was measured with are unchanged"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from summarize_gamg_traffic import gamg_source_hash
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))["gamg"]
+        if rec.get("workload") == f"{nx}x{ny}x{nz}" and rec.get("gamg_source_sha256_16") == gamg_source_hash() \
+                and not any(os.environ.get(k) for k in ("MI_TILE_CELLS", "MI_TILE_SLOTS", "MI_ENTRY16", "MI_TILE_FLAGS", "MI_ENGINE_LIB", "MI_SMALL_TILES")):
+            return float(rec["traffic_bytes_per_cycle"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(case, syn, iters):
     """CPU leg: upstream OpenFOAM's lduMatrix path as it runs on this node -- one rank per core over a z-slab decomposition,
     face-loop Amul, diagonal PCG (oracle/baseline_oracle.c; one OpenMP thread plays each MPI rank).  Reported, not a target.
@@ -137,8 +152,9 @@ def bench_gamg(args, eng, syn, ctx, dev, json_fd):
                    "solve_to_1e-6": {"cycles": pc["nIterations"], "seconds": t_conv}},
         "roofline": {"kernel": "whole V-cycle (tile_kernel<OP_JACOBI> / <OP_AMUL> on every level + transfer and scaling passes)", "bound": "hbm",
                      "achieved": alg / (elapsed / K) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
-                     "algorithmic_bytes_per_cycle": alg, "traffic": None,
-                     "traffic_unit": "not measured (profiles/r02_gamg_rocprof_summary.md has the per-kernel times)"},
+                     "algorithmic_bytes_per_cycle": alg, "traffic": gamg_traffic_from_profile(nx, ny, nz),
+                     "traffic_unit": "bytes per V-cycle (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE over all dispatches, 25-cycle minus 5-cycle solve; profiles/r03_g_gamg_cycle_traffic.json)"
+                                     if gamg_traffic_from_profile(nx, ny, nz) is not None else "not measured for this configuration"},
     }
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
@@ -287,6 +303,7 @@ def main():
             try:
                 t0 = time.perf_counter()
                 sup_gamg, G = workloads.gamg_supplement(eng, case, addr, mat, dev)
+                sup_gamg["traffic_bytes_per_cycle"] = gamg_traffic_from_profile(nx, ny, nz)   # PMC (profiles/traffic_latest.json), null off this workload
                 supplements["gamg_216"] = sup_gamg
                 log(f"[bench] supplement GAMG: {sup_gamg['ms_per_v_cycle']:.3f} ms per V-cycle ({time.perf_counter() - t0:.1f}s)")
                 t0 = time.perf_counter()
