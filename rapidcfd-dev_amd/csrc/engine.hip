@@ -1487,9 +1487,12 @@ extern "C" int mi_pcg_iterate_sampled(mi_matrix_t m, int32_t n_iters, int32_t ev
     HIPCHK(hipSetDevice(m->addr->ctx->device));
     const int stride = amul_ms_sum ? (event_stride > 0 ? event_stride : 1) : 0;
     if (!amul_ms_sum && pcg_persist_usable(m, m->pcgPrecond)) { // small matrix: the whole batch is ONE cooperative launch (persist.inc)
-        MICHK(pcg_persist_enqueue(m, n_iters, m->pcgPrecond));
-        m->pcgIt += n_iters;
-        return MI_OK;
+        const int rcP = pcg_persist_enqueue(m, n_iters, m->pcgPrecond);
+        if (rcP != MI_ERR_UNSUPPORTED) {
+            MICHK(rcP);
+            m->pcgIt += n_iters;
+            return MI_OK;
+        }   // (the runtime refused the cooperative grid; nothing ran: the five launches below take over, here and from now on)
     }
     MICHK(pcg_enqueue(m, m->pcgIt, n_iters, m->pcgPrecond, stride));
     m->pcgIt += n_iters;
