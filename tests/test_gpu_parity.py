@@ -549,6 +549,35 @@ def test_persistent_pcg_kernel_small_matrices(pkg, orc, name, precond, monkeypat
     assert ctx.stat(0) > 0                                   # the persistent kernel really ran
 
 
+@pytest.mark.parametrize("zp", ["0", "1", "5"])
+def test_persistent_pcg_kernel_with_and_without_its_first_barrier(pkg, orc, zp, monkeypatch):
+    """csrc/persist.inc, ZP: from the second iteration of a batch on, the residual update publishes z = rD o rA and every tile
+    forms the pA of its halo cells itself (the owner's fma on the owner's operands), so the barrier between p-update and Amul is
+    gone.  MI_PERSIST_ZP = largest number of tiles per workgroup that takes this form (default 1): 0 (never), the default and 5
+    (always) must give the SAME BITS on a matrix with one tile per workgroup and on one with two (500 tiles), and the oracle's
+    history"""
+    monkeypatch.setenv("MI_PCG_PERSIST", "1")
+    monkeypatch.setenv("MI_PERSIST_ZP", zp)
+    eng = pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    for dims, precond in (((40, 32, 24), "diagonal"), ((40, 32, 24), "none"), ((80, 80, 78), "diagonal")):
+        case = pkg.synthetic.box_case(*dims)
+        addr, mat = make(pkg, ctx, case)
+        psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+        perf = mat.pcg(psi, dev(case.source), precond, tolerance=1e-8, maxIter=300)
+        key = (dims, precond)
+        if key not in _ZP_SEEN:
+            ref_psi, ref = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, precond, tolerance=1e-8, maxIter=300)
+            assert perf["nIterations"] == ref["nIterations"] and np.max(np.abs(perf["history"] - ref["history"])) < HIST_RTOL * ref["history"][0]
+            _ZP_SEEN[key] = (perf["history"].copy(), host(psi))
+        else:   # every setting: the bits of the first one
+            assert np.array_equal(perf["history"], _ZP_SEEN[key][0]) and np.array_equal(host(psi), _ZP_SEEN[key][1])
+    assert ctx.stat(0) > 0
+
+
+_ZP_SEEN = {}
+
+
 def test_fused_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, monkeypatch):
     """Round 3: the THREE-launch distributed PCG iteration (k_dpcg_update_p with the halo pack into the neighbours' windows,
     tile_kernel_dist with boundary tiles polling the flags + the fused wA.pA all-reduce, k_dpcg_update_psi_r with the fused
