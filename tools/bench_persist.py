@@ -8,7 +8,8 @@ g.build()
 pkg = g.load_package(); syn, eng = pkg.synthetic, pkg.engine
 out = {}
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
-for dims in ((32, 32, 32), (54, 54, 54), (80, 80, 80), (108, 108, 108)):
+DIMS = [tuple(int(v) for v in d.split("x")) for d in os.environ.get("DIMS", "32x32x32,54x54x54,80x80x80,108x108x108").split(",")]   # DIMS=108x108x108: one size
+for dims in DIMS:
     case = syn.box_case(*dims)
     row = {}
     for mode in ("0", "1"):
