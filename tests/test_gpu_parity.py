@@ -129,7 +129,10 @@ def test_reductions(pkg, orc, ctx, n):
     assert ctx.sum_prod(ad, bd) == ctx.sum_prod(ad, bd)
 
 
-def _check_hist(perf, ref):
+def _check_hist(perf, ref, rel=1e-5):
+    """rel: per-iteration relative bar over the WHOLE history.  1e-5 for every pipeline whose sums are grouped like the
+    five-launch loop's (they were bit-identical to each other before the persistent kernel existed); the persistent kernel's
+    tests pass 1e-3 (sums grouped per workgroup: 5e-5 seen at a residual of 1e-9 of the initial one)."""
     assert perf["nIterations"] == ref["nIterations"]
     assert perf["converged"] == ref["converged"] and perf["singular"] == ref["singular"]
     h, hr = perf["history"], ref["history"]
@@ -140,7 +143,7 @@ def _check_hist(perf, ref):
     # sums are grouped per workgroup, was seen at 5e-5 of a residual that had fallen to 1e-9 of the initial one: 7e-14 of the bar's unit)
     assert np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
     assert np.max(np.abs(h[:10] - hr[:10]) / np.maximum(np.abs(hr[:10]), 1e-300)) < HIST_RTOL
-    assert np.max(np.abs(h - hr) / np.maximum(np.abs(hr), 1e-300)) < 1e-3
+    assert np.max(np.abs(h - hr) / np.maximum(np.abs(hr), 1e-300)) < rel
     assert abs(perf["normFactor"] - ref["normFactor"]) < 1e-13 * ref["normFactor"]
 
 
@@ -578,6 +581,70 @@ def test_persistent_pcg_kernel_with_and_without_its_first_barrier(pkg, orc, zp, 
 _ZP_SEEN = {}
 
 
+def test_persistent_kernel_on_an_unattached_subdomain_with_processor_patches(pkg, orc, monkeypatch):
+    """a sub-domain matrix with processor patches and NO communicator attached takes the single-rank persistent
+    kernel; its halo lists index the ext region behind the owned cells (zero in every engine vector).  The ZP form gathers z
+    there too: the z buffer used to be n_cells long and uninitialised.  Same history as the five-launch pipeline on the same
+    matrix (1e-10), whatever MI_PERSIST_ZP says."""
+    eng, syn = pkg.engine, pkg.synthetic
+    sub = syn.box_subdomain((40, 32, 24), (1, 2, 2), 1)          # three processor patches, 7 680 cells = 8 tiles
+    assert len(sub.interfaces) >= 2
+    out = {}
+    for persist, zp in (("0", "1"), ("1", "0"), ("1", "1"), ("1", "5")):
+        monkeypatch.setenv("MI_PCG_PERSIST", persist); monkeypatch.setenv("MI_PERSIST_ZP", zp)
+        ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+        addr = eng.Addressing(ctx, sub.n_cells, sub.lower_addr, sub.upper_addr, [i.face_cells for i in sub.interfaces])
+        assert addr.n_ext > 0
+        mat = eng.Matrix(addr)
+        mat.set_coeffs(dev(sub.diag), dev(sub.upper), None)
+        for p, itf in enumerate(sub.interfaces):
+            mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None)
+        psi = torch.zeros(sub.n_cells, dtype=torch.float64, device="cuda:0")
+        perf = mat.pcg(psi, dev(sub.source), "diagonal", tolerance=1e-9, maxIter=400)
+        assert (ctx.stat(0) > 0) == (persist == "1")
+        out[persist, zp] = (perf, host(psi))
+    ref, ref_psi = out["0", "1"]
+    for key, (perf, psi) in out.items():
+        assert perf["nIterations"] == ref["nIterations"] and perf["converged"] == 1, key
+        assert np.max(np.abs(perf["history"] - ref["history"])) < HIST_RTOL * ref["history"][0], key
+        assert np.max(np.abs(psi - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi)), key
+    assert np.array_equal(out["1", "0"][0]["history"], out["1", "5"][0]["history"])     # ZP never changes a bit
+
+
+def test_persistent_kernel_barrier_litmus_and_recovery_after_a_timeout(pkg, orc, monkeypatch):
+    """Hardening of the cooperative path: (i) the grid barrier's litmus (64 generations with payload and
+    sum checks on the full cooperative grid) runs once per context before the persistent kernel is used and gates it;
+    (ii) a workgroup that never arrives at a barrier (injected: MI_PERSIST_SKIP_ARRIVAL, with a short poll limit) makes the
+    solve fail with MI_ERR_DEVICE instead of hanging or returning garbage; (iii) the NEXT solve on the same matrix runs through
+    the persistent kernel again and reproduces the oracle -- the barrier words are re-zeroed after a fault (they used to
+    stay out of step for every later solve on that matrix)."""
+    monkeypatch.setenv("MI_PCG_PERSIST", "1")
+    eng = pkg.engine
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    case = pkg.synthetic.box_case(40, 32, 24)
+    addr, mat = make(pkg, ctx, case)
+    S = orc.System([case])
+    kw = dict(tolerance=1e-9, maxIter=400)
+    ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", **kw)
+    psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+    perf = mat.pcg(psi, dev(case.source), "diagonal", **kw)
+    assert ctx.stat(2) == 1 and ctx.stat(0) > 0                   # the litmus ran (once) and let the kernel through
+    assert perf["nIterations"] == ref["nIterations"]
+    for skip in ("2", "7"):                                      # a plain barrier of the first iteration / one of the third
+        monkeypatch.setenv("MI_PERSIST_SKIP_ARRIVAL", skip); monkeypatch.setenv("MI_PERSIST_BAR_POLLS", "20000")
+        psi.zero_()
+        with pytest.raises(eng.MiError) as ei:
+            mat.pcg(psi, dev(case.source), "diagonal", **kw)
+        assert "grid barrier" in str(ei.value)
+        monkeypatch.delenv("MI_PERSIST_SKIP_ARRIVAL"); monkeypatch.delenv("MI_PERSIST_BAR_POLLS")
+        before = ctx.stat(0)
+        psi.zero_()
+        perf = mat.pcg(psi, dev(case.source), "diagonal", **kw)
+        assert ctx.stat(0) > before and ctx.stat(2) == 1
+        assert perf["nIterations"] == ref["nIterations"] and np.max(np.abs(perf["history"] - ref["history"])) < HIST_RTOL * ref["history"][0]
+        assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+
+
 def test_fused_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, monkeypatch):
     """Round 3: the THREE-launch distributed PCG iteration (k_dpcg_update_p with the halo pack into the neighbours' windows,
     tile_kernel_dist with boundary tiles polling the flags + the fused wA.pA all-reduce, k_dpcg_update_psi_r with the fused
@@ -632,7 +699,7 @@ def test_persistent_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, di
         assert ctx.stat(1) > before                              # the persistent kernel really ran
         assert solver.ops.mat.peer_halo_status() == (True, 0) and solver.comms[0].peer_status()[0] == 0
         ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=1e-9, maxIter=500)
-        _check_hist(st, ref)
+        _check_hist(st, ref, rel=1e-3)
         assert np.max(np.abs(solver.ops.solution() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
         # mixed batches: persistent, five-launch (Amul timing), persistent
         solver.begin(tolerance=0.0, max_iter=200)
@@ -655,7 +722,7 @@ def test_persistent_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, di
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=1e-9, maxIter=500)
     ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-9, maxIter=500)
-    _check_hist(perf, ref)
+    _check_hist(perf, ref, rel=1e-3)
     assert ctx.stat(1) > before and np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
     mat.detach_comm(); comm.close()
 
