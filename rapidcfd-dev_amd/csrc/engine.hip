@@ -22,6 +22,7 @@
 #include <vector>
 
 using namespace mi;
+constexpr int HALO_NV = 6;    // operand vectors one halo exchange carries (peer.inc: a window holds that many per parity; multi.inc: pA and pT of three components)
 
 namespace {
 
@@ -95,6 +96,8 @@ struct mi_ctx_s {
     int persistShared = 0;
     int persistCoop = -1; // cooperative launch of the persistent kernel possible on this device AND its barrier litmus clean (-1: not asked yet)
     uint64_t faultEpoch = 0; // faults of the persistent kernel reported on this context so far (fetch_state); a matrix re-zeroes its barrier words when it has missed one
+    int winDirect = 1; // MI_WIN_DIRECT: tile operators of attached matrices read neighbour-rank values straight from the halo window (one launch for all tiles) instead of k_halo_pull + a second launch (A/B hook)
+    int gamgGraphAttached = 1; // MI_GAMG_GRAPH_ATTACHED: the V-cycle of a decomposed case replays as a hipGraph when every exchange of it is stream work (peer windows)
     int pairAT = 1;    // MI_PBICG_PAIR: PBiCG's A p / A^T pT (and the DILU pair) in one pass over the coefficients (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
     int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1; // MI_* switches, read once per context
@@ -187,6 +190,9 @@ int comm_allreduce(mi_matrix_s* m, double* dev, size_t n);
 bool peer_halo_ready(const mi_matrix_s* m);                      // halo windows mapped by the neighbours (peer.inc)
 int peer_exchange_push(mi_matrix_s* m, const double* x);         // x's patch values into the neighbours' windows
 int peer_exchange_pull(mi_matrix_s* m, double* x);               // wait, then window -> x's ext region (patch factors applied)
+int peer_exchange_push_n(mi_matrix_s* m, int nv, const double* const* xs);   // the same for up to HALO_NV operand vectors in ONE exchange (multi.inc)
+int peer_exchange_pull_n(mi_matrix_s* m, int nv, double* const* xs);
+bool peer_win_direct(mi_matrix_s* m);                            // boundary tiles may read the window themselves (no transformed patches, no AMI, default entries)
 int peer_check(mi_matrix_s* m);                                  // MI_ERR_DEVICE when a window wait ran out of polls
 int dpcg_flush_if_fused(mi_matrix_s* m);
 int pcg_solve_attached(mi_matrix_s* m, double* psi_io, const double* source, const mi_solver_controls* ctl, int precond,
@@ -240,6 +246,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->fusePerm = env_int("MI_FUSE_PERM", 1);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->pairAT = env_int("MI_PBICG_PAIR", 1);
+    c->winDirect = env_int("MI_WIN_DIRECT", 1); c->gamgGraphAttached = env_int("MI_GAMG_GRAPH_ATTACHED", 1);
     c->pcgPersist = env_int("MI_PCG_PERSIST", 1);
     c->persistGrid = env_int("MI_PERSIST_GRID", 0);
     c->persistShared = env_int("MI_PERSIST_SHARED", 0);
@@ -275,15 +282,19 @@ extern "C" int mi_ctx_synchronize(mi_ctx_t c)
 
 // run-time switches of a context (the environment variables of the same meaning are read once, at mi_ctx_create):
 //   "pcg_persist"  0 / 1: the persistent PCG kernel for matrices that fit the CUs' registers (MI_PCG_PERSIST)
+//   "win_direct"   0 / 1: boundary tiles of attached matrices read the halo window themselves (MI_WIN_DIRECT)
+//   "gamg_graph_attached" 0 / 1: hipGraph replay of the V-cycle of a decomposed case (MI_GAMG_GRAPH_ATTACHED)
 extern "C" int mi_ctx_set_option(mi_ctx_t c, const char* name, int32_t value)
 {
     if (!c || !name) return fail(MI_ERR_ARG, "mi_ctx_set_option: bad argument");
     if (std::string(name) == "pcg_persist") { c->pcgPersist = value; return MI_OK; }
+    if (std::string(name) == "win_direct") { c->winDirect = value; return MI_OK; }                     // MI_WIN_DIRECT
+    if (std::string(name) == "gamg_graph_attached") { c->gamgGraphAttached = value; return MI_OK; }   // MI_GAMG_GRAPH_ATTACHED
     return fail(MI_ERR_ARG, "mi_ctx_set_option: unknown option");
 }
 
-// which solver paths ran on this context: MI_STAT_PERSIST_PCG / MI_STAT_PERSIST_DPCG = launches of the persistent PCG kernel
-// (one per batch of iterations) on plain / attached matrices
+// which solver paths ran on this context: 0 / 1 = launches of the persistent PCG kernel (one per batch of iterations) on plain /
+// attached matrices, 2 = grid-barrier litmus runs (persist.inc), 3 = V-cycles of a decomposed case replayed as a hipGraph
 extern "C" int mi_ctx_stat(mi_ctx_t c, int32_t which, int64_t* out)
 {
     if (!c || !out || which < 0 || which >= 4) return fail(MI_ERR_ARG, "mi_ctx_stat: bad argument");
@@ -742,6 +753,11 @@ int launch_tile_bs(mi_matrix_s* m, const TileArgs& args, int nTiles, size_t lds)
     return MI_OK;
 }
 
+// all tiles of an attached matrix in ONE launch, boundary tiles reading the halo window (peer.inc: tile_kernel_win)
+template <int OP>
+int launch_tile_win(mi_matrix_s* m, bool trans, const double* x, const double* b, const double* rD, double* y,
+                    double omega, double* dotPartial, double* dotPartial2);
+
 // which: 0 all tiles, 1 interior only, 2 boundary only
 template <int OP>
 int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, const double* rD, double* y,
@@ -878,8 +894,10 @@ int tile_op(mi_matrix_s* m, bool trans, const double* x, const double* b, const 
     mi_addr_s* a = m->addr;
     if (readsNbr && !a->ami.empty()) MICHK(ami_fill(m, x));
     if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial, dotPartial2);
-    if (peer_halo_ready(m)) { // stores into the neighbours' windows instead of send/recv calls: two small launches, no second stream
+    if (peer_halo_ready(m)) { // stores into the neighbours' windows instead of send/recv calls, no second stream
         MICHK(peer_exchange_push(m, x));
+        // one launch for all tiles: interior first, a boundary tile waits for the flags itself and reads the window
+        if (peer_win_direct(m)) return launch_tile_win<OP>(m, trans, x, b, rD, y, omega, dotPartial, dotPartial2);
         MICHK(launch_tile<OP>(m, trans, x, b, rD, y, omega, 1, dotPartial, dotPartial2));
         MICHK(peer_exchange_pull(m, const_cast<double*>(x)));
         return launch_tile<OP>(m, trans, x, b, rD, y, omega, 2, dotPartial ? dotPartial + a->nInterior : nullptr, dotPartial2 ? dotPartial2 + a->nInterior : nullptr);
@@ -1748,6 +1766,7 @@ namespace {
 // y0 = Op x0, y1 = Op^T x1 in ONE pass over the coefficients (multi.inc: tile_kernel_multi with one component), Op = A or the
 // AINV apply; gate: &PcgState::done of the running solve or nullptr
 int tile_pair(mi_matrix_s* m, bool ainv, const double* x0, const double* x1, double* y0, double* y1, const int32_t* gate, double* dotPartial, bool* fused);
+int multi_exchange(mi_matrix_s* m, int nv, double* const* xs);   // multi.inc: one halo exchange for several operand vectors
 // enqueue PBiCG iteration bodies it0 .. it0+count-1 (no host sync): precondition both residuals (+ fused sum wA.rT),
 // update pA/pT, Amul, Tmul, sum wA.pT, update psi/rA/rT (+ sum|rA|), convergence test
 int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, double* pA, double* wA, double* rA,
@@ -1762,7 +1781,9 @@ int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, d
     if (m->tilePartial.n < (size_t)a->L.nTiles) MICHK(m->tilePartial.alloc((size_t)a->L.nTiles));
     struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
     for (int it = it0; it < it0 + count; ++it) {
-        const bool paired = !comm_attached(m) && c->pairAT;   // the plain and the transposed pass share one staging of the coefficients
+        // the plain and the transposed pass share one staging of the coefficients; on a decomposed case (round 4) pA and pT also
+        // share ONE halo exchange (cyclicAMI patches are interpolated per operand inside tile_op: they keep the separate passes)
+        const bool paired = c->pairAT && (!comm_attached(m) || (a->ami.empty() && !a->compact));
         if (precond == MI_PRECOND_AINV) {
             bool fusedDot = false;   // sum wA.rT out of the preconditioner pass (per-tile partials, folded like the Amul's in PCG)
             if (paired) MICHK(tile_pair(m, true, rA, rT, wA, wT, &c->state.p->done, m->tilePartial.p, &fusedDot));
@@ -1777,8 +1798,10 @@ int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, d
         MICHK(globalize(m, P1));
         k_bicg_update_p<<<RG, RB, 0, s>>>(c->state.p, it, P1, wA, wT, pA, pT, n);
         bool fusedDot2 = false;      // sum wA.pT out of the Amul / Tmul pass
-        if (paired) MICHK(tile_pair(m, false, pA, pT, wA, wT, &c->state.p->done, m->tilePartial.p, &fusedDot2));
-        else {
+        if (paired) {
+            if (comm_attached(m)) { double* ops[2] = {pA, pT}; MICHK(multi_exchange(m, 2, ops)); }
+            MICHK(tile_pair(m, false, pA, pT, wA, wT, &c->state.p->done, m->tilePartial.p, &fusedDot2));
+        } else {
         MICHK(tile_op<OP_AMUL>(m, false, pA, nullptr, nullptr, wA, 0.0));   // halo exchange inside when attached
         MICHK(tile_op<OP_AMUL>(m, true, pT, nullptr, nullptr, wT, 0.0));
         }

@@ -92,6 +92,15 @@ def test_two_rank_rehearsal_with_peer_windows_and_the_persistent_kernel():
     d = _check(lines[0], 2)
     assert "one persistent cooperative kernel per batch" in d["config"]["host_loop"], d["config"]["host_loop"]
     assert d["config"]["allreduce"].startswith("peer windows"), d["config"]["allreduce"]
+    # round 4: configs 3 / 4 / 5 as decomposed workloads ride in the N > 1 line too (GAMG with processor interfaces, a whole time
+    # step with attached matrices), on the weak sub-domain and on the strong share
+    sup = d["config"]["supplements"]
+    assert sup and "error" not in sup, sup
+    for cells in (96 * 64 * 48, 96 * 64 * 24):
+        q = sup[f"decomposed_{cells}_cells_per_rank"]
+        assert q["gamg"]["ms_per_v_cycle"] > 0 and q["gamg"]["halo_through_peer_windows"] and q["gamg"]["wait_timeouts"] == 0
+        assert q["gamg"]["cycles_replayed_as_hipGraph"] > 0, q["gamg"]
+        assert q["timestep"]["ms_per_time_step"] > 0 and q["timestep"]["momentum_solve"].startswith("one batched"), q["timestep"]
 
 
 def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():

@@ -206,6 +206,13 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
         kw = dict(kw)
         if solver == "GAMG":
             kw["face_weights"] = weights[rank]
+        if solver == "PBiCG3":   # the components of a vector equation in ONE solve on the attached matrix (mi_pbicg_solve_multi)
+            psis = [torch.zeros(sub.n_cells, dtype=torch.float64, device=dname) for _ in PBICG3_COMPONENTS]
+            perfs = dm.mat.pbicg_multi(psis, [dev(a * sub.source + b) for a, b in PBICG3_COMPONENTS], **kw)
+            torch.cuda.synchronize()
+            for c, (q, pf) in enumerate(zip(psis, perfs)):
+                res[f"{name}{c}_psi"] = q.cpu().numpy(); res[f"{name}{c}_hist"] = pf["history"]; res[f"{name}{c}_nit"] = pf["nIterations"]
+            continue
         psi = torch.zeros(sub.n_cells, dtype=torch.float64, device=dname)
         perf = dm.solve(solver, psi, dev(sub.source), **kw)
         torch.cuda.synchronize()
@@ -223,6 +230,9 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
+
+
+PBICG3_COMPONENTS = ((1.0, 0.0), (0.5, 0.01), (-0.3, 0.0))   # source of component c = a * source + b
 
 
 def _native_case(pkg, spec, world):
@@ -253,7 +263,8 @@ NATIVE_SPECS = {
                           ("smooth", "smoothSolver", dict(n_sweeps=2, tolerance=1e-4, maxIter=300)), ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=60))]),
     "box_4_asym": dict(kind="box", dims=(16, 14, 12), parts=(2, 2, 1), symmetric=False,
                        solves=[("bicg", "PBiCG", dict(precond="AINV", tolerance=1e-10, maxIter=300)), ("stab", "PBiCGStab", dict(precond="diagonal", tolerance=1e-10, maxIter=300)),
-                               ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=60))]),
+                               ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=60)),
+                               ("bicg3_", "PBiCG3", dict(precond="AINV", tolerance=1e-10, maxIter=300))]),   # round 4: batched momentum solve on attached matrices
     # a box cut in 2 x 2 whose processor patches all carry a transformation factor != 1 (the transformed RECEIVE path: VERDICT r02
     # "missing" 5); the factors make the global operator non-symmetric, so the bi-conjugate solvers run on it
     "box_4_transformed": dict(kind="box", dims=(16, 14, 12), parts=(2, 2, 1), symmetric=False, transform=(0.8, -0.6, 0.9),
@@ -364,6 +375,16 @@ def _check_native(pkg, orc, spec, world, tmp_path):
     assert np.array_equal(np.concatenate([d["amul"] for d in data]), S.amul(x))          # bit-exact across the cut
     H = None
     for sname, solver, kw in spec["solves"]:
+        if solver == "PBiCG3":
+            for c, (a, b) in enumerate(PBICG3_COMPONENTS):
+                ref_psi, ref = S.pbicg(np.zeros(n), a * src + b, **kw)
+                for r, d in enumerate(data):
+                    assert int(d[f"{sname}{c}_nit"]) == ref["nIterations"], (sname, c, r, int(d[f"{sname}{c}_nit"]), ref["nIterations"])
+                    h = d[f"{sname}{c}_hist"]
+                    assert h.shape == ref["history"].shape and np.max(np.abs(h - ref["history"])) < 1e-10 * ref["history"][0], (sname, c, r)
+                psi = np.concatenate([d[f"{sname}{c}_psi"] for d in data])
+                assert np.max(np.abs(psi - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi)), (sname, c)
+            continue
         if solver == "GAMG":
             H = orc.GamgSysHierarchy(S, weights, 10)
             ref_psi, ref = H.solve(np.zeros(n), src, **kw)

@@ -819,6 +819,96 @@ def test_attached_comm_operators_and_solvers(pkg, orc, ctx, symmetric):
     comm.close()
 
 
+@pytest.mark.parametrize("mode", ["peer_direct", "peer_pull", "rccl"])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_decomposed_solver_paths_self_exchange(pkg, orc, symmetric, mode, monkeypatch):
+    """Round 4: the paths a DECOMPOSED case takes through GAMG and the momentum solvers, on a 1-rank
+    communicator whose processor patches point at the rank itself (every store, flag and all-reduce issued):
+      * every tile operator of an attached matrix in ONE launch, boundary tiles reading the halo window (peer_direct), against
+        the round-3 form (k_halo_pull + a second launch: peer_pull) and the send / recv path (rccl): Amul, Tmul, residual and
+        Jacobi sweeps bit for bit against the oracle in all three;
+      * the attached V-cycle -- processor interfaces on every level, both sums of the scaling factor out of the Amul pass,
+        fold + window all-reduce in one launch, fused finest residual -- replayed as a hipGraph over peer windows; cycle by
+        cycle against the multi-domain oracle (1e-10), graph on and off;
+      * mi_pbicg_solve_multi on an attached matrix: ONE halo exchange for pA and pT of the three components per pass, the
+        components' sums in one all-reduce; per component the oracle's history (1e-10) and the single attached solve's."""
+    syn, eng = pkg.synthetic, pkg.engine
+    monkeypatch.setenv("MI_PCG_PERSIST", "0")
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("win_direct", 0 if mode == "peer_pull" else 1)
+    case = syn.add_cyclic_y(syn.box_case(40, 32, 24, symmetric=symmetric), asym_shift=0.0 if symmetric else 0.25)   # 30 tiles: interior and boundary ones
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, [i.face_cells for i in case.interfaces])
+    mat = eng.Matrix(addr)
+    mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+    for p, itf in enumerate(case.interfaces):
+        mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if symmetric else dev(itf.int_coeffs))
+    comm = eng.Comm(ctx, 1, 0, eng.Comm.unique_id())
+    if mode != "rccl":
+        assert comm.peer_auto()
+    mat.attach_comm(comm, comm, [0, 0], [1, 0], n_global=case.n_cells)
+    assert mat.peer_halo_status()[0] == (mode != "rccl")
+    S = orc.System([case])
+    n = case.n_cells
+    x = syn.splitmix_uniform(3, n) - 0.5
+    out = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    for _ in range(3):          # consecutive exchanges alternate the window parity
+        mat.amul(dev(x), out); assert np.array_equal(host(out), S.amul(x))
+        mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
+    mat.residual(dev(x), dev(case.source), out); assert np.array_equal(host(out), S.residual(x, case.source))
+    psi = dev(x.copy()); mat.jacobi_smooth(psi, dev(case.source), 3)
+    assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 3))
+    # ---- GAMG with processor interfaces on every level
+    w = orc.box_face_weights(case)
+    G = eng.Gamg(addr, w, 10, comms=(comm, comm), patch_rank=[0, 0], patch_nbr_patch=[1, 0])
+    H = orc.GamgSysHierarchy(S, [w], 10)
+    for graph in (1, 0):
+        ctx.set_option("gamg_graph_attached", graph)
+        for kw in (dict(tolerance=1e-9, maxIter=60), dict(tolerance=1e-9, maxIter=60, nPreSweeps=1, nFinestSweeps=3)):
+            before = ctx.stat(3)
+            psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+            perf = G.solve(mat, psi, dev(case.source), **kw)
+            ref_psi, ref = H.solve(np.zeros(n), case.source, **kw)
+            assert perf["nIterations"] == ref["nIterations"] and perf["nIterations"] > 3
+            assert np.max(np.abs(perf["history"] - ref["history"])) < HIST_RTOL * ref["history"][0]
+            assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+            assert (ctx.stat(3) > before) == (graph == 1 and mode != "rccl"), (graph, mode, ctx.stat(3), before)
+    # ---- the momentum solvers: single (paired passes, one exchange for pA and pT) and batched
+    if not symmetric:
+        kw = dict(tolerance=1e-10, maxIter=300)
+        srcs = [case.source, 0.5 * case.source + 0.01, np.zeros(n)]
+        single = []
+        for b in srcs[:2]:
+            psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+            perf = mat.pbicg(psi, dev(b), "AINV", **kw)
+            ref_psi, ref = S.pbicg(np.zeros(n), b, "AINV", **kw)
+            _check_hist(perf, ref)
+            assert np.max(np.abs(host(psi) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+            single.append((perf, host(psi)))
+        for precond in ("AINV", "diagonal"):
+            psis = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+            got = mat.pbicg_multi(psis, [dev(b) for b in srcs], precond, **kw)
+            assert got[2]["nIterations"] == 0
+            for c in range(2):
+                ref_psi, ref = S.pbicg(np.zeros(n), srcs[c], precond, **kw)
+                _check_hist(got[c], ref)
+                assert np.max(np.abs(host(psis[c]) - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+                if precond == "AINV":
+                    assert got[c]["nIterations"] == single[c][0]["nIterations"]
+                    assert np.allclose(got[c]["history"], single[c][0]["history"], rtol=1e-9, atol=0.0)
+        # per-component diagonals on an attached matrix
+        diags = [case.diag * (1.0 + 0.05 * c) for c in range(3)]
+        psis = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+        got = mat.pbicg_multi(psis, [dev(srcs[0])] * 3, "AINV", diags=[dev(d) for d in diags], **kw)
+        import copy
+        for c in range(3):
+            cc = copy.copy(case); cc.diag = diags[c]
+            ref_psi, ref = orc.System([cc]).pbicg(np.zeros(n), srcs[0], "AINV", **kw)
+            _check_hist(got[c], ref)
+    assert mat.peer_halo_status()[1] == 0
+    del G
+    mat.detach_comm(); comm.close()
+
+
 def test_distributed_matrix_single_rank(pkg, orc, ctx):
     """parallel.DistributedMatrix (the per-rank object of a decomposed case) on one rank: comm creation, attach, every solver."""
     syn, par = pkg.synthetic, pkg.parallel

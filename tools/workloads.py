@@ -82,10 +82,14 @@ def gamg_supplement(eng, case, addr, mat, dev, cycles=20, repeats=3, hbm_peak_gb
     return out, G
 
 
-def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batched=None):
+def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batched=None, coupled=None):
     """One PISO-like time step on the box (configs 4 / 5 per rank): stage times by HIP events, wall time per step.
     batched: solve the three momentum components with ONE multi-right-hand-side PBiCG (mi_pbicg_solve_multi) -- default: when
-    the engine has it (MI_TIMESTEP_SEGREGATED=1 forces three single solves)."""
+    the engine has it (MI_TIMESTEP_SEGREGATED=1 forces three single solves).
+    coupled = dict(case=<LduCase with interfaces on addr's patches>, comms=(reduce, halo) | None, n_global=N): the step of a
+    DECOMPOSED case -- both matrices carry the coupled patches' coefficients (re-bound every step like the internal ones);
+    with communicators they are attached (every tile operator exchanges its halo, every sum is all-reduced, GAMG has
+    processor interfaces on every level), without them the patches are local cyclic ones (the single-rank reference)."""
     import torch
     N, F = case.n_cells, case.n_faces
     nx = case.dims[0]
@@ -101,6 +105,19 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
     U = [t(0.1 * (syn.splitmix_uniform(10 + d, N) - 0.5)) for d in range(3)]
     p = t(np.zeros(N))
     UM, PM = eng.Matrix(addr), eng.Matrix(addr)
+    cpl = None
+    if coupled is not None:
+        itfs = coupled["case"].interfaces
+        pr, pn = [i.nbr_domain for i in itfs], [i.nbr_patch for i in itfs]
+        kU, kP = -1e-3 * h, 1e-3 * h            # off-diagonal of the momentum / pressure matrix across a coupled face
+        cpl = [dict(patch=eng.Patch(ctx, N, itf.face_cells), dU=t(np.full(len(itf.face_cells), -kU)), bU=t(np.full(len(itf.face_cells), -kU)),
+                    dP=t(np.full(len(itf.face_cells), -kP)), bP=t(np.full(len(itf.face_cells), -kP))) for itf in itfs]
+        if coupled["comms"] is not None:
+            # (coefficients must be bound before the first operator; the attach itself only needs the addressing)
+            for M in (UM, PM):
+                M.attach_comm(coupled["comms"][0], coupled["comms"][1], pr, pn, coupled["n_global"])
+            if gamg is None:
+                gamg = eng.Gamg(addr, box_pair_weights(case), 100, comms=coupled["comms"], patch_rank=pr, patch_nbr_patch=pn)
     G = gamg if gamg is not None else eng.Gamg(addr, box_pair_weights(case), 100)
     xmin = np.nonzero(np.arange(N) % nx == 0)[0]
     patch = eng.Patch(ctx, N, xmin)
@@ -129,9 +146,13 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
             asm.axpby(1.0, cl, -1.0, lu, ul); asm.axpby(1.0, cu, -1.0, lu, uu)
             asm.axpby(1.0, dd, 1.0, cd, ud); asm.axpby(1.0, ud, -1.0, ld, ud)
             patch.add(icU, ud, 0)
+            if cpl:
+                for q in cpl: q["patch"].add(q["dU"], ud, 0)
         with stage("momentum: relax(0.7) + bind coefficients"):
             asm.relax(0.7, ud, ul, uu, ds[0], U[0])
             UM.set_coeffs(ud, uu, ul)
+            if cpl:
+                for k, q in enumerate(cpl): UM.set_interface_coeffs(k, q["bU"], q["bU"])
         with stage("momentum: PBiCG + DILU, 3 components (relTol 0.1)" + (" -- one batched solve" if batched else "")):
             if batched:
                 its = [q["nIterations"] for q in UM.pbicg_multi(U, ds, "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)]
@@ -141,7 +162,11 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
             torch.reciprocal(ud, out=rAU); rAU.mul_(vol)
             asm.face_interpolate(wts, rAU, rAUf); rAUf.mul_(magSf)
             asm.fvm_laplacian(delta, rAUf, pu, pd); patch.add(icP, pd, 0)
+            if cpl:
+                for q in cpl: q["patch"].add(q["dP"], pd, 0)
             PM.set_coeffs(pd, pu, None)
+            if cpl:
+                for k, q in enumerate(cpl): PM.set_interface_coeffs(k, q["bP"], None)
             asm.surface_integrate(phi, None, psrc)
         with stage("pressure: GAMG (relTol 0.05)"):
             p.zero_()                   # same work every step: V-cycles from a zero start (a restart from the old p takes fewer)
@@ -165,3 +190,40 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
             "momentum_solve": "one batched 3-right-hand-side PBiCG" if batched else "three segregated PBiCG solves",
             "stages_ms": {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()},
             "timing": f"mean of {steps} steps after one warm-up step; stages by HIP events on the engine's stream"}
+
+
+def decomposed_supplements(eng, syn, par, sub, ctx, dev, comms, n_global, cycles=10, steps=3, reduce_max=lambda v: v):
+    """BASELINE configs 3 / 4 / 5 as DECOMPOSED workloads, per rank (`bench.py --gpus N` measured diagonal PCG
+    only): `sub` is this rank's sub-domain with its processor patches, `comms` the (reduce, halo) communicators the PCG bench
+    already runs on.  GAMG with processor interfaces on every level (V-cycles/s, max over ranks) and one PISO-like time step with
+    attached matrices (batched momentum PBiCG, GAMG pressure).  All ranks call together; reduce_max(x) = max of x over the ranks."""
+    import torch
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = {}
+    dm = par.DistributedMatrix(ctx, sub, dev, n_global=n_global, comms=comms)
+    t0 = time.perf_counter()
+    G = dm.gamg(box_pair_weights(sub), 100)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    src = t(sub.source)
+    psi = torch.zeros(sub.n_cells, dtype=torch.float64, device=dev)
+    G.solve(dm.mat, psi, src, tolerance=0.0, maxIter=3)
+    g0 = ctx.stat(3)
+    rep = []
+    for _ in range(3):
+        psi.zero_(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        perf = G.solve(dm.mat, psi, src, tolerance=0.0, maxIter=cycles)
+        torch.cuda.synchronize()
+        rep.append(reduce_max(time.perf_counter() - t0))
+        assert perf["nIterations"] == cycles, perf
+    el = float(np.median(rep))
+    used, bad = dm.mat.peer_halo_status()
+    out["gamg"] = {"workload": f"GAMG pressure solve of the decomposed box, {sub.n_cells} cells on this rank, {G.n_levels} levels with processor interfaces on every level, "
+                               "global coarsest system", "ms_per_v_cycle": 1e3 * el / cycles, "v_cycles_per_s": cycles / el,
+                   "cycles_replayed_as_hipGraph": int(ctx.stat(3) - g0), "halo_through_peer_windows": bool(used), "wait_timeouts": int(bad),
+                   "hierarchy_build_s": reduce_max(t_build), "timing": f"median of 3 mi_gamg_solve calls of {cycles} V-cycles, max over ranks"}
+    ts = timestep_supplement(eng, syn, sub, dm.addr, ctx, dev, gamg=G, steps=steps, coupled=dict(case=sub, comms=comms, n_global=n_global))
+    ts["ms_per_time_step"] = reduce_max(ts["ms_per_time_step"])
+    out["timestep"] = ts
+    return out
