@@ -86,6 +86,7 @@ struct mi_ctx_s {
     int persist = 0;      // MI_TILE_PERSIST: persistent tile launches (workgroups = resident slots, each walks a run of tiles)
     int nCU = 0;
     bool coarseLevelBuild = false; // set by the GAMG hierarchy builder around its level addressings (tile size choice)
+    bool keepSlotTables = false;   // ... and: keep the host copies of slotFace / faceSlot (the builder derives its slot-to-slot children lists from them, then drops them)
     int attachEvents = 1; // MI_EVENT_ATTACH=0: plain hipEventRecord pairs around the Amul launch instead of kernel-attached events (A/B hook)
     int fusePerm = 1;  // MI_FUSE_PERM: caller-order operators gather / scatter through e2c inside the tile kernel (A/B hook)
     int deferPsi = 1;  // MI_PCG_DEFER_PSI: psi += alpha pA rides in the next k_pcg_update_p (one vector read less per iteration; A/B hook)
@@ -526,10 +527,10 @@ static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, cons
     std::vector<uint32_t>().swap(L.entries16);
     std::vector<int32_t>().swap(L.sliceEntryStart16);
     std::vector<uint16_t>().swap(L.slotBase);
-    std::vector<int32_t>().swap(L.slotFace);
+    if (!ctx->keepSlotTables) std::vector<int32_t>().swap(L.slotFace);
     std::vector<int32_t>().swap(L.haloCell);
     std::vector<int32_t>().swap(L.sliceEntryStart);
-    std::vector<int32_t>().swap(L.faceSlot);
+    if (!ctx->keepSlotTables) std::vector<int32_t>().swap(L.faceSlot);
     *out = a;
     return MI_OK;
 }
@@ -895,9 +896,10 @@ int tile_op(mi_matrix_s* m, bool trans, const double* x, const double* b, const 
     if (readsNbr && !a->ami.empty()) MICHK(ami_fill(m, x));
     if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial, dotPartial2);
     if (peer_halo_ready(m)) { // stores into the neighbours' windows instead of send/recv calls, no second stream
-        MICHK(peer_exchange_push(m, x));
-        // one launch for all tiles: interior first, a boundary tile waits for the flags itself and reads the window
+        // ONE launch: its first blocks push this rank's patch values, interior tiles follow, a boundary tile waits for the
+        // neighbours' flags itself and reads the window (peer.inc: tile_kernel_win)
         if (peer_win_direct(m)) return launch_tile_win<OP>(m, trans, x, b, rD, y, omega, dotPartial, dotPartial2);
+        MICHK(peer_exchange_push(m, x));
         MICHK(launch_tile<OP>(m, trans, x, b, rD, y, omega, 1, dotPartial, dotPartial2));
         MICHK(peer_exchange_pull(m, const_cast<double*>(x)));
         return launch_tile<OP>(m, trans, x, b, rD, y, omega, 2, dotPartial ? dotPartial + a->nInterior : nullptr, dotPartial2 ? dotPartial2 + a->nInterior : nullptr);

@@ -168,6 +168,11 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     persist = isinstance(peer, str) and peer.startswith("persist")
+    if peer == "auto":
+        # boundary tiles read the halo window themselves, waiting for the OTHER process's push inside the tile kernel -- the form
+        # one-rank-per-device runs take; between processes that share a device it is opt-in (small cases only: many waiting
+        # workgroups of one process could keep the other's kernel off the device)
+        os.environ["MI_WIN_DIRECT"] = "2"
     if persist:
         # the persistent kernel between processes that SHARE the GPU: every rank's cooperative grid gets a share of the CUs
         # (all grids must be resident together, or they wait for each other until the polls run out -- bounded, and shortened here)

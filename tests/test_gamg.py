@@ -723,3 +723,47 @@ def test_register_resident_coarsest_inverse_equals_the_host_elimination(pkg, orc
     assert out["global"][0].shape == out["host"][0].shape and np.max(np.abs(out["global"][0] - out["host"][0])) < 1e-10 * out["host"][0][0]
     _, ref = orc.GamgHierarchy(case, w, ncoarsest).solve(np.zeros(case.n_cells), case.source, **args)
     assert out["registers"][0].shape == ref["history"].shape and np.max(np.abs(out["registers"][0] - ref["history"])) < 1e-10 * ref["history"][0]
+
+
+@pytest.mark.gpu
+def test_level_matrices_straight_into_the_tile_slots(pkg, orc, monkeypatch):
+    """Round 4: mi_gamg_update forms every level matrix in the coarse level's ENGINE arrays (tile slots,
+    engine-order diagonal) from the fine level's engine arrays through slot-to-slot children lists (k_gamg_agg_slots /
+    k_gamg_agg_diag_e), instead of caller-order arrays + mi_matrix_set_coeffs per level.  Same children, same order: the solve
+    histories are BIT-identical to the round-3 path (MI_GAMG_DIRECT_SLOTS=0), symmetric and asymmetric, with coupled patches,
+    and equal to the oracle's (1e-10)."""
+    import torch
+    eng, syn = pkg.engine, pkg.synthetic
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    def host(t):
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+    out = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("MI_GAMG_DIRECT_SLOTS", direct)
+        ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+        for name, case in (("sym", syn.box_case(40, 32, 24)), ("asym", syn.box_case(24, 20, 16, symmetric=False)),
+                           ("cyclic", syn.add_cyclic_y(syn.box_case(24, 20, 16)))):
+            itfs = case.interfaces
+            addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, [i.face_cells for i in itfs],
+                                  [itfs[i.nbr_patch].face_cells for i in itfs] if itfs else ())
+            mat = eng.Matrix(addr)
+            mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+            for p, itf in enumerate(itfs):
+                mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None if case.lower is None else dev(itf.int_coeffs))
+            w = orc.box_face_weights(case)
+            G = eng.Gamg(addr, w, 10)
+            psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+            perf = G.solve(mat, psi, dev(case.source), tolerance=1e-9, maxIter=60)
+            # a re-bind with other coefficients, then back: the level matrices follow
+            mat.set_coeffs(dev(1.5 * case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+            psi2 = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+            perf2 = G.solve(mat, psi2, dev(case.source), tolerance=1e-9, maxIter=60)
+            out[direct, name] = (perf["history"], host(psi), perf2["history"])
+            if direct == "1":
+                H = orc.GamgSysHierarchy(orc.System([case]), [w], 10) if itfs else orc.GamgHierarchy(case, w, 10)
+                ref_psi, ref = H.solve(np.zeros(case.n_cells), case.source, tolerance=1e-9, maxIter=60)
+                assert perf["nIterations"] == ref["nIterations"] and np.max(np.abs(perf["history"] - ref["history"])) < 1e-10 * ref["history"][0], name
+    for name in ("sym", "asym", "cyclic"):
+        for k in range(3):
+            assert np.array_equal(out["1", name][k], out["0", name][k]), (name, k)
