@@ -86,13 +86,20 @@ typedef struct {
 int mi_ctx_create(int device, void *hip_stream, mi_ctx_t *out);
 int mi_ctx_destroy(mi_ctx_t ctx);
 int mi_ctx_synchronize(mi_ctx_t ctx);
-/* which solver paths ran on this context (diagnostics, tests): launches of the persistent PCG kernel -- one per batch of
- * iterations -- on plain (MI_STAT_PERSIST_PCG) / communicator-attached (MI_STAT_PERSIST_DPCG) matrices */
-/* run-time switch of a context; name "pcg_persist" (0 / 1): the persistent PCG kernel for matrices whose tiles fit the
- * CUs' registers (csrc/persist.inc); the environment variable MI_PCG_PERSIST sets the value a new context starts with */
+/* run-time switches of a context (the environment variable of the same meaning sets the value a new context starts with):
+ *   "pcg_persist" 0 / 1          the persistent PCG kernel for matrices whose tiles fit the CUs' registers (MI_PCG_PERSIST)
+ *   "win_direct" 0 / 1 / 2       operators of attached matrices as ONE launch whose boundary tiles read the halo window
+ *                                (MI_WIN_DIRECT; 2: also between ranks that share a device -- tests)
+ *   "gamg_graph_attached" 0 / 1  hipGraph replay of the V-cycle of a decomposed case (MI_GAMG_GRAPH_ATTACHED)             */
 int mi_ctx_set_option(mi_ctx_t ctx, const char *name, int32_t value);
+/* which solver paths ran on this context (diagnostics, tests): launches of the persistent PCG kernel -- one per batch of
+ * iterations -- on plain (MI_STAT_PERSIST_PCG) / communicator-attached (MI_STAT_PERSIST_DPCG) matrices; runs of the grid
+ * barrier litmus that gates that kernel (MI_STAT_BARRIER_LITMUS); V-cycles of a decomposed case replayed as a hipGraph
+ * (MI_STAT_GAMG_GRAPH_ATTACHED) */
 #define MI_STAT_PERSIST_PCG 0
 #define MI_STAT_PERSIST_DPCG 1
+#define MI_STAT_BARRIER_LITMUS 2
+#define MI_STAT_GAMG_GRAPH_ATTACHED 3
 int mi_ctx_stat(mi_ctx_t ctx, int32_t which, int64_t *out);
 const char *mi_last_error(void);
 /* 1 if a usable gfx950 device is visible to this process, else 0 */
@@ -641,8 +648,10 @@ int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, float *ms_out
  * components with one copy.  diag_dev: nrhs device pointers to the components' DIAGONALS (caller order) -- solveSegregated adds
  * the boundary contribution per component, addBoundaryDiag(diag, cmpt), so the components share upper / lower but not
  * necessarily the diagonal -- or NULL: the bound diagonal for all.  psi_dev / source_dev: nrhs device pointers; perf_out: nrhs records;
- * residual_history_host: nrhs rows of history_len doubles (or NULL).  On a matrix with communicators attached the components
- * are solved one after the other (each tile operator exchanges the halo of ITS operand).
+ * residual_history_host: nrhs rows of history_len doubles (or NULL).  On a matrix with communicators attached (all ranks call
+ * together) the shared passes stay: pA and pT of all components cross the processor patches in ONE halo exchange per pass, the
+ * components' sums at a sum point travel in one all-reduce (round 4); only with cyclicAMI patches on an attached matrix are
+ * the components solved one after the other.
  * mi_pbicg_solve itself uses the one-component form of the same kernel: A pA and A^T pT in one pass (MI_PBICG_PAIR=0: two).   */
 int mi_pbicg_solve_multi(mi_matrix_t m, int32_t nrhs, const double *const *diag_dev_or_null, double *const *psi_dev, const double *const *source_dev,
                          const mi_solver_controls *controls, int precond, mi_solver_perf *perf_out,

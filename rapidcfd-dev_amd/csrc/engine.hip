@@ -196,6 +196,8 @@ int peer_exchange_pull_n(mi_matrix_s* m, int nv, double* const* xs);
 bool peer_win_direct(mi_matrix_s* m);                            // boundary tiles may read the window themselves (no transformed patches, no AMI, default entries)
 int peer_check(mi_matrix_s* m);                                  // MI_ERR_DEVICE when a window wait ran out of polls
 int dpcg_flush_if_fused(mi_matrix_s* m);
+bool peer_reduce_ready(const mi_matrix_s* m);                    // the matrix's all-reduces go through peer windows
+int peer_globalize(mi_matrix_s* m, int n, double* const* P);     // n <= 6 arrays of RG block partials -> global sums, spread back as {sum, 0, ...}: ONE launch (peer.inc)
 int pcg_solve_attached(mi_matrix_s* m, double* psi_io, const double* source, const mi_solver_controls* ctl, int precond,
                        mi_solver_perf* perf, double* hist_host, int32_t hist_len);
 
@@ -1381,6 +1383,7 @@ int copy_hist(mi_matrix_s* m, double* hist_host, int len, int nIter)
 int globalize(mi_matrix_s* m, double* PA, double* PB = nullptr)
 {
     if (!comm_attached(m)) return MI_OK;
+    if (peer_reduce_ready(m)) { double* P[2] = {PA, PB}; return peer_globalize(m, PB ? 2 : 1, P); }   // final reduction, window all-reduce and spread in one launch
     mi_ctx_s* c = m->addr->ctx;
     hipStream_t s = c->stream;
     double* sc = c->scalars.p + 10;

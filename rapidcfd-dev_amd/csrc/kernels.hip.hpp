@@ -112,6 +112,12 @@ struct TileArgs {
     const int32_t* haloSrc = nullptr;
     const double* xExt = nullptr;
     int32_t nCells = 0; // EXTWIN launches (peer.inc: tile_kernel_dist): halo entries >= nCells read xExt[entry - nCells], the rank's halo WINDOW
+    // EXTWIN == 2 (peer.inc: tile_kernel_win): the window holds self-validating PAIRS {bits, bits ^ xKey}; a halo entry >= nCells
+    // polls its own pair until the two words agree for the key of the current exchange (bounded: xPolls, then *xStatus = 1)
+    const unsigned long long* xPairs = nullptr;
+    unsigned long long xKey = 0;
+    int32_t* xStatus = nullptr;
+    long long xPolls = 0;
     const double* x;  // psi (Amul, residual, H, Jacobi) or r (AINV)
     const double* b;  // source (residual, Jacobi)
     const double* rD; // AINV
@@ -188,7 +194,7 @@ __device__ __forceinline__ void stage_dma8(const double* __restrict__ src, doubl
 }
 
 // one tile: position p of the launch (p indexes tileList / dotPartial)
-template <int OP, bool ASYM, bool TRANS, int BS, bool C16, bool PERM = false, bool EXTWIN = false>
+template <int OP, bool ASYM, bool TRANS, int BS, bool C16, bool PERM = false, int EXTWIN = 0>
 __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double* __restrict__ smem)
 {
     double* cU = smem;
@@ -226,7 +232,27 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
             for (int k = tid; k < nh; k += BS) { const int src = a.haloSrc[h0 + k]; xs[nc + k] = src >= 0 ? a.x[src] : a.xExt[-1 - src]; }
         } else {
         stage_dma8<BS>(a.x + c0, xs, nc, tid);
-        if (EXTWIN) { // neighbour ranks' values come straight from this rank's halo window (written by the peers, system scope)
+        if (EXTWIN == 2) { // ... as self-validating pairs: no flag, no fence between value and flag on the writer's side -- the value IS the flag
+            for (int k = tid; k < nh; k += BS) {
+                const int idx = a.haloCell[h0 + k];
+                double v;
+                if (idx < a.nCells) v = a.x[idx];
+                else {
+                    const unsigned long long* q = a.xPairs + 2 * (size_t)(idx - a.nCells);
+                    unsigned long long bits = 0;
+                    long long polls = 0;
+                    for (;;) {
+                        bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const unsigned long long chk = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if ((bits ^ chk) == a.xKey) break;
+                        if (++polls > a.xPolls || *a.xStatus != 0) { *a.xStatus = 1; break; }   // a neighbour that never arrives must not hang the device
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    v = __longlong_as_double((long long)bits);
+                }
+                xs[nc + k] = v;
+            }
+        } else if (EXTWIN) { // neighbour ranks' values come straight from this rank's halo window (written by the peers, system scope)
             for (int k = tid; k < nh; k += BS) {
                 const int idx = a.haloCell[h0 + k];
                 xs[nc + k] = idx < a.nCells ? a.x[idx] : __hip_atomic_load(a.xExt + (idx - a.nCells), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
