@@ -129,6 +129,9 @@ def test_reductions(pkg, orc, ctx, n):
     assert ctx.sum_prod(ad, bd) == ctx.sum_prod(ad, bd)
 
 
+PERSIST_REL = 1e-3   # late per-iteration bar of solves that may run through the persistent kernel (sums grouped per workgroup)
+
+
 def _check_hist(perf, ref, rel=1e-5):
     """rel: per-iteration relative bar over the WHOLE history.  1e-5 for every pipeline whose sums are grouped like the
     five-launch loop's (they were bit-identical to each other before the persistent kernel existed); the persistent kernel's
@@ -155,7 +158,7 @@ def test_pcg_residual_history(pkg, orc, ctx, name, precond):
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(psi, dev(case.source), precond, tolerance=1e-9, maxIter=400)
     ref_psi, ref = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, precond, tolerance=1e-9, maxIter=400)
-    _check_hist(perf, ref)
+    _check_hist(perf, ref, rel=PERSIST_REL if precond in ("none", "diagonal") else 1e-5)   # (small matrix, diagonal / none: the persistent kernel)
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-10 * np.max(np.abs(ref_psi))
 
 
@@ -169,14 +172,14 @@ def test_pcg_controls(pkg, orc, ctx):
         psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
         perf = mat.pcg(psi, dev(case.source), "diagonal", **kw)
         ref_psi, ref = S.pcg(z, case.source, "diagonal", **kw)
-        _check_hist(perf, ref)
+        _check_hist(perf, ref, rel=PERSIST_REL)
         assert np.max(np.abs(host(psi) - ref_psi)) <= 1e-10 * max(np.max(np.abs(ref_psi)), 1e-300)
     # non-zero initial guess
     x0 = pkg.synthetic.splitmix_uniform(8, case.n_cells) * 1e-3
     psi = dev(x0.copy())
     perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=1e-8)
     _, ref = S.pcg(x0, case.source, "diagonal", tolerance=1e-8)
-    _check_hist(perf, ref)
+    _check_hist(perf, ref, rel=PERSIST_REL)
     # singular: zero residual => wApA == 0 => break without counting the iteration
     zero = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(zero.clone(), zero, "diagonal", tolerance=0.0, maxIter=5)
@@ -405,7 +408,7 @@ def test_cyclic_interfaces(pkg, orc, ctx, symmetric):
         mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
         perf = mat.pbicg(psi, dev(case.source), "DILU", tolerance=1e-10, maxIter=300)
         ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV", tolerance=1e-10, maxIter=300)
-    _check_hist(perf, ref)
+    _check_hist(perf, ref, rel=PERSIST_REL)
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
 
 
@@ -954,7 +957,7 @@ def test_pcg_session_owns_the_context_scratch(pkg, orc, ctx):
     mat.pcg_iterate(400)
     perf = mat.pcg_end(psi0, history_len=302)
     _, ref = orc.System([case]).pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-9, maxIter=300)
-    _check_hist(perf, ref)
+    _check_hist(perf, ref, rel=PERSIST_REL)
     assert abs(ctx.sum(x) - float(np.sum(host(x).astype(np.longdouble)))) < 1e-12 * n   # usable again after mi_pcg_end
 
 
@@ -1004,7 +1007,7 @@ def test_ordered_addressing_runs_on_the_callers_numbering(pkg, orc, ctx, name):
     else:
         perf = mat.pbicg(psi, bd, "AINV", tolerance=1e-10, maxIter=300)
         ref_psi, ref = S.pbicg(np.zeros(n), rc.source, "AINV", tolerance=1e-10, maxIter=300)
-    _check_hist(perf, ref)
+    _check_hist(perf, ref, rel=PERSIST_REL)
     # greedy tiles (no tile starts given): still the identity, still exact
     addr_g = eng.Addressing(ctx, rc.n_cells, rc.lower_addr, rc.upper_addr, ordered=True)
     assert addr_g.is_ordered
