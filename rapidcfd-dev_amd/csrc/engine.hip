@@ -80,6 +80,8 @@ struct mi_ctx_s {
     PcgState* hostState = nullptr; // pinned
     double* hostScal = nullptr;    // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t sideStream = nullptr;              // second stream (lazy): the GAMG coarsest-level inversion runs there beside the solve's prologue and first down-sweep
+    hipEvent_t evSideGo = nullptr, evSideDone = nullptr;
     int amulBS = 0;
     int tileFlags = 0;
     int xcdRows = 1;      // MI_XCD_ROWS: XCD-aware block mapping of the caller-order row passes
@@ -271,6 +273,9 @@ extern "C" int mi_ctx_destroy(mi_ctx_t c)
     if (c->hostScal) (void)hipHostFree(c->hostScal);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->sideStream) { (void)hipStreamSynchronize(c->sideStream); (void)hipStreamDestroy(c->sideStream); }
+    if (c->evSideGo) (void)hipEventDestroy(c->evSideGo);
+    if (c->evSideDone) (void)hipEventDestroy(c->evSideDone);
     if (c->ownStream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MI_OK;
