@@ -147,6 +147,22 @@ int mi_addr_create_coupled(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces,
 int mi_addr_set_ami_patch(mi_addr_t addr, int32_t patch, int32_t nbr_patch, const int32_t *start_host_or_null,
                           const int32_t *address_host_or_null, const double *weights_host_or_null,
                           const uint8_t *low_weight_host_or_null);
+/* cyclicAMI whose PARTNER patch lives on another rank (round 4; the reference's distributed AMI: singlePatchProc_ == -1,
+ * src/meshTools/AMIInterpolation/AMIInterpolation/AMIInterpolation.C:940-1091 calcProcMap + mapDistribute, :281-520 agglomerate
+ * with targetMapPtr).  The partner's patch-internal field travels through an ordinary PROCESSOR patch of this addressing, the
+ * transport patch: created like any processor patch (no neighbour cells), the SAME size on both ranks (the larger AMI side,
+ * padded), its faceCells = this side's AMI faceCells (padding entries: any cell), its interface coefficients zero
+ * (mi_matrix_set_interface_coeffs), so the matrix never sees it and every transport of the engine carries it as it is; in
+ * mi_matrix_attach_comm it names the partner rank and the partner's transport patch.
+ *     pnf[i] = sum_k weights[k] * ( factor * received[ address[k] ] ),  address[k] = face of the transport patch whose
+ * received value is meant (finest level: the partner's face number; < n_partner_faces <= size of the transport patch).
+ * The interpolation runs after the halo exchange of the operator (such a matrix exchanges first and runs all tiles in one
+ * launch).  GAMG: as for a local cyclicAMI patch; the partner side's coarse faces follow from the coarse cells the transport
+ * patch receives on every level, no further talk between the ranks.  An AMI side that is ITSELF split over several ranks
+ * (address entries on different partner ranks) is not handled: one partner rank per cyclicAMI patch.                      */
+int mi_addr_set_ami_patch_remote(mi_addr_t addr, int32_t patch, int32_t transport_patch, int32_t n_partner_faces,
+                                 const int32_t *start_host, const int32_t *address_host, const double *weights_host,
+                                 const uint8_t *low_weight_host_or_null);
 /* face areas |Sf| of a cyclicAMI patch's faces (AMIInterpolation::srcMagSf / tgtMagSf), read by the GAMG agglomeration only */
 int mi_addr_set_ami_face_areas(mi_addr_t addr, int32_t patch, const double *mag_sf_host);
 /* ORDERED addressing -- the caller's numbering is kept: engine order == caller order, mi_addr_cell_perm is the identity and the

@@ -131,10 +131,12 @@ struct mi_addr_s {
     // interpolated locally from the partner patch's cells before every operator that reads them
     struct AmiPatch {
         int32_t patch = 0, nbrPatch = 0, n = 0, extOff = 0;
+        int32_t transport = -1, nPartner = 0;   // cyclicAMI whose partner patch lives on ANOTHER rank: the processor patch that carries the partner's internal field; partner patch size
         DevBuf<int32_t> start, cellE, ownE; DevBuf<double> w; bool hasLow = false;
         std::vector<int32_t> hStart, hAddr; std::vector<double> hW, hMagSf; // host copies: the GAMG builder agglomerates them
     };
     std::vector<AmiPatch*> ami;
+    bool amiRemote = false;   // some cyclicAMI patch interpolates from a transport patch: interpolate AFTER the halo exchange
     ~mi_addr_s() { for (AmiPatch* q : ami) delete q; }
     bool identity = false; // engine order == caller order (ordered addressing, or a mesh whose numbering happens to be tile-contiguous)
     const int32_t* perm() const { return identity ? nullptr : e2c.p; } // nullptr: the permutation kernels degenerate to copies
@@ -186,6 +188,7 @@ struct mi_matrix_s {
 // coupled-patch neighbour values exchanges them itself and every global sum is all-reduced over the ranks
 bool comm_remote(const mi_matrix_s* m);                         // attached and has processor patches
 bool comm_attached(const mi_matrix_s* m);
+bool comm_any_ami(const mi_matrix_s* m);                         // cyclicAMI patches here or -- agreed at attach time -- on any other rank of the case
 int64_t comm_n_global(const mi_matrix_s* m);                     // global cell count (gAverage)
 int comm_exchange_start(mi_matrix_s* m, const double* send, double* vec);
 int comm_exchange_wait(mi_matrix_s* m);
@@ -593,6 +596,57 @@ extern "C" int mi_addr_set_ami_patch(mi_addr_t a, int32_t patch, int32_t nbr_pat
     return MI_OK;
 }
 
+// cyclicAMI whose partner patch lives on another rank (AMIInterpolation with singlePatchProc == -1, AMIInterpolation.C:940-1091:
+// the reference ships the partner's field with a mapDistribute).  Here the partner's patch-internal field arrives through an
+// ordinary PROCESSOR patch of this addressing, the TRANSPORT patch: same size on both ranks (the larger of the two AMI sides,
+// padded), faceCells = this side's AMI faceCells (padding: any cell), zero interface coefficients -- so every transport the
+// engine has (send / recv, peer windows, the external callbacks) carries it unchanged, and the matrix never sees it.  The
+// interpolation then reads the transport patch's ext region: address[k] = index of the transport-patch face whose received
+// value is the k-th contribution (finest level: the partner's face number).  Everything else -- weights, low-weight faces,
+// transformCoupleField factor, agglomeration per GAMG level -- as mi_addr_set_ami_patch.
+extern "C" int mi_addr_set_ami_patch_remote(mi_addr_t a, int32_t patch, int32_t transport_patch, int32_t n_partner_faces, const int32_t* start,
+                                            const int32_t* address, const double* weights, const uint8_t* low_weight)
+{
+    if (!a || patch < 0 || patch >= a->L.nPatches || transport_patch < 0 || transport_patch >= a->L.nPatches || patch == transport_patch || !start || !address || !weights)
+        return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: bad argument");
+    if (a->patchIsLocal[(size_t)patch] || a->patchIsLocal[(size_t)transport_patch])
+        return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: both patches must be created without neighbour cells (ext regions); the transport patch stays a processor patch");
+    HIPCHK(hipSetDevice(a->ctx->device));
+    const std::vector<int32_t>& mine = a->patchFaceCellsHost[(size_t)patch];
+    const int32_t n = (int32_t)mine.size();
+    const int32_t nT = a->L.patchOffset[(size_t)transport_patch + 1] - a->L.patchOffset[(size_t)transport_patch];
+    if (n_partner_faces < 0 || n_partner_faces > nT) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: the transport patch is smaller than the partner patch");
+    if (start[0] != 0) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: start[0] must be 0");
+    for (int32_t i = 0; i < n; ++i) if (start[i + 1] < start[i]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: start must be non-decreasing");
+    const int32_t na = start[n];
+    std::vector<int32_t> st(start, start + n + 1), ce((size_t)na), own;
+    const int32_t src0 = a->L.nCells + a->L.patchOffset[(size_t)transport_patch];   // engine vectors: ext region behind the owned cells
+    for (int32_t k = 0; k < na; ++k) {
+        if (address[k] < 0 || address[k] >= nT) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: address outside the transport patch");
+        ce[(size_t)k] = src0 + address[k];
+    }
+    mi_addr_s::AmiPatch* q = new mi_addr_s::AmiPatch();
+    q->patch = patch; q->nbrPatch = transport_patch; q->n = n; q->extOff = a->L.patchOffset[(size_t)patch];
+    q->transport = transport_patch; q->nPartner = n_partner_faces;
+    q->hStart = st; q->hW.assign(weights, weights + na); q->hAddr.assign(address, address + na);
+    if (low_weight) {
+        own.assign((size_t)n, -1);
+        for (int32_t i = 0; i < n; ++i) if (low_weight[i]) { own[i] = a->L.c2e[(size_t)mine[i]]; q->hasLow = true; }
+    }
+    hipStream_t s = a->ctx->stream;
+    int r = q->start.upload(st, s);
+    if (r == MI_OK && !ce.empty()) r = q->cellE.upload(ce, s);
+    if (r == MI_OK && na > 0) r = q->w.upload(q->hW, s);
+    if (r == MI_OK && q->hasLow) r = q->ownE.upload(own, s);
+    if (r != MI_OK) { delete q; return r; }
+    HIPCHK(hipStreamSynchronize(s));
+    a->ami.push_back(q);
+    a->patchIsLocal[(size_t)patch] = 2;   // no exchange for the AMI patch itself: its values are interpolated from the transport patch's
+    a->nLocalPatches++;
+    a->amiRemote = true;
+    return MI_OK;
+}
+
 extern "C" int mi_addr_set_ami_face_areas(mi_addr_t a, int32_t patch, const double* mag_sf)
 {
     if (!a || !mag_sf) return fail(MI_ERR_ARG, "mi_addr_set_ami_face_areas: bad argument");
@@ -900,6 +954,20 @@ int tile_op(mi_matrix_s* m, bool trans, const double* x, const double* b, const 
 {
     constexpr bool readsNbr = (OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_JACOBI);
     mi_addr_s* a = m->addr;
+    if (readsNbr && a->amiRemote && comm_remote(m)) {
+        // a cyclicAMI patch whose partner lives on another rank interpolates from what its transport patch RECEIVES: whole
+        // exchange first, then the interpolation, then all tiles in one launch (no interior / boundary overlap on such a matrix)
+        if (peer_halo_ready(m)) { MICHK(peer_exchange_push(m, x)); MICHK(peer_exchange_pull(m, const_cast<double*>(x))); }
+        else {
+            if (m->sendBuf.n < (size_t)a->L.nExt) MICHK(m->sendBuf.alloc((size_t)a->L.nExt));
+            MICHK(mi_halo_pack_engine(a, x, m->sendBuf.p));
+            MICHK(comm_exchange_start(m, m->sendBuf.p, const_cast<double*>(x)));
+            MICHK(comm_exchange_wait(m));
+            MICHK(scale_received(m, x));
+        }
+        MICHK(ami_fill(m, x));
+        return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial, dotPartial2);
+    }
     if (readsNbr && !a->ami.empty()) MICHK(ami_fill(m, x));
     if (!readsNbr || !comm_remote(m)) return launch_tile<OP>(m, trans, x, b, rD, y, omega, 0, dotPartial, dotPartial2);
     if (peer_halo_ready(m)) { // stores into the neighbours' windows instead of send/recv calls, no second stream
@@ -1793,7 +1861,7 @@ int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, d
     for (int it = it0; it < it0 + count; ++it) {
         // the plain and the transposed pass share one staging of the coefficients; on a decomposed case (round 4) pA and pT also
         // share ONE halo exchange (cyclicAMI patches are interpolated per operand inside tile_op: they keep the separate passes)
-        const bool paired = c->pairAT && (!comm_attached(m) || (a->ami.empty() && !a->compact));
+        const bool paired = c->pairAT && (!comm_attached(m) || (!comm_any_ami(m) && !a->compact));
         if (precond == MI_PRECOND_AINV) {
             bool fusedDot = false;   // sum wA.rT out of the preconditioner pass (per-tile partials, folded like the Amul's in PCG)
             if (paired) MICHK(tile_pair(m, true, rA, rT, wA, wT, &c->state.p->done, m->tilePartial.p, &fusedDot));

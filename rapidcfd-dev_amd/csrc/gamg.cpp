@@ -142,6 +142,14 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
         const GamgCoupling::Ami& A = pami[(size_t)p];
         if (A.nbrPatch < 0 || A.nbrPatch >= nPatches || A.start.size() != pfc[p].size() + 1 || A.magSf.size() != pfc[p].size())
             return "cyclicAMI patch without complete AMI tables / face areas (mi_addr_set_ami_face_areas)";
+        if (A.transport >= 0 && (A.transport >= nPatches || cpl->isLocal[(size_t)A.transport] != 0 || A.nPartner > (int32_t)pfc[(size_t)A.transport].size()))
+            return "cyclicAMI patch with a partner on another rank: its transport patch must be a processor patch at least as large as the partner patch";
+    }
+    // partner on another rank: transport-patch face that carries the value behind partner face J, on the current fine level
+    std::vector<std::vector<int32_t>> amiSrc((size_t)nPatches);
+    for (int32_t p = 0; p < nPatches; ++p) if (cpl && cpl->isLocal[p] == 2 && pami[(size_t)p].transport >= 0) {
+        amiSrc[(size_t)p].resize((size_t)pami[(size_t)p].nPartner);
+        for (int32_t j = 0; j < pami[(size_t)p].nPartner; ++j) amiSrc[(size_t)p][(size_t)j] = j;
     }
     int nPairLevels = 0;
     while ((int)H.levels.size() < maxLevels - 1) {
@@ -231,7 +239,29 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                 const GamgCoupling::Ami& F = pami[(size_t)p];
                 GamgPatchHost& P = L.patches[p];
                 const std::vector<int32_t>& srcR = P.faceRestrict;
-                const std::vector<int32_t>& tgtR = L.patches[(size_t)F.nbrPatch].faceRestrict;
+                std::vector<int32_t> remoteR, nextSrc;
+                if (F.transport >= 0) {
+                    // The partner's face restrict map, derived here: its coarse faces are its distinct coarse cells in order of
+                    // first appearance over its faces (cyclicAMIGAMGInterface.C:47-165 -- what the partner rank builds for its
+                    // own side), and the coarse cell behind partner face J is what the transport patch received for its face
+                    // amiSrc[J] (theirs[transport]).  nextSrc: the coarse transport face that carries each new partner face.
+                    const std::vector<int32_t>& th = theirs[(size_t)F.transport];
+                    const std::vector<int32_t>& trR = L.patches[(size_t)F.transport].faceRestrict;
+                    const std::vector<int32_t>& src = amiSrc[(size_t)p];
+                    std::unordered_map<int32_t, int32_t> cellToFace;
+                    remoteR.resize(src.size());
+                    for (size_t J = 0; J < src.size(); ++J) {
+                        const int32_t cc = th[(size_t)src[J]];
+                        auto it = cellToFace.find(cc);
+                        if (it == cellToFace.end()) {
+                            const int32_t k = (int32_t)nextSrc.size();
+                            cellToFace.emplace(cc, k);
+                            nextSrc.push_back(trR[(size_t)src[J]]);
+                            remoteR[J] = k;
+                        } else remoteR[J] = it->second;
+                    }
+                }
+                const std::vector<int32_t>& tgtR = F.transport >= 0 ? remoteR : L.patches[(size_t)F.nbrPatch].faceRestrict;
                 const size_t nc = P.faceCells.size();
                 std::vector<std::vector<int32_t>> el(nc);
                 std::vector<std::vector<double>> wl(nc);
@@ -259,6 +289,8 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                 }
                 GamgCoupling::Ami& N = next[(size_t)p];
                 N.nbrPatch = F.nbrPatch; N.start = P.amiStart; N.addr = P.amiAddr; N.w = P.amiW; N.magSf = P.amiMagSf;
+                N.transport = F.transport; N.nPartner = (int32_t)nextSrc.size();
+                if (F.transport >= 0) { P.amiSrcFace = nextSrc; amiSrc[(size_t)p].swap(nextSrc); }
             }
             for (int32_t p = 0; p < nPatches; ++p) if (cpl->isLocal[p] == 2) pami[(size_t)p] = std::move(next[(size_t)p]);
         }

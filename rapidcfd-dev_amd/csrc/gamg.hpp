@@ -27,6 +27,10 @@ struct GamgPatchHost {
     // side is the fine one agglomerated over both sides' face maps (AMIInterpolation::agglomerate, AMIInterpolation.C:279-540)
     std::vector<int32_t> amiStart, amiAddr; // [nCoarse+1], coarse face of the neighbour patch
     std::vector<double> amiW, amiMagSf;     // weights normalised per coarse face; agglomerated face areas
+    // cyclicAMI whose partner patch lives on another rank: amiAddr numbers the PARTNER's coarse faces (its own order: distinct
+    // partner coarse cells in order of first appearance); amiSrcFace[J] = face of this level's TRANSPORT patch whose received
+    // value is the coarse cell behind partner face J (what mi_addr_set_ami_patch_remote takes as address)
+    std::vector<int32_t> amiSrcFace;
 };
 
 struct GamgLevelHost {
@@ -52,7 +56,9 @@ struct GamgCoupling {
     std::vector<std::vector<int32_t>> faceCells;   // finest level, per patch
     std::vector<std::vector<int32_t>> nbrCells;    // finest level, per patch; empty vector = processor patch
     std::vector<char> isLocal;                     // per patch: 0 processor, 1 cyclic (nbrCells), 2 cyclicAMI (ami tables)
-    struct Ami { int32_t nbrPatch = -1; std::vector<int32_t> start, addr; std::vector<double> w, magSf; };
+    // transport >= 0: the partner patch lives on another rank; `transport` is the processor patch of THIS domain that carries the
+    // partner's patch-internal field (same size on both ranks), nPartner the partner patch's face count, addr numbers its faces
+    struct Ami { int32_t nbrPatch = -1; std::vector<int32_t> start, addr; std::vector<double> w, magSf; int32_t transport = -1, nPartner = 0; };
     std::vector<Ami> ami;                          // per patch (nbrPatch < 0: not an AMI patch); finest level
     bool (*allAnd)(void* user, bool v) = nullptr;
     // in: send[p] = local coarse ids of patch p's cells (processor patches only); out: recv[p] same length

@@ -41,7 +41,7 @@ class SolverControls(C.Structure):
 
 # every exported symbol of include/mi_ldu.h (tests check the library exports all of them)
 SYMBOLS = [
-    "mi_addr_set_ami_patch", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
+    "mi_addr_set_ami_patch", "mi_addr_set_ami_patch_remote", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
     "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy", "mi_gamg_host_build_ami",
     "mi_addr_create_adopted", "mi_layout_adopt_host", "mi_pbicg_solve_multi", "mi_comm_peer_auto", "mi_comm_peer_selftest", "mi_comm_peer_enable", "mi_matrix_peer_halo_auto", "mi_matrix_peer_halo_status",
     "mi_pcg_iterate_sampled",
@@ -291,6 +291,17 @@ class Addressing:
         cp = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if a is not None else None
         _chk(lib().mi_addr_set_ami_patch(self.h, C.c_int32(patch), C.c_int32(nbr_patch), cp(st, C.c_int32), cp(ad, C.c_int32),
                                          cp(w, C.c_double), cp(lw, C.c_uint8)))
+
+    def set_ami_patch_remote(self, patch: int, transport_patch: int, n_partner_faces: int, start, address, weights, low_weight=None):
+        """cyclicAMI patch whose partner lives on another rank: its neighbour values are interpolated from what the processor
+        patch `transport_patch` receives (mi_addr_set_ami_patch_remote)"""
+        st = np.ascontiguousarray(start, dtype=np.int32); ad = np.ascontiguousarray(address, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        lw = None if low_weight is None else np.ascontiguousarray(low_weight, dtype=np.uint8)
+        _chk(lib().mi_addr_set_ami_patch_remote(self.h, C.c_int32(patch), C.c_int32(transport_patch), C.c_int32(n_partner_faces),
+                                                st.ctypes.data_as(C.POINTER(C.c_int32)), ad.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                w.ctypes.data_as(C.POINTER(C.c_double)),
+                                                lw.ctypes.data_as(C.POINTER(C.c_uint8)) if lw is not None else C.POINTER(C.c_uint8)()))
 
     def set_ami_face_areas(self, patch: int, mag_sf):
         """face areas of a cyclicAMI patch (srcMagSf / tgtMagSf): the GAMG hierarchy agglomerates the AMI with them"""

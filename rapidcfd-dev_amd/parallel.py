@@ -359,22 +359,44 @@ class DistributedMatrix:
         self.device = torch.device(device)
         self.sub = sub
         self.comms = comms if comms is not None else make_comms(ctx)
-        self.addr = eng.Addressing(ctx, sub.n_cells, sub.lower_addr, sub.upper_addr, [i.face_cells for i in sub.interfaces])
+        # engine patches: the interfaces in order; a cyclicAMI interface whose partner lives on another rank gets a TRANSPORT
+        # patch behind them (mi_addr_set_ami_patch_remote): a processor patch of the larger side's size that carries this side's
+        # patch-internal field to the partner rank and receives the partner's, with zero coefficients
+        patches = [np.asarray(i.face_cells, dtype=np.int32) for i in sub.interfaces]
+        self.patch_rank = [i.nbr_domain for i in sub.interfaces]
+        self.patch_nbr_patch = [i.nbr_patch for i in sub.interfaces]
+        transport = {}
+        for k, itf in enumerate(sub.interfaces):
+            if getattr(itf, "ami_transport_nbr_patch", None) is not None:
+                transport[k] = len(patches)
+                patches.append(np.resize(np.asarray(itf.face_cells, dtype=np.int32), max(len(itf.face_cells), int(itf.ami_partner_size))))
+                self.patch_rank.append(itf.nbr_domain); self.patch_nbr_patch.append(int(itf.ami_transport_nbr_patch))
+        self.addr = eng.Addressing(ctx, sub.n_cells, sub.lower_addr, sub.upper_addr, patches)
+        for k, itf in enumerate(sub.interfaces):
+            if getattr(itf, "ami_start", None) is None:
+                continue
+            if k in transport:
+                self.addr.set_ami_patch_remote(k, transport[k], int(itf.ami_partner_size), itf.ami_start, itf.ami_addr, itf.ami_w, itf.ami_low)
+            else:
+                self.addr.set_ami_patch(k, itf.nbr_patch, itf.ami_start, itf.ami_addr, itf.ami_w, itf.ami_low)
+            if itf.ami_magsf is not None:
+                self.addr.set_ami_face_areas(k, itf.ami_magsf)
         self.mat = eng.Matrix(self.addr)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
         self.mat.set_coeffs(t(sub.diag), t(sub.upper), None if sub.lower is None else t(sub.lower))
         for p, itf in enumerate(sub.interfaces):
             self.mat.set_interface_coeffs(p, t(itf.bou_coeffs), None if sub.lower is None else t(itf.int_coeffs))
-            if getattr(itf, "transform", 1.0) != 1.0:       # processorCyclic: transformCoupleField on the received values
+            if getattr(itf, "transform", 1.0) != 1.0:       # processorCyclic / cyclicAMI: transformCoupleField factor
                 self.mat.set_patch_transform(p, itf.transform)
+        for k, p in transport.items():
+            z = t(np.zeros(len(patches[p])))
+            self.mat.set_interface_coeffs(p, z, None if sub.lower is None else z)
         if n_global is None:
             ng = torch.tensor([float(sub.n_cells)], dtype=torch.float64, device=self.device)
             self.comms[0].allreduce_sum(ng)
             torch.cuda.synchronize()
             n_global = int(round(float(ng.item())))
         self.n_global = n_global
-        self.patch_rank = [i.nbr_domain for i in sub.interfaces]
-        self.patch_nbr_patch = [i.nbr_patch for i in sub.interfaces]
         self.mat.attach_comm(self.comms[0], self.comms[1], self.patch_rank, self.patch_nbr_patch, n_global)
         self._gamg = None
 

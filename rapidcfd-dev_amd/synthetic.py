@@ -65,6 +65,10 @@ class Interface:
     ami_low: Optional[np.ndarray] = None     # uint8 [Pf]: weight sum under lowWeightCorrection -> the face's own cell value
     ami_magsf: Optional[np.ndarray] = None   # float64 [Pf] face areas of this side (GAMG agglomerates the AMI with them)
     transform: float = 1.0                   # transformCoupleField factor (rotational cyclic, component solves)
+    # cyclicAMI whose partner interface lives in ANOTHER domain (decompose_cyclic_ami_y): the partner's face count and, for the
+    # engine's transport patch, the index that patch has in the partner rank's engine patch list
+    ami_partner_size: Optional[int] = None
+    ami_transport_nbr_patch: Optional[int] = None
 
 
 @dataclass
@@ -351,6 +355,37 @@ def add_cyclic_ami_y(case: LduCase, shift: float = 0.37, low_weight_every: int =
     out.interfaces[0].ami_magsf = h * h * (1.0 + 0.05 * splitmix_uniform(seed + 4, ymin.shape[0]))
     out.interfaces[1].ami_magsf = 0.5 * h * h * (1.0 + 0.05 * splitmix_uniform(seed + 5, ymax.shape[0]))
     return out
+
+
+def decompose_cyclic_ami_y(base: LduCase, py: int, **ami_kw) -> List[LduCase]:
+    """The box with the non-conformal y-min / y-max interface of add_cyclic_ami_y, cut into `py` slabs in y: the two sides of
+    the cyclicAMI pair end up on DIFFERENT ranks (slab 0 holds y-min, slab py-1 holds y-max; the reference's distributed AMI,
+    AMIInterpolation.C:940-1091), with ordinary processor patches between neighbouring slabs.  Every sub-domain: processor
+    interfaces first (as decompose_box orders them), the AMI interface last; its ami_addr numbers the faces of the partner
+    interface, which lives in domain nbr_domain.  The multi-domain oracle takes the list as it is; the engine adds one
+    transport patch per remote AMI interface (parallel.DistributedMatrix)."""
+    import copy
+    full = add_cyclic_ami_y(base, **ami_kw)
+    bare = copy.copy(full); bare.interfaces = []
+    subs = decompose_box(bare, (1, py, 1))
+    a, b = full.interfaces
+    first, last = subs[0], subs[-1]
+    loc = lambda sub, cells: np.searchsorted(sub.global_cells, cells).astype(np.int32)
+    na, nb = len(first.interfaces), len(last.interfaces)
+    if py == 1:
+        ia, ib = copy.copy(a), copy.copy(b)
+        ia.nbr_patch, ib.nbr_patch = na + 1, na
+        first.interfaces += [ia, ib]
+        return subs
+    ia, ib = copy.copy(a), copy.copy(b)
+    ia.face_cells, ib.face_cells = loc(first, a.face_cells), loc(last, b.face_cells)
+    ia.nbr_domain, ia.nbr_patch, ia.ami_partner_size = py - 1, nb, len(b.face_cells)
+    ib.nbr_domain, ib.nbr_patch, ib.ami_partner_size = 0, na, len(a.face_cells)
+    # engine patch lists: the interfaces in order, then one transport patch per remote AMI interface
+    ia.ami_transport_nbr_patch = nb + 1
+    ib.ami_transport_nbr_patch = na + 1
+    first.interfaces.append(ia); last.interfaces.append(ib)
+    return subs
 
 
 def _chunks(nd: int, p: int) -> np.ndarray:

@@ -249,6 +249,10 @@ def _native_case(pkg, spec, world):
         dom = (syn.splitmix_uniform(5, case.n_cells) * world).astype(np.int64)
         subs = syn.decompose(case, dom, world)
         weights = [0.5 + syn.splitmix_uniform(40 + d, s.n_faces) for d, s in enumerate(subs)]
+    elif spec["kind"] == "ami_y":
+        # the non-conformal y-interface of tests/test_ami.py with its two sides on DIFFERENT ranks (slabs in y)
+        subs = syn.decompose_cyclic_ami_y(syn.box_case(*spec["dims"], symmetric=spec["symmetric"]), world, **spec.get("ami", {}))
+        weights = [orc.box_face_weights(s) for s in subs]
     else:
         case = syn.box_case(*spec["dims"], symmetric=spec["symmetric"])
         subs = syn.decompose_box(case, spec["parts"])
@@ -289,6 +293,15 @@ NATIVE_SPECS = {
                            solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=40)), ("pcg0", "PCG", dict(precond="none", tolerance=1e-3, maxIter=600))]),
     "box_4_persist": dict(kind="box", dims=(64, 64, 48), parts=(2, 2, 1), symmetric=True,
                           solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=1e-3, maxIter=600)), ("pcg0", "PCG", dict(precond="none", tolerance=0.0, maxIter=25))]),
+    # row f3: cyclicAMI whose halves live on different ranks (AMIInterpolation.C:940-1091): y-slabs, slab 0 holds the y-min side,
+    # the last slab the refined and shifted y-max side (different face counts), processor patches between the slabs
+    "ami_sym": dict(kind="ami_y", dims=(20, 16, 12), symmetric=True, ami=dict(shift=0.37),
+                    solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=1e-9, maxIter=500)), ("dic", "PCG", dict(precond="AINV", tolerance=1e-9, maxIter=500)),
+                            ("smooth", "smoothSolver", dict(n_sweeps=2, tolerance=1e-4, maxIter=300)),
+                            ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=60, directSolveCoarsest=False))]),
+    "ami_asym": dict(kind="ami_y", dims=(20, 16, 12), symmetric=False, ami=dict(shift=0.37, low_weight_every=7, transform=0.6),
+                     solves=[("bicg", "PBiCG", dict(precond="AINV", tolerance=1e-10, maxIter=300)), ("stab", "PBiCGStab", dict(precond="diagonal", tolerance=1e-10, maxIter=300)),
+                             ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=60, directSolveCoarsest=False))]),
     "graph_3": dict(kind="graph", n=3000, symmetric=True,
                     solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=1e-9, maxIter=400)), ("gamg", "GAMG", dict(tolerance=1e-9, maxIter=80))]),
 }
@@ -353,6 +366,22 @@ def test_native_solvers_entirely_over_peer_windows(pkg, orc, tmp_path, name, wor
     windows over hipIpc.  Only what does not fit the windows (all-reduces > 8 doubles, the hierarchy build) still uses gloo."""
     spec = NATIVE_SPECS[name]
     mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, "auto"), nprocs=world, join=True)
+    _check_native(pkg, orc, spec, world, str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("peer", [False, "auto"])
+@pytest.mark.parametrize("name,world", [("ami_sym", 2), ("ami_asym", 2), ("ami_sym", 4)])
+def test_cyclic_ami_whose_halves_live_on_different_ranks(pkg, orc, tmp_path, name, world, peer):
+    """Row f3 (round 4): the non-conformal interface of tests/test_ami.py cut across ranks -- the y-min side on rank 0, the
+    refined / shifted y-max side on the last rank (the reference's distributed AMI, singlePatchProc == -1).  The partner's
+    patch-internal field travels through a TRANSPORT processor patch (padded to the larger side, zero coefficients:
+    mi_addr_set_ami_patch_remote), the interpolation reads what that patch receives, and every GAMG level derives the partner
+    side's coarse faces from the coarse cells the transport patch receives.  Amul bit-exact across the interface; PCG / DIC-PCG /
+    smoothSolver / PBiCG / PBiCGStab / GAMG (ICCG / BICCG on the coarsest level) against the multi-domain oracle (1e-10), over
+    the external transport and over peer windows, with low-weight faces and a transformation factor in the asymmetric case."""
+    spec = NATIVE_SPECS[name]
+    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, peer), nprocs=world, join=True)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 
