@@ -5,6 +5,15 @@
 #include <algorithm>
 #include <cmath>
 #include <unordered_map>
+#ifdef MI_TIMING
+#include <chrono>
+#include <cstdio>
+namespace { struct GamgTick { const char* what; int level; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~GamgTick() { fprintf(stderr, "[gamg-host] level %2d %-28s %.4f s\n", level, what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } }; }
+#define MI_TICK(what, level) GamgTick tick_##__LINE__{what, (int)(level)}
+#else
+#define MI_TICK(what, level)
+#endif
 
 namespace mi {
 
@@ -162,16 +171,19 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
             L.nCoarse = nFine;
             cont = (int32_t)H.levels.size() < dummyLevels;
         } else {
-        L.nCoarse = match_pairs(nFine, nF, lo, up, w, forward, L.restrictMap);
+        { MI_TICK("pair matching", H.levels.size()); L.nCoarse = match_pairs(nFine, nF, lo, up, w, forward, L.restrictMap); }
         forward = !forward;
         cont = !(L.nCoarse < nCellsInCoarsestLevel || L.nCoarse == nFine); // continueAgglomerating
         }
         if (cpl && cpl->allAnd) cont = cpl->allAnd(cpl->user, cont);              // ... on all processors
         if (!cont) break;
-        build_coarse_faces(L, lo, up);
+        { MI_TICK("coarse faces", H.levels.size()); build_coarse_faces(L, lo, up); }
+        {
+        MI_TICK("face weights", H.levels.size());
         std::vector<double> cw((size_t)L.nCoarseFaces, 0.0); // restrictFaceField (host): plain summation
         for (int32_t f = 0; f < nF; ++f) if (L.faceRestrict[f] >= 0) cw[L.faceRestrict[f]] += w[f];
         w.swap(cw);
+        }
         if (nPatches > 0) {
             // coarse-cell ids on both sides of every coupled patch face
             std::vector<std::vector<int32_t>> mine((size_t)nPatches), theirs((size_t)nPatches), send((size_t)nPatches);
@@ -319,6 +331,7 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
         GamgLevelHost& B = H.levels.back();
         nFine = B.nCoarse; nF = B.nCoarseFaces; lo = B.cLower.data(); up = B.cUpper.data();
     }
+    MI_TICK("children lists (all levels)", -1);
     if (!pipelined) for (GamgLevelHost& B : H.levels) finish_gamg_level(B); // device tables from the final (possibly combined) maps
     H.forwardOut = forward;
     return std::string();
