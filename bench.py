@@ -47,20 +47,19 @@ def parts_for(n):
 
 
 def layout_source_hash():
-    """hash of the sources that decide the bytes an Amul launch moves (tile layout + tile kernel): the committed PMC figure
-    is only quoted while these are the files it was measured with"""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("tiling.cpp", "tiling.hpp", "kernels.hip.hpp"):
-        h.update(open(os.path.join(ROOT, "rapidcfd-dev_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    """what the committed PMC figure of an Amul launch is tied to: the tile kernel's source text and the tile layout's OUTPUT on
+    fixed reference cases (tools/source_fingerprint.py) -- host-side changes that leave every layout table bit-identical keep
+    the figure, anything that moves a slot or touches the kernel voids it"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import source_fingerprint
+    return source_fingerprint.layout_source_hash()
 
 
 def traffic_from_profile(nx, ny, nz, n_gpus):
     """HBM bytes per Amul launch from the committed rocprofv3 PMC passes (profiles/traffic_latest.json: FETCH_SIZE x 2 +
     WRITE_SIZE as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read inside this process, so the value is the
-    one measured on this exact workload AND this exact layout/kernel source (sha256 prefix stored with the figure by
-    tools/prof_round.sh); null for any other configuration or once those sources have changed."""
+    one measured on this exact workload AND this exact kernel source / layout output (layout_source_hash, stored with the
+    figure by tools/prof_round.sh); null for any other configuration or once those have changed."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if rec.get("workload") == f"{nx}x{ny}x{nz}" and rec.get("n_gpus") == n_gpus and rec.get("layout_source_sha256_16") == layout_source_hash() \
@@ -76,7 +75,7 @@ def gamg_traffic_from_profile(nx, ny, nz):
     5-cycle solve, tools/gpu_r03_g.sh); quoted only for this workload and while the sources it was measured with are unchanged"""
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from summarize_gamg_traffic import gamg_source_hash
+        from source_fingerprint import gamg_source_hash
         rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))["gamg"]
         if rec.get("workload") == f"{nx}x{ny}x{nz}" and rec.get("gamg_source_sha256_16") == gamg_source_hash() \
                 and not any(os.environ.get(k) for k in ("MI_TILE_CELLS", "MI_TILE_SLOTS", "MI_ENTRY16", "MI_TILE_FLAGS", "MI_ENGINE_LIB", "MI_SMALL_TILES")):

@@ -189,6 +189,9 @@ struct mi_matrix_s {
 bool comm_remote(const mi_matrix_s* m);                         // attached and has processor patches
 bool comm_attached(const mi_matrix_s* m);
 bool comm_any_ami(const mi_matrix_s* m);                         // cyclicAMI patches here or -- agreed at attach time -- on any other rank of the case
+bool comm_any_factor(const mi_matrix_s* m);                      // ... transformed patches (factor != 1) ...
+bool comm_any_compact(const mi_matrix_s* m);                     // ... the 16-bit entry form ...
+bool matrix_has_factor(const mi_matrix_s* m);
 int64_t comm_n_global(const mi_matrix_s* m);                     // global cell count (gAverage)
 int comm_exchange_start(mi_matrix_s* m, const double* send, double* vec);
 int comm_exchange_wait(mi_matrix_s* m);
@@ -659,6 +662,9 @@ extern "C" int mi_matrix_set_patch_transform(mi_matrix_t m, int32_t patch, doubl
     if (!m || patch < 0 || patch >= m->addr->L.nPatches) return fail(MI_ERR_ARG, "mi_matrix_set_patch_transform: bad argument");
     if (m->addr->patchIsLocal[(size_t)patch] == 1 && factor != 1.0)
         return fail(MI_ERR_UNSUPPORTED, "mi_matrix_set_patch_transform: a transformed cyclic patch is declared through mi_addr_set_ami_patch (one-to-one, unit weights)");
+    // the ranks of a decomposed case agreed on their solver pipelines when the matrix was attached (comm_any_factor)
+    if (comm_attached(m) && factor != 1.0 && !comm_any_factor(m))
+        return fail(MI_ERR_STATE, "mi_matrix_set_patch_transform: the first transformed patch of a decomposed case is declared BEFORE mi_matrix_attach_comm (the ranks agree on the solver pipeline there)");
     if (m->patchFactor.empty()) m->patchFactor.assign((size_t)m->addr->L.nPatches, 1.0);
     if (m->patchFactor[(size_t)patch] != factor) ++m->epoch; // a GAMG hierarchy keeps the factors with its level matrices: rebuild them
     m->patchFactor[(size_t)patch] = factor;
@@ -1702,7 +1708,7 @@ extern "C" int mi_dpcg_set_buffers(mi_matrix_t m, double* psi_e, double* src_e, 
     if (!m || !psi_e || !src_e || !pA_e || !wA_e || !rA_e || !scal8 || !ctl) return fail(MI_ERR_ARG, "mi_dpcg_set_buffers: bad argument");
     if (precond != MI_PRECOND_DIAGONAL && precond != MI_PRECOND_NONE) return fail(MI_ERR_ARG, "distributed PCG supports the diagonal / none preconditioners");
     if (!m->bound) return fail(MI_ERR_STATE, "matrix coefficients not bound");
-    if (!m->addr->ami.empty() || !m->patchFactor.empty())
+    if (comm_any_ami(m) || comm_any_factor(m))
         return fail(MI_ERR_UNSUPPORTED, "the phase-split distributed PCG does not interpolate cyclicAMI / transformed patches: use mi_pcg_solve on the attached matrix");
     mi_ctx_s* c = m->addr->ctx;
     HIPCHK(hipSetDevice(c->device));
@@ -1861,7 +1867,7 @@ int bicg_enqueue(mi_matrix_s* m, int it0, int count, int precond, double* psi, d
     for (int it = it0; it < it0 + count; ++it) {
         // the plain and the transposed pass share one staging of the coefficients; on a decomposed case (round 4) pA and pT also
         // share ONE halo exchange (cyclicAMI patches are interpolated per operand inside tile_op: they keep the separate passes)
-        const bool paired = c->pairAT && (!comm_attached(m) || (!comm_any_ami(m) && !a->compact));
+        const bool paired = c->pairAT && (!comm_attached(m) || (!comm_any_ami(m) && !comm_any_compact(m)));
         if (precond == MI_PRECOND_AINV) {
             bool fusedDot = false;   // sum wA.rT out of the preconditioner pass (per-tile partials, folded like the Amul's in PCG)
             if (paired) MICHK(tile_pair(m, true, rA, rT, wA, wT, &c->state.p->done, m->tilePartial.p, &fusedDot));

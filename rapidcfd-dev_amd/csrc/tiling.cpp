@@ -518,6 +518,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         O.nSlots = nSlots; O.nHalo = nHalo; O.boundary = boundary; O.fits16 = fits16;
     }
     });
+    MI_T("  tiles (threads)");
     // ---- lay the tiles end to end ----------------------------------------------------------------------------------
     for (int32_t t = 0; t < nT; ++t) {
         if (!outs[(size_t)t].err.empty()) return outs[(size_t)t].err;

@@ -168,7 +168,12 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     persist = isinstance(peer, str) and peer.startswith("persist")
-    if peer == "auto":
+    if peer == "mixed":
+        # even ranks run the one-launch operators (boundary tiles poll their pairs), odd ranks the four-launch form (k_halo_push /
+        # k_halo_pull behind flags) -- what a case with cyclicAMI / transformed patches on SOME ranks looks like
+        os.environ["MI_WIN_DIRECT"] = "2" if rank % 2 == 0 else "0"
+        peer = "auto"
+    elif peer == "auto":
         # boundary tiles read the halo window themselves, waiting for the OTHER process's push inside the tile kernel -- the form
         # one-rank-per-device runs take; between processes that share a device it is opt-in (small cases only: many waiting
         # workgroups of one process could keep the other's kernel off the device)
@@ -366,6 +371,18 @@ def test_native_solvers_entirely_over_peer_windows(pkg, orc, tmp_path, name, wor
     windows over hipIpc.  Only what does not fit the windows (all-reduces > 8 doubles, the hierarchy build) still uses gloo."""
     spec = NATIVE_SPECS[name]
     mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, "auto"), nprocs=world, join=True)
+    _check_native(pkg, orc, spec, world, str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("box_2", 2), ("box_4_asym", 4)])
+def test_neighbours_in_different_window_forms(pkg, orc, tmp_path, name, world):
+    """Which form a rank READS its halo in is its own choice (every push writes pairs AND values behind flags): ranks in the
+    one-launch form next to ranks in the four-launch form must count the same exchanges -- also in the iterations a batch
+    enqueues after the solve has converged, which the one-launch operators used to skip entirely while k_halo_push /
+    k_halo_pull went on (round 4: a 4-rank cyclicAMI case ran out of polls exactly there)."""
+    spec = NATIVE_SPECS[name]
+    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, "mixed"), nprocs=world, join=True)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 

@@ -10,10 +10,9 @@ def total(d):
         out[c] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == c)
     return 2 * 1024 * out["FETCH_SIZE"], 1024 * out["WRITE_SIZE"]
 def gamg_source_hash():
-    h = hashlib.sha256()
-    for f in ("tiling.cpp", "tiling.hpp", "kernels.hip.hpp", "gamg_engine.inc", "gamg.cpp"):
-        h.update(open(os.path.join(ROOT, "rapidcfd-dev_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import source_fingerprint
+    return source_fingerprint.gamg_source_hash()
 if __name__ == "__main__":
     d1, c1, d2, c2 = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     (r1, w1), (r2, w2) = total(d1), total(d2)
