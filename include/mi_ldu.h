@@ -237,7 +237,10 @@ int mi_matrix_set_interface_coeffs(mi_matrix_t m, int32_t patch, const double *b
  * before they enter result -= coeffs*pnf -- 1 for scalars (rank 0) and untransformed patches, the caller's number for the
  * component solves of a vector across a rotational cyclic / processorCyclic.  Processor patches: applied to the received
  * values; cyclicAMI and one-to-one patches declared with mi_addr_set_ami_patch: applied before the interpolation.  A plain
- * cyclic patch (created with neighbour cells) only accepts 1.  Held per matrix: Ux, Uy, Uz solves set their own.          */
+ * cyclic patch (created with neighbour cells) only accepts 1.  Held per matrix: Ux, Uy, Uz solves set their own.
+ * Decomposed case: the FIRST factor of a matrix is set before mi_matrix_attach_comm -- the ranks agree there whether the case
+ * has transformed patches anywhere (it decides the solver pipeline of EVERY rank); afterwards the values may change freely,
+ * but a first factor != 1 on a case that was attached without any is refused (MI_ERR_STATE).                              */
 int mi_matrix_set_patch_transform(mi_matrix_t m, int32_t patch, double factor);
 
 /* ---- halo (replaces init/updateMatrixInterfaces + processorFvPatchField
