@@ -6,6 +6,7 @@
 #include "../../include/mi_ldu.h"
 #include "kernels.hip.hpp"
 #include "tiling.hpp"
+#include "host_parallel.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -54,7 +55,8 @@ struct DevBuf {
         n = count;
         return MI_OK;
     }
-    int upload(const std::vector<T>& v, hipStream_t s)
+    template <class A>
+    int upload(const std::vector<T, A>& v, hipStream_t s)
     {
         MICHK(alloc(v.size()));
         if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
@@ -499,11 +501,18 @@ static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, cons
     prm.reorder = env_int("MI_TILE_REORDER", -1); // -1: Cuthill-McKee pre-ordering when the numbering has no locality (tiling.hpp)
     prm.compact = env_int("MI_ENTRY16", 0) != 0; // opt-in: half the entry bytes, measured 2-4 % slower (profiles/r01_n_compact_entries_ab.md)
     prm.keepOrder = ordered; prm.givenTileStart = tile_cell_start; prm.nGivenTiles = n_tiles;
+#ifdef MI_TIMING
+    auto ta__ = std::chrono::steady_clock::now();
+    auto ta_tick = [&](const char* what) { auto n = std::chrono::steady_clock::now(); if (n_cells > 1000000) fprintf(stderr, "[addr] %-28s %.4f s\n", what, std::chrono::duration<double>(n - ta__).count()); ta__ = n; };
+#endif
     if (prebuilt) a->L = std::move(*prebuilt);
     else {
     const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, a->L, patch_nbr_cells);
     if (!err.empty()) { delete a; return fail(MI_ERR_LIMIT, "mi_addr_create: " + err); }
     }
+#ifdef MI_TIMING
+    ta_tick("tile layout (host)");
+#endif
     a->identity = true;
     for (int32_t e = 0; e < n_cells; ++e) if (a->L.e2c[(size_t)e] != e) { a->identity = false; break; }
     a->nLocalPatches = 0;
@@ -524,26 +533,34 @@ static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, cons
 #undef UP
     if (r != MI_OK) { delete a; return r; }
     if (hipStreamSynchronize(s) != hipSuccess) { delete a; return fail(MI_ERR_DEVICE, "upload failed"); }
+#ifdef MI_TIMING
+    ta_tick("uploads + synchronise");
+#endif
     a->nInterior = (int32_t)L.interiorTiles.size();
     a->nBoundary = (int32_t)L.boundaryTiles.size();
     a->nEntries = (int64_t)(L.compact ? L.entries16.size() : L.entries.size()); // 32-bit words of row entries on the device
     a->nHaloTot = (int64_t)L.haloCell.size();
-    a->lowerHost.assign(lower, lower + n_faces);
-    a->upperHost.assign(upper, upper + n_faces);
+    a->lowerHost.resize((size_t)n_faces); a->upperHost.resize((size_t)n_faces);
+    mi::parallel_blocks(n_faces, 1 << 20, [&](int64_t b, int64_t e, int) {
+        std::memcpy(a->lowerHost.data() + b, lower + b, sizeof(int32_t) * (size_t)(e - b));
+        std::memcpy(a->upperHost.data() + b, upper + b, sizeof(int32_t) * (size_t)(e - b));
+    });
     a->patchFaceCellsHost.resize((size_t)n_patches); a->patchNbrCellsHost.resize((size_t)n_patches);
     for (int32_t p = 0; p < n_patches; ++p) {
         a->patchFaceCellsHost[(size_t)p].assign(patch_face_cells[p], patch_face_cells[p] + patch_sizes[p]);
         if (a->patchIsLocal[(size_t)p]) a->patchNbrCellsHost[(size_t)p].assign(patch_nbr_cells[p], patch_nbr_cells[p] + patch_sizes[p]);
     }
-    // drop the big host tables that only the device needs
-    std::vector<uint32_t>().swap(L.entries);
-    std::vector<uint32_t>().swap(L.entries16);
-    std::vector<int32_t>().swap(L.sliceEntryStart16);
-    std::vector<uint16_t>().swap(L.slotBase);
-    if (!ctx->keepSlotTables) std::vector<int32_t>().swap(L.slotFace);
-    std::vector<int32_t>().swap(L.haloCell);
-    std::vector<int32_t>().swap(L.sliceEntryStart);
-    if (!ctx->keepSlotTables) std::vector<int32_t>().swap(L.faceSlot);
+    // drop the big host tables that only the device needs (their memory goes back to the system on another thread)
+    {
+        std::vector<int32_t> slotFace, faceSlot;
+        if (!ctx->keepSlotTables) { slotFace.swap(L.slotFace); faceSlot.swap(L.faceSlot); }
+        mi::free_in_background(L.entries, L.entries16, L.sliceEntryStart16, L.slotBase, slotFace, L.haloCell, L.sliceEntryStart, faceSlot);
+        L.entries = std::vector<uint32_t>(); L.entries16 = std::vector<uint32_t>(); L.sliceEntryStart16 = std::vector<int32_t>(); L.slotBase = std::vector<uint16_t>();
+        L.haloCell = std::vector<int32_t>(); L.sliceEntryStart = std::vector<int32_t>();
+    }
+#ifdef MI_TIMING
+    ta_tick("host copies + frees");
+#endif
     *out = a;
     return MI_OK;
 }

@@ -1,6 +1,7 @@
 // gamg.cpp -- see gamg.hpp.
 #include "gamg.hpp"
 #include "host_parallel.hpp"
+#include "host_match.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -19,20 +20,81 @@ namespace mi {
 
 namespace {
 
-// Greedy pair matching of one level.  Visiting order and tie-breaking follow the reference
-// (strict '>' => first maximum wins; a cell's faces are listed neighbour-side first, then
-// owner-side; unmatched cells join the cluster across their heaviest face; leftovers become
-// singletons; reverse sweeps mirror the coarse numbering).
-int32_t match_pairs(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32_t* upper,
-                    const std::vector<double>& w, bool forward, std::vector<int32_t>& coarseOf)
+// faces of every cell in the reference's visiting order: neighbour side (upper == c) ascending, then owner side (lower == c)
+// ascending.  Upper-triangular order (lduAddressing; the coarse levels built here as well) has the owners ascending, so the owner
+// side is a RANGE of faces and needs no list (oF empty).
+struct CellFaces {
+    std::vector<int32_t> uS, oS; IndexList uF, oF;
+    template <class Fn> void for_each_other(int32_t c, Fn fn) const { for (int32_t j = uS[(size_t)c]; j < uS[(size_t)c + 1]; ++j) fn(uF[(size_t)j]); }
+    template <class Fn> void for_each_owned(int32_t c, Fn fn) const
+    {
+        if (oF.empty()) for (int32_t f = oS[(size_t)c]; f < oS[(size_t)c + 1]; ++f) fn(f);
+        else for (int32_t j = oS[(size_t)c]; j < oS[(size_t)c + 1]; ++j) fn(oF[(size_t)j]);
+    }
+    template <class Fn> void for_each(int32_t c, Fn fn) const { for_each_other(c, fn); for_each_owned(c, fn); }
+    int32_t degree(int32_t c) const { return uS[(size_t)c + 1] - uS[(size_t)c] + oS[(size_t)c + 1] - oS[(size_t)c]; }
+};
+// owner side as ranges (false: the owners are not ascending -- lists instead)
+bool owner_ranges(int32_t nFine, int32_t nFaces, const int32_t* lower, std::vector<int32_t>& oS)
 {
-    std::vector<int32_t> start((size_t)nFine + 1, 0);
-    for (int32_t f = 0; f < nFaces; ++f) { ++start[(size_t)upper[f] + 1]; ++start[(size_t)lower[f] + 1]; }
-    for (int32_t c = 0; c < nFine; ++c) start[(size_t)c + 1] += start[c];
-    std::vector<int32_t> faces((size_t)2 * nFaces), fill(start.begin(), start.end() - 1);
-    for (int32_t f = 0; f < nFaces; ++f) faces[(size_t)fill[upper[f]]++] = f;
-    for (int32_t f = 0; f < nFaces; ++f) faces[(size_t)fill[lower[f]]++] = f;
+    std::atomic<bool> unsorted{false};
+    parallel_blocks(nFaces, 1 << 18, [&](int64_t b, int64_t e, int) { bool u = false; for (int64_t f = std::max<int64_t>(b, 1); f < e; ++f) u |= lower[f] < lower[f - 1]; if (u) unsorted = true; });
+    if (unsorted) return false;
+    oS.resize((size_t)nFine + 1);
+    parallel_for(nFaces, 1 << 18, [&](int64_t f) { for (int32_t c = f > 0 ? lower[f - 1] + 1 : 0; c <= lower[f]; ++c) oS[(size_t)c] = (int32_t)f; });
+    for (int32_t c = nFaces > 0 ? lower[nFaces - 1] + 1 : 0; c <= nFine; ++c) oS[(size_t)c] = nFaces;
+    return true;
+}
+void cell_faces(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32_t* upper, CellFaces& F)
+{
+    bucket_items(nFaces, nFine, [&](int64_t f) { return upper[f]; }, F.uS, F.uF);
+    F.oF.clear();
+    if (!owner_ranges(nFine, nFaces, lower, F.oS)) bucket_items(nFaces, nFine, [&](int64_t f) { return lower[f]; }, F.oS, F.oF);
+}
 
+// A FORWARD sweep over a level whose owners are ascending, every weight choosable (see match_pairs_sequential: laterOnly): the
+// candidates of a cell are across the faces it owns -- a range of faces, no list -- so the neighbour-side lists are not built at
+// all.  They are only missed by the cells that find no free neighbour and JOIN across their heaviest face: those are collected,
+// their neighbour-side faces bucketed in one pass over the faces, and the joins resolved in visiting order afterwards (a join
+// reads the coarse cell of its target, which was paired, or joined at an earlier turn: the same value at either time).
+int32_t match_pairs_forward_owned(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32_t* upper, const std::vector<int32_t>& oS,
+                                  const double* w, std::vector<int32_t>& coarseOf)
+{
+    (void)lower;
+    coarseOf.assign((size_t)nFine, -1);
+    int32_t nCoarse = 0;
+    const double NEG = -1e20;
+    std::vector<int32_t> joiners;
+    for (int32_t c = 0; c < nFine; ++c) {
+        if (coarseOf[c] >= 0) continue;
+        int32_t pick = -1; double best = NEG;
+        for (int32_t f = oS[(size_t)c]; f < oS[(size_t)c + 1]; ++f) if (w[f] > best && coarseOf[upper[f]] < 0) { pick = f; best = w[f]; }
+        if (pick >= 0) coarseOf[upper[pick]] = coarseOf[c] = nCoarse++;
+        else joiners.push_back(c);
+    }
+    if (!joiners.empty()) {
+        std::vector<int32_t> jIndex((size_t)nFine, -1), jS; IndexList jF;
+        for (size_t k = 0; k < joiners.size(); ++k) jIndex[(size_t)joiners[k]] = (int32_t)k;
+        bucket_items(nFaces, (int32_t)joiners.size(), [&](int64_t f) { return jIndex[(size_t)upper[f]]; }, jS, jF);
+        for (size_t k = 0; k < joiners.size(); ++k) {
+            const int32_t c = joiners[k];
+            int32_t join = -1; double jbest = NEG;
+            for (int32_t j = jS[k]; j < jS[k + 1]; ++j) { const int32_t f = jF[(size_t)j]; if (w[f] > jbest) { join = f; jbest = w[f]; } }
+            for (int32_t f = oS[(size_t)c]; f < oS[(size_t)c + 1]; ++f) if (w[f] > jbest) { join = f; jbest = w[f]; }
+            if (join >= 0) coarseOf[c] = std::max(coarseOf[upper[join]], coarseOf[lower[join]]);
+        }
+    }
+    for (int32_t c = 0; c < nFine; ++c) if (coarseOf[c] < 0) coarseOf[c] = nCoarse++;
+    return nCoarse;
+}
+
+// the sequential loop (the default: see match_pairs).  laterOnly (every weight can be chosen: > -1e20, not NaN): a cell whose
+// turn has passed belongs to a coarse cell -- paired, or joined across its heaviest face -- so only the neighbours whose turn
+// is still to come can be free: on a forward sweep those are across the faces the cell OWNS, on a backward sweep across the
+// others, and the other half of the list is skipped without a look at its state (same picks: it never held a free cell).
+int32_t match_pairs_sequential(int32_t nFine, const int32_t* lower, const int32_t* upper, const CellFaces& F,
+                               const double* w, bool forward, bool laterOnly, std::vector<int32_t>& coarseOf)
+{
     coarseOf.assign((size_t)nFine, -1);
     int32_t nCoarse = 0;
     const double NEG = -1e20;
@@ -40,90 +102,189 @@ int32_t match_pairs(int32_t nFine, int32_t nFaces, const int32_t* lower, const i
         const int32_t c = forward ? k : nFine - 1 - k;
         if (coarseOf[c] >= 0) continue;
         int32_t pick = -1; double best = NEG;
-        for (int32_t j = start[c]; j < start[(size_t)c + 1]; ++j) {
-            const int32_t f = faces[j];
-            if (coarseOf[upper[f]] < 0 && coarseOf[lower[f]] < 0 && w[f] > best) { pick = f; best = w[f]; }
-        }
+        if (laterOnly && forward) F.for_each_owned(c, [&](int32_t f) { if (w[f] > best && coarseOf[upper[f]] < 0) { pick = f; best = w[f]; } });
+        else if (laterOnly) F.for_each_other(c, [&](int32_t f) { if (w[f] > best && coarseOf[lower[f]] < 0) { pick = f; best = w[f]; } });
+        else
+        F.for_each(c, [&](int32_t f) { if (coarseOf[upper[f]] < 0 && coarseOf[lower[f]] < 0 && w[f] > best) { pick = f; best = w[f]; } });
         if (pick >= 0) { coarseOf[upper[pick]] = coarseOf[lower[pick]] = nCoarse++; continue; }
         int32_t join = -1; double jbest = NEG;
-        for (int32_t j = start[c]; j < start[(size_t)c + 1]; ++j) {
-            const int32_t f = faces[j];
-            if (w[f] > jbest) { join = f; jbest = w[f]; }
-        }
+        F.for_each(c, [&](int32_t f) { if (w[f] > jbest) { join = f; jbest = w[f]; } });
         if (join >= 0) coarseOf[c] = std::max(coarseOf[upper[join]], coarseOf[lower[join]]);
     }
     for (int32_t k = 0; k < nFine; ++k) {
         const int32_t c = forward ? k : nFine - 1 - k;
         if (coarseOf[c] < 0) coarseOf[c] = nCoarse++;
     }
-    if (!forward) for (int32_t c = 0; c < nFine; ++c) coarseOf[c] = nCoarse - 1 - coarseOf[c];
+    if (!forward) parallel_for(nFine, 1 << 18, [&](int64_t c) { coarseOf[(size_t)c] = nCoarse - 1 - coarseOf[(size_t)c]; });
+    return nCoarse;
+}
+
+struct PairGraph {   // the cell graph of one level for greedy_match_parallel (host_match.hpp)
+    typedef double Weight;
+    static double none() { return -1e20; }
+    int32_t n; bool forward;
+    const int32_t *start, *nbr; const double* wj;   // per list entry: the cell across the face, the face's weight
+    int64_t begin(int32_t v) const { return start[v]; }
+    int64_t end(int32_t v) const { return start[(size_t)v + 1]; }
+    int32_t other(int32_t, int64_t j) const { return nbr[j]; }
+    bool better(int32_t, int64_t j, int32_t, double best) const { return wj[j] > best; }
+    double weight(int32_t, int64_t j) const { return wj[j]; }
+};
+
+// Greedy pair matching of one level.  Visiting order and tie-breaking follow the reference
+// (strict '>' => first maximum wins; a cell's faces are listed neighbour-side first, then
+// owner-side; unmatched cells join the cluster across their heaviest face; leftovers become
+// singletons; reverse sweeps mirror the coarse numbering).
+// MI_MATCH_PARALLEL=1: large levels are matched by the host threads (greedy_match_parallel: the decisions of the sequential loop,
+// taken as soon as what they depend on is known), the numbering follows from prefix counts in visiting order: a pair gets the rank of
+// the cell whose turn made it, a cell that joined gets the coarse cell across its heaviest face (which that cell had at that
+// moment: it was paired, or had joined at an earlier turn), singletons come last.
+int32_t match_pairs(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32_t* upper,
+                    const double* w, bool forward, std::vector<int32_t>& coarseOf)
+{
+#ifdef MI_TIMING
+    auto t__ = std::chrono::steady_clock::now();
+    auto sub = [&](const char* what) { auto n = std::chrono::steady_clock::now(); if (nFaces > 4000000) fprintf(stderr, "[gamg-host]     %-30s %.4f s\n", what, std::chrono::duration<double>(n - t__).count()); t__ = n; };
+#else
+    auto sub = [](const char*) {};
+#endif
+    std::atomic<bool> odd{false};
+    parallel_blocks(nFaces, 1 << 18, [&](int64_t b, int64_t e, int) { bool any = false; for (int64_t f = b; f < e; ++f) any |= !(w[(size_t)f] > -1e20); if (any) odd = true; });
+    const bool parallel = !odd && host_threads() > 1 && nFine >= (1 << 15) && env_int_host("MI_MATCH_PARALLEL", 0) != 0;
+    const bool laterOnly = !odd && env_int_host("MI_MATCH_LATER_ONLY", 1) != 0;
+    sub("weights check");
+    CellFaces F;
+    if (laterOnly && forward && !parallel && owner_ranges(nFine, nFaces, lower, F.oS)) {
+        const int32_t nc = match_pairs_forward_owned(nFine, nFaces, lower, upper, F.oS, w, coarseOf);
+        sub("forward sweep over owned faces");
+        return nc;
+    }
+    cell_faces(nFine, nFaces, lower, upper, F);
+    sub("faces of every cell");
+    // The parallel form (opt-in, MI_MATCH_PARALLEL=1: measured slower than the sequential loop on the 64-core host of the GPU
+    // box, profiles/r04_p_*) relies on "a cell whose turn has passed is never free again", which holds when every face can be
+    // chosen (weight > -1e20, not NaN: face areas and coefficient magnitudes are); anything else takes the sequential loop.
+    if (!parallel) { const int32_t nc = match_pairs_sequential(nFine, lower, upper, F, w, forward, laterOnly, coarseOf); sub("the sequential loop"); return nc; }
+    // per list entry: the cell across and the weight (the decisions are taken in wavefront order, not in index order: every
+    // indirection less is a cache miss less)
+    std::vector<int32_t> start((size_t)nFine + 1, 0);
+    parallel_for(nFine, 1 << 18, [&](int64_t c) { start[(size_t)c + 1] = F.degree((int32_t)c); });
+    parallel_inclusive_scan(start.data() + 1, (int64_t)nFine);
+    std::vector<int32_t> nbr((size_t)start[(size_t)nFine]);
+    std::vector<double> wj((size_t)start[(size_t)nFine]);
+    parallel_for(nFine, 1 << 16, [&](int64_t c) {
+        int32_t o = start[(size_t)c];
+        F.for_each((int32_t)c, [&](int32_t f) { nbr[(size_t)o] = upper[f] == (int32_t)c ? lower[f] : upper[f]; wj[(size_t)o] = w[(size_t)f]; ++o; });
+    });
+    PairGraph g{nFine, forward, start.data(), nbr.data(), wj.data()};
+    std::vector<int32_t> mate; std::vector<uint8_t> proposer;
+    greedy_match_parallel(g, mate, proposer);
+    // the cell across the heaviest face (first maximum in list order), or -1: where an unmatched cell joins
+    auto join_target = [&](int32_t c) {
+        int32_t join = -1; double jbest = -1e20;
+        for (int32_t j = start[(size_t)c]; j < start[(size_t)c + 1]; ++j) if (wj[(size_t)j] > jbest) { join = nbr[(size_t)j]; jbest = wj[(size_t)j]; }
+        return join;
+    };
+    // ranks in visiting order: pairs by the cell whose turn made them, then the singletons
+    std::vector<int32_t> rank((size_t)nFine);
+    auto cell_at = [&](int64_t k) { return forward ? (int32_t)k : nFine - 1 - (int32_t)k; };
+    parallel_for(nFine, 1 << 18, [&](int64_t k) { rank[(size_t)k] = proposer[(size_t)cell_at(k)]; });
+    parallel_inclusive_scan(rank.data(), (int64_t)nFine);
+    const int32_t nPairs = nFine > 0 ? rank[(size_t)nFine - 1] : 0;
+    std::vector<int32_t> single((size_t)nFine);
+    parallel_for(nFine, 1 << 16, [&](int64_t k) { const int32_t c = cell_at(k); single[(size_t)k] = (mate[(size_t)c] == c && join_target(c) < 0) ? 1 : 0; });
+    parallel_inclusive_scan(single.data(), (int64_t)nFine);
+    const int32_t nCoarse = nPairs + (nFine > 0 ? single[(size_t)nFine - 1] : 0);
+    coarseOf.resize((size_t)nFine);
+    auto pos = [&](int32_t c) { return forward ? c : nFine - 1 - c; };
+    parallel_for(nFine, 1 << 16, [&](int64_t cc) {
+        int32_t c = (int32_t)cc, id;
+        if (mate[(size_t)c] == c && join_target(c) < 0) id = nPairs + single[(size_t)pos(c)] - 1;
+        else {
+            while (mate[(size_t)c] == c) c = join_target(c);                       // joined: the cluster of the cell across the heaviest face
+            const int32_t lead = proposer[(size_t)c] ? c : mate[(size_t)c];
+            id = rank[(size_t)pos(lead)] - 1;
+        }
+        coarseOf[(size_t)cc] = forward ? id : nCoarse - 1 - id;
+    });
     return nCoarse;
 }
 
 // Coarse faces: one per unordered pair of distinct coarse cells, numbered so that they are
 // grouped by owner (= smaller coarse cell) and, inside an owner, in order of first appearance
 // among the fine faces -- the numbering the reference's per-cell neighbour lists produce.
-void build_coarse_faces(GamgLevelHost& L, const int32_t* lower, const int32_t* upper)
+// w / cw: the face weights of the fine level and (filled here) of the coarse one: restrictFaceField, plain summation in ascending
+// fine-face order per coarse face -- every coarse face belongs to one owner, whose faces are visited in that order.
+void build_coarse_faces(GamgLevelHost& L, const int32_t* lower, const int32_t* upper, const double* w, HostVec<double>& cw)
 {
     const int32_t nF = L.nFineFaces, nC = L.nCoarse;
-    L.faceRestrict.assign((size_t)nF, 0);
-    L.faceFlip.assign((size_t)nF, 0);
-    // cut faces bucketed by owner (= smaller coarse cell), ascending fine face inside a bucket (counting sort is stable);
-    // flat arrays and per-owner work only, so the owners are processed by the host threads independently
-    std::vector<int32_t> oStart((size_t)nC + 1, 0);
-    for (int32_t f = 0; f < nF; ++f) {
-        const int32_t ru = L.restrictMap[upper[f]], rl = L.restrictMap[lower[f]];
-        if (ru == rl) L.faceRestrict[f] = -(ru + 1);
-        else ++oStart[(size_t)std::min(ru, rl) + 1];
-    }
-    for (int32_t c = 0; c < nC; ++c) oStart[(size_t)c + 1] += oStart[c];
-    std::vector<int32_t> oFace((size_t)oStart[nC]), fill(oStart.begin(), oStart.end() - 1);
-    for (int32_t f = 0; f < nF; ++f) if (L.faceRestrict[f] >= 0) oFace[(size_t)fill[std::min(L.restrictMap[upper[f]], L.restrictMap[lower[f]])]++] = f;
-    // distinct neighbours of every owner in order of first appearance: first their number ...
-    std::vector<int32_t> base((size_t)nC + 1, 0);
-    auto nei_of = [&](int32_t f) { return std::max(L.restrictMap[upper[f]], L.restrictMap[lower[f]]); };
+#ifdef MI_TIMING
+    auto t__ = std::chrono::steady_clock::now();
+    auto sub = [&](const char* what) { auto n = std::chrono::steady_clock::now(); if (nF > 4000000) fprintf(stderr, "[gamg-host]     %-30s %.4f s\n", what, std::chrono::duration<double>(n - t__).count()); t__ = n; };
+#else
+    auto sub = [](const char*) {};
+#endif
+    L.faceRestrict.resize((size_t)nF);
+    L.faceFlip.resize((size_t)nF);
+    sub("allocate");
+    // cut faces bucketed by owner (= smaller coarse cell), ascending fine face inside a bucket (bucket_items: the stable counting
+    // sort, threaded); flat arrays and per-owner work only, so the owners are processed by the host threads independently
+    std::vector<int32_t> oStart; IndexList oFace;
+    parallel_for(nF, 1 << 16, [&](int64_t f) {   // interior: -(coarse cell + 1); cut: for now the owner
+        const int32_t ru = L.restrictMap[(size_t)upper[f]], rl = L.restrictMap[(size_t)lower[f]];
+        L.faceRestrict[(size_t)f] = ru == rl ? -(ru + 1) : std::min(ru, rl);
+        L.faceFlip[(size_t)f] = 0;
+    });
+    sub("classify faces");
+    bucket_items(nF, nC, [&](int64_t f) { return L.faceRestrict[(size_t)f] < 0 ? -1 : L.faceRestrict[(size_t)f]; }, oStart, oFace);
+    sub("bucket cut faces by owner");
+    // distinct neighbours of every owner in order of first appearance: per cut face its position in that list (and the flip:
+    // the fine lower -> upper direction runs against the coarse owner -> neighbour one when the UPPER cell is in the owner) ...
+    std::vector<int32_t> base((size_t)nC + 1, 0); IndexList oAt(oFace.size()), oNei(oFace.size());
     parallel_blocks(nC, 32768, [&](int64_t b, int64_t e, int) {
         std::vector<int32_t> seen;
         for (int32_t c = (int32_t)b; c < (int32_t)e; ++c) {
             seen.clear();
             for (int32_t j = oStart[c]; j < oStart[(size_t)c + 1]; ++j) {
-                const int32_t nei = nei_of(oFace[j]);
-                if (std::find(seen.begin(), seen.end(), nei) == seen.end()) seen.push_back(nei);
+                const int32_t f = oFace[(size_t)j];
+                const int32_t ru = L.restrictMap[(size_t)upper[f]], rl = L.restrictMap[(size_t)lower[f]];
+                const int32_t nei = std::max(ru, rl);
+                const size_t at = std::find(seen.begin(), seen.end(), nei) - seen.begin();
+                if (at == seen.size()) seen.push_back(nei);
+                oAt[(size_t)j] = (int32_t)at; oNei[(size_t)j] = nei;
+                if (ru == c) L.faceFlip[(size_t)f] = 1;
             }
             base[(size_t)c + 1] = (int32_t)seen.size();
         }
     });
-    for (int32_t c = 0; c < nC; ++c) base[(size_t)c + 1] += base[c];
+    sub("distinct neighbours");
+    parallel_inclusive_scan(base.data() + 1, (int64_t)nC);
     const int32_t nCF = base[nC];
     L.nCoarseFaces = nCF;
     L.cLower.resize(nCF); L.cUpper.resize(nCF);
+    cw.resize((size_t)nCF);
     // ... then the numbering: coarse faces grouped by owner, inside an owner in order of first appearance among the fine faces
     parallel_blocks(nC, 32768, [&](int64_t b, int64_t e, int) {
-        std::vector<int32_t> seen;
         for (int32_t c = (int32_t)b; c < (int32_t)e; ++c) {
-            seen.clear();
+            int32_t known = 0;
+            for (int32_t t = base[c]; t < base[(size_t)c + 1]; ++t) cw[(size_t)t] = 0.0;
             for (int32_t j = oStart[c]; j < oStart[(size_t)c + 1]; ++j) {
-                const int32_t f = oFace[j], nei = nei_of(f);
-                size_t at = std::find(seen.begin(), seen.end(), nei) - seen.begin();
-                if (at == seen.size()) { seen.push_back(nei); L.cLower[(size_t)base[c] + at] = c; L.cUpper[(size_t)base[c] + at] = nei; }
-                const int32_t t = base[c] + (int32_t)at;
-                L.faceRestrict[f] = t;
-                // flipped when the fine (lower -> upper) direction is opposite to the coarse (owner -> neighbour)
-                if (c == L.restrictMap[upper[f]] && nei == L.restrictMap[lower[f]]) L.faceFlip[f] = 1;
+                const int32_t f = oFace[(size_t)j], t = base[c] + oAt[(size_t)j];
+                if (oAt[(size_t)j] == known) { L.cLower[(size_t)t] = c; L.cUpper[(size_t)t] = oNei[(size_t)j]; ++known; }
+                L.faceRestrict[(size_t)f] = t;
+                cw[(size_t)t] += w[(size_t)f];
             }
         }
     });
+    sub("numbering + weights");
+    free_in_background(oStart, oFace, oAt, oNei, base);
 }
 
-void segment(int32_t nTargets, const std::vector<int32_t>& target, std::vector<int32_t>& start, std::vector<int32_t>& child)
+template <class Vec>
+void segment(int32_t nTargets, const Vec& target, std::vector<int32_t>& start, std::vector<int32_t>& child)
 {
-    // children of target t = all i with target[i] == t, ascending i (counting sort is stable); negatives skipped
-    start.assign((size_t)nTargets + 1, 0);
-    for (int32_t t : target) if (t >= 0) ++start[(size_t)t + 1];
-    for (int32_t t = 0; t < nTargets; ++t) start[(size_t)t + 1] += start[t];
-    child.resize((size_t)start[nTargets]);
-    std::vector<int32_t> fill(start.begin(), start.end() - 1);
-    for (int32_t i = 0; i < (int32_t)target.size(); ++i) if (target[i] >= 0) child[(size_t)fill[target[i]]++] = i;
+    // children of target t = all i with target[i] == t, ascending i (the stable counting sort, threaded); negatives skipped
+    bucket_items((int64_t)target.size(), nTargets, [&](int64_t i) { return target[(size_t)i]; }, start, child);
 }
 
 } // namespace
@@ -139,7 +300,10 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
     const int maxLevels = 50;
     H.levels.reserve((size_t)maxLevels);          // element addresses stay valid for the onLevel consumers
     const bool pipelined = (bool)H.onLevel && mergeLevels == 1;
-    std::vector<double> w = faceWeights ? std::vector<double>(faceWeights, faceWeights + nFaces) : std::vector<double>((size_t)nFaces, 0.0);
+    // face weights of the current fine level: the caller's array on the finest level (no copy), then the restricted ones
+    HostVec<double> wOwn;
+    if (!faceWeights) wOwn.assign((size_t)nFaces, 0.0);
+    const double* w = faceWeights ? faceWeights : wOwn.data();
     int32_t nFine = nCells, nF = nFaces;
     const int32_t *lo = lower, *up = upper;
     const int32_t nPatches = cpl ? cpl->nPatches : 0;
@@ -177,12 +341,12 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
         }
         if (cpl && cpl->allAnd) cont = cpl->allAnd(cpl->user, cont);              // ... on all processors
         if (!cont) break;
-        { MI_TICK("coarse faces", H.levels.size()); build_coarse_faces(L, lo, up); }
         {
-        MI_TICK("face weights", H.levels.size());
-        std::vector<double> cw((size_t)L.nCoarseFaces, 0.0); // restrictFaceField (host): plain summation
-        for (int32_t f = 0; f < nF; ++f) if (L.faceRestrict[f] >= 0) cw[L.faceRestrict[f]] += w[f];
-        w.swap(cw);
+            MI_TICK("coarse faces + face weights", H.levels.size());
+            HostVec<double> cw;   // restrictFaceField (host): plain summation, inside the per-owner pass
+            build_coarse_faces(L, lo, up, w, cw);
+            wOwn.swap(cw);
+            w = wOwn.data();
         }
         if (nPatches > 0) {
             // coarse-cell ids on both sides of every coupled patch face
@@ -341,9 +505,7 @@ void finish_gamg_level(GamgLevelHost& B)
 {
     segment(B.nCoarse, B.restrictMap, B.cellChildStart, B.cellChild);
     segment(B.nCoarseFaces, B.faceRestrict, B.faceChildStart, B.faceChild);
-    std::vector<int32_t> interior((size_t)B.nFineFaces);
-    for (int32_t f = 0; f < B.nFineFaces; ++f) interior[f] = B.faceRestrict[f] < 0 ? -1 - B.faceRestrict[f] : -1;
-    segment(B.nCoarse, interior, B.diagChildStart, B.diagChild);
+    bucket_items(B.nFineFaces, B.nCoarse, [&](int64_t f) { return B.faceRestrict[(size_t)f] < 0 ? -1 - B.faceRestrict[(size_t)f] : -1; }, B.diagChildStart, B.diagChild);
 }
 
 // Gauss-Jordan with partial pivoting on [A | I].  Row k of A is zero left of the pivot once the earlier columns are

@@ -8,6 +8,7 @@
 // and derives the device tables the MI355X kernels need (segmented children lists instead of
 // the reference's sort/target/targetStart triplets, GAMGAgglomerateLduAddressing.C:37-120).
 #pragma once
+#include "host_parallel.hpp"
 #include <cstdint>
 #include <functional>
 #include <string>
@@ -33,12 +34,14 @@ struct GamgPatchHost {
     std::vector<int32_t> amiSrcFace;
 };
 
+// (the per-face tables are written completely by threaded passes: a resize() that zeroes 100+ MB on one thread first is time)
+template <class T> using HostVec = std::vector<T, NoInitAlloc<T>>;
 struct GamgLevelHost {
     int32_t nFine = 0, nFineFaces = 0, nCoarse = 0, nCoarseFaces = 0;
     std::vector<int32_t> restrictMap;    // [nFine] -> coarse cell
-    std::vector<int32_t> faceRestrict;   // [nFineFaces] coarse face or -(coarseCell+1)
-    std::vector<uint8_t> faceFlip;       // [nFineFaces]
-    std::vector<int32_t> cLower, cUpper; // coarse addressing
+    HostVec<int32_t> faceRestrict;       // [nFineFaces] coarse face or -(coarseCell+1)
+    HostVec<uint8_t> faceFlip;           // [nFineFaces]
+    HostVec<int32_t> cLower, cUpper;     // coarse addressing
     // segmented children (ascending fine index inside every segment = the reference's stable sort)
     std::vector<int32_t> cellChildStart, cellChild;   // children cells of every coarse cell
     std::vector<int32_t> faceChildStart, faceChild;   // fine faces mapped onto every coarse face

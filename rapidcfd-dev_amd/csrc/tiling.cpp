@@ -3,6 +3,7 @@
 // and caches them: lduAddressing.C:169-400, GAMGAgglomeration.C:132-182).
 #include "tiling.hpp"
 #include "host_parallel.hpp"
+#include "host_match.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -24,13 +25,6 @@ namespace mi {
 
 namespace {
 
-// vector whose resize() leaves new elements uninitialised: the big edge arrays are written completely by the (threaded) fill
-// pass right after, so a zeroing pass over hundreds of MB by one thread would only add page-touch time
-template <class T>
-struct NoInitAlloc : std::allocator<T> {
-    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
-    template <class U, class... A> void construct(U* p, A&&... a) { if (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...); }
-};
 // One level of the multilevel clustering graph (CSR, undirected, both directions stored).
 struct Graph {
     int32_t n = 0;
@@ -42,19 +36,56 @@ struct Graph {
     std::vector<int32_t> vint; // faces internal to the cluster
 };
 
+struct ClusterGraph {   // one level of the clustering graph for greedy_match_parallel (host_match.hpp)
+    typedef int32_t Weight;
+    static int32_t none() { return 0; }
+    int32_t n; bool forward;
+    const Graph* g; int32_t cellCap, slotCap;
+    int64_t begin(int32_t v) const { return g->xadj[(size_t)v]; }
+    int64_t end(int32_t v) const { return g->xadj[(size_t)v + 1]; }
+    int32_t other(int32_t, int64_t e) const { return g->adj[(size_t)e]; }
+    bool better(int32_t v, int64_t e, int32_t u, int32_t best) const
+    {
+        if (g->vw[(size_t)v] + g->vw[(size_t)u] > cellCap) return false;
+        if (g->vinc[(size_t)v] + g->vinc[(size_t)u] - (g->vint[(size_t)v] + g->vint[(size_t)u] + g->ew[(size_t)e]) > slotCap) return false;
+        return g->ew[(size_t)e] > best;
+    }
+    int32_t weight(int32_t, int64_t e) const { return g->ew[(size_t)e]; }
+};
+
 // Heavy-edge matching with size caps; returns number of coarse vertices and cmap.
-int32_t match_level(const Graph& g, int32_t cellCap, int32_t slotCap, std::vector<int32_t>& cmap)
+// Large levels: the same decisions taken by the host threads (host_match.hpp); coarse vertex ids are the ranks of the vertices
+// whose turn made a pair or that stayed alone, in index order.
+int32_t match_level(const Graph& g, int32_t cellCap, int32_t slotCap, std::vector<int32_t>& cmap, std::vector<int32_t>& match)
 {
     const int32_t n = g.n;
-    std::vector<int32_t> match(n, -1);
-    cmap.assign(n, -1);
+    match.resize((size_t)n);
+    cmap.resize((size_t)n);
+    if (host_threads() > 1 && n >= (1 << 15) && env_int_host("MI_MATCH_PARALLEL", 0) != 0) {
+        ClusterGraph cg{n, true, &g, cellCap, slotCap};
+        std::vector<uint8_t> proposer;
+        greedy_match_parallel(cg, match, proposer);
+        std::vector<int32_t> rank((size_t)n);
+        parallel_for(n, 1 << 18, [&](int64_t v) { rank[(size_t)v] = (proposer[(size_t)v] || match[(size_t)v] == (int32_t)v) ? 1 : 0; });
+        parallel_inclusive_scan(rank.data(), (int64_t)n);
+        parallel_for(n, 1 << 18, [&](int64_t v) {
+            const int32_t lead = (proposer[(size_t)v] || match[(size_t)v] == (int32_t)v) ? (int32_t)v : match[(size_t)v];
+            cmap[(size_t)v] = rank[(size_t)lead] - 1;
+        });
+        return n > 0 ? rank[(size_t)n - 1] : 0;
+    }
+    // The sequential loop.  A vertex whose turn has passed is matched (with a partner or with itself), so only LATER neighbours
+    // can be free: the earlier part of an adjacency list is skipped without a look at its state.  (A variant with the per-vertex
+    // data packed into 16-byte records and the coarse ids from a prefix count measured 20 % SLOWER on the GPU box's host:
+    // profiles/r04_p_startup_timing.md.)
+    std::fill(match.begin(), match.end(), -1);
     int32_t nc = 0;
     for (int32_t v = 0; v < n; ++v) {
         if (match[v] >= 0) continue;
         int32_t best = -1, bw = 0;
         for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
             const int32_t u = g.adj[e];
-            if (u == v || match[u] >= 0) continue;
+            if (u <= v || match[u] >= 0) continue;
             if (g.vw[v] + g.vw[u] > cellCap) continue;
             const int32_t slots = g.vinc[v] + g.vinc[u] - (g.vint[v] + g.vint[u] + g.ew[e]);
             if (slots > slotCap) continue;
@@ -66,17 +97,20 @@ int32_t match_level(const Graph& g, int32_t cellCap, int32_t slotCap, std::vecto
     return nc;
 }
 
-void coarsen(const Graph& g, const std::vector<int32_t>& cmap, int32_t nc, Graph& c)
+void coarsen(const Graph& g, const std::vector<int32_t>& cmap, const std::vector<int32_t>& match, int32_t nc, Graph& c)
 {
     c.n = nc;
-    c.vw.assign(nc, 0); c.vinc.assign(nc, 0); c.vint.assign(nc, 0);
-    // members of each coarse vertex (1 or 2)
+    c.vw.resize(nc); c.vinc.resize(nc); c.vint.resize(nc);
+    // members of each coarse vertex (1 or 2): the vertex that was visited first (the smaller one) and its partner
     std::vector<int32_t> first(nc, -1), second(nc, -1);
-    for (int32_t v = 0; v < g.n; ++v) {
-        const int32_t cv = cmap[v];
-        if (first[cv] < 0) first[cv] = v; else second[cv] = v;
-        c.vw[cv] += g.vw[v]; c.vinc[cv] += g.vinc[v]; c.vint[cv] += g.vint[v];
-    }
+    parallel_for(g.n, 1 << 16, [&](int64_t v) {
+        const int32_t u = match[(size_t)v];
+        if (u < (int32_t)v) return;
+        const int32_t cv = cmap[(size_t)v];
+        first[(size_t)cv] = (int32_t)v;
+        c.vw[(size_t)cv] = g.vw[(size_t)v]; c.vinc[(size_t)cv] = g.vinc[(size_t)v]; c.vint[(size_t)cv] = g.vint[(size_t)v];
+        if (u != (int32_t)v) { second[(size_t)cv] = u; c.vw[(size_t)cv] += g.vw[(size_t)u]; c.vinc[(size_t)cv] += g.vinc[(size_t)u]; c.vint[(size_t)cv] += g.vint[(size_t)u]; }
+    });
     // Row of a coarse vertex = the neighbours of its members, mapped, merged (weights added) and sorted by id (deterministic
     // tie-breaking in match_level).  Rows are independent: built twice under OpenMP (count, then fill), merged through a small
     // per-thread sort instead of a global scratch table, so the result does not depend on the number of threads.
@@ -110,7 +144,8 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, int32_t nc, Graph
         for (int32_t cv = (int32_t)b; cv < (int32_t)e; ++cv) { build_row(cv, tmp, internal); c.xadj[(size_t)cv + 1] = (int64_t)tmp.size(); vintAdd[(size_t)cv] = internal; }
     });
     MI_T("    coarsen: count");
-    for (int32_t cv = 0; cv < nc; ++cv) { c.xadj[(size_t)cv + 1] += c.xadj[cv]; c.vint[cv] += vintAdd[(size_t)cv]; }
+    parallel_for(nc, 1 << 18, [&](int64_t cv) { c.vint[(size_t)cv] += vintAdd[(size_t)cv]; });
+    parallel_inclusive_scan(c.xadj.data() + 1, (int64_t)nc);
     c.adj.resize((size_t)c.xadj[nc]); c.ew.resize((size_t)c.xadj[nc]);
     MI_T("    coarsen: prefix+alloc");
     parallel_blocks(nc, 16384, [&](int64_t b, int64_t e, int) {
@@ -127,8 +162,8 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, int32_t nc, Graph
 // Reverse Cuthill-McKee ordering of the cell graph (new -> old): components started from their lowest-degree cell, neighbours
 // appended in order of increasing degree (ties by cell index: deterministic).  Host, sequential, only for meshes whose
 // numbering has no locality.
-void cuthill_mckee(int32_t n, const std::vector<int32_t>& ownStart, const std::vector<int32_t>& neiStart, const std::vector<int32_t>& ownFaces,
-                   const std::vector<int32_t>& neiFaces, const int32_t* lower, const int32_t* upper, std::vector<int32_t>& order)
+void cuthill_mckee(int32_t n, const std::vector<int32_t>& ownStart, const std::vector<int32_t>& neiStart, const IndexList& ownFaces,
+                   const IndexList& neiFaces, const int32_t* lower, const int32_t* upper, std::vector<int32_t>& order)
 {
     std::vector<int32_t> deg((size_t)n);
     int32_t maxDeg = 0;
@@ -167,13 +202,20 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
 {
     if (nCells <= 0) return "n_cells must be positive";
     if (prm.slotCap > 32766) return "slotCap exceeds the 15-bit slot field";
-    for (int32_t f = 0; f < nFaces; ++f) {
-        if (lower[f] < 0 || upper[f] >= nCells || lower[f] >= upper[f])
-            return "addressing must satisfy 0 <= lowerAddr[f] < upperAddr[f] < nCells";
-    }
 #ifdef MI_TIMING
     auto t__ = std::chrono::steady_clock::now();
 #endif
+    std::atomic<bool> lowerUnsorted{false};   // upper-triangular order (lduAddressing) has the owners ascending: their face lists are ranges
+    {
+        std::atomic<bool> bad{false};
+        parallel_blocks(nFaces, 1 << 18, [&](int64_t b, int64_t e, int) {
+            bool any = false, unsorted = false;
+            for (int64_t f = b; f < e; ++f) { any |= lower[f] < 0 || upper[f] >= nCells || lower[f] >= upper[f]; unsorted |= f > 0 && lower[f] < lower[f - 1]; }
+            if (any) bad = true;
+            if (unsorted) lowerUnsorted = true;
+        });
+        if (bad) return "addressing must satisfy 0 <= lowerAddr[f] < upperAddr[f] < nCells";
+    }
     L = TileLayout();
     L.nCells = nCells; L.nFaces = nFaces; L.nPatches = nPatches;
     L.patchOffset.assign((size_t)nPatches + 1, 0);
@@ -183,17 +225,20 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     // ---- per-cell face lists in the reference's row order -------------------
     // owner side: faces with lower==c ascending (ownerStartAddr); neighbour side:
     // faces with upper==c in losort order (stable sort by upper) -- lduAddressing.C:169-344
-    std::vector<int32_t> ownStart((size_t)nCells + 1, 0), neiStart((size_t)nCells + 1, 0);
-    for (int32_t f = 0; f < nFaces; ++f) { ownStart[(size_t)lower[f] + 1]++; neiStart[(size_t)upper[f] + 1]++; }
-    for (int32_t c = 0; c < nCells; ++c) { ownStart[(size_t)c + 1] += ownStart[c]; neiStart[(size_t)c + 1] += neiStart[c]; }
-    std::vector<int32_t> ownFaces((size_t)nFaces), neiFaces((size_t)nFaces), ownPos((size_t)nFaces); // ownPos: rank of f among its owner's faces
-    {
-        std::vector<int32_t> co(ownStart.begin(), ownStart.end() - 1), cn(neiStart.begin(), neiStart.end() - 1);
-        for (int32_t f = 0; f < nFaces; ++f) {
-            ownPos[f] = co[lower[f]] - ownStart[lower[f]];
-            ownFaces[(size_t)co[lower[f]]++] = f; neiFaces[(size_t)cn[upper[f]]++] = f;
-        }
+    // (threaded: buckets filled through atomic cursors, then sorted -- ascending face id inside a cell as the stable passes give)
+    std::vector<int32_t> ownStart, neiStart;
+    IndexList ownFaces, neiFaces, ownPos((size_t)nFaces); // ownPos: rank of f among its owner's faces
+    if (lowerUnsorted) bucket_items(nFaces, nCells, [&](int64_t f) { return lower[f]; }, ownStart, ownFaces);
+    else {
+        ownStart.resize((size_t)nCells + 1); ownFaces.resize((size_t)nFaces);
+        parallel_for(nFaces, 1 << 18, [&](int64_t f) {
+            ownFaces[(size_t)f] = (int32_t)f;
+            for (int32_t c = f > 0 ? lower[f - 1] + 1 : 0; c <= lower[f]; ++c) ownStart[(size_t)c] = (int32_t)f;   // (empty unless f opens a new owner)
+        });
+        for (int32_t c = nFaces > 0 ? lower[nFaces - 1] + 1 : 0; c <= nCells; ++c) ownStart[(size_t)c] = nFaces;
     }
+    bucket_items(nFaces, nCells, [&](int64_t f) { return upper[f]; }, neiStart, neiFaces);
+    parallel_for(nCells, 1 << 16, [&](int64_t c) { for (int32_t j = ownStart[(size_t)c]; j < ownStart[(size_t)c + 1]; ++j) ownPos[(size_t)ownFaces[(size_t)j]] = j - ownStart[(size_t)c]; });
     // patch faces per cell (patch order, then face order)
     std::vector<int32_t> pfStart((size_t)nCells + 1, 0), pfList((size_t)L.nExt);
     for (int32_t p = 0; p < nPatches; ++p)
@@ -302,15 +347,15 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         if (tooMany) return "a single cell has more faces than a tile can hold";
         if (reorder) for (int32_t c = 0; c < nCells; ++c) part[c] = cmRank[(size_t)c];
         // multi-edges (two faces between the same cell pair) are legal in LDU addressing; merge them
-        std::vector<int32_t> cmap;
+        std::vector<int32_t> cmap, partner;
         for (int level = 0; level < 64; ++level) {
-            const int32_t nc = match_level(g, prm.tileCells, prm.slotCap, cmap);
+            const int32_t nc = match_level(g, prm.tileCells, prm.slotCap, cmap, partner);
             MI_T("  match");
             if (nc == g.n) break;
-            for (int32_t c = 0; c < nCells; ++c) part[c] = cmap[part[c]];
+            parallel_for(nCells, 1 << 18, [&](int64_t c) { part[(size_t)c] = cmap[(size_t)part[(size_t)c]]; });
             MI_T("  part update");
             Graph cg;
-            coarsen(g, cmap, nc, cg);
+            coarsen(g, cmap, partner, nc, cg);
             MI_T("  coarsen");
             g = std::move(cg);
             nClusters = nc;
@@ -323,24 +368,21 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     L.nTiles = nT;
     const bool byRank = !cmRank.empty(); // tiles and the cells inside them follow the ordering the clustering ran on
     {
-        std::vector<int32_t> tileMin((size_t)nT, INT32_MAX);
-        if (byRank) for (int32_t v = nCells - 1; v >= 0; --v) tileMin[part[cmOrder[v]]] = v;
-        else
-        for (int32_t c = nCells - 1; c >= 0; --c) tileMin[part[c]] = c;
+        std::vector<int32_t> tileMin((size_t)nT, INT32_MAX);   // smallest vertex of every tile (a minimum: any order of visits)
+        parallel_for(nCells, 1 << 16, [&](int64_t v) { atomic_min_i32(&tileMin[(size_t)part[(size_t)(byRank ? cmOrder[(size_t)v] : (int32_t)v)]], (int32_t)v); });
         std::vector<int32_t> order((size_t)nT);
         std::iota(order.begin(), order.end(), 0);
         std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return tileMin[a] < tileMin[b]; });
         std::vector<int32_t> rank((size_t)nT);
         for (int32_t i = 0; i < nT; ++i) rank[order[i]] = i;
-        for (int32_t c = 0; c < nCells; ++c) part[c] = rank[part[c]];
+        parallel_for(nCells, 1 << 18, [&](int64_t c) { part[(size_t)c] = rank[(size_t)part[(size_t)c]]; });
     }
-    L.tileCellStart.assign((size_t)nT + 1, 0);
-    for (int32_t c = 0; c < nCells; ++c) L.tileCellStart[(size_t)part[c] + 1]++;
-    for (int32_t t = 0; t < nT; ++t) L.tileCellStart[(size_t)t + 1] += L.tileCellStart[t];
     L.e2c.resize(nCells); L.c2e.resize(nCells);
     {
-        std::vector<int32_t> cur(L.tileCellStart.begin(), L.tileCellStart.end() - 1);
-        for (int32_t v = 0; v < nCells; ++v) { const int32_t c = byRank ? cmOrder[v] : v; const int32_t e = cur[part[c]]++; L.e2c[e] = c; L.c2e[c] = e; }
+        // vertices of every tile, ascending (bucket_items: the stable count / fill passes, threaded); engine cell e = position
+        IndexList members;
+        bucket_items(nCells, nT, [&](int64_t v) { return part[(size_t)(byRank ? cmOrder[(size_t)v] : (int32_t)v)]; }, L.tileCellStart, members);
+        parallel_for(nCells, 1 << 16, [&](int64_t e) { const int32_t v = members[(size_t)e]; const int32_t c = byRank ? cmOrder[(size_t)v] : v; L.e2c[(size_t)e] = c; L.c2e[(size_t)c] = (int32_t)e; });
     }
 
     MI_T("renumbering");
@@ -530,39 +572,49 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         if (nEntTot > (size_t)INT32_MAX - 4096 || nSlotTot > (size_t)INT32_MAX - 4096) return "mesh too large for 32-bit layout offsets";
         L.slotFace.resize(nSlotTot); L.entries.resize(nEntTot); L.haloCell.resize(nHaloTot);
         if (L.compact) { L.entries16.resize(nEnt16Tot); L.slotBase.resize(nSbTot); }
-        L.sliceEntryStart.reserve(nSlTot + 1); L.sliceEntryStart16.reserve(nSlTot + 1);
+        (void)nSlTot;
     }
     {
-        size_t sAt = 0, eAt = 0, e16At = 0, hAt = 0, sbAt = 0;
+        // offsets of every tile (sequential: nT additions), then the copies and the face / ext slot scatters by the host threads
+        std::vector<size_t> sAt((size_t)nT + 1, 0), eAt((size_t)nT + 1, 0), e16At((size_t)nT + 1, 0), hAt((size_t)nT + 1, 0), sbAt((size_t)nT + 1, 0), slAt((size_t)nT + 1, 0);
         for (int32_t t = 0; t < nT; ++t) {
-            TileOut& O = outs[(size_t)t];
-            std::copy(O.slotFace.begin(), O.slotFace.end(), L.slotFace.begin() + (std::ptrdiff_t)sAt);
-            std::copy(O.entries.begin(), O.entries.end(), L.entries.begin() + (std::ptrdiff_t)eAt);
-            std::copy(O.haloCell.begin(), O.haloCell.end(), L.haloCell.begin() + (std::ptrdiff_t)hAt);
-            if (L.compact) {
-                std::copy(O.entries16.begin(), O.entries16.end(), L.entries16.begin() + (std::ptrdiff_t)e16At);
-                std::copy(O.slotBase.begin(), O.slotBase.end(), L.slotBase.begin() + (std::ptrdiff_t)sbAt);
-            }
-            for (size_t k = 1; k < O.sliceEntryStart.size(); ++k) {
-                L.sliceEntryStart.push_back((int32_t)(eAt + (size_t)O.sliceEntryStart[k]));
-                L.sliceEntryStart16.push_back((int32_t)(e16At + (size_t)(L.compact ? O.sliceEntryStart16[k] : 0)));
-            }
-            for (const auto& q : O.extSlot) L.extSlot[(size_t)q.first] = (int32_t)(sAt + (size_t)q.second);
-            for (const auto& q : O.faceSlot) L.faceSlot[(size_t)q.first] = (int32_t)(sAt + (size_t)q.second);
+            const TileOut& O = outs[(size_t)t];
+            sAt[(size_t)t + 1] = sAt[(size_t)t] + O.slotFace.size(); eAt[(size_t)t + 1] = eAt[(size_t)t] + O.entries.size(); hAt[(size_t)t + 1] = hAt[(size_t)t] + O.haloCell.size();
+            e16At[(size_t)t + 1] = e16At[(size_t)t] + (L.compact ? O.entries16.size() : 0); sbAt[(size_t)t + 1] = sbAt[(size_t)t] + (L.compact ? O.slotBase.size() : 0);
+            slAt[(size_t)t + 1] = slAt[(size_t)t] + (O.sliceEntryStart.size() - 1);
             L.tileIfaceSlot0[t] = O.ifaceSlot0;
-            sAt += O.slotFace.size(); eAt += O.entries.size(); hAt += O.haloCell.size();
-            if (L.compact) { e16At += O.entries16.size(); sbAt += O.slotBase.size(); }
-            L.tileSlotStart[(size_t)t + 1] = (int32_t)sAt;
-            L.tileHaloStart[(size_t)t + 1] = (int32_t)hAt;
-            L.tileSbStart.push_back((int32_t)(sbAt / 2));
-            L.tileSliceStart[(size_t)t + 1] = L.tileSliceStart[t] + (int32_t)(O.sliceEntryStart.size() - 1);
+            L.tileSlotStart[(size_t)t + 1] = (int32_t)sAt[(size_t)t + 1];
+            L.tileHaloStart[(size_t)t + 1] = (int32_t)hAt[(size_t)t + 1];
+            L.tileSbStart.push_back((int32_t)(sbAt[(size_t)t + 1] / 2));
+            L.tileSliceStart[(size_t)t + 1] = (int32_t)slAt[(size_t)t + 1];
             L.maxCells = std::max(L.maxCells, O.nc);
             L.maxSlots = std::max(L.maxSlots, O.nSlots + 2);
             L.maxHalo = std::max(L.maxHalo, O.nHalo);
             (O.boundary ? L.boundaryTiles : L.interiorTiles).push_back(t);
-            TileOut().slotFace.swap(O.slotFace); std::vector<uint32_t>().swap(O.entries); std::vector<uint32_t>().swap(O.entries16); // free as we go
         }
+        L.sliceEntryStart.resize(slAt[(size_t)nT] + 1); L.sliceEntryStart16.resize(slAt[(size_t)nT] + 1);
+        L.sliceEntryStart[0] = 0; L.sliceEntryStart16[0] = 0;
+        parallel_blocks(nT, 4, [&](int64_t t0, int64_t t1, int) {
+            for (int64_t t = t0; t < t1; ++t) {
+                TileOut& O = outs[(size_t)t];
+                std::copy(O.slotFace.begin(), O.slotFace.end(), L.slotFace.begin() + (std::ptrdiff_t)sAt[(size_t)t]);
+                std::copy(O.entries.begin(), O.entries.end(), L.entries.begin() + (std::ptrdiff_t)eAt[(size_t)t]);
+                std::copy(O.haloCell.begin(), O.haloCell.end(), L.haloCell.begin() + (std::ptrdiff_t)hAt[(size_t)t]);
+                if (L.compact) {
+                    std::copy(O.entries16.begin(), O.entries16.end(), L.entries16.begin() + (std::ptrdiff_t)e16At[(size_t)t]);
+                    std::copy(O.slotBase.begin(), O.slotBase.end(), L.slotBase.begin() + (std::ptrdiff_t)sbAt[(size_t)t]);
+                }
+                for (size_t k = 1; k < O.sliceEntryStart.size(); ++k) {
+                    L.sliceEntryStart[slAt[(size_t)t] + k] = (int32_t)(eAt[(size_t)t] + (size_t)O.sliceEntryStart[k]);
+                    L.sliceEntryStart16[slAt[(size_t)t] + k] = (int32_t)(e16At[(size_t)t] + (size_t)(L.compact ? O.sliceEntryStart16[k] : 0));
+                }
+                for (const auto& q : O.extSlot) L.extSlot[(size_t)q.first] = (int32_t)(sAt[(size_t)t] + (size_t)q.second);
+                for (const auto& q : O.faceSlot) L.faceSlot[(size_t)q.first] = (int32_t)(sAt[(size_t)t] + (size_t)q.second);
+                TileOut().slotFace.swap(O.slotFace); std::vector<uint32_t>().swap(O.entries); std::vector<uint32_t>().swap(O.entries16); // free as we go
+            }
+        });
     }
+    free_in_background(outs, ownStart, neiStart, ownFaces, neiFaces, ownPos, pfStart, pfList, part, ifaceLocalNbr);
     MI_T("slots / halos / entries");
     if (!L.compact) { std::vector<uint32_t>().swap(L.entries16); std::vector<int32_t>().swap(L.sliceEntryStart16); }
     L.nSlices = L.tileSliceStart[nT];

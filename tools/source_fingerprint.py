@@ -19,10 +19,32 @@ def _pkg():
     return graft.load_package()
 
 
+def _product_text(path):
+    """the file without its `#ifdef MI_TIMING ... [#else ...] #endif` hooks (tools/timing_build.sh builds them in; the product
+    never does; the #else branch, if any, is kept) and without the regions marked `// [start-up begin]` ... `// [start-up end]`
+    (hierarchy creation in gamg_engine.inc: once-per-mesh host code whose RESULT the output fingerprints cover)"""
+    out, depth, keep, startup = [], 0, True, False
+    for line in open(path, "r").read().split("\n"):
+        t = line.strip()
+        if t.startswith("// [start-up begin]"): startup = True
+        if startup:
+            if t.startswith("// [start-up end]"): startup = False
+            continue
+        if depth == 0 and t.startswith("#ifdef MI_TIMING"): depth, keep = 1, False; continue
+        if depth > 0:
+            if t.startswith("#if"): depth += 1
+            elif t.startswith("#endif"):
+                depth -= 1
+                if depth == 0: keep = True; continue
+            elif depth == 1 and t.startswith("#else"): keep = True; continue
+        if keep: out.append(line)
+    return "\n".join(out).encode()
+
+
 def text_hash(files):
     h = hashlib.sha256()
     for f in files:
-        h.update(open(os.path.join(CSRC, f), "rb").read())
+        h.update(_product_text(os.path.join(CSRC, f)))
     return h.hexdigest()
 
 
@@ -83,8 +105,9 @@ def layout_source_hash():
 
 
 def gamg_source_hash():
-    """the V-cycle figure: additionally the GAMG kernels / engine by text and the hierarchy by its output"""
-    return hashlib.sha256((text_hash(("kernels.hip.hpp", "tiling.hpp", "gamg_engine.inc", "gamg.hpp")) + layout_fingerprint() + hierarchy_fingerprint()).encode()).hexdigest()[:16]
+    """the V-cycle figure: additionally the GAMG kernels / cycle code by text (gamg_engine.inc outside its start-up region) and
+    the hierarchy by its output (gamg.hpp / gamg.cpp hold host structures and builders only)"""
+    return hashlib.sha256((text_hash(("kernels.hip.hpp", "tiling.hpp", "gamg_engine.inc")) + layout_fingerprint() + hierarchy_fingerprint()).encode()).hexdigest()[:16]
 
 
 if __name__ == "__main__":

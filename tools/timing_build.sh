@@ -1,8 +1,15 @@
 #!/bin/bash
 # timing build of the engine (MI_TIMING) on the GPU box: where the layout / hierarchy seconds go
+# (build/libtiming.so built in the container travels with the snapshot: `tools/timing_build.sh --build-only` there first saves
+#  the two minutes of hipcc on the box)
 set -e
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -pthread -DMI_TIMING rapidcfd-dev_amd/csrc/engine.hip rapidcfd-dev_amd/csrc/tiling.cpp rapidcfd-dev_amd/csrc/gamg.cpp -o /tmp/libtiming.so
-MI_ENGINE_LIB=/tmp/libtiming.so python - 2> /tmp/timing.err <<'PY'
+LIB=build/libtiming.so
+if [ ! -f $LIB ] || [ "$1" = "--build-only" ]; then
+  mkdir -p build
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -pthread -DMI_TIMING rapidcfd-dev_amd/csrc/engine.hip rapidcfd-dev_amd/csrc/tiling.cpp rapidcfd-dev_amd/csrc/gamg.cpp -o $LIB
+fi
+[ "$1" = "--build-only" ] && exit 0
+MI_ENGINE_LIB=$PWD/$LIB python - 2> /tmp/timing.err <<'PY'
 import os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import numpy as np, torch
@@ -19,14 +26,21 @@ for rep in range(2):
     print(f"== hierarchy done {t2-t1:.3f}", file=sys.stderr, flush=True)
     del G, addr
 PY
+mkdir -p gpurun_out && cp /tmp/timing.err gpurun_out/timing_build_${TAG:-latest}.err
 python - <<'PY'
 import collections, re
 lines = open("/tmp/timing.err").read().splitlines()
 i = max(k for k, l in enumerate(lines) if l.startswith("== rep"))
 agg = collections.OrderedDict(); build = 0
 for l in lines[i:]:
-    if l.startswith("=="): print(l); continue
-    if l.startswith("[gamg]"): print(l); continue
+    if l.startswith("[gamg]   level"):
+        if int(l.split()[2]) < 3: print(l)
+        continue
+    if l.startswith("==") or l.startswith("[gamg]") or l.startswith("[addr]"): print(l); continue
+    m = re.match(r"\[gamg-host\] level +(-?\d+) (.*?) +([0-9.]+) s", l)
+    if m:
+        if int(m.group(1)) < 3: print(l)
+        continue
     m = re.match(r"\[tiling\]\s+(.*?)\s+([0-9.]+) s", l)
     if not m: continue
     key = (build, m.group(1).strip()); agg[key] = agg.get(key, 0.0) + float(m.group(2))
