@@ -120,6 +120,7 @@ struct mi_addr_s {
     bool compact = false; // 16-bit row entries in use (MI_ENTRY16=1)
     DevBuf<int32_t> slotFace, extSlot, interiorTiles, boundaryTiles, patchFaceCellsE, faceSlot, lowerAddr, upperAddr;
     DevBuf<int32_t> ownerStartC, losortStartC, losortC; // caller-order row tables for the assembly sweeps (lazy)
+    DevBuf<uint32_t> row16; DevBuf<uint16_t> losort16; DevBuf<int32_t> rowEsc, rowEscStart; // their block-local 16-bit form (assembly.inc: R16)
     struct RowPlan { bool tiles = false; int bs = 256, blocks = 0, maxFaces = 0, capForced = 0; } rowPlan[2]; // blocks of the assembly row passes: [0] sums / fused schemes, [1] gradient (assembly.inc)
     DevBuf<double> relaxD0, relaxSumOff;
     std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
