@@ -195,6 +195,7 @@ bool comm_any_ami(const mi_matrix_s* m);                         // cyclicAMI pa
 bool comm_any_factor(const mi_matrix_s* m);                      // ... transformed patches (factor != 1) ...
 bool comm_any_compact(const mi_matrix_s* m);                     // ... the 16-bit entry form ...
 bool matrix_has_factor(const mi_matrix_s* m);
+void comm_inherit_factor_flag(mi_matrix_s* level, const mi_matrix_s* fine);
 int64_t comm_n_global(const mi_matrix_s* m);                     // global cell count (gAverage)
 int comm_exchange_start(mi_matrix_s* m, const double* send, double* vec);
 int comm_exchange_wait(mi_matrix_s* m);
