@@ -338,3 +338,37 @@ def test_engine_host_builder_agglomerates_the_ami_like_the_oracle(pkg, orc):
                 assert np.array_equal(got["amiStart"], A["start"]) and np.array_equal(got["amiAddr"], A["addr"])
                 assert np.array_equal(got["amiW"], A["w"]) and np.array_equal(got["amiMagSf"], A["magsf"])
             n_fine = [L[l]["patches"][p]["faceCells"].shape[0] for p in range(2)]
+
+
+@pytest.mark.parametrize("py", [2, 4])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_oracle_with_the_ami_sides_in_different_domains_agrees_with_the_single_domain_oracle(pkg, orc, py, symmetric):
+    """The multi-domain oracle is what the cyclicAMI-across-ranks tests of tests/test_distributed.py compare the engine with
+    (AMIInterpolation.C:940-1091: the partner patch lives on another processor).  Pin it here, on the CPU: the y-slab
+    decomposition of synthetic.decompose_cyclic_ami_y, its two AMI sides in the first and the last domain, against the SAME
+    case as one domain (the form tests/golden and test_ami's GPU tests pin) -- Amul to round-off (the row sums of the cut
+    cells are ordered differently), Krylov histories to 1e-10 of the initial residual, same iteration counts."""
+    syn = pkg.synthetic
+    base = syn.box_case(14, 12, 10, symmetric=symmetric)
+    kw = dict(shift=0.37, low_weight_every=(0 if symmetric else 7), transform=(1.0 if symmetric else 0.6))
+    one = syn.add_cyclic_ami_y(base, **kw)
+    subs = syn.decompose_cyclic_ami_y(base, py, **kw)
+    assert len(subs) == py and sum(s.n_cells for s in subs) == one.n_cells
+    assert subs[0].interfaces[-1].nbr_domain == py - 1 and subs[-1].interfaces[-1].nbr_domain == 0
+    S1, S = orc.System([one]), orc.System(subs)
+    cells = np.concatenate([s.global_cells for s in subs])
+    x = syn.splitmix_uniform(3, one.n_cells) - 0.5
+    a1, a = S1.amul(x), S.amul(x[cells])
+    assert np.max(np.abs(a - a1[cells])) < 1e-13 * np.max(np.abs(a1))
+    src = one.source
+    solvers = [("pcg", dict(precond="diagonal")), ("pcg", dict(precond="AINV"))] if symmetric else [("pbicg", dict(precond="AINV")), ("pbicgstab", dict(precond="diagonal"))]
+    for name, skw in solvers:
+        p1, r1 = getattr(S1, name)(np.zeros(one.n_cells), src, tolerance=1e-9, maxIter=300, **skw)
+        p, r = getattr(S, name)(np.zeros(one.n_cells), src[cells], tolerance=1e-9, maxIter=300, **skw)
+        if skw.get("precond") == "AINV":   # DIC / DILU of the decomposed case is block-local (as in the reference): another preconditioner
+            assert r["converged"] and r1["converged"]
+            assert np.max(np.abs(p - p1[cells])) < 1e-6 * np.max(np.abs(p1))
+            continue
+        assert r["nIterations"] == r1["nIterations"], (name, r["nIterations"], r1["nIterations"])
+        assert np.max(np.abs(r["history"] - r1["history"])) < 1e-10 * r1["history"][0], name
+        assert np.max(np.abs(p - p1[cells])) < 1e-8 * np.max(np.abs(p1))
