@@ -15,12 +15,19 @@
 namespace mi {
 // Host threads for the one-time layout build: plain std::thread workers pulling blocks of `grain` indices from an atomic
 // counter (no OpenMP runtime to clash with the caller's).  Everything built under it is independent per index, so the
-// layout does not depend on the number of threads (MI_HOST_THREADS; default: the hardware's, at most 64).
+// layout does not depend on the number of threads (MI_HOST_THREADS; default: the hardware's, at most 64 -- divided by the
+// number of ranks the launcher started on this node, so that eight ranks building their sub-domains at the same time do not
+// put 8 x 64 threads on the host: LOCAL_WORLD_SIZE of torchrun, the local sizes of Open MPI / MVAPICH / Slurm).
 inline int host_threads()
 {
     static int n = [] {
         const char* e = getenv("MI_HOST_THREADS");
-        int v = (e && *e) ? atoi(e) : (int)std::thread::hardware_concurrency();
+        if (e && *e) { const int v = atoi(e); return v < 1 ? 1 : (v > 64 ? 64 : v); }
+        int v = (int)std::thread::hardware_concurrency();
+        for (const char* name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"}) {
+            const char* l = getenv(name);
+            if (l && atoi(l) > 1) { v /= atoi(l); break; }
+        }
         return v < 1 ? 1 : (v > 64 ? 64 : v);
     }();
     return n;
