@@ -187,7 +187,10 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
         peer = "auto"
     else:
         os.environ["MI_PCG_PERSIST"] = "0"
-    d = rank if rccl else 0                                   # RCCL: one device per rank; gloo transport: the ranks share device 0
+    # RCCL: one device per rank; gloo transport: the ranks share device 0 -- unless the node has a device for every rank and
+    # MI_TEST_DEVICE_PER_RANK=1 asks for it (tools/first_lease.sh: the windows then cross xGMI instead of staying in one HBM)
+    per_rank = os.environ.get("MI_TEST_DEVICE_PER_RANK") == "1" and torch.cuda.device_count() >= world
+    d = rank if (rccl or per_rank) else 0
     torch.cuda.set_device(d)
     if rccl:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", d))

@@ -3,11 +3,12 @@
 # has ever run between two devices (the build box and every gpurun lease have one GPU): this script runs, in order of cost,
 #   1. the set-up self-tests between devices: mi_comm_peer_auto (all-reduce windows over hipIpc, fine-grained coherence),
 #      halo windows of an attached matrix, the grid-barrier litmus of the persistent kernel, the GAMG gather window;
-#   2. the GPU tests that skip on a one-GPU box (RCCL with one device per rank, 2 and 4 ranks);
+#   2. the GPU tests that skip on a one-GPU box (RCCL with one device per rank, 2 and 4 ranks), and the window tests of
+#      tests/test_distributed.py with one device per rank instead of ranks sharing device 0;
 #   3. bench.py --gpus N for N in 2 4 8, once per FORCED path -- persistent kernel over windows / five launches over windows /
 #      RCCL phase loop -- each with the path that really ran, the fall-back reason and the wait time-outs in its JSON line.
 # Usage (on a node with >= 2 MI355X, from the repository root):   bash tools/first_lease.sh [max_gpus]
-# Output: gpurun_out/first_lease/{selftests.log, tests_rccl.log, bench_<N>_<path>.json, table.md}
+# Output: gpurun_out/first_lease/{selftests.log, tests_rccl.log, tests_windows_per_device.log, bench_<N>_<path>.json, table.md}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/first_lease
@@ -29,6 +30,12 @@ done
 # ---- 2. the tests that skip on one GPU
 timeout 1800 python -m pytest tests/test_distributed.py -q -k "over_rccl_one_device_per_rank" > $O/tests_rccl.log 2>&1
 echo "[first_lease] RCCL one-device-per-rank tests: rc=$? ($(tail -n 1 $O/tests_rccl.log))" | tee -a $O/selftests.log
+
+# ---- 2b. the window tests with ONE DEVICE PER RANK (host transport gloo, halo / all-reduce / gather windows across xGMI): every
+# solver over windows, neighbours in different window forms, cyclicAMI across ranks, the persistent distributed kernel
+MI_TEST_DEVICE_PER_RANK=1 timeout 2400 python -m pytest tests/test_distributed.py -q \
+    -k "entirely_over_peer_windows or different_window_forms or cyclic_ami_whose or persistent_distributed or transformed_processor" > $O/tests_windows_per_device.log 2>&1
+echo "[first_lease] window tests, one device per rank: rc=$? ($(tail -n 1 $O/tests_windows_per_device.log))" | tee -a $O/selftests.log
 
 # ---- 3. bench.py per forced path
 run_bench() {  # N path env...
