@@ -97,6 +97,35 @@ def test_layout_clustering_by_the_host_threads_gives_the_same_layout(pkg):
             assert np.array_equal(a[k], b[k]), k
 
 
+_BIG = """
+import sys, hashlib, numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+import __graft_entry__ as g, workloads
+pkg = g.load_package(); eng, syn = pkg.engine, pkg.synthetic
+case = syn.box_case(60, 56, 48)          # 161 280 cells: the two-pass prefix scans and every threaded pass take their parallel form
+h = hashlib.sha256()
+L = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr)
+for k in sorted(L): h.update(k.encode()); h.update(np.ascontiguousarray(L[k]).tobytes())
+for fwd in (True, False):
+    for lvl in eng.gamg_host_hierarchy(case.n_cells, case.lower_addr, case.upper_addr, 0.5 + syn.splitmix_uniform(5, case.n_faces), 50, fwd):
+        for k in sorted(lvl):
+            if isinstance(lvl[k], np.ndarray): h.update(k.encode()); h.update(np.ascontiguousarray(lvl[k]).tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_larger_case_one_host_thread_against_all(pkg):
+    outs = []
+    for threads in ("1", "0"):
+        env = dict(os.environ)
+        env.pop("MI_HOST_THREADS", None)
+        if threads != "0": env["MI_HOST_THREADS"] = threads
+        out = subprocess.run([sys.executable, "-c", _BIG], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out.stdout.split()[-1])
+    assert outs[0] == outs[1]
+
+
 def test_tables_do_not_depend_on_the_number_of_host_threads(pkg):
     """the fingerprints of tools/source_fingerprint.py (every table of the layout / hierarchy of its reference cases) computed
     with ONE host thread in a fresh process equal those of this process (all cores)"""
