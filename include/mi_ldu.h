@@ -706,6 +706,14 @@ int mi_layout_build_host(int32_t n_cells, int32_t n_faces, const int32_t *lower_
                          const int32_t *const *patch_nbr_cells_host_or_null, int32_t tile_cells,
                          int32_t slot_cap, void **layout_out);
 int mi_layout_array(void *layout, const char *name, const void **data, int64_t *len);
+/* test hooks (round 4): the layout of a GIVEN partition (part[c] in [0, n_parts): tile of caller cell c; the partition of a
+ * clustered layout gives that layout back), and the tiles a coarse GAMG level inherits from its fine level's tiles
+ * (csrc/tiling.hpp inherit_tiles; part_out: n_coarse ids) */
+int mi_layout_build_host_given(int32_t n_cells, int32_t n_faces, const int32_t *lower_addr_host, const int32_t *upper_addr_host,
+                               int32_t n_parts, const int32_t *part_host, void **layout_out);
+int mi_layout_inherit_tiles(int32_t n_fine, const int32_t *restrict_map, const int32_t *fine_tile_of_cell, int32_t n_fine_tiles,
+                            int32_t n_coarse, int32_t n_coarse_faces, const int32_t *c_lower, const int32_t *c_upper,
+                            int32_t cell_cap, int32_t slot_cap, int32_t *part_out, int32_t *n_parts_out);
 int mi_layout_free(void *layout);
 
 #ifdef __cplusplus

@@ -2269,6 +2269,33 @@ extern "C" int mi_layout_build_host(int32_t n_cells, int32_t n_faces, const int3
     return MI_OK;
 }
 
+// test hooks of the given-partition layout and of the inherited tiles (tiling.hpp: TileParams::givenPart, inherit_tiles)
+extern "C" int mi_layout_build_host_given(int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_parts, const int32_t* part, void** out)
+{
+    if (!out || !part) return fail(MI_ERR_ARG, "mi_layout_build_host_given: bad argument");
+    TileLayout* L = new TileLayout();
+    TileParams prm;
+    prm.givenPart = part; prm.nGivenParts = n_parts;
+    const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, 0, nullptr, nullptr, prm, *L, nullptr);
+    if (!err.empty()) { delete L; return fail(MI_ERR_LIMIT, "mi_layout_build_host_given: " + err); }
+    *out = L;
+    return MI_OK;
+}
+extern "C" int mi_layout_inherit_tiles(int32_t n_fine, const int32_t* restrict_map, const int32_t* fine_tile_of_cell, int32_t n_fine_tiles, int32_t n_coarse,
+                                       int32_t n_coarse_faces, const int32_t* c_lower, const int32_t* c_upper, int32_t cell_cap, int32_t slot_cap,
+                                       int32_t* part_out, int32_t* n_parts_out)
+{
+    if (!restrict_map || !fine_tile_of_cell || !part_out || !n_parts_out) return fail(MI_ERR_ARG, "mi_layout_inherit_tiles: bad argument");
+    std::vector<int32_t> part;
+    int32_t nParts = 0;
+    const std::string err = inherit_tiles(n_fine, restrict_map, fine_tile_of_cell, n_fine_tiles, n_coarse, n_coarse_faces, c_lower, c_upper, 0, nullptr, nullptr,
+                                          cell_cap > 0 ? cell_cap : 1024, slot_cap > 0 ? slot_cap : 4094, part, nParts);
+    if (!err.empty()) return fail(MI_ERR_LIMIT, "mi_layout_inherit_tiles: " + err);
+    std::copy(part.begin(), part.end(), part_out);
+    *n_parts_out = nParts;
+    return MI_OK;
+}
+
 extern "C" int mi_layout_array(void* handle, const char* name, const void** data, int64_t* len)
 {
     if (!handle || !name || !data || !len) return fail(MI_ERR_ARG, "mi_layout_array: bad argument");

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <utility>
@@ -272,7 +273,27 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     std::iota(part.begin(), part.end(), 0);
     int32_t nClusters = nCells;
     std::vector<int32_t> cmOrder, cmRank; // Cuthill-McKee ordering (new -> old) and its inverse, when the clustering runs on it
-    if (prm.keepOrder) {
+    if (prm.givenPart) {
+        // given partition: checked against the caps (cells; slots = face incidences + patch faces - faces inside the tile)
+        const int32_t nP = prm.nGivenParts;
+        if (nP <= 0) return "given partition: no tiles";
+        std::vector<int32_t> cells((size_t)nP, 0), inc((size_t)nP, 0), internal((size_t)nP, 0);
+        std::atomic<bool> bad{false};
+        parallel_for(nCells, 1 << 16, [&](int64_t c) {
+            const int32_t t = prm.givenPart[c];
+            if (t < 0 || t >= nP) { bad = true; return; }
+            part[(size_t)c] = t;
+            atomic_add_i32(&cells[(size_t)t], 1);
+            atomic_add_i32(&inc[(size_t)t], (ownStart[(size_t)c + 1] - ownStart[(size_t)c]) + (neiStart[(size_t)c + 1] - neiStart[(size_t)c]) + (pfStart[(size_t)c + 1] - pfStart[(size_t)c]));
+        });
+        if (bad) return "given partition: tile id out of range";
+        parallel_for(nFaces, 1 << 16, [&](int64_t f) { const int32_t t = part[(size_t)lower[f]]; if (t == part[(size_t)upper[f]]) atomic_add_i32(&internal[(size_t)t], 1); });
+        for (int32_t t = 0; t < nP; ++t) {
+            if (cells[(size_t)t] == 0) return "given partition: empty tile";
+            if (cells[(size_t)t] > prm.tileCells || cells[(size_t)t] > 65535 - 4096 || inc[(size_t)t] - internal[(size_t)t] > prm.slotCap) return "a given tile exceeds the tile caps (cells or coefficient slots)";
+        }
+        nClusters = nP;
+    } else if (prm.keepOrder) {
         // ordered layout: tiles are ranges of the caller's numbering (given, or cut greedily under the caps)
         if (prm.givenTileStart) {
             if (prm.nGivenTiles <= 0 || prm.givenTileStart[0] != 0 || prm.givenTileStart[prm.nGivenTiles] != nCells) return "tile_cell_start must run from 0 to n_cells";
@@ -619,6 +640,107 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     if (!L.compact) { std::vector<uint32_t>().swap(L.entries16); std::vector<int32_t>().swap(L.sliceEntryStart16); }
     L.nSlices = L.tileSliceStart[nT];
     L.totalSlots = (int64_t)L.slotFace.size();
+    return std::string();
+}
+
+std::string inherit_tiles(int32_t nFine, const int32_t* restrictMap, const int32_t* fineTileOfCell, int32_t nFineTiles,
+                          int32_t nCoarse, int32_t nCoarseFaces, const int32_t* cLower, const int32_t* cUpper,
+                          int32_t nPatches, const int32_t* patchSizes, const int32_t* const* patchFaceCells,
+                          int32_t cellCap, int32_t slotCap, std::vector<int32_t>& part, int32_t& nParts)
+{
+    if (nFine <= 0 || nCoarse <= 0 || nFineTiles <= 0) return "inherit_tiles: bad argument";
+    const int32_t nT = nFineTiles;
+    // a coarse cell goes where its first (smallest) child is
+    std::vector<int32_t> firstChild((size_t)nCoarse, INT32_MAX);
+    parallel_for(nFine, 1 << 16, [&](int64_t fc) { atomic_min_i32(&firstChild[(size_t)restrictMap[fc]], (int32_t)fc); });
+    part.resize((size_t)nCoarse);
+    std::vector<int32_t> vw((size_t)nT, 0), vinc((size_t)nT, 0), vint((size_t)nT, 0);
+    std::atomic<bool> bad{false};
+    parallel_for(nCoarse, 1 << 16, [&](int64_t c) {
+        if (firstChild[(size_t)c] == INT32_MAX) { bad = true; return; }
+        const int32_t t = fineTileOfCell[firstChild[(size_t)c]];
+        if (t < 0 || t >= nT) { bad = true; return; }
+        part[(size_t)c] = t;
+        atomic_add_i32(&vw[(size_t)t], 1);
+    });
+    if (bad) return "inherit_tiles: a coarse cell without children, or a fine tile id out of range";
+    for (int32_t p = 0; p < nPatches; ++p) for (int32_t i = 0; i < patchSizes[p]; ++i) ++vinc[(size_t)part[(size_t)patchFaceCells[p][i]]];
+    // tile graph: faces between two tiles counted per unordered pair (thread-local tables, merged)
+    struct EdgeMap { std::vector<uint64_t> key; std::vector<int32_t> val; size_t mask = 0, used = 0;
+        void init(size_t cap) { size_t c = 64; while (c < cap) c <<= 1; key.assign(c, ~0ull); val.assign(c, 0); mask = c - 1; used = 0; }
+        void grow() { EdgeMap g; g.init(key.size() * 2); for (size_t i = 0; i < key.size(); ++i) if (key[i] != ~0ull) g.add(key[i], val[i]); *this = std::move(g); }
+        void add(uint64_t k, int32_t v) { if (2 * (used + 1) > key.size()) grow(); size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & mask; while (key[h] != ~0ull && key[h] != k) h = (h + 1) & mask; if (key[h] == ~0ull) { key[h] = k; ++used; } val[h] += v; } };
+    EdgeMap all;
+    all.init(4096);
+    std::mutex mu;
+    parallel_blocks(nCoarseFaces, 1 << 18, [&](int64_t b, int64_t e, int) {
+        EdgeMap local;
+        local.init(1024);
+        for (int64_t f = b; f < e; ++f) {
+            const int32_t a = part[(size_t)cLower[f]], c2 = part[(size_t)cUpper[f]];
+            atomic_add_i32(&vinc[(size_t)a], 1); atomic_add_i32(&vinc[(size_t)c2], 1);
+            if (a == c2) atomic_add_i32(&vint[(size_t)a], 1);
+            else local.add(((uint64_t)(uint32_t)std::min(a, c2) << 32) | (uint32_t)std::max(a, c2), 1);
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < local.key.size(); ++i) if (local.key[i] != ~0ull) all.add(local.key[i], local.val[i]);
+    });
+    // sorted edge list (tile pairs ascending): deterministic whatever order the blocks were merged in
+    std::vector<std::pair<uint64_t, int32_t>> edges;
+    edges.reserve(all.used);
+    for (size_t i = 0; i < all.key.size(); ++i) if (all.key[i] != ~0ull) edges.push_back({all.key[i], all.val[i]});
+    std::sort(edges.begin(), edges.end());
+    // rounds of pairwise merges: tiles in index order take the free neighbour across the heaviest common boundary that fits
+    std::vector<int32_t> rep((size_t)nT);
+    std::iota(rep.begin(), rep.end(), 0);
+    for (int round = 0; round < 4; ++round) {
+        std::vector<std::pair<uint64_t, int32_t>> cur;
+        cur.reserve(edges.size());
+        for (const auto& q : edges) {
+            const int32_t a = rep[(size_t)(q.first >> 32)], b = rep[(size_t)(uint32_t)q.first];
+            if (a != b) cur.push_back({((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b), q.second});
+        }
+        std::sort(cur.begin(), cur.end());
+        size_t w = 0;
+        for (size_t i = 0; i < cur.size(); ++i) { if (w > 0 && cur[w - 1].first == cur[i].first) cur[w - 1].second += cur[i].second; else cur[w++] = cur[i]; }
+        cur.resize(w);
+        std::vector<int32_t> start((size_t)nT + 1, 0);
+        for (const auto& q : cur) { ++start[(size_t)(q.first >> 32) + 1]; ++start[(size_t)(uint32_t)q.first + 1]; }
+        for (int32_t t = 0; t < nT; ++t) start[(size_t)t + 1] += start[(size_t)t];
+        std::vector<int32_t> nbr((size_t)start[(size_t)nT]), wgt((size_t)start[(size_t)nT]), fill(start.begin(), start.end() - 1);
+        for (const auto& q : cur) {   // (ascending pairs: every tile's list comes out ascending by neighbour)
+            const int32_t a = (int32_t)(q.first >> 32), b = (int32_t)(uint32_t)q.first;
+            nbr[(size_t)fill[(size_t)a]] = b; wgt[(size_t)fill[(size_t)a]++] = q.second;
+            nbr[(size_t)fill[(size_t)b]] = a; wgt[(size_t)fill[(size_t)b]++] = q.second;
+        }
+        std::vector<char> used((size_t)nT, 0);
+        std::vector<int32_t> into((size_t)nT, -1);
+        int merged = 0;
+        for (int32_t t = 0; t < nT; ++t) {
+            if (rep[(size_t)t] != t || used[(size_t)t] || vw[(size_t)t] == 0) continue;
+            int32_t best = -1, bw = 0;
+            for (int32_t j = start[(size_t)t]; j < start[(size_t)t + 1]; ++j) {
+                const int32_t u = nbr[(size_t)j];
+                if (used[(size_t)u] || vw[(size_t)t] + vw[(size_t)u] > cellCap) continue;
+                if (vinc[(size_t)t] + vinc[(size_t)u] - (vint[(size_t)t] + vint[(size_t)u] + wgt[(size_t)j]) > slotCap) continue;
+                if (wgt[(size_t)j] > bw) { bw = wgt[(size_t)j]; best = u; }
+            }
+            if (best < 0) continue;
+            used[(size_t)t] = used[(size_t)best] = 1; ++merged;
+            vw[(size_t)t] += vw[(size_t)best]; vinc[(size_t)t] += vinc[(size_t)best]; vint[(size_t)t] += vint[(size_t)best] + bw; vw[(size_t)best] = 0;
+            into[(size_t)best] = t;
+        }
+        if (!merged) break;
+        for (int32_t k = 0; k < nT; ++k) { const int32_t r = rep[(size_t)k]; if (into[(size_t)r] >= 0) rep[(size_t)k] = into[(size_t)r]; }
+    }
+    // compact ids (tiles that hold cells), caps
+    std::vector<int32_t> id((size_t)nT, -1);
+    nParts = 0;
+    for (int32_t t = 0; t < nT; ++t) if (rep[(size_t)t] == t && vw[(size_t)t] > 0) {
+        if (vw[(size_t)t] > cellCap || vinc[(size_t)t] - vint[(size_t)t] > slotCap) return "inherit_tiles: an inherited tile exceeds the caps";
+        id[(size_t)t] = nParts++;
+    }
+    parallel_for(nCoarse, 1 << 18, [&](int64_t c) { part[(size_t)c] = id[(size_t)rep[(size_t)part[(size_t)c]]]; });
     return std::string();
 }
 

@@ -71,6 +71,12 @@ struct TileParams {
     // |upperAddr - lowerAddr| says the numbering has no locality (> 4 N^(2/3)), the clustering runs on a Cuthill-McKee
     // ordering of the cell graph instead (same tiles as for the well-numbered mesh); 0 = never; 1 = always.
     int32_t reorder = -1;
+    // GIVEN partition (round 4; the GAMG level layouts that inherit their tiles, inherit_tiles below): givenPart[c] in
+    // [0, nGivenParts) names the tile of caller cell c, every tile non-empty and within the caps; no clustering.  Tiles are
+    // ordered by their smallest cell and their cells ascend, exactly as after the clustering -- the partition a clustered layout
+    // has gives that layout's tables back.
+    const int32_t* givenPart = nullptr;
+    int32_t nGivenParts = 0;
 };
 
 // returns empty string on success, else an error message
@@ -79,6 +85,17 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
                               const int32_t* patchSizes, const int32_t* const* patchFaceCells,
                               const TileParams& prm, TileLayout& out,
                               const int32_t* const* patchNbrCells = nullptr);
+// Tiles of a coarse GAMG level INHERITED from the tiles of its fine level instead of clustered from scratch (the clustering's
+// sequential heavy-edge matching is what the level layouts of a hierarchy spend their time in): a coarse cell goes where its
+// first child is (pair agglomeration halves a 1024-cell tile), then tiles are merged pairwise along their heaviest common
+// boundary under the caps (tile graph of a few thousand vertices, in index order: deterministic).  On the levels of the 216^3
+// box this gives the clustering's own tiles on the first two levels and +-0.6 % halo entries below (tools/exp/inherit_tiles.cpp).
+// fineTileOfCell: tile of every fine cell in the fine level's CALLER numbering.  Returns an error text when a tile cannot be
+// formed within the caps (the caller then clusters as before).
+std::string inherit_tiles(int32_t nFine, const int32_t* restrictMap, const int32_t* fineTileOfCell, int32_t nFineTiles,
+                          int32_t nCoarse, int32_t nCoarseFaces, const int32_t* cLower, const int32_t* cUpper,
+                          int32_t nPatches, const int32_t* patchSizes, const int32_t* const* patchFaceCells,
+                          int32_t cellCap, int32_t slotCap, std::vector<int32_t>& part, int32_t& nParts);
 // patchNbrCells[p] != nullptr marks patch p as a LOCAL coupled patch (cyclic): face i couples faceCells[i]
 // with the local cell patchNbrCells[p][i] (cyclicLduInterfaceField); nullptr = values arrive in the ext region.
 

@@ -60,7 +60,7 @@ SYMBOLS = [
     "mi_pcg_solve", "mi_pcg_begin", "mi_pcg_iterate", "mi_pcg_end",
     "mi_pbicg_solve", "mi_pbicgstab_solve", "mi_smooth_solve",
     "mi_bench_amul", "mi_bench_pcg_iters", "mi_debug_occupancy",
-    "mi_layout_build_host", "mi_layout_array", "mi_layout_free",
+    "mi_layout_build_host", "mi_layout_array", "mi_layout_free", "mi_layout_build_host_given", "mi_layout_inherit_tiles",
     "mi_dpcg_set_buffers", "mi_dpcg_phase", "mi_dpcg_status", "mi_event_record", "mi_event_elapsed_ms",
     "mi_gamg_create", "mi_gamg_update", "mi_gamg_level_matrix", "mi_gamg_scale", "mi_gamg_solve_coarsest", "mi_gamg_destroy", "mi_gamg_n_levels", "mi_gamg_forward_out", "mi_gamg_level_sizes",
     "mi_gamg_solve", "mi_gamg_restrict", "mi_gamg_prolong", "mi_gamg_level_coeffs",
@@ -141,6 +141,41 @@ def host_layout(n_cells, lower_addr, upper_addr, patch_face_cells=(), tile_cells
     finally:
         lib().mi_layout_free(h)
     return out
+
+
+_LAYOUT_ARRAYS = ("e2c", "c2e", "tileCellStart", "tileSlotStart", "tileIfaceSlot0", "tileHaloStart", "haloCell", "tileSliceStart", "sliceEntryStart",
+                  "entries", "slotFace", "extSlot", "interiorTiles", "boundaryTiles", "patchOffset", "patchFaceCellsE", "faceSlot")
+
+
+def host_layout_given(n_cells, lower_addr, upper_addr, part, n_parts) -> dict:
+    """Host-only layout of a GIVEN partition (mi_layout_build_host_given; tests)."""
+    I32 = C.POINTER(C.c_int32)
+    lo = np.ascontiguousarray(lower_addr, dtype=np.int32); up = np.ascontiguousarray(upper_addr, dtype=np.int32)
+    pt = np.ascontiguousarray(part, dtype=np.int32)
+    h = C.c_void_p()
+    _chk(lib().mi_layout_build_host_given(C.c_int32(n_cells), C.c_int32(lo.shape[0]), lo.ctypes.data_as(I32), up.ctypes.data_as(I32), C.c_int32(n_parts), pt.ctypes.data_as(I32), C.byref(h)))
+    out = {}
+    try:
+        for name in _LAYOUT_ARRAYS:
+            data, ln = C.c_void_p(), C.c_int64()
+            _chk(lib().mi_layout_array(h, name.encode(), C.byref(data), C.byref(ln)))
+            dt = np.uint32 if name == "entries" else np.int32
+            out[name] = np.frombuffer((C.c_char * (ln.value * 4)).from_address(data.value), dtype=dt).copy() if ln.value else np.zeros(0, dtype=dt)
+    finally:
+        lib().mi_layout_free(h)
+    return out
+
+
+def inherit_tiles(restrict_map, fine_tile_of_cell, n_fine_tiles, n_coarse, c_lower, c_upper, cell_cap=0, slot_cap=0):
+    """Tiles of a coarse GAMG level inherited from its fine level's tiles (mi_layout_inherit_tiles; tests): (part, n_parts)."""
+    I32 = C.POINTER(C.c_int32)
+    rm = np.ascontiguousarray(restrict_map, dtype=np.int32); ft = np.ascontiguousarray(fine_tile_of_cell, dtype=np.int32)
+    cl = np.ascontiguousarray(c_lower, dtype=np.int32); cu = np.ascontiguousarray(c_upper, dtype=np.int32)
+    part = np.empty(n_coarse, dtype=np.int32); n_parts = C.c_int32()
+    _chk(lib().mi_layout_inherit_tiles(C.c_int32(rm.shape[0]), rm.ctypes.data_as(I32), ft.ctypes.data_as(I32), C.c_int32(n_fine_tiles), C.c_int32(n_coarse),
+                                       C.c_int32(cl.shape[0]), cl.ctypes.data_as(I32), cu.ctypes.data_as(I32), C.c_int32(cell_cap), C.c_int32(slot_cap),
+                                       part.ctypes.data_as(I32), C.byref(n_parts)))
+    return part, int(n_parts.value)
 
 
 def lib():

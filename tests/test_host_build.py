@@ -137,3 +137,53 @@ def test_tables_do_not_depend_on_the_number_of_host_threads(pkg):
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert tuple(out.stdout.split()[-2:]) == here
+
+
+def _tile_of_cell(L, n_cells):
+    t = np.empty(n_cells, dtype=np.int32)
+    starts = L["tileCellStart"]
+    for k in range(len(starts) - 1):
+        t[L["e2c"][starts[k]:starts[k + 1]]] = k
+    return t
+
+
+def test_the_partition_of_a_clustered_layout_gives_that_layout_back(pkg):
+    """TileParams::givenPart (mi_layout_build_host_given): no clustering, tiles ordered by their smallest cell, cells ascending
+    -- fed with the tiles the clustering made, every table of the layout comes out the same"""
+    eng, syn = pkg.engine, pkg.synthetic
+    case = syn.box_case(40, 36, 44)
+    L = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr)
+    part = _tile_of_cell(L, case.n_cells)
+    G = eng.host_layout_given(case.n_cells, case.lower_addr, case.upper_addr, part, len(L["tileCellStart"]) - 1)
+    for k in G:
+        assert np.array_equal(G[k], L[k]), k
+    with pytest.raises(eng.MiError):      # a tile beyond the caps is refused (the caller then clusters)
+        eng.host_layout_given(case.n_cells, case.lower_addr, case.upper_addr, np.zeros(case.n_cells, dtype=np.int32), 1)
+
+
+def test_tiles_inherited_from_the_finer_gamg_level(pkg):
+    """inherit_tiles (csrc/tiling.hpp): a coarse cell goes where its first child is, tiles merged pairwise under the caps.  Every
+    inherited partition must be a valid layout input, and on the levels of a box it must be as good as clustering that level
+    from scratch (tools/exp/inherit_tiles.cpp: identical tiles on the first two levels of the 216^3 box)."""
+    eng, syn = pkg.engine, pkg.synthetic
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads
+    case = syn.box_case(64, 48, 48)
+    fineL = eng.host_layout(case.n_cells, case.lower_addr, case.upper_addr)
+    tile_of, n_tiles = _tile_of_cell(fineL, case.n_cells), len(fineL["tileCellStart"]) - 1
+    H = eng.gamg_host_hierarchy(case.n_cells, case.lower_addr, case.upper_addr, workloads.box_pair_weights(case), 50, True)
+    checked = 0
+    for lvl in H[:3]:
+        n_coarse = int(lvl["restrictMap"].max()) + 1
+        if n_coarse < 4096:
+            break
+        part, n_parts = eng.inherit_tiles(lvl["restrictMap"], tile_of, n_tiles, n_coarse, lvl["cLower"], lvl["cUpper"])
+        assert part.min() == 0 and part.max() == n_parts - 1 and np.bincount(part).max() <= 1024
+        inherited = eng.host_layout_given(n_coarse, lvl["cLower"], lvl["cUpper"], part, n_parts)
+        clustered = eng.host_layout(n_coarse, lvl["cLower"], lvl["cUpper"])
+        assert np.array_equal(np.sort(inherited["e2c"]), np.arange(n_coarse))
+        assert len(inherited["haloCell"]) <= 1.05 * len(clustered["haloCell"]), (len(inherited["haloCell"]), len(clustered["haloCell"]))
+        assert len(inherited["slotFace"]) <= 1.02 * len(clustered["slotFace"])
+        tile_of, n_tiles = part, n_parts          # the next level inherits from this one
+        checked += 1
+    assert checked >= 2

@@ -100,14 +100,15 @@ def hierarchy_fingerprint():
 
 
 def layout_source_hash():
-    """the Amul figure: tile kernel + layout structs by text, the layout by its output"""
-    return hashlib.sha256((text_hash(("kernels.hip.hpp", "tiling.hpp")) + layout_fingerprint()).encode()).hexdigest()[:16]
+    """the Amul figure: the tile kernels by text, the layout by its output (tiling.hpp / tiling.cpp hold the host structures and
+    the builder: every table they hand to the kernels is in the fingerprint)"""
+    return hashlib.sha256((text_hash(("kernels.hip.hpp",)) + layout_fingerprint()).encode()).hexdigest()[:16]
 
 
 def gamg_source_hash():
     """the V-cycle figure: additionally the GAMG kernels / cycle code by text (gamg_engine.inc outside its start-up region) and
     the hierarchy by its output (gamg.hpp / gamg.cpp hold host structures and builders only)"""
-    return hashlib.sha256((text_hash(("kernels.hip.hpp", "tiling.hpp", "gamg_engine.inc")) + layout_fingerprint() + hierarchy_fingerprint()).encode()).hexdigest()[:16]
+    return hashlib.sha256((text_hash(("kernels.hip.hpp", "gamg_engine.inc")) + layout_fingerprint() + hierarchy_fingerprint()).encode()).hexdigest()[:16]
 
 
 if __name__ == "__main__":
