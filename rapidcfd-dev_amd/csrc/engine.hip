@@ -157,9 +157,9 @@ struct mi_matrix_s {
     std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
     DevBuf<double> hist, tilePartial;
     DevBuf<PcgState> mstate; DevBuf<double> mpartial, mhist, mtilePartial; PcgState* mhostState = nullptr;   // multi-right-hand-side solves (multi.inc): one state / partial block / history per component
-    DevBuf<double> persistScratch;
+    DevBuf<double> persistScratch;   // per-workgroup partials + the grid barrier of the persistent PCG kernel (persist.inc)
     uint64_t persistFaultEpoch = 0;   // mi_ctx_s::faultEpoch when persistScratch was last zeroed
-    DevBuf<double> persistZ;   // z = rD o rA published by the persistent PCG kernel (persist.inc, ZP)   // per-workgroup partials + the grid barrier of the persistent PCG kernel (persist.inc) PcgState* mhostState = nullptr;   // multi-right-hand-side solves (multi.inc): one state / partial block / history per component
+    DevBuf<double> persistZ;   // z = rD o rA published by the persistent PCG kernel (persist.inc, ZP)
     int histLen = 0;
     // running PCG session (mi_pcg_begin/iterate/end)
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;

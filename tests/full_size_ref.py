@@ -1,0 +1,132 @@
+"""Oracle results at the BASELINE sizes as committed fixtures (VERDICT r04 "next" 1b).
+
+The serial CPU oracle needs minutes per 10 M / 40 M / 80 M-cell solve; inside the GPU suite that was ~40 % of the driver's
+window.  tests/golden/make_full_size.py runs the oracle ON THE CPU BOX and writes, for every full-size GPU test,
+
+  * residual histories, iteration counts, flags and normFactor (small arrays, stored whole),
+  * sha256 of the result BITS of every operator that is compared bit for bit,
+  * of every solution vector: its values at SAMPLE positions (sample_idx: a fixed multiplicative walk over the cells), its
+    max |.|, its sum and its sum of magnitudes,
+  * sha256 of the oracle's C sources and of the case generator, so that a fixture older than the code it restates fails a CPU
+    test (tests/test_full_size_fixture.py) instead of passing silently; that file also RE-DERIVES a sample of the records
+    with the live oracle.
+
+The GPU tests (test_gpu_full_size.py, test_gpu_configs.py) compare the engine against these records with the bars they had
+against the live oracle.  With MI_LIVE_ORACLE=1 they run the oracle in-process again (the pre-r05 behaviour).
+"""
+import hashlib
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FIXTURE = os.path.join(HERE, "golden", "full_size_v1.npz")
+N_SAMPLE = 4096
+PERF_KEYS = ("nIterations", "converged", "singular")
+PERF_REALS = ("normFactor", "initialResidual", "finalResidual")
+
+
+def live_oracle():
+    return os.environ.get("MI_LIVE_ORACLE", "0") == "1"
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def sample_idx(n, k=N_SAMPLE):
+    """k positions spread over [0, n): a multiplicative walk (golden-ratio hashing), first and last cell included"""
+    i = (np.arange(k, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(n)
+    i = i.astype(np.int64)
+    i[0], i[-1] = 0, n - 1
+    return i
+
+
+def source_hashes():
+    """what the records were derived from: the oracle's C sources and the synthetic case generator"""
+    h = {}
+    for rel in ("oracle/ldu_oracle.c", "oracle/gamg_oracle.c", "oracle/ldu_oracle.h", "rapidcfd-dev_amd/synthetic.py"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h[rel] = hashlib.sha256(f.read()).hexdigest()
+    return h
+
+
+# ---- writing (make_full_size.py) ----------------------------------------------------------------------------------------
+def pack_perf(out, key, perf):
+    out[key + "/history"] = np.asarray(perf["history"], dtype=np.float64)
+    out[key + "/flags"] = np.array([int(perf[k]) for k in PERF_KEYS], dtype=np.int64)
+    out[key + "/reals"] = np.array([float(perf.get(k, np.nan)) for k in PERF_REALS], dtype=np.float64)
+
+
+def pack_solution(out, key, psi):
+    psi = np.asarray(psi)
+    out[key + "/psi_sample"] = psi[sample_idx(psi.shape[0])].copy()
+    out[key + "/psi_stats"] = np.array([np.max(np.abs(psi)), psi.sum(), np.abs(psi).sum(), psi.shape[0]], dtype=np.float64)
+
+
+def pack_sha(out, key, a):
+    out[key + "/sha256"] = np.array(sha(a))
+
+
+# ---- reading (the GPU tests) ---------------------------------------------------------------------------------------------
+class Records:
+    def __init__(self, path=FIXTURE):
+        self.z = np.load(path)
+
+    def has(self, key):
+        return any(k.startswith(key + "/") for k in self.z.files)
+
+    def perf(self, key):
+        """the oracle's perf dict of that solve (history, nIterations, converged, singular, normFactor, ...)"""
+        d = {"history": self.z[key + "/history"]}
+        for k, v in zip(PERF_KEYS, self.z[key + "/flags"]):
+            d[k] = int(v)
+        for k, v in zip(PERF_REALS, self.z[key + "/reals"]):
+            d[k] = float(v)
+        return d
+
+    def scalar(self, key):
+        return self.z[key]
+
+    def sha(self, key):
+        return str(self.z[key + "/sha256"])
+
+    def solution(self, key):
+        return SolutionRecord(self.z[key + "/psi_sample"], self.z[key + "/psi_stats"])
+
+
+class SolutionRecord:
+    """stands in for the oracle's solution vector: check(psi, tol) is the test's  max|psi - ref| < tol * max|ref|  on the sample
+    positions plus the vector's sum and sum of magnitudes to the same tolerance (of the sum of magnitudes)"""
+
+    def __init__(self, sample, stats):
+        self.sample = sample
+        self.maxabs, self.sum, self.abssum, self.n = float(stats[0]), float(stats[1]), float(stats[2]), int(stats[3])
+
+    def deviation(self, psi):
+        psi = np.asarray(psi)
+        assert psi.shape[0] == self.n
+        return float(np.max(np.abs(psi[sample_idx(self.n)] - self.sample)) / self.maxabs)
+
+    def check(self, psi, tol):
+        psi = np.asarray(psi)
+        assert self.deviation(psi) < tol
+        assert abs(float(psi.sum()) - self.sum) < tol * self.abssum
+        assert abs(float(np.abs(psi).sum()) - self.abssum) < tol * self.abssum
+
+
+def check_solution(psi, ref, tol):
+    """ref: the oracle's vector (live oracle) or a SolutionRecord (fixture)"""
+    if isinstance(ref, SolutionRecord):
+        ref.check(psi, tol)
+    else:
+        assert np.max(np.abs(np.asarray(psi) - ref)) < tol * np.max(np.abs(ref))
+
+
+def check_bits(got, ref):
+    """ref: the oracle's vector (live oracle) or the sha256 of its bits (fixture)"""
+    if isinstance(ref, str):
+        assert sha(got) == ref
+    else:
+        assert np.array_equal(got, ref)

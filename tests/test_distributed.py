@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from rank_pool import run_ranks
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -19,12 +21,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, parts, dims, kw, out_dir):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _cpu_body(rank, world, parts, dims, kw, out_dir):
+    """one rank of the CPU test (tests/rank_pool.py has joined the gloo group)"""
     import __graft_entry__ as graft
     pkg = graft.load_package()
     from importlib import import_module
@@ -38,7 +36,6 @@ def _worker(rank, world, port, parts, dims, kw, out_dir):
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), psi=solver.ops.solution(), cells=sub.global_cells,
              hist=perf["history"], nit=perf["nIterations"], conv=perf["converged"], n_global=solver.n_global)
     dist.barrier()
-    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("parts,kw", [((1, 1, 2), dict(tolerance=1e-8, max_iter=300)),
@@ -48,7 +45,7 @@ def _worker(rank, world, port, parts, dims, kw, out_dir):
 def test_distributed_pcg_matches_serial_oracle(pkg, orc, tmp_path, parts, kw):
     dims = (10, 8, 6)
     world = parts[0] * parts[1] * parts[2]
-    mp.spawn(_worker, args=(world, _free_port(), parts, dims, kw, str(tmp_path)), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_cpu_body", parts, dims, kw, str(tmp_path))
     case = pkg.synthetic.box_case(*dims)
     okw = dict(tolerance=kw["tolerance"], maxIter=kw["max_iter"], minIter=kw.get("min_iter", 0))
     ref_psi, ref = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, "diagonal", **okw)
@@ -86,12 +83,9 @@ def test_direct_subdomain_equals_decomposed_global_case(pkg):
 
 
 # ---- the same N>1 path with the REAL engine: several ranks share the one GPU of the box, torch.distributed over gloo ----
-def _gpu_worker(rank, world, port, parts, dims, kw, out_dir, driver):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def _gpu_body(rank, world, parts, dims, kw, out_dir, driver):
     os.environ["MI_DPCG_DRIVER"] = driver
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kw = dict(kw)
     import __graft_entry__ as graft
     pkg = graft.load_package()
     from importlib import import_module
@@ -111,7 +105,6 @@ def _gpu_worker(rank, world, port, parts, dims, kw, out_dir, driver):
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), psi=solver.ops.solution(), cells=sub.global_cells, hist=perf["history"],
              nit=perf["nIterations"], conv=perf["converged"], n_global=solver.n_global, driver=solver.driver)
     dist.barrier()
-    dist.destroy_process_group()
 
 
 @pytest.mark.gpu
@@ -126,7 +119,7 @@ def test_distributed_pcg_real_engine_ranks_share_one_gpu(pkg, orc, tmp_path, par
     here (duplicate GPU), so all ranks must agree to fall back to the torch.distributed loop."""
     dims = (20, 16, 12)
     world = parts[0] * parts[1] * parts[2]
-    mp.spawn(_gpu_worker, args=(world, _free_port(), parts, dims, dict(kw), str(tmp_path), driver), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_gpu_body", parts, dims, dict(kw), str(tmp_path), driver)
     case = pkg.synthetic.box_case(*dims)
     okw = dict(tolerance=kw["tolerance"], maxIter=kw["max_iter"], minIter=kw.get("min_iter", 0))
     ref_psi, ref = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, "diagonal", **okw)
@@ -148,7 +141,7 @@ def test_distributed_pcg_real_engine_ragged_graph_random_partition(pkg, orc, tmp
     from conftest import random_graph_case
     n, world = 3000, 3
     kw = dict(tolerance=1e-9, max_iter=400)
-    mp.spawn(_gpu_worker, args=(world, _free_port(), "graph", (n,), dict(kw), str(tmp_path), "torch"), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_gpu_body", "graph", (n,), dict(kw), str(tmp_path), "torch")
     case = random_graph_case(pkg, n, extra=2.0, seed=11)
     ref_psi, ref = orc.System([case]).pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-9, maxIter=400)
     psi = np.zeros(n)
@@ -161,12 +154,20 @@ def test_distributed_pcg_real_engine_ragged_graph_random_partition(pkg, orc, tmp
 
 
 # ---- the engine's OWN (C++) loops with several ranks: communicators over the caller's transport (mi_comm_create_external) ----
-def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
+def _native_rccl_worker(rank, world, port, spec, out_dir):
+    """RCCL proper needs its own group (backend nccl, one device per rank): fresh processes, not the pooled gloo ranks"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    _native_body(rank, world, spec, out_dir, True)
+    dist.destroy_process_group()
+
+
+def _native_body(rank, world, spec, out_dir, rccl=False, peer=False):
     persist = isinstance(peer, str) and peer.startswith("persist")
     if peer == "mixed":
         # even ranks run the one-launch operators (boundary tiles poll their pairs), odd ranks the four-launch form (k_halo_push /
@@ -192,10 +193,6 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
     per_rank = os.environ.get("MI_TEST_DEVICE_PER_RANK") == "1" and torch.cuda.device_count() >= world
     d = rank if (rccl or per_rank) else 0
     torch.cuda.set_device(d)
-    if rccl:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", d))
-    else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as graft
     pkg = graft.load_package()
     from importlib import import_module
@@ -242,7 +239,6 @@ def _native_worker(rank, world, port, spec, out_dir, rccl=False, peer=False):
         assert ctx.stat(1) > 0, "the persistent distributed kernel did not run"
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
-    dist.destroy_process_group()
 
 
 PBICG3_COMPONENTS = ((1.0, 0.0), (0.5, 0.01), (-0.3, 0.0))   # source of component c = a * source + b
@@ -323,7 +319,7 @@ def test_transformed_processor_patches_between_engine_ranks(pkg, orc, tmp_path, 
     peer windows).  Amul bit-exact across the cuts, PBiCG + DILU / PBiCGStab / smoothSolver histories against the multi-domain
     oracle whose interfaces carry the same factors."""
     spec = NATIVE_SPECS["box_4_transformed"]
-    mp.spawn(_native_worker, args=(4, _free_port(), spec, str(tmp_path), False, peer), nprocs=4, join=True)
+    run_ranks(4, "test_distributed", "_native_body", spec, str(tmp_path), False, peer)
     _check_native(pkg, orc, spec, 4, str(tmp_path))
 
 
@@ -337,7 +333,7 @@ def test_native_attached_solvers_on_several_engine_ranks(pkg, orc, tmp_path, nam
     RCCL build issues is issued here too, by the same C++ code, between distinct ranks with distinct sub-domains.  Reference:
     the multi-domain oracle on the same decomposition."""
     spec = NATIVE_SPECS[name]
-    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path)), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path))
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 
@@ -349,7 +345,7 @@ def test_native_attached_solvers_over_rccl_one_device_per_rank(pkg, orc, tmp_pat
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs, {torch.cuda.device_count()} visible")
     spec = NATIVE_SPECS[name]
-    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), True), nprocs=world, join=True)
+    mp.spawn(_native_rccl_worker, args=(world, _free_port(), spec, str(tmp_path)), nprocs=world, join=True)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 
@@ -361,7 +357,7 @@ def test_native_solvers_with_the_one_shot_peer_allreduce(pkg, orc, tmp_path, nam
     into every rank's window and adds the nRanks contributions in rank order.  Here the ranks are processes that share the
     GPU and map each other's windows over hipIpc; halo exchange and the large all-reduces stay on the gloo transport."""
     spec = NATIVE_SPECS[name]
-    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, True), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, True)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 
@@ -373,7 +369,7 @@ def test_native_solvers_entirely_over_peer_windows(pkg, orc, tmp_path, name, wor
     k_halo_pull) and the fused three-launch distributed PCG iteration, between 2, 3 and 4 processes that map each other's
     windows over hipIpc.  Only what does not fit the windows (all-reduces > 8 doubles, the hierarchy build) still uses gloo."""
     spec = NATIVE_SPECS[name]
-    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, "auto"), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, "auto")
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 
@@ -385,7 +381,7 @@ def test_neighbours_in_different_window_forms(pkg, orc, tmp_path, name, world):
     enqueues after the solve has converged, which the one-launch operators used to skip entirely while k_halo_push /
     k_halo_pull went on (round 4: a 4-rank cyclicAMI case ran out of polls exactly there)."""
     spec = NATIVE_SPECS[name]
-    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, "mixed"), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, "mixed")
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 
@@ -401,7 +397,7 @@ def test_cyclic_ami_whose_halves_live_on_different_ranks(pkg, orc, tmp_path, nam
     smoothSolver / PBiCG / PBiCGStab / GAMG (ICCG / BICCG on the coarsest level) against the multi-domain oracle (1e-10), over
     the external transport and over peer windows, with low-weight faces and a transformation factor in the asymmetric case."""
     spec = NATIVE_SPECS[name]
-    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, peer), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, peer)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 
@@ -413,7 +409,7 @@ def test_persistent_distributed_pcg_between_processes(pkg, orc, tmp_path, name, 
     replicated window slots, rank-order sums -- inside their persistent cooperative kernels, which share the one GPU of this
     box (MI_PERSIST_GRID workgroups each).  Iteration counts, histories (1e-10) and solutions against the multi-domain oracle."""
     spec = NATIVE_SPECS[name]
-    mp.spawn(_native_worker, args=(world, _free_port(), spec, str(tmp_path), False, f"persist:{grid}"), nprocs=world, join=True)
+    run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, f"persist:{grid}")
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
 

@@ -9,7 +9,9 @@
             V-cycles (processor interfaces agglomerated on every level, the global coarsest system assembled from the eight
             ranks' block rows), against the multi-domain oracle.  RCCL refuses ranks that share a device; the C++ loops, the
             halo / all-reduce call sites and the per-rank kernels are the ones an 8-GPU node runs.
-Both need a host with room for the oracle's copy of the case (they skip below 48 GB of RAM)."""
+Round 5: the oracle's side is a committed record (tests/golden/full_size_v1.npz, sections config4 / config5, written on the CPU
+box by tests/golden/make_full_size.py; tests/full_size_ref.py) -- the 40 M / 80 M-cell oracle runs took 140 s of GPU-suite time.
+MI_LIVE_ORACLE=1 runs the oracle in-process again (needs 48 / 96 GB of host memory)."""
 import os
 import sys
 import time
@@ -19,6 +21,10 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+import full_size_ref as fs
+from full_size_ref import check_bits, check_solution
+from rank_pool import run_ranks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,8 +55,9 @@ def _record(name, **vals):
 
 
 def test_config4_periodic_channel_40M_cells(pkg, orc):
-    if _ram_gb() < 48:
-        pytest.skip("needs 48 GB of host memory for the oracle's copy of the 40 M-cell case")
+    rec = None if fs.live_oracle() else fs.Records()
+    if _ram_gb() < (24 if rec else 48):
+        pytest.skip("needs 24 GB of host memory for the 40 M-cell case (48 with the live oracle's copy)")
     syn, eng = pkg.synthetic, pkg.engine
     dims = (640, 250, 250)
     t0 = time.perf_counter()
@@ -64,33 +71,40 @@ def test_config4_periodic_channel_40M_cells(pkg, orc):
     mat.set_coeffs(dev(case.diag), dev(case.upper), None)
     for p, itf in enumerate(case.interfaces):
         mat.set_interface_coeffs(p, dev(itf.bou_coeffs), None)
-    S = orc.System([case])
+    S = None if rec else orc.System([case])
     t_setup = time.perf_counter() - t0
     # Amul across the periodic pair, bit for bit
     x = syn.splitmix_uniform(5, n) - 0.5
     out = torch.empty(n, dtype=torch.float64, device="cuda:0")
     mat.amul(dev(x), out); torch.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy(), S.amul(x))
+    check_bits(out.cpu().numpy(), rec.sha("config4/amul") if rec else S.amul(x))
     # diagonal PCG, 20 iterations
     psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=0.0, maxIter=20)
-    ref_psi, ref = S.pcg(np.zeros(n), case.source, "diagonal", tolerance=0.0, maxIter=20)
+    if rec:
+        ref_psi, ref = rec.solution("config4/pcg_diagonal_20"), rec.perf("config4/pcg_diagonal_20")
+    else:
+        ref_psi, ref = S.pcg(np.zeros(n), case.source, "diagonal", tolerance=0.0, maxIter=20)
     assert perf["nIterations"] == ref["nIterations"] == 21
     h, hr = perf["history"], ref["history"]
     _record("config4_channel_40M_pcg_20_iterations", max_dev_over_initial=float(np.max(np.abs(h - hr)) / hr[0]), bar=HIST_RTOL)
     assert np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
     torch.cuda.synchronize()
-    assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-10 * np.max(np.abs(ref_psi))
+    check_solution(psi.cpu().numpy(), ref_psi, 1e-10)
     # GAMG, 5 V-cycles; cyclic GAMG interfaces on every level (cyclicGAMGInterface)
     w = orc.box_face_weights(case)
     t0 = time.perf_counter()
-    H = orc.GamgSysHierarchy(S, [w], 100)
-    ref_psi, ref = H.solve(np.zeros(n), case.source, tolerance=0.0, maxIter=5)
+    if rec:
+        ref_psi, ref, n_levels = rec.solution("config4/gamg_5"), rec.perf("config4/gamg_5"), int(rec.scalar("config4/gamg_levels"))
+    else:
+        H = orc.GamgSysHierarchy(S, [w], 100)
+        ref_psi, ref = H.solve(np.zeros(n), case.source, tolerance=0.0, maxIter=5)
+        n_levels = H.n_levels
     t_orc = time.perf_counter() - t0
     t0 = time.perf_counter()
     G = eng.Gamg(addr, w, 100)
     t_h = time.perf_counter() - t0
-    assert G.n_levels == H.n_levels
+    assert G.n_levels == n_levels
     psi.zero_()
     perf = G.solve(mat, psi, dev(case.source), tolerance=0.0, maxIter=5)
     assert perf["nIterations"] == ref["nIterations"] == 5
@@ -99,21 +113,16 @@ def test_config4_periodic_channel_40M_cells(pkg, orc):
             seconds_case_layout_oracle_system=t_setup, seconds_engine_hierarchy=t_h, seconds_oracle_hierarchy_and_cycles=t_orc)
     assert h.shape == hr.shape and np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
     torch.cuda.synchronize()
-    assert np.max(np.abs(psi.cpu().numpy() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+    check_solution(psi.cpu().numpy(), ref_psi, 1e-9)
 
 
 # ---- config 5 --------------------------------------------------------------------------------------------------------
 DIMS5, PARTS5 = (432, 432, 432), (2, 2, 2)
 
 
-def _config5_worker(rank, world, port, out_dir):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+def _config5_body(rank, world, out_dir):
+    """one of the eight engine ranks (tests/rank_pool.py has joined them in a gloo group)"""
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as graft
     pkg = graft.load_package()
     from importlib import import_module
@@ -145,19 +154,44 @@ def _config5_worker(rank, world, port, out_dir):
     assert not dm.comms[0].errors, dm.comms[0].errors
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
+
+
+def _config5_live_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _config5_body(rank, world, out_dir)
     dist.destroy_process_group()
 
 
+def _config5_recorded(rec):
+    ref = {"gamg_levels": int(rec.scalar("config5/gamg_levels"))}
+    for tag in ("bicg", "gamg"):
+        ref[tag] = rec.perf(f"config5/{tag}")
+        ref[tag + "_sum"] = [float(v) for v in rec.scalar(f"config5/{tag}/rank_sum")]
+        ref[tag + "_abs"] = [float(v) for v in rec.scalar(f"config5/{tag}/rank_abs")]
+    return ref
+
+
 def test_config5_eight_engine_ranks_80M_cells(pkg, orc, tmp_path):
-    if _ram_gb() < 96:
-        pytest.skip("needs 96 GB of host memory: the oracle's eight 10 M-cell domains (twice) next to eight engine processes")
+    rec = None if fs.live_oracle() else fs.Records()
+    if _ram_gb() < (48 if rec else 96):
+        pytest.skip("needs 48 GB of host memory for eight engine processes (96 with the live oracle's eight 10 M-cell domains next to them)")
     syn = pkg.synthetic
     world = 8
     t0 = time.perf_counter()
-    procs = mp.spawn(_config5_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
-    # the multi-domain oracle meanwhile (its rows run under OpenMP)
-    ref = {}
-    for tag, symmetric in (("bicg", False), ("gamg", True)):
+    if rec:
+        run_ranks(world, "test_gpu_configs", "_config5_body", str(tmp_path), timeout=500.0)
+        ref = _config5_recorded(rec)
+        procs = None
+    else:
+        procs = mp.spawn(_config5_live_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+        ref = {}
+    # (live oracle:) the multi-domain oracle meanwhile (its rows run under OpenMP)
+    for tag, symmetric in ((("bicg", False), ("gamg", True)) if not rec else ()):
         subs = [syn.box_subdomain(DIMS5, PARTS5, r, symmetric=symmetric) for r in range(world)]
         S = orc.System(subs)
         n = sum(s.n_cells for s in subs)
@@ -175,7 +209,7 @@ def test_config5_eight_engine_ranks_80M_cells(pkg, orc, tmp_path):
         assert n == 432 ** 3
         del S, subs, rp
     t_orc = time.perf_counter() - t0
-    while not procs.join(timeout=5):
+    while procs is not None and not procs.join(timeout=5):
         pass
     t_all = time.perf_counter() - t0
     data = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]

@@ -12,12 +12,18 @@ reduction trees differ most from the oracle's long-double sums and where a tile-
   * GAMG (nCellsInCoarsestLevel 100, the config-3 solve) against orc.GamgHierarchy cycle by cycle (GAMGSolverSolve.C:59-160);
   * the box cut 2 x 2 x 2 (the 8-GPU partition of SURVEY.md 8e) through the distributed PCG phases on one GPU.
 
-The oracle's rows / vector updates run under OpenMP here (bitwise identical to its serial loops) so that the whole file
-stays within a few minutes on the GPU box's host cores.
+Round 5: the oracle's side of every comparison is a committed record (tests/golden/full_size_v1.npz, written on the CPU box by
+tests/golden/make_full_size.py from the same oracle calls; tests/full_size_ref.py says what is stored and
+tests/test_full_size_fixture.py re-derives a sample of it with the live oracle) -- the serial oracle at 10 M cells used to take
+~6 of the GPU suite's minutes.  MI_LIVE_ORACLE=1 runs the oracle in-process again (its rows / vector updates under OpenMP,
+bitwise identical to its serial loops).
 """
 import numpy as np
 import pytest
 import torch
+
+import full_size_ref as fs
+from full_size_ref import check_bits, check_solution
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +55,12 @@ def big(pkg, orc, ctx):
     addr = pkg.engine.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
     mat = pkg.engine.Matrix(addr)
     mat.set_coeffs(dev(case.diag), dev(case.upper), None)
-    return case, addr, mat, orc.System([case])
+    return case, addr, mat, (orc.System([case]) if fs.live_oracle() else None)
+
+
+@pytest.fixture(scope="module")
+def rec():
+    return None if fs.live_oracle() else fs.Records()
 
 
 def record(name, **vals):
@@ -87,73 +98,84 @@ def check_hist(perf, ref, name=None):
     assert abs(perf["normFactor"] - ref["normFactor"]) < 1e-13 * ref["normFactor"]
 
 
-def test_spmv_family_bit_exact_at_10M_cells(pkg, big):
+def test_spmv_family_bit_exact_at_10M_cells(pkg, big, rec):
     case, addr, mat, S = big
     n = case.n_cells
     x = pkg.synthetic.splitmix_uniform(99, n) - 0.5
     xd, bd = dev(x), dev(case.source)
     out = torch.empty(n, dtype=torch.float64, device="cuda:0")
-    mat.amul(xd, out); assert np.array_equal(host(out), S.amul(x))
-    mat.tmul(xd, out); assert np.array_equal(host(out), S.tmul(x))
-    mat.sumA(out); assert np.array_equal(host(out), S.sumA())
-    mat.residual(xd, bd, out); assert np.array_equal(host(out), S.residual(x, case.source))
-    mat.H(xd, out); assert np.array_equal(host(out), S.H(x))
-    mat.H1(out); assert np.array_equal(host(out), S.H1())
+    k = "box216_sym/"
+    ref = (lambda name, live: rec.sha(k + name)) if rec else (lambda name, live: live())      # sha256 of the oracle's result bits, or the bits
+    mat.amul(xd, out); check_bits(host(out), ref("amul", lambda: S.amul(x)))
+    mat.tmul(xd, out); check_bits(host(out), ref("tmul", lambda: S.tmul(x)))
+    mat.sumA(out); check_bits(host(out), ref("sumA", lambda: S.sumA()))
+    mat.residual(xd, bd, out); check_bits(host(out), ref("residual", lambda: S.residual(x, case.source)))
+    mat.H(xd, out); check_bits(host(out), ref("H", lambda: S.H(x)))
+    mat.H1(out); check_bits(host(out), ref("H1", lambda: S.H1()))
     for kind in ("diagonal", "AINV"):
         mat.precondition(kind, xd, out)
-        assert np.array_equal(host(out), S.precondition(kind, x)), kind
+        check_bits(host(out), ref("precondition_" + kind, lambda: S.precondition(kind, x)))
     psi = dev(x.copy())
     mat.jacobi_smooth(psi, bd, 2, omega=0.9)
-    assert np.array_equal(host(psi), S.jacobi_smooth(x, case.source, 2, omega=0.9))
+    check_bits(host(psi), ref("jacobi_2_sweeps", lambda: S.jacobi_smooth(x, case.source, 2, omega=0.9)))
 
 
-def test_asymmetric_spmv_bit_exact_at_10M_cells(pkg, orc, ctx):
+@pytest.fixture(scope="module")
+def big_asym(pkg, orc, ctx):
+    """the asymmetric 216^3 case (config 5's momentum-like matrix at the per-GPU size), its engine matrix, its oracle system"""
     case = pkg.synthetic.box_case(N, N, N, symmetric=False)
     addr = pkg.engine.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
     mat = pkg.engine.Matrix(addr)
     mat.set_coeffs(dev(case.diag), dev(case.upper), dev(case.lower))
-    S = orc.System([case])
+    return case, addr, mat, (orc.System([case]) if fs.live_oracle() else None)
+
+
+def test_asymmetric_spmv_bit_exact_at_10M_cells(pkg, big_asym, rec):
+    case, addr, mat, S = big_asym
     x = pkg.synthetic.splitmix_uniform(98, case.n_cells) - 0.5
     xd = dev(x)
     out = torch.empty(case.n_cells, dtype=torch.float64, device="cuda:0")
-    mat.amul(xd, out); assert np.array_equal(host(out), S.amul(x))
-    mat.tmul(xd, out); assert np.array_equal(host(out), S.tmul(x))
+    k = "box216_asym/"
+    mat.amul(xd, out); check_bits(host(out), rec.sha(k + "amul") if rec else S.amul(x))
+    mat.tmul(xd, out); check_bits(host(out), rec.sha(k + "tmul") if rec else S.tmul(x))
     for tr in (False, True):
         mat.precondition("AINV", xd, out, transpose=tr)
-        assert np.array_equal(host(out), S.precondition("AINV", x, transpose=tr)), tr
+        check_bits(host(out), rec.sha(f"{k}precondition_AINV_transpose{int(tr)}") if rec else S.precondition("AINV", x, transpose=tr))
 
 
 @pytest.mark.parametrize("precond", ["diagonal", "AINV"])
-def test_pcg_history_120_iterations_at_10M_cells(pkg, big, precond):
+def test_pcg_history_120_iterations_at_10M_cells(pkg, big, rec, precond):
     case, addr, mat, S = big
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(psi, dev(case.source), precond, tolerance=0.0, maxIter=120)
-    ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=0.0, maxIter=120)
+    if rec:
+        ref_psi, ref = rec.solution(f"box216_sym/pcg_{precond}_120"), rec.perf(f"box216_sym/pcg_{precond}_120")
+    else:
+        ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=0.0, maxIter=120)
     assert ref["nIterations"] == 121
     check_hist(perf, ref, f"pcg_{precond}_120_iterations")
-    assert np.max(np.abs(host(psi) - ref_psi)) < 1e-10 * np.max(np.abs(ref_psi))
+    check_solution(host(psi), ref_psi, 1e-10)
 
 
-def test_pcg_to_convergence_same_iteration_count_at_10M_cells(pkg, big):
+def test_pcg_to_convergence_same_iteration_count_at_10M_cells(pkg, big, rec):
     case, addr, mat, S = big
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=1e-6, maxIter=5000)
-    ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-6, maxIter=5000)
+    if rec:
+        ref_psi, ref = rec.solution("box216_sym/pcg_diagonal_to_1e-6"), rec.perf("box216_sym/pcg_diagonal_to_1e-6")
+    else:
+        ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-6, maxIter=5000)
     assert ref["converged"] and ref["nIterations"] > 500
     check_hist(perf, ref, "pcg_diagonal_to_1e-6")
-    assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+    check_solution(host(psi), ref_psi, 1e-9)
 
 
 @pytest.mark.parametrize("solver", ["PBiCG", "PBiCGStab"])
-def test_asymmetric_krylov_history_at_10M_cells(pkg, orc, ctx, solver):
+def test_asymmetric_krylov_history_at_10M_cells(pkg, big_asym, rec, solver):
     """BASELINE config 5's momentum solve (PBiCG + DILU; PBiCGStab as the reference writes it) at 216^3: 40 / 24 fixed iterations
     of the device-resident loops against the oracle, every entry within 1e-10 of the normalised initial residual
     (PBiCG.C:67-246, PBiCGStab.C:67-300)"""
-    case = pkg.synthetic.box_case(N, N, N, symmetric=False)
-    addr = pkg.engine.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
-    mat = pkg.engine.Matrix(addr)
-    mat.set_coeffs(dev(case.diag), dev(case.upper), dev(case.lower))
-    S = orc.System([case])
+    case, addr, mat, S = big_asym
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     # (PBiCGStab's residual recursion amplifies rounding differences -- between any two summation orders -- by about a decade
     #  every three iterations on this matrix: 1e-17 at the start, 1e-10 after ~35 iterations, 6e-6 after 41; 24 iterations keep
@@ -161,18 +183,20 @@ def test_asymmetric_krylov_history_at_10M_cells(pkg, orc, ctx, solver):
     kw = dict(tolerance=0.0, maxIter=40 if solver == "PBiCG" else 24)
     if solver == "PBiCG":
         perf = mat.pbicg(psi, dev(case.source), "DILU", **kw)
-        ref_psi, ref = S.pbicg(np.zeros(case.n_cells), case.source, "AINV", **kw)
+        key = "box216_asym/pbicg_AINV_40"
+        ref_psi, ref = (rec.solution(key), rec.perf(key)) if rec else S.pbicg(np.zeros(case.n_cells), case.source, "AINV", **kw)
     else:
         perf = mat.pbicgstab(psi, dev(case.source), "DILU", **kw)
-        ref_psi, ref = S.pbicgstab(np.zeros(case.n_cells), case.source, "AINV", **kw)
+        key = "box216_asym/pbicgstab_AINV_24"
+        ref_psi, ref = (rec.solution(key), rec.perf(key)) if rec else S.pbicgstab(np.zeros(case.n_cells), case.source, "AINV", **kw)
     assert perf["nIterations"] == ref["nIterations"]
     h, hr = perf["history"], ref["history"]
     record(f"{solver}_DILU_{kw['maxIter']}_iterations", max_dev_over_initial=hist_dev(h, hr)[0], max_rel_dev_first_10=hist_dev(h, hr)[1], bar=HIST_RTOL)
     assert h.shape == hr.shape and np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
-    assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+    check_solution(host(psi), ref_psi, 1e-9)
 
 
-def test_pbicgstab_past_the_comparable_window_true_residuals_agree(pkg, orc, ctx):
+def test_pbicgstab_past_the_comparable_window_true_residuals_agree(pkg, big_asym, rec):
     """VERDICT r02 "weak" 3: PBiCGStab's residual RECURSION amplifies any rounding difference between two summation orders (about
     a decade per 3 iterations with DILU, per ~8 with the diagonal preconditioner on this matrix), so histories are only compared
     for 24 iterations above.  The later iterations are not simply unobserved: after 48 iterations (zA form, PBiCGStab.C:263-270
@@ -180,19 +204,25 @@ def test_pbicgstab_past_the_comparable_window_true_residuals_agree(pkg, orc, ctx
     of the engine's psi -- evaluated with the oracle's operator --
       * equals the engine's own recursive residual to 1e-6 relative (the recursion has not drifted from the solution it
         describes; observed 1e-13 between two orders of the oracle at 96^3),
-      * and lies within a factor 10 of the oracle's true residual at the same iteration (observed there: 12 %)."""
-    case = pkg.synthetic.box_case(N, N, N, symmetric=False)
-    addr = pkg.engine.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
-    mat = pkg.engine.Matrix(addr)
-    mat.set_coeffs(dev(case.diag), dev(case.upper), dev(case.lower))
-    S = orc.System([case])
+      * and lies within a factor 10 of the oracle's true residual at the same iteration (observed there: 12 %).
+    (With the recorded oracle the engine's psi is evaluated by the engine's own residual operator -- bit-identical to the oracle's
+    on this very matrix, test_asymmetric_spmv_bit_exact_at_10M_cells / test_spmv_family_bit_exact_at_10M_cells -- and summed on the
+    host.)"""
+    case, addr, mat, S = big_asym
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     kw = dict(tolerance=0.0, maxIter=48)
     perf = mat.pbicgstab(psi, dev(case.source), "diagonal", replicate_quirk=False, **kw)
-    ref_psi, ref = S.pbicgstab(np.zeros(case.n_cells), case.source, "diagonal", replicate_quirk=False, **kw)
+    if rec:
+        ref = rec.perf("box216_asym/pbicgstab_diagonal_zA_48")
+        true_o = float(rec.scalar("box216_asym/pbicgstab_diagonal_zA_48/true_residual"))
+        rA = torch.empty_like(psi)
+        mat.residual(psi, dev(case.source), rA)
+        true_e = float(np.abs(host(rA)).sum() / ref["normFactor"])
+    else:
+        ref_psi, ref = S.pbicgstab(np.zeros(case.n_cells), case.source, "diagonal", replicate_quirk=False, **kw)
+        true_e = float(np.abs(S.residual(host(psi), case.source)).sum() / ref["normFactor"])
+        true_o = float(np.abs(S.residual(ref_psi, case.source)).sum() / ref["normFactor"])
     assert perf["nIterations"] == ref["nIterations"] == 49
-    true_e = float(np.abs(S.residual(host(psi), case.source)).sum() / ref["normFactor"])
-    true_o = float(np.abs(S.residual(ref_psi, case.source)).sum() / ref["normFactor"])
     rec_e = float(perf["history"][-1])
     record("PBiCGStab_diagonal_zA_48_iterations", engine_true_residual=true_e, engine_recursive_residual=rec_e, oracle_true_residual=true_o,
            oracle_recursive_residual=float(ref["history"][-1]), history_dev_over_initial=hist_dev(perf["history"], ref["history"])[0])
@@ -201,13 +231,17 @@ def test_pbicgstab_past_the_comparable_window_true_residuals_agree(pkg, orc, ctx
     assert true_e < 1e-3 * perf["history"][0]          # and the solve has really progressed by then
 
 
-def test_gamg_history_at_10M_cells(pkg, orc, big):
+def test_gamg_history_at_10M_cells(pkg, orc, big, rec):
     case, addr, mat, S = big
     w = orc.box_face_weights(case)
-    H = orc.GamgHierarchy(case, w, 100)
-    ref_psi, ref = H.solve(np.zeros(case.n_cells), case.source, tolerance=1e-6, maxIter=100)
+    if rec:
+        ref_psi, ref, n_levels = rec.solution("box216_sym/gamg_to_1e-6"), rec.perf("box216_sym/gamg_to_1e-6"), int(rec.scalar("box216_sym/gamg_levels"))
+    else:
+        H = orc.GamgHierarchy(case, w, 100)
+        ref_psi, ref = H.solve(np.zeros(case.n_cells), case.source, tolerance=1e-6, maxIter=100)
+        n_levels = H.n_levels
     G = pkg.engine.Gamg(addr, w, 100)
-    assert G.n_levels == H.n_levels
+    assert G.n_levels == n_levels
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = G.solve(mat, psi, dev(case.source), tolerance=1e-6, maxIter=100)
     assert ref["converged"]
@@ -215,22 +249,25 @@ def test_gamg_history_at_10M_cells(pkg, orc, big):
     h, hr = perf["history"], ref["history"]
     record("gamg_to_1e-6", cycles=int(ref["nIterations"]), max_dev_over_initial=hist_dev(h, hr)[0], max_rel_dev_first_10=hist_dev(h, hr)[1], bar=HIST_RTOL)
     assert h.shape == hr.shape and np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
-    assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+    check_solution(host(psi), ref_psi, 1e-9)
 
 
-def test_decomposed_2x2x2_pcg_at_10M_cells(pkg, orc, big):
+def test_decomposed_2x2x2_pcg_at_10M_cells(pkg, orc, big, rec):
     """the 8-GPU block partition of the 216^3 box, all eight sub-domains on this one GPU: per-rank tiled
     matrices, interface slots, interior / boundary tile split, halo pack, with the exchange done by device copies and the
     all-reduce by summing the ranks' scalar blocks -- against the SERIAL oracle on the undivided box"""
     from test_gpu_parity import run_decomposed_pcg
     case, addr, mat, S = big
     kw = dict(tolerance=0.0, relTol=0.0, maxIter=60, minIter=0)
-    ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=0.0, maxIter=60)
+    if rec:
+        ref_psi, ref = rec.solution("box216_sym/pcg_diagonal_60"), rec.perf("box216_sym/pcg_diagonal_60")
+    else:
+        ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=0.0, maxIter=60)
     run_decomposed_pcg(pkg, case, (2, 2, 2), kw, ref_psi, ref)
 
 
 @pytest.mark.parametrize("form", ["single_rank", "distributed_self_exchange"])
-def test_persistent_pcg_kernel_at_its_design_point_108_cubed(pkg, orc, form, monkeypatch):
+def test_persistent_pcg_kernel_at_its_design_point_108_cubed(pkg, orc, rec, form, monkeypatch):
     """csrc/persist.inc AT THE SIZE IT WAS BUILT FOR (VERDICT r03 "weak" 1): 108^3 cells = the 8-GPU share of the 10 M-cell
     benchmark = 1 231 tiles on the full 256-workgroup grid, five tiles per workgroup (96 % of the kernel's capacity) -- the
     single-rank form and the distributed form (y-periodic box posed as processor patches to self: every halo store, flag and
@@ -245,10 +282,13 @@ def test_persistent_pcg_kernel_at_its_design_point_108_cubed(pkg, orc, form, mon
     if dist:
         monkeypatch.setenv("MI_ALLREDUCE", "peer")
         case = syn.add_cyclic_y(case)
-    S = orc.System([case])
+    S = None if rec else orc.System([case])
     n = case.n_cells
     for tag, okw in (("300_iterations", dict(tolerance=0.0, maxIter=299)), ("to_1e-8", dict(tolerance=1e-8, maxIter=3000))):
-        ref_psi, ref = S.pcg(np.zeros(n), case.source, "diagonal", **okw)
+        if rec:
+            ref_psi, ref = rec.solution(f"persist108/{form}/{tag}"), rec.perf(f"persist108/{form}/{tag}")
+        else:
+            ref_psi, ref = S.pcg(np.zeros(n), case.source, "diagonal", **okw)
         if dist:
             solver = par.DistributedPCG(ctx, case, "cuda:0", precond="diagonal", n_global=n)
             assert solver.driver == "native" and solver.ops.addr.n_tiles > 4 * 256
@@ -273,7 +313,7 @@ def test_persistent_pcg_kernel_at_its_design_point_108_cubed(pkg, orc, form, mon
         late = float(np.max(np.abs(h - hr) / np.maximum(np.abs(hr), 1e-300)))
         record(f"persistent_kernel_108_cubed_{form}_{tag}", iterations=int(ref["nIterations"]), max_dev_over_initial=d_all, max_rel_dev_first_10=d_first,
                max_rel_dev_any_iteration=late, final_residual_over_initial=float(hr[-1] / hr[0]), bar=HIST_RTOL,
-               psi_rel_dev=float(np.max(np.abs(got - ref_psi)) / np.max(np.abs(ref_psi))))
+               psi_rel_dev=ref_psi.deviation(got) if rec else float(np.max(np.abs(got - ref_psi)) / np.max(np.abs(ref_psi))))
         assert d_all < HIST_RTOL and d_first < HIST_RTOL
-        assert late < 1e-3                                  # per-workgroup sum grouping: rounding-level drift late in the solve
-        assert np.max(np.abs(got - ref_psi)) < 1e-8 * np.max(np.abs(ref_psi))
+        assert late < 1e-9                                  # per-workgroup sum grouping: rounding-level drift late in the solve (seen: 1.1e-12 at a residual of 1e-8)
+        check_solution(got, ref_psi, 1e-8)

@@ -4,6 +4,8 @@ Bars (north_star): SpMV-family outputs are BIT-EXACT against the oracle (same fm
 order); reductions agree to 1e-14 relative (different but deterministic tree); solver residual
 histories agree to 1e-10 relative with identical iteration counts.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -129,25 +131,55 @@ def test_reductions(pkg, orc, ctx, n):
     assert ctx.sum_prod(ad, bd) == ctx.sum_prod(ad, bd)
 
 
-PERSIST_REL = 1e-3   # late per-iteration bar of solves that may run through the persistent kernel (sums grouped per workgroup)
+# Solves that may run through the persistent kernel (csrc/persist.inc): its sums are grouped per workgroup, not per 1024-cell
+# chunk like the five-launch loop's, and CG amplifies that rounding difference as the residual falls.  The bar follows what the
+# kernel delivers (VERDICT r04 "next" 2; gpurun_out/parity_small_observed.json keeps the observed figures, profiles/ the round's
+# copy): every history entry within 1e-6 RELATIVE of the oracle's, except where the residual has fallen so far that 1e-6 of it is
+# below 2e-13 of the INITIAL residual -- there the absolute deviation must stay under that floor (seen: 6.8e-14 at a residual of
+# 1e-9, i.e. 5e-5 relative, box_sym / none; 1.1e-12 relative at 108^3 down to 1e-8).
+PERSIST_REL = 1e-6
+PERSIST_FLOOR = 2e-13
 
 
-def _check_hist(perf, ref, rel=1e-5):
+def _observe(name, h, hr, rel, floor):
+    """append the observed deviations of one history comparison to gpurun_out/parity_small_observed.json"""
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    f = os.path.join(out, "parity_small_observed.json")
+    try:
+        d = json.load(open(f))
+    except Exception:
+        d = {}
+    dev_abs = np.abs(h - hr) / hr[0]
+    dev_rel = np.abs(h - hr) / np.maximum(np.abs(hr), 1e-300)
+    above = np.abs(hr) * rel >= floor * hr[0] if floor > 0 else np.ones(hr.shape, bool)
+    d[name] = dict(iterations=int(h.shape[0] - 1), final_residual_over_initial=float(hr[-1] / hr[0]), max_dev_over_initial=float(dev_abs.max()),
+                   max_rel_dev_any_iteration=float(dev_rel.max()), max_rel_dev_where_the_relative_bar_applies=float(dev_rel[above].max()) if above.any() else 0.0,
+                   max_dev_over_initial_below_it=float(dev_abs[~above].max()) if (~above).any() else 0.0, rel_bar=rel, floor_over_initial=floor)
+    json.dump(d, open(f, "w"), indent=1, sort_keys=True)
+
+
+def _check_hist(perf, ref, rel=1e-5, floor=0.0):
     """rel: per-iteration relative bar over the WHOLE history.  1e-5 for every pipeline whose sums are grouped like the
-    five-launch loop's (they were bit-identical to each other before the persistent kernel existed); the persistent kernel's
-    tests pass 1e-3 (sums grouped per workgroup: 5e-5 seen at a residual of 1e-9 of the initial one)."""
+    five-launch loop's (they were bit-identical to each other before the persistent kernel existed); solves that may take the
+    persistent kernel pass rel=PERSIST_REL, floor=PERSIST_FLOOR: |h - hr| < max(rel * hr, floor * hr[0]) entry by entry."""
     assert perf["nIterations"] == ref["nIterations"]
     assert perf["converged"] == ref["converged"] and perf["singular"] == ref["singular"]
     h, hr = perf["history"], ref["history"]
     assert h.shape == hr.shape
+    if floor > 0:
+        _observe(os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0], h, hr, rel, floor)
     # north_star bar: residual histories within 1e-10 relative (to the normalised initial residual;
     # CG amplifies last-bit differences of the reduction tree as the residual falls, so the
-    # per-iteration relative check is looser -- the oracle's own serial-vs-decomposed drift is 1e-8; the persistent kernel, whose
-    # sums are grouped per workgroup, was seen at 5e-5 of a residual that had fallen to 1e-9 of the initial one: 7e-14 of the bar's unit)
+    # per-iteration relative check is looser -- the oracle's own serial-vs-decomposed drift is 1e-8)
     assert np.max(np.abs(h - hr)) < HIST_RTOL * hr[0]
     assert np.max(np.abs(h[:10] - hr[:10]) / np.maximum(np.abs(hr[:10]), 1e-300)) < HIST_RTOL
-    assert np.max(np.abs(h - hr) / np.maximum(np.abs(hr), 1e-300)) < rel
+    assert np.all(np.abs(h - hr) < np.maximum(rel * np.abs(hr), floor * hr[0]))
     assert abs(perf["normFactor"] - ref["normFactor"]) < 1e-13 * ref["normFactor"]
+
+
+PERSIST = dict(rel=PERSIST_REL, floor=PERSIST_FLOOR)
 
 
 @pytest.mark.parametrize("precond", ["none", "diagonal", "AINV", "DIC"])
@@ -158,7 +190,7 @@ def test_pcg_residual_history(pkg, orc, ctx, name, precond):
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(psi, dev(case.source), precond, tolerance=1e-9, maxIter=400)
     ref_psi, ref = orc.System([case]).pcg(np.zeros(case.n_cells), case.source, precond, tolerance=1e-9, maxIter=400)
-    _check_hist(perf, ref, rel=PERSIST_REL if precond in ("none", "diagonal") else 1e-5)   # (small matrix, diagonal / none: the persistent kernel)
+    _check_hist(perf, ref, **(PERSIST if precond in ("none", "diagonal") else {}))   # (small matrix, diagonal / none: the persistent kernel)
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-10 * np.max(np.abs(ref_psi))
 
 
@@ -172,14 +204,14 @@ def test_pcg_controls(pkg, orc, ctx):
         psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
         perf = mat.pcg(psi, dev(case.source), "diagonal", **kw)
         ref_psi, ref = S.pcg(z, case.source, "diagonal", **kw)
-        _check_hist(perf, ref, rel=PERSIST_REL)
+        _check_hist(perf, ref, **PERSIST)
         assert np.max(np.abs(host(psi) - ref_psi)) <= 1e-10 * max(np.max(np.abs(ref_psi)), 1e-300)
     # non-zero initial guess
     x0 = pkg.synthetic.splitmix_uniform(8, case.n_cells) * 1e-3
     psi = dev(x0.copy())
     perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=1e-8)
     _, ref = S.pcg(x0, case.source, "diagonal", tolerance=1e-8)
-    _check_hist(perf, ref, rel=PERSIST_REL)
+    _check_hist(perf, ref, **PERSIST)
     # singular: zero residual => wApA == 0 => break without counting the iteration
     zero = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(zero.clone(), zero, "diagonal", tolerance=0.0, maxIter=5)
@@ -329,7 +361,8 @@ def run_decomposed_pcg(pkg, case, parts, kw, ref_psi, ref):
         assert st["history"].shape == ref["history"].shape
         assert np.max(np.abs(st["history"] - ref["history"])) < HIST_RTOL * ref["history"][0]
         psi[s.global_cells] = o.solution()
-    assert np.max(np.abs(psi - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
+    from full_size_ref import check_solution
+    check_solution(psi, ref_psi, 1e-9)       # ref_psi: the oracle's vector, or its committed record (tests/full_size_ref.py)
 
 
 def test_error_behaviour_of_the_abi(pkg, ctx):
@@ -408,7 +441,7 @@ def test_cyclic_interfaces(pkg, orc, ctx, symmetric):
         mat.tmul(dev(x), out); assert np.array_equal(host(out), S.tmul(x))
         perf = mat.pbicg(psi, dev(case.source), "DILU", tolerance=1e-10, maxIter=300)
         ref_psi, ref = S.pbicg(np.zeros(n), case.source, "AINV", tolerance=1e-10, maxIter=300)
-    _check_hist(perf, ref, rel=PERSIST_REL)
+    _check_hist(perf, ref, **PERSIST)
     assert np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
 
 
@@ -702,7 +735,7 @@ def test_persistent_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, di
         assert ctx.stat(1) > before                              # the persistent kernel really ran
         assert solver.ops.mat.peer_halo_status() == (True, 0) and solver.comms[0].peer_status()[0] == 0
         ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, precond, tolerance=1e-9, maxIter=500)
-        _check_hist(st, ref, rel=1e-3)
+        _check_hist(st, ref, **PERSIST)
         assert np.max(np.abs(solver.ops.solution() - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
         # mixed batches: persistent, five-launch (Amul timing), persistent
         solver.begin(tolerance=0.0, max_iter=200)
@@ -725,7 +758,7 @@ def test_persistent_distributed_pcg_over_peer_windows_self_exchange(pkg, orc, di
     psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
     perf = mat.pcg(psi, dev(case.source), "diagonal", tolerance=1e-9, maxIter=500)
     ref_psi, ref = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=1e-9, maxIter=500)
-    _check_hist(perf, ref, rel=1e-3)
+    _check_hist(perf, ref, **PERSIST)
     assert ctx.stat(1) > before and np.max(np.abs(host(psi) - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
     mat.detach_comm(); comm.close()
 
@@ -957,7 +990,7 @@ def test_pcg_session_owns_the_context_scratch(pkg, orc, ctx):
     mat.pcg_iterate(400)
     perf = mat.pcg_end(psi0, history_len=302)
     _, ref = orc.System([case]).pcg(np.zeros(n), case.source, "diagonal", tolerance=1e-9, maxIter=300)
-    _check_hist(perf, ref, rel=PERSIST_REL)
+    _check_hist(perf, ref, **PERSIST)
     assert abs(ctx.sum(x) - float(np.sum(host(x).astype(np.longdouble)))) < 1e-12 * n   # usable again after mi_pcg_end
 
 
@@ -1007,7 +1040,7 @@ def test_ordered_addressing_runs_on_the_callers_numbering(pkg, orc, ctx, name):
     else:
         perf = mat.pbicg(psi, bd, "AINV", tolerance=1e-10, maxIter=300)
         ref_psi, ref = S.pbicg(np.zeros(n), rc.source, "AINV", tolerance=1e-10, maxIter=300)
-    _check_hist(perf, ref, rel=PERSIST_REL)
+    _check_hist(perf, ref, **PERSIST)
     # greedy tiles (no tile starts given): still the identity, still exact
     addr_g = eng.Addressing(ctx, rc.n_cells, rc.lower_addr, rc.upper_addr, ordered=True)
     assert addr_g.is_ordered
