@@ -245,7 +245,14 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
                         bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         const unsigned long long chk = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         if ((bits ^ chk) == a.xKey) break;
-                        if (++polls > a.xPolls || *a.xStatus != 0) { *a.xStatus = 1; break; }   // a neighbour that never arrives must not hang the device
+                        // a neighbour that never arrives must not hang the device: the status word is read and written with atomics
+                        // (every lane sees another lane's fault; a plain load could be hoisted out of the loop), and the lane that
+                        // gives up stages a NaN, so the fault reaches the sums and the caller's peer_check
+                        if (++polls > a.xPolls || __hip_atomic_load(a.xStatus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            __hip_atomic_store(a.xStatus, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bits = 0x7ff8000000000000ull;
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(1);
                     }
                     v = __longlong_as_double((long long)bits);
@@ -467,10 +474,22 @@ __global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const 
     constexpr int NV = (OP == OP_SUMA) ? NRHS : 2 * NRHS;
     constexpr int NRD = SRD ? 1 : NRHS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    // ONE workgroup per CU (the image of 2 NRHS operands + both triangles takes 134-148 KB of LDS): nothing else hides a memory
+    // round trip, so the staging is written as THREE dependent rounds, not one per array (round 4 had ~17: the `done` flags one
+    // after the other, then per operand  index -> wait -> value -> wait  behind the coefficient DMA, then the diagonal after the
+    // barrier; 19.6 us per tile, 0.28-0.32 of the HBM roofline -- profiles/r04_pbicg_rocprof_summary.md):
+    //   1. the components' `done` flags, together;
+    //   2. the tile's halo indices (the same for every operand), the first slice's entries;
+    //   3. everything else at once: coefficient and own-cell DMA, every operand's halo values, the first slice's diagonals.
     bool act[NRHS];
     bool any = false;
+    {
+        int dn[NRHS];
 #pragma unroll
-    for (int c = 0; c < NRHS; ++c) { act[c] = !(V.done[c] && *V.done[c]); any = any || act[c]; }
+        for (int c = 0; c < NRHS; ++c) dn[c] = *(V.done[c] ? V.done[c] : &a.tileCellStart[0]);   // (any readable word when there is no flag)
+#pragma unroll
+        for (int c = 0; c < NRHS; ++c) { act[c] = !(V.done[c] && dn[c]); any = any || act[c]; }
+    }
     if (!any) return;
     const int b = blockIdx.x, per = gridDim.x >> 3;
     const int t = (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;     // XCD-aware, as tile_kernel
@@ -484,27 +503,11 @@ __global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const 
     const int s0 = a.tileSlotStart[t], ns = a.tileSlotStart[t + 1] - s0;
     const int h0 = a.tileHaloStart[t], nh = a.tileHaloStart[t + 1] - h0;
     const int ifs0 = (OP == OP_AINV) ? a.tileIfaceSlot0[t] : 0;
-    stage_dma16<BS, true>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid >> 6, tid & 63);
-    stage_dma16<BS, true>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
-    if (OP != OP_SUMA) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            if (!act[v % NRHS]) continue;
-            stage_dma8<BS>(V.x[v] + c0, xs + v * xlen, nc, tid);
-            stage_gather<BS>(V.x[v], a.haloCell + h0, xs + v * xlen + nc, nh, tid);
-        }
-    }
-    if (OP == OP_AINV) {
-#pragma unroll
-        for (int c = 0; c < NRD; ++c) {
-            stage_dma8<BS>(V.rD[c] + c0, rDs + c * xlen, nc, tid);
-            stage_gather<BS>(V.rD[c], a.haloCell + h0, rDs + c * xlen + nc, nh, tid);
-        }
-    }
     const int sl0 = a.tileSliceStart[t], nsl = a.tileSliceStart[t + 1] - sl0;
     const int wave = tid >> 6, lane = tid & 63;
     constexpr int NW = BS / 64;
     constexpr int PRE = 8;
+    constexpr int HK = 2;                   // halo values through registers: HK per lane (more halo cells than HK * BS: the loop below)
     const uint32_t padEnt = (uint32_t)(ns - 1) << 16;   // last slot of the segment is always 0.0
     uint32_t ecur[PRE];
     int wcur = 0, e0cur = 0;
@@ -516,10 +519,72 @@ __global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const 
 #pragma unroll
         for (int j = 0; j < PRE; ++j) e[j] = (j < width) ? ent[j * 64] : padEnt;
     };
+    // round 2
+    int hidx[HK];
+#pragma unroll
+    for (int k = 0; k < HK; ++k) hidx[k] = (OP != OP_SUMA && tid + k * BS < nh) ? a.haloCell[h0 + tid + k * BS] : -1;
     if (wave < nsl) fetch(wave, ecur, e0cur, wcur);
     else {
 #pragma unroll
         for (int j = 0; j < PRE; ++j) ecur[j] = padEnt;
+    }
+    asm volatile("" ::: "memory");          // (round 2 is issued before round 3, not sunk to its uses)
+    // round 3
+    double hv[(OP == OP_SUMA) ? 1 : NV][HK], hr[NRD][HK];
+    if (OP != OP_SUMA) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < HK; ++k) hv[v][k] = (hidx[k] >= 0 && act[v % NRHS]) ? V.x[v][hidx[k]] : 0.0;
+    }
+    if (OP == OP_AINV) {
+#pragma unroll
+        for (int c = 0; c < NRD; ++c)
+#pragma unroll
+            for (int k = 0; k < HK; ++k) hr[c][k] = hidx[k] >= 0 ? V.rD[c][hidx[k]] : 0.0;
+    }
+    double dg0[NRHS];                       // the first slice's diagonals (every wave has exactly one slice when nsl <= NW)
+    {
+        const int i = wave * 64 + lane;
+        const int gi = c0 + ((wave < nsl && i < nc) ? i : 0);
+#pragma unroll
+        for (int c = 0; c < NRHS; ++c) dg0[c] = (OP == OP_AINV) ? 0.0 : V.diag[c][gi];
+    }
+    stage_dma16<BS, true>(reinterpret_cast<const double2*>(a.up + s0), reinterpret_cast<double2*>(cU), ns >> 1, tid >> 6, tid & 63);
+    stage_dma16<BS, true>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
+    if (OP != OP_SUMA) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!act[v % NRHS]) continue;
+            stage_dma8<BS>(V.x[v] + c0, xs + v * xlen, nc, tid);
+        }
+    }
+    if (OP == OP_AINV) {
+#pragma unroll
+        for (int c = 0; c < NRD; ++c) stage_dma8<BS>(V.rD[c] + c0, rDs + c * xlen, nc, tid);
+    }
+    // every load of round 3 is in flight before the first wait: the LDS writes of the gathered values (which wait for ALL
+    // outstanding loads -- one counter) must not be scheduled above the DMA issue
+    asm volatile("" ::: "memory");
+    if (OP != OP_SUMA) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k = 0; k < HK; ++k) if (hidx[k] >= 0 && act[v % NRHS]) xs[v * xlen + nc + tid + k * BS] = hv[v][k];
+        if (nh > HK * BS) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) if (act[v % NRHS]) stage_gather<BS>(V.x[v], a.haloCell + h0 + HK * BS, xs + v * xlen + nc + HK * BS, nh - HK * BS, tid);
+        }
+    }
+    if (OP == OP_AINV) {
+#pragma unroll
+        for (int c = 0; c < NRD; ++c)
+#pragma unroll
+            for (int k = 0; k < HK; ++k) if (hidx[k] >= 0) rDs[c * xlen + nc + tid + k * BS] = hr[c][k];
+        if (nh > HK * BS) {
+#pragma unroll
+            for (int c = 0; c < NRD; ++c) stage_gather<BS>(V.rD[c], a.haloCell + h0 + HK * BS, rDs + c * xlen + nc + HK * BS, nh - HK * BS, tid);
+        }
     }
     __syncthreads();
     double dot[NRHS];
@@ -540,8 +605,9 @@ __global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const 
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             xi[v] = (OP != OP_SUMA && live && act[v % NRHS]) ? xs[v * xlen + i] : 0.0;
-            if (OP == OP_AMUL) acc[v] = V.diag[v % NRHS][gi] * xi[v];
-            else if (OP == OP_SUMA) acc[v] = V.diag[v][gi];
+            const double dgv = (OP == OP_AINV) ? 0.0 : (s == wave ? dg0[v % NRHS] : V.diag[v % NRHS][gi]);
+            if (OP == OP_AMUL) acc[v] = dgv * xi[v];
+            else if (OP == OP_SUMA) acc[v] = dgv;
             else acc[v] = 0.0;
         }
         auto accumulate = [&](uint32_t en) {
