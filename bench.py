@@ -255,6 +255,7 @@ def main():
     host_enqueue_us = None
     host_loop = "single-GPU device-resident pipeline (mi_pcg_iterate)"
     allreduce_kind = "none (one rank)"
+    path_taken, fallback_reason = "single-gpu five-launch pipeline", None
     weak = None
     supplements = {}
     if single:
@@ -308,6 +309,17 @@ def main():
                 t0 = time.perf_counter()
                 supplements["timestep_216"] = workloads.timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=G, steps=3)
                 log(f"[bench] supplement time step: {supplements['timestep_216']['ms_per_time_step']:.2f} ms ({time.perf_counter() - t0:.1f}s)")
+                # BASELINE config 5's own solver: rhoPimpleFoam's UEqn / EEqn / pEqn (non-transonic, and the transonic form whose pressure
+                # matrix is asymmetric), per-rank share, on the same box
+                t0 = time.perf_counter()
+                try:
+                    supplements["rhopimple_timestep_216"] = {"non_transonic": workloads.rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=G, steps=3),
+                                                             "transonic": workloads.rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=G, steps=3, transonic=True)}
+                    log(f"[bench] supplement rhoPimpleFoam step: {supplements['rhopimple_timestep_216']['non_transonic']['ms_per_time_step']:.2f} ms, transonic "
+                        f"{supplements['rhopimple_timestep_216']['transonic']['ms_per_time_step']:.2f} ms ({time.perf_counter() - t0:.1f}s)")
+                except Exception as e:
+                    supplements["rhopimple_timestep_216"] = {"error": f"{type(e).__name__}: {e}"}
+                    log(f"[bench] rhoPimpleFoam supplement failed: {type(e).__name__}: {e}")
                 del G
             except Exception as e:  # a supplement must never cost the headline line
                 supplements["error"] = f"{type(e).__name__}: {e}"
@@ -379,6 +391,16 @@ def main():
                          ("one persistent cooperative kernel per batch of iterations (csrc/persist.inc)" if in_kernel else "five launches per iteration") +
                          " (mi_dpcg_comm_iterate)")
         allreduce_kind = (getattr(solver, "allreduce", "torch.distributed") + peer_note) if world > 1 else "none (one rank)"
+        # the same, machine-readable (VERDICT r04 "next" 9): which inner loop the timed region ran and, if it is not the first choice, why
+        if world == 1:
+            path_taken = "single-gpu five-launch pipeline"
+        elif solver.driver == "native" and getattr(solver.comms[0], "peer_mode", False):
+            path_taken = "peer windows, persistent kernel" if in_kernel else "peer windows, five launches"
+        elif solver.driver == "native":
+            path_taken = "rccl, five launches"
+        else:
+            path_taken = "torch.distributed loop"
+        fallback_reason = peer_note.strip(" ()") or None
         for _ in range(R):
             torch.cuda.synchronize()
             if world > 1:
@@ -485,7 +507,7 @@ def main():
             "cells": N, "faces": F, "parallelism": f"domain-decomposition {parts_for(world)}" if world > 1 else "single GPU",
             "pcg_algorithmic_GBps": (160 * N + 16 * F) * its / 1e9,
             "host_enqueue_us_per_step": host_enqueue_us, "host_loop": host_loop,
-            "allreduce": allreduce_kind,
+            "allreduce": allreduce_kind, "path_taken": path_taken, "fallback_reason": fallback_reason,
             "timing": f"median of {R} repeats of the timed region of {K} steps (barrier + synchronize on both sides of each repeat, max over ranks)",
             "repeat_ms_per_step": [1e3 * t / K for t in rep_s], "repeat_amul_us_in_loop": [1e3 * a / K for a in rep_amul_ms],
             "amul_alone_us_rotating_buffers": amul_alone_us,

@@ -453,6 +453,37 @@ int mi_limited_linear_weights(mi_addr_t addr, double k, const double *cd_weights
 int mi_gauss_grad(mi_addr_t addr, const double *sfx_dev, const double *sfy_dev, const double *sfz_dev,
                   const double *ssf_dev, const double *vol_dev_or_null, double *gx_dev, double *gy_dev, double *gz_dev);
 int mi_vec_axpby(mi_ctx_t ctx, int64_t n, double a, const double *x_dev, double b, const double *y_dev, double *out_dev);
+/* ---- the compressible operators of rhoPimpleFoam (BASELINE config 5; round 5) ----
+ * mi_fvm_ddt_euler_rho: fvm::ddt(rho, vf) with a density FIELD -- EulerDdtScheme<Type>::fvmDdt(const volScalarField& rho, vf),
+ *   src/finiteVolume/finiteVolume/ddtSchemes/EulerDdtScheme/EulerDdtScheme.C:403-440:
+ *     diag = rDeltaT*rho*V, source = rDeltaT*rho.oldTime()*vf.oldTime()*V   (rhoPimpleFoam/UEqn.H:5, EEqn.H:6; with psi in rho's
+ *   place fvm::ddt(psi, p), pEqn.H:38,62).
+ * mi_fvm_su / mi_fvm_sp / mi_fvm_susp: src/finiteVolume/finiteVolume/fvm/fvmSup.C:34-54 (source -= V*su), :100-170 (diag += V*sp;
+ *   sp_dev NULL => the dimensionedScalar form with sp_value), :190-214 (diag += V*max(susp,0); source -= V*min(susp,0)*vf) -- in
+ *   place on the matrix's diagonal / source (fvOptions(rho, U), the explicit terms of EEqn.H).
+ * mi_flux_div: phi = Sf & linear-interpolate([cell_scale *] V) [+ add_a [* add_b]] on the internal faces AND
+ *   div = fvc::surfaceIntegrate(phi) [/ vol] in ONE row pass: every workgroup computes the flux of the faces its cells own, keeps
+ *   them in LDS for the row sums and recomputes only the faces cut by its boundary -- pEqn.H:49-71's
+ *   phiHbyA = (fvc::interpolate(rho*HbyA) & mesh.Sf()) + rhorAUf*fvc::ddtCorr(rho, U, phi) followed by fvc::div(phiHbyA)
+ *   (finiteVolume/fvc/fvcSurfaceIntegrate.C:40-96), which the reference computes with seven field passes.  lambda = the
+ *   interpolation weights (surfaceInterpolationScheme.C:275-280); boundary faces: mi_patch_add on div as the reference adds them.
+ * mi_ddt_phi_corr: fvc::ddtCorr(rho, U, phi) on the internal faces, EulerDdtScheme<Type>::fvcDdtPhiCorr(rho, U, phi)
+ *   (EulerDdtScheme.C:663-720, first branch; rho_old NULL: fvcDdtPhiCorr(U, phi) :523-551) with ddtScheme<Type>::fvcDdtPhiCoeff
+ *   (ddtSchemes/ddtScheme/ddtScheme.C:139-174) in one face pass:
+ *     phiCorr = phi0 - (Sf & interpolate(rho0*U0)); out = (1 - min(|phiCorr|/(|phi0| + SMALL), 1))*rDeltaT*phiCorr.          */
+int mi_fvm_ddt_euler_rho(mi_ctx_t ctx, int64_t n, double r_delta_t, const double *rho_dev, const double *rho_old_dev,
+                         const double *vol_dev, const double *psi_old_dev, double *diag_out_dev, double *source_out_dev);
+int mi_fvm_su(mi_ctx_t ctx, int64_t n, const double *vol_dev, const double *su_dev, double *source_inout_dev);
+int mi_fvm_sp(mi_ctx_t ctx, int64_t n, const double *vol_dev, const double *sp_dev_or_null, double sp_value, double *diag_inout_dev);
+int mi_fvm_susp(mi_ctx_t ctx, int64_t n, const double *vol_dev, const double *susp_dev, const double *vf_dev,
+                double *diag_inout_dev, double *source_inout_dev);
+int mi_flux_div(mi_addr_t addr, const double *lambda_dev, const double *sfx_dev, const double *sfy_dev, const double *sfz_dev,
+                const double *vx_dev, const double *vy_dev, const double *vz_dev, const double *cell_scale_dev_or_null,
+                const double *add_a_dev_or_null, const double *add_b_dev_or_null, double *phi_out_dev,
+                const double *vol_dev_or_null, double *div_out_dev);
+int mi_ddt_phi_corr(mi_addr_t addr, double r_delta_t, const double *lambda_dev, const double *sfx_dev, const double *sfy_dev,
+                    const double *sfz_dev, const double *ux_old_dev, const double *uy_old_dev, const double *uz_old_dev,
+                    const double *rho_old_dev_or_null, const double *phi_old_dev, double *out_dev);
 /* out = x / y element-wise (fvMatrix::A = D/V, fvMatrix::H /= V; fvMatrix.C:1424-1506); out may alias x */
 int mi_vec_div(mi_ctx_t ctx, int64_t n, const double *x_dev, const double *y_dev, double *out_dev);
 /* Non-orthogonal correction of fvm::laplacian (row a22): gaussLaplacianScheme<Type, scalar>::fvmLaplacian with a `corrected`

@@ -164,6 +164,84 @@ void orc_fvm_ddt_euler(label n, scalar rDeltaT, scalar rho, const scalar *vol, c
     }
 }
 
+/* ---- fvm::ddt(rho, vf), Euler, with a density FIELD (EulerDdtScheme.C:403-440: rhoPimpleFoam's fvm::ddt(rho, U), fvm::ddt(rho, he),
+ *      and fvm::ddt(psi, p) with psi in rho's place):
+ *   fvm.diag()   = rDeltaT*rho.internalField()*mesh().Vsc()
+ *   fvm.source() = rDeltaT*rho.oldTime().internalField()*vf.oldTime().internalField()*mesh().Vsc()
+ * every product a field operation, left to right                                                                    */
+void orc_fvm_ddt_euler_rho(label n, scalar rDeltaT, const scalar *rho, const scalar *rhoOld, const scalar *vol, const scalar *psiOld,
+                           scalar *diag, scalar *source)
+{
+    for (label c = 0; c < n; c++) {
+        diag[c] = (rDeltaT * rho[c]) * vol[c];
+        source[c] = ((rDeltaT * rhoOld[c]) * psiOld[c]) * vol[c];
+    }
+}
+
+/* ---- implicit / explicit source terms (finiteVolume/fvm/fvmSup.C):
+ *   fvm::Su   (:34-54)    source -= V*su
+ *   fvm::Sp   (:100-122)  diag   += V*sp            (field sp; :150-170 the same with a dimensionedScalar: sp == NULL, spValue)
+ *   fvm::SuSp (:190-214)  diag   += V*max(susp, 0) ; source -= V*min(susp, 0)*vf    (products left to right)          */
+void orc_fvm_su(label n, const scalar *vol, const scalar *su, scalar *source)
+{
+    for (label c = 0; c < n; c++) source[c] -= vol[c] * su[c];
+}
+void orc_fvm_sp(label n, const scalar *vol, const scalar *sp, scalar spValue, scalar *diag)
+{
+    for (label c = 0; c < n; c++) diag[c] += vol[c] * (sp ? sp[c] : spValue);
+}
+void orc_fvm_susp(label n, const scalar *vol, const scalar *susp, const scalar *vf, scalar *diag, scalar *source)
+{
+    for (label c = 0; c < n; c++) {
+        const scalar mx = susp[c] > 0 ? susp[c] : 0.0, mn = susp[c] < 0 ? susp[c] : 0.0;   /* max(susp, 0), min(susp, 0) */
+        diag[c] += vol[c] * mx;
+        source[c] -= (vol[c] * mn) * vf[c];
+    }
+}
+
+/* ---- face flux of an interpolated cell vector, internal faces:  phi[f] = Sf[f] & linear.interpolate(V)[f]  with V = U or
+ *      V = rho*U (a cell field: the product is rounded per cell, as rhoU0 = rho.oldTime()*U.oldTime() is, EulerDdtScheme.C:683-686);
+ *      the interpolate one fma per component (surfaceInterpolationScheme.C:275-280), a & b = ax*bx + ay*by + az*bz contracted left to
+ *      right; optionally  + addA[f]*addB[f]  (a rounded field product, e.g. rhorAUf*fvc::ddtCorr(rho, U, phi), pEqn.H:49-56) or
+ *      + addA[f]                                                                                                           */
+static scalar flux_face(label f, const label *lo, const label *up, const scalar *lambda, const scalar *sx, const scalar *sy, const scalar *sz,
+                        const scalar *vx, const scalar *vy, const scalar *vz, const scalar *sc, const scalar *addA, const scalar *addB)
+{
+    const label P = lo[f], N = up[f];
+    scalar px = vx[P], py = vy[P], pz = vz[P], nx = vx[N], ny = vy[N], nz = vz[N];
+    if (sc) { px = sc[P] * px; py = sc[P] * py; pz = sc[P] * pz; nx = sc[N] * nx; ny = sc[N] * ny; nz = sc[N] * nz; }
+    const scalar ix = fma(lambda[f], px - nx, nx), iy = fma(lambda[f], py - ny, ny), iz = fma(lambda[f], pz - nz, nz);
+    scalar d = fma(iz, sz[f], fma(iy, sy[f], ix * sx[f]));
+    if (addA) d = d + (addB ? addA[f] * addB[f] : addA[f]);
+    return d;
+}
+/* phi (face) and, when div != NULL, fvc::surfaceIntegrate(phi) in the reference's row order (own faces ascending +, then the
+ * losort faces -, fvcSurfaceIntegrate.C:40-96), divided by V when vol != NULL -- phiHbyA and fvc::div(phiHbyA) of pEqn.H:49-71 */
+void orc_flux_div(label n, label nf, const label *lo, const label *up, const scalar *lambda, const scalar *sx, const scalar *sy, const scalar *sz,
+                  const scalar *vx, const scalar *vy, const scalar *vz, const scalar *sc, const scalar *addA, const scalar *addB,
+                  scalar *phi, const scalar *vol, scalar *div)
+{
+    for (label f = 0; f < nf; f++) phi[f] = flux_face(f, lo, up, lambda, sx, sy, sz, vx, vy, vz, sc, addA, addB);
+    if (div) orc_surface_integrate(n, nf, lo, up, phi, vol, div);
+}
+
+/* ---- fvc::ddtCorr(rho, U, phi), Euler (EulerDdtScheme.C:663-720, first branch: U a velocity, phi a mass flux; rho == NULL: the
+ *      incompressible fvcDdtPhiCorr(U, phi) :523-551), internal faces:
+ *   phiCorr = phi.oldTime() - (mesh().Sf() & fvc::interpolate(rho.oldTime()*U.oldTime()))
+ *   result  = fvcDdtPhiCoeff(rhoU0, phi.oldTime(), phiCorr)*rDeltaT*phiCorr
+ *   fvcDdtPhiCoeff = 1 - min(mag(phiCorr)/(mag(phi) + SMALL), 1)                       (ddtScheme.C:139-174; SMALL = 1e-15)   */
+void orc_ddt_phi_corr(label nf, const label *lo, const label *up, scalar rDeltaT, const scalar *lambda, const scalar *sx, const scalar *sy,
+                      const scalar *sz, const scalar *ux, const scalar *uy, const scalar *uz, const scalar *rhoOld, const scalar *phiOld,
+                      scalar *out)
+{
+    for (label f = 0; f < nf; f++) {
+        const scalar phiCorr = phiOld[f] - flux_face(f, lo, up, lambda, sx, sy, sz, ux, uy, uz, rhoOld, NULL, NULL);
+        const scalar q = fabs(phiCorr) / (fabs(phiOld[f]) + 1e-15);
+        const scalar coeff = 1.0 - (q < 1.0 ? q : 1.0);
+        out[f] = (coeff * rDeltaT) * phiCorr;
+    }
+}
+
 /* ---- upwind weights: pos(faceFlux) (interpolation/surfaceInterpolation/limitedSchemes/upwind/upwind.H:limiter 0 =>
  *      weights = pos(flux), limitedSurfaceInterpolationScheme.C:177-187)                                          */
 void orc_upwind_weights(label nf, const scalar *faceFlux, scalar *w)

@@ -476,6 +476,63 @@ def fvm_ddt_euler(r_delta_t, rho, vol, psi_old):
     return diag, src
 
 
+def fvm_ddt_euler_rho(r_delta_t, rho, rho_old, vol, psi_old):
+    """fvm::ddt(rho, vf) with a density field (EulerDdtScheme.C:403-440) -> (diag, source)"""
+    v, p0, r, r0 = _d(vol), _d(psi_old), _d(rho), _d(rho_old)
+    diag, src = np.empty_like(v), np.empty_like(v)
+    lib().orc_fvm_ddt_euler_rho(C.c_int32(v.shape[0]), C.c_double(r_delta_t), _p(r, C.c_double), _p(r0, C.c_double), _p(v, C.c_double),
+                                _p(p0, C.c_double), _p(diag, C.c_double), _p(src, C.c_double))
+    return diag, src
+
+
+def fvm_su(vol, su, source):
+    """fvm::Su (fvmSup.C:34-54): returns source - V*su"""
+    out = _d(source).copy()
+    lib().orc_fvm_su(C.c_int32(out.shape[0]), _p(_d(vol), C.c_double), _p(_d(su), C.c_double), _p(out, C.c_double))
+    return out
+
+
+def fvm_sp(vol, sp, diag):
+    """fvm::Sp (fvmSup.C:100-170): returns diag + V*sp; sp a field or a number"""
+    out = _d(diag).copy()
+    if np.isscalar(sp):
+        lib().orc_fvm_sp(C.c_int32(out.shape[0]), _p(_d(vol), C.c_double), None, C.c_double(sp), _p(out, C.c_double))
+    else:
+        lib().orc_fvm_sp(C.c_int32(out.shape[0]), _p(_d(vol), C.c_double), _p(_d(sp), C.c_double), C.c_double(0.0), _p(out, C.c_double))
+    return out
+
+
+def fvm_susp(vol, susp, vf, diag, source):
+    """fvm::SuSp (fvmSup.C:190-214): returns (diag + V*max(susp,0), source - V*min(susp,0)*vf)"""
+    d, s = _d(diag).copy(), _d(source).copy()
+    lib().orc_fvm_susp(C.c_int32(d.shape[0]), _p(_d(vol), C.c_double), _p(_d(susp), C.c_double), _p(_d(vf), C.c_double), _p(d, C.c_double),
+                       _p(s, C.c_double))
+    return d, s
+
+
+def flux_div(n_cells, lower_addr, upper_addr, lam, sf, v, scale=None, add_a=None, add_b=None, vol=None, want_div=True):
+    """phi = Sf & interpolate([scale *] v) [+ add_a [* add_b]] on the internal faces and fvc::surfaceIntegrate(phi) [/ vol]"""
+    lo, up = _i(lower_addr), _i(upper_addr)
+    nf = lo.shape[0]
+    phi = np.empty(nf)
+    div = np.empty(n_cells) if want_div else None
+    q = lambda a: _p(_d(a), C.c_double) if a is not None else None
+    keep = [_d(a) for a in (lam, *sf, *v)]
+    lib().orc_flux_div(C.c_int32(n_cells), C.c_int32(nf), _p(lo, C.c_int32), _p(up, C.c_int32), *[_p(a, C.c_double) for a in keep],
+                       q(scale), q(add_a), q(add_b), _p(phi, C.c_double), q(vol), _p(div, C.c_double) if want_div else None)
+    return (phi, div) if want_div else phi
+
+
+def ddt_phi_corr(lower_addr, upper_addr, r_delta_t, lam, sf, u_old, rho_old, phi_old):
+    """fvc::ddtCorr(rho, U, phi) on the internal faces (EulerDdtScheme.C:663-720; rho_old None: :523-551)"""
+    lo, up = _i(lower_addr), _i(upper_addr)
+    out = np.empty(lo.shape[0])
+    keep = [_d(a) for a in (lam, *sf, *u_old)]
+    lib().orc_ddt_phi_corr(C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), C.c_double(r_delta_t), *[_p(a, C.c_double) for a in keep],
+                           _p(_d(rho_old), C.c_double) if rho_old is not None else None, _p(_d(phi_old), C.c_double), _p(out, C.c_double))
+    return out
+
+
 def upwind_weights(face_flux):
     f = _d(face_flux)
     w = np.empty_like(f)

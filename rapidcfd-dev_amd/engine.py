@@ -45,7 +45,7 @@ SYMBOLS = [
     "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy", "mi_gamg_host_build_ami",
     "mi_addr_create_adopted", "mi_layout_adopt_host", "mi_pbicg_solve_multi", "mi_comm_peer_auto", "mi_comm_peer_selftest", "mi_comm_peer_enable", "mi_matrix_peer_halo_auto", "mi_matrix_peer_halo_status",
     "mi_pcg_iterate_sampled",
-    "mi_fvm_ddt_euler", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
+    "mi_fvm_ddt_euler", "mi_fvm_ddt_euler_rho", "mi_fvm_su", "mi_fvm_sp", "mi_fvm_susp", "mi_flux_div", "mi_ddt_phi_corr", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
     "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm", "mi_matrix_patch_neighbour_field",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_synchronize", "mi_ctx_stat", "mi_ctx_set_option", "mi_last_error", "mi_device_available",
@@ -911,6 +911,34 @@ class Assembly:
     def fvm_ddt_euler(self, r_delta_t, rho, vol, psi_old, diag_out, source_out):
         _chk(lib().mi_fvm_ddt_euler(self.addr.ctx.h, C.c_int64(vol.numel()), C.c_double(r_delta_t), C.c_double(rho), _ptr(vol), _ptr(psi_old),
                                     _ptr(diag_out), _ptr(source_out)))
+
+    def fvm_ddt_euler_rho(self, r_delta_t, rho, rho_old, vol, psi_old, diag_out, source_out):
+        """fvm::ddt(rho, vf) with a density field (EulerDdtScheme.C:403-440)"""
+        _chk(lib().mi_fvm_ddt_euler_rho(self.addr.ctx.h, C.c_int64(vol.numel()), C.c_double(r_delta_t), _ptr(rho), _ptr(rho_old), _ptr(vol),
+                                        _ptr(psi_old), _ptr(diag_out), _ptr(source_out)))
+
+    def fvm_su(self, vol, su, source_inout):
+        _chk(lib().mi_fvm_su(self.addr.ctx.h, C.c_int64(vol.numel()), _ptr(vol), _ptr(su), _ptr(source_inout)))
+
+    def fvm_sp(self, vol, sp, diag_inout):
+        """sp: a cell field or a number (fvmSup.C:100-170)"""
+        if isinstance(sp, (int, float)):
+            _chk(lib().mi_fvm_sp(self.addr.ctx.h, C.c_int64(vol.numel()), _ptr(vol), None, C.c_double(sp), _ptr(diag_inout)))
+        else:
+            _chk(lib().mi_fvm_sp(self.addr.ctx.h, C.c_int64(vol.numel()), _ptr(vol), _ptr(sp), C.c_double(0.0), _ptr(diag_inout)))
+
+    def fvm_susp(self, vol, susp, vf, diag_inout, source_inout):
+        _chk(lib().mi_fvm_susp(self.addr.ctx.h, C.c_int64(vol.numel()), _ptr(vol), _ptr(susp), _ptr(vf), _ptr(diag_inout), _ptr(source_inout)))
+
+    def flux_div(self, lam, sf, v, phi_out, div_out, cell_scale=None, add_a=None, add_b=None, vol=None):
+        """phi = Sf & interpolate([cell_scale *] v) [+ add_a [* add_b]] and div = surfaceIntegrate(phi) [/ vol] in one row pass"""
+        _chk(lib().mi_flux_div(self.addr.h, _ptr(lam), _ptr(sf[0]), _ptr(sf[1]), _ptr(sf[2]), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(cell_scale),
+                               _ptr(add_a), _ptr(add_b), _ptr(phi_out), _ptr(vol), _ptr(div_out)))
+
+    def ddt_phi_corr(self, r_delta_t, lam, sf, u_old, rho_old, phi_old, out):
+        """fvc::ddtCorr(rho, U, phi) on the internal faces (EulerDdtScheme.C:663-720; rho_old None: :523-551)"""
+        _chk(lib().mi_ddt_phi_corr(self.addr.h, C.c_double(r_delta_t), _ptr(lam), _ptr(sf[0]), _ptr(sf[1]), _ptr(sf[2]), _ptr(u_old[0]), _ptr(u_old[1]),
+                                   _ptr(u_old[2]), _ptr(rho_old), _ptr(phi_old), _ptr(out)))
 
     def upwind_weights(self, face_flux, w_out):
         _chk(lib().mi_upwind_weights(self.addr.ctx.h, C.c_int64(face_flux.numel()), _ptr(face_flux), _ptr(w_out)))

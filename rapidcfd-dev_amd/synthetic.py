@@ -96,7 +96,34 @@ class LduCase:
 
 
 def box_addressing(nx: int, ny: int, nz: int):
-    """(lowerAddr, upperAddr, direction) of the internal faces in OpenFOAM order."""
+    """(lowerAddr, upperAddr, direction) of the internal faces in OpenFOAM order: owner-major, every cell's faces in the order
+    +x, +y, +z.  (Positions by a prefix sum over the cells' face counts and three strided fills: 1 s at 10 M cells where the
+    masked (n, 3) int64 table of rounds 1-4 took 11 s -- the same arrays, tests/test_layout.py pins them against that form.)"""
+    n = nx * ny * nz
+    c = np.arange(n, dtype=np.int32)
+    i = c % np.int32(nx)
+    jk = c // np.int32(nx)
+    j = jk % np.int32(ny)
+    k = jk // np.int32(ny)
+    hx, hy, hz = i < nx - 1, j < ny - 1, k < nz - 1
+    del i, j, k, jk
+    start = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(hx.astype(np.int8) + hy.astype(np.int8) + hz.astype(np.int8), dtype=np.int64, out=start[1:])
+    nf = int(start[-1])
+    own, nei, direction = np.empty(nf, dtype=np.int32), np.empty(nf, dtype=np.int32), np.empty(nf, dtype=np.int8)
+    pos = start[:-1]
+    for d, (has, step) in enumerate(((hx, 1), (hy, nx), (hz, nx * ny))):
+        q, cells = pos[has], c[has]
+        own[q] = cells
+        nei[q] = cells + np.int32(step)
+        direction[q] = d
+        if d < 2:
+            pos = pos + has
+    return own, nei, direction
+
+
+def box_addressing_reference(nx: int, ny: int, nz: int):
+    """the rounds 1-4 form of box_addressing (a masked (n, 3) neighbour table), kept as the statement the fast form is tested against"""
     n = nx * ny * nz
     c = np.arange(n, dtype=np.int64)
     i = c % nx

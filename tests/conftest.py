@@ -22,11 +22,38 @@ _FILE_ORDER = ("test_abi", "test_gpu_parity", "test_gpu_fuzz", "test_ref_dropin"
                "test_full_size_fixture", "test_distributed", "test_bench_contract", "test_gpu_full_size", "test_gpu_configs")
 
 
+def _world_of(item):
+    """ranks a multi-process test runs on (0: none): tests/rank_pool.py keeps ONE pool of rank processes alive, so the tests of
+    test_distributed.py run grouped by world size"""
+    p = getattr(getattr(item, "callspec", None), "params", {})
+    if "world" in p:
+        return int(p["world"])
+    if "parts" in p and isinstance(p["parts"], tuple):
+        return int(np.prod(p["parts"]))
+    name = item.name.split("[")[0]
+    return {"test_transformed_processor_patches_between_engine_ranks": 4, "test_distributed_pcg_real_engine_ragged_graph_random_partition": 3}.get(name, 0)
+
+
 def pytest_collection_modifyitems(config, items):
     def key(item):
         name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
-        return _FILE_ORDER.index(name) if name in _FILE_ORDER else _FILE_ORDER.index("test_distributed") - 0.5
-    items.sort(key=key)          # stable: the order inside a file stays the file's
+        rank = _FILE_ORDER.index(name) if name in _FILE_ORDER else _FILE_ORDER.index("test_distributed") - 0.5
+        return (rank, _world_of(item) if name == "test_distributed" else 0)
+    items.sort(key=key)          # stable: apart from the grouping by world size the order inside a file stays the file's
+
+
+def pytest_runtest_logreport(report):
+    """every phase's duration as it completes (gpurun_out/test_durations.tsv): a suite that is cut short still says where its time
+    went -- pytest's own --durations table is only printed at the end"""
+    if os.environ.get("MI_TEST_DURATIONS", "1") == "0" or report.duration < 0.05:
+        return
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "test_durations.tsv"), "a") as f:
+            f.write(f"{report.duration:9.2f}\t{report.when}\t{report.outcome}\t{report.nodeid}\n")
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -7,8 +7,8 @@ window.  tests/golden/make_full_size.py runs the oracle ON THE CPU BOX and write
   * sha256 of the result BITS of every operator that is compared bit for bit,
   * of every solution vector: its values at SAMPLE positions (sample_idx: a fixed multiplicative walk over the cells), its
     max |.|, its sum and its sum of magnitudes,
-  * sha256 of the oracle's C sources and of the case generator, so that a fixture older than the code it restates fails a CPU
-    test (tests/test_full_size_fixture.py) instead of passing silently; that file also RE-DERIVES a sample of the records
+  * sha256 of the oracle's C sources and of the case generator's OUTPUT on small reference cases, so that a fixture older than
+    the code it restates fails a CPU test (tests/test_full_size_fixture.py) instead of passing silently; that file also RE-DERIVES a sample of the records
     with the live oracle.
 
 The GPU tests (test_gpu_full_size.py, test_gpu_configs.py) compare the engine against these records with the bars they had
@@ -43,12 +43,43 @@ def sample_idx(n, k=N_SAMPLE):
     return i
 
 
+def _hash_case(h, case):
+    for name in ("lower_addr", "upper_addr", "diag", "upper", "lower", "source", "global_cells"):
+        a = getattr(case, name, None)
+        h.update(name.encode())
+        if a is not None:
+            a = np.ascontiguousarray(a)
+            h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    for itf in case.interfaces:
+        h.update(f"{itf.nbr_domain},{itf.nbr_patch}".encode())
+        for a in (itf.face_cells, itf.bou_coeffs, itf.int_coeffs):
+            a = np.ascontiguousarray(a)
+            h.update(str(a.dtype).encode()); h.update(a.tobytes())
+
+
+def synthetic_fingerprint():
+    """the case generator by its OUTPUT on small cases of every kind the records use (box, symmetric and asymmetric, the cyclic
+    pairs, directly built sub-domains): synthetic.py may be rewritten for speed, its arrays may not change"""
+    import __graft_entry__ as graft
+    syn = graft.load_package().synthetic
+    h = hashlib.sha256()
+    for symmetric in (True, False):
+        _hash_case(h, syn.box_case(12, 10, 8, symmetric=symmetric))
+        for r in range(8):
+            _hash_case(h, syn.box_subdomain((8, 6, 6), (2, 2, 2), r, symmetric=symmetric))
+    _hash_case(h, syn.add_cyclic_x(syn.box_case(7, 5, 4)))
+    _hash_case(h, syn.add_cyclic_y(syn.box_case(6, 5, 4)))
+    h.update(syn.splitmix_uniform(99, 1000).tobytes())
+    return h.hexdigest()
+
+
 def source_hashes():
-    """what the records were derived from: the oracle's C sources and the synthetic case generator"""
+    """what the records were derived from: the oracle's C sources (by text) and the synthetic case generator (by output)"""
     h = {}
-    for rel in ("oracle/ldu_oracle.c", "oracle/gamg_oracle.c", "oracle/ldu_oracle.h", "rapidcfd-dev_amd/synthetic.py"):
+    for rel in ("oracle/ldu_oracle.c", "oracle/gamg_oracle.c", "oracle/ldu_oracle.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h[rel] = hashlib.sha256(f.read()).hexdigest()
+    h["synthetic.py outputs"] = synthetic_fingerprint()
     return h
 
 

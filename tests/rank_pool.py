@@ -137,7 +137,7 @@ class RankPool:
             except Exception:
                 pass
         for p in self.procs:
-            p.join(timeout=10)
+            p.join(timeout=20)
         self.kill()
 
     def kill(self):
@@ -164,6 +164,12 @@ def run_ranks(world, module, fn, *args, timeout=600.0):
     if pool is None or not pool.alive():
         if pool is not None:
             pool.kill()
+        # ONE pool at a time: every process with a HIP context takes one of the device's few process slots, and beyond them the
+        # hardware scheduler swaps whole processes in and out -- ranks that wait for each other INSIDE kernels (windows, persistent
+        # grids) then pay a scheduling quantum per exchange.  tests/conftest.py orders the multi-process tests by world size, so
+        # the suite starts 2 + 3 + 4 + 8 rank processes in all.
+        for w in list(_POOLS):
+            _POOLS.pop(w).close()
         pool = _POOLS[world] = RankPool(world)
     try:
         pool.run(module, fn, *args, timeout=timeout)

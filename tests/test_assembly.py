@@ -188,10 +188,144 @@ def test_row_passes_bit_exact_for_every_block_shape(pkg, orc, monkeypatch, name,
     asm.gauss_grad([dev(x) for x in Sf], dev(phi), dev(vol), g)
     for a, b in zip(g, orc.gauss_grad(n, lo, up, Sf, phi, vol)):
         assert np.array_equal(host(a), b)
+    # round 5: the flux of an interpolated (scaled) cell vector and its surfaceIntegrate in one row pass (pEqn.H:49-71)
+    lam = syn.splitmix_uniform(30, nf)
+    V = [syn.splitmix_uniform(31 + k, n) - 0.5 for k in range(3)]
+    rho, aA, aB = 0.8 + syn.splitmix_uniform(35, n), syn.splitmix_uniform(36, nf) - 0.5, syn.splitmix_uniform(37, nf)
+    po, dv = E(nf), E(n)
+    for kw in (dict(), dict(scale=rho), dict(scale=rho, add_a=aA, add_b=aB, vol=vol), dict(add_a=aA)):
+        asm.flux_div(dev(lam), [dev(x) for x in Sf], [dev(x) for x in V], po, dv, cell_scale=dev(kw["scale"]) if "scale" in kw else None,
+                     add_a=dev(kw["add_a"]) if "add_a" in kw else None, add_b=dev(kw["add_b"]) if "add_b" in kw else None,
+                     vol=dev(kw["vol"]) if "vol" in kw else None)
+        rp, rd = orc.flux_div(n, lo, up, lam, Sf, V, **kw)
+        assert np.array_equal(host(po), rp) and np.array_equal(host(dv), rd), sorted(kw)
     # the fused passes recompute cut faces from their inputs: an output aliasing an input is refused
     d = dev(delta)
     with pytest.raises(eng.MiError):
         asm.fvm_laplacian(d, dev(gam), d, do)
+    l = dev(lam)
+    with pytest.raises(eng.MiError):
+        asm.flux_div(l, [dev(x) for x in Sf], [dev(x) for x in V], l, dv)
+
+
+def test_compressible_operators_oracle_against_plain_numpy(pkg, orc):
+    """fvm::ddt(rho, vf), fvm::Su / Sp / SuSp, fvc::ddtCorr(rho, U, phi) and the interpolated flux + its surfaceIntegrate
+    (EulerDdtScheme.C:403-440, 663-720; fvmSup.C:34-214; ddtScheme.C:139-174; pEqn.H:49-71): the C restatements against the
+    formulas written out with numpy field operations -- one rounding per operation, so bit for bit (the fused multiply-adds of
+    the interpolate / dot product are evaluated in exact rational arithmetic and rounded once)"""
+    from fractions import Fraction
+
+    def fma(a, b, c):       # one rounding: exact rational arithmetic, then float() rounds to nearest even
+        return float(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+    syn = pkg.synthetic
+    case = syn.box_case(7, 6, 5)
+    n, nf, lo, up = case.n_cells, case.n_faces, case.lower_addr, case.upper_addr
+    u = lambda seed, m: syn.splitmix_uniform(seed, m)
+    rho, rho0, vol, psi0 = 0.9 + u(1, n), 0.8 + u(2, n), 0.5 + u(3, n), u(4, n) - 0.5
+    rdt = 1.0 / 3e-4
+    d, s = orc.fvm_ddt_euler_rho(rdt, rho, rho0, vol, psi0)
+    assert np.array_equal(d, (rdt * rho) * vol) and np.array_equal(s, ((rdt * rho0) * psi0) * vol)
+    d1, s1 = orc.fvm_ddt_euler(rdt, 1.0, vol, psi0)
+    d2, s2 = orc.fvm_ddt_euler_rho(rdt, np.ones(n), np.ones(n), vol, psi0)
+    assert np.array_equal(d1, d2) and np.array_equal(s1, s2)                  # rho = 1: the plain fvm::ddt(vf)
+    su, sp, susp, vf = u(5, n) - 0.5, u(6, n), u(7, n) - 0.5, u(8, n) - 0.5
+    assert np.array_equal(orc.fvm_su(vol, su, s), s - vol * su)
+    assert np.array_equal(orc.fvm_sp(vol, sp, d), d + vol * sp) and np.array_equal(orc.fvm_sp(vol, 0.25, d), d + vol * 0.25)
+    dd, ss = orc.fvm_susp(vol, susp, vf, d, s)
+    assert np.array_equal(dd, d + vol * np.maximum(susp, 0.0)) and np.array_equal(ss, s - (vol * np.minimum(susp, 0.0)) * vf)
+    lam, Sf, U = u(9, nf), [u(10 + k, nf) - 0.5 for k in range(3)], [u(13 + k, n) - 0.5 for k in range(3)]
+    aA, aB = u(16, nf) - 0.5, u(17, nf)
+
+    def flux(scale):
+        V = [scale * c for c in U] if scale is not None else U
+        out = np.empty(nf)
+        for f in range(nf):
+            P, N = lo[f], up[f]
+            i = [fma(lam[f], V[k][P] - V[k][N], V[k][N]) for k in range(3)]
+            out[f] = fma(i[2], Sf[2][f], fma(i[1], Sf[1][f], i[0] * Sf[0][f]))
+        return out
+    phi, div = orc.flux_div(n, lo, up, lam, Sf, U, scale=rho0, add_a=aA, add_b=aB, vol=vol)
+    ref = flux(rho0) + aA * aB
+    assert np.array_equal(phi, ref) and np.array_equal(div, orc.surface_integrate(n, lo, up, ref, vol))
+    phi0 = u(18, nf) - 0.5
+    got = orc.ddt_phi_corr(lo, up, rdt, lam, Sf, U, rho0, phi0)
+    corr = phi0 - flux(rho0)
+    coeff = 1.0 - np.minimum(np.abs(corr) / (np.abs(phi0) + 1e-15), 1.0)
+    assert np.array_equal(got, (coeff * rdt) * corr)
+    assert np.all((coeff >= 0) & (coeff <= 1)) and np.any(coeff == 0) and np.any(coeff > 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(13, 11, 9), (3, 2, 2)])
+def test_engine_compressible_operators_bit_exact(pkg, orc, dims):
+    """rhoPimpleFoam's operators (BASELINE config 5; VERDICT r04 "missing" 3): mi_fvm_ddt_euler_rho, mi_fvm_su / sp / susp,
+    mi_ddt_phi_corr, mi_flux_div against the oracle, bit for bit"""
+    import torch
+    eng, syn = pkg.engine, pkg.synthetic
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to("cuda:0")
+    host = lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1]
+    case = syn.box_case(*dims)
+    n, nf, lo, up = case.n_cells, case.n_faces, case.lower_addr, case.upper_addr
+    asm = eng.Assembly(eng.Addressing(ctx, n, lo, up))
+    E = lambda m: torch.empty(m, dtype=torch.float64, device="cuda:0")
+    u = lambda seed, m: syn.splitmix_uniform(seed, m)
+    rho, rho0, vol, psi0 = 0.9 + u(1, n), 0.8 + u(2, n), 0.5 + u(3, n), u(4, n) - 0.5
+    rdt = 1.0 / 3e-4
+    d, s = E(n), E(n)
+    asm.fvm_ddt_euler_rho(rdt, dev(rho), dev(rho0), dev(vol), dev(psi0), d, s)
+    rd, rs = orc.fvm_ddt_euler_rho(rdt, rho, rho0, vol, psi0)
+    assert np.array_equal(host(d), rd) and np.array_equal(host(s), rs)
+    su, sp, susp, vf = u(5, n) - 0.5, u(6, n), u(7, n) - 0.5, u(8, n) - 0.5
+    asm.fvm_su(dev(vol), dev(su), s); rs = orc.fvm_su(vol, su, rs); assert np.array_equal(host(s), rs)
+    asm.fvm_sp(dev(vol), dev(sp), d); rd = orc.fvm_sp(vol, sp, rd); assert np.array_equal(host(d), rd)
+    asm.fvm_sp(dev(vol), 0.25, d); rd = orc.fvm_sp(vol, 0.25, rd); assert np.array_equal(host(d), rd)
+    asm.fvm_susp(dev(vol), dev(susp), dev(vf), d, s); rd, rs = orc.fvm_susp(vol, susp, vf, rd, rs)
+    assert np.array_equal(host(d), rd) and np.array_equal(host(s), rs)
+    lam, Sf, U = u(9, nf), [u(10 + k, nf) - 0.5 for k in range(3)], [u(13 + k, n) - 0.5 for k in range(3)]
+    phi0, out = u(18, nf) - 0.5, E(nf)
+    for r0 in (rho0, None):
+        asm.ddt_phi_corr(rdt, dev(lam), [dev(x) for x in Sf], [dev(x) for x in U], dev(r0) if r0 is not None else None, dev(phi0), out)
+        assert np.array_equal(host(out), orc.ddt_phi_corr(lo, up, rdt, lam, Sf, U, r0, phi0))
+    ddt = orc.ddt_phi_corr(lo, up, rdt, lam, Sf, U, rho0, phi0)
+    rAUf = u(19, nf)
+    po, dv = E(nf), E(n)
+    asm.flux_div(dev(lam), [dev(x) for x in Sf], [dev(x) for x in U], po, dv, cell_scale=dev(rho), add_a=dev(rAUf), add_b=dev(ddt))
+    rp, rdv = orc.flux_div(n, lo, up, lam, Sf, U, scale=rho, add_a=rAUf, add_b=ddt)
+    assert np.array_equal(host(po), rp) and np.array_equal(host(dv), rdv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transonic", [False, True])
+def test_rhopimple_step_and_its_pressure_solve_against_the_oracle(pkg, orc, transonic):
+    """tools/workloads.py: rhopimple_supplement (BASELINE config 5's solver: UEqn.H / EEqn.H / pEqn.H of rhoPimpleFoam through the
+    C ABI) on a small box.  The pressure system it assembled and bound -- symmetric for the non-transonic pEqn, ASYMMETRIC for the
+    transonic one (fvm::ddt(psi,p) + fvm::div(phid,p) - fvm::laplacian(rhorAUf,p), pEqn.H:36-46) -- is solved again by the oracle's
+    GAMG from the same start field: same cycle count, histories within 1e-10, same solution (GAMGSolverSolve.C:59-160)."""
+    import os, sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import workloads
+    eng, syn = pkg.engine, pkg.synthetic
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    case = syn.box_case(24, 20, 16)
+    addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    cap = {}
+    out = workloads.rhopimple_supplement(eng, syn, case, addr, ctx, torch.device("cuda:0"), steps=1, transonic=transonic, capture=cap)
+    assert out["ms_per_time_step"] > 0 and len(out["stages_ms"]) == 7 and out["gamg_cycles"] >= 1 and len(out["pbicg_iterations_per_component"]) == 3
+    assert out["pressure_matrix"] == ("asymmetric" if transonic else "symmetric")
+    assert (cap["lower"] is not None) == transonic
+    if transonic:
+        assert np.max(np.abs(cap["lower"] - cap["upper"])) > 1e-6 * np.max(np.abs(cap["upper"]))        # really asymmetric
+    pcase = syn.LduCase(case.n_cells, case.lower_addr, case.upper_addr, cap["diag"], cap["upper"], cap["lower"], cap["source"])
+    pcase.dims = case.dims
+    H = orc.GamgHierarchy(pcase, workloads.box_pair_weights(case), 100)
+    ref_psi, ref = H.solve(cap["start"], cap["source"], tolerance=1e-12, relTol=0.05, maxIter=50)
+    perf = cap["perf"]
+    assert perf["nIterations"] == ref["nIterations"] and perf["converged"] == ref["converged"]
+    h, hr = perf["history"], ref["history"]
+    assert h.shape == hr.shape and np.max(np.abs(h - hr)) < 1e-10 * hr[0]
+    assert np.max(np.abs(cap["solution"] - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
 
 
 @pytest.mark.gpu

@@ -387,3 +387,12 @@ def test_renumber_at_bind_is_what_renumberMesh_does_with_the_engine_order(pkg):
         rnbs = [ref.interfaces[i.nbr_patch].face_cells for i in ref.interfaces]
         Lo = eng.host_layout(ref.n_cells, ref.lower_addr, ref.upper_addr, rfcs, patch_nbr_cells=rnbs)
         assert np.array_equal(np.sort(Lo["e2c"]), np.arange(case.n_cells))
+
+
+def test_box_addressing_equals_its_reference_form(pkg):
+    """synthetic.box_addressing (prefix sum + strided fills, round 5) against the masked-neighbour-table form of rounds 1-4 that
+    every committed record was generated with: the same arrays and dtypes, degenerate boxes included"""
+    syn = pkg.synthetic
+    for dims in [(1, 1, 1), (2, 1, 1), (1, 3, 1), (1, 1, 4), (5, 4, 3), (7, 1, 3), (1, 6, 5), (13, 11, 9), (40, 3, 2), (33, 32, 31)]:
+        for a, b in zip(syn.box_addressing(*dims), syn.box_addressing_reference(*dims)):
+            assert a.dtype == b.dtype and np.array_equal(a, b), dims

@@ -192,6 +192,173 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
             "timing": f"mean of {steps} steps after one warm-up step; stages by HIP events on the engine's stream"}
 
 
+def rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=3, transonic=False, capture=None):
+    """One rhoPimpleFoam time step (BASELINE config 5's solver, per-rank share) on the box: UEqn.H, EEqn.H, pEqn.H of
+    applications/solvers/compressible/rhoPimpleFoam with one outer corrector, one PISO corrector and no non-orthogonal corrector --
+
+      UEqn   fvm::ddt(rho, U) + fvm::div(phi, U) [upwind] - fvm::laplacian(muEff, U) == -fvc::grad(p); relax; PBiCG + DILU, the three
+             components in one batched solve                                   (UEqn.H:3-21; the explicit part of divDevRhoReff is left out)
+      EEqn   fvm::ddt(rho, he) + fvm::div(phi, he) + fvc::ddt(rho, K) + fvc::div(phi, K) - dpdt - fvm::laplacian(alphaEff, he); relax;
+             PBiCG + DILU; rho = psi p                                                                                  (EEqn.H:4-33)
+      pEqn   rAU = 1/A, rhorAUf = interpolate(rho rAU), HbyA = rAU H, fvc::ddtCorr(rho, U, phi) (mi_ddt_phi_corr),
+             non-transonic: phiHbyA = (interpolate(rho HbyA) & Sf) + rhorAUf ddtCorr and fvc::div(phiHbyA) in ONE pass (mi_flux_div);
+                            fvm::ddt(psi, p) + fvc::div(phiHbyA) - fvm::laplacian(rhorAUf, p): symmetric, GAMG       (pEqn.H:47-82)
+             transonic:     phid = interpolate(psi) ((interpolate(HbyA) & Sf) + rhorAUf ddtCorr / interpolate(rho));
+                            fvm::ddt(psi, p) + fvm::div(phid, p) - fvm::laplacian(rhorAUf, p): ASYMMETRIC, GAMG       (pEqn.H:17-46)
+             phi = phiHbyA + pEqn.flux(); U = HbyA - rAU grad(p)                                                        (pEqn.H:78-101)
+
+    every matrix operator, solver and face / row pass through the C ABI; the cell-wise algebra of the thermodynamics (K, rho = psi p,
+    products with rAU) with torch element-wise kernels on the same stream.
+    capture: a dict that receives host copies of the pressure system of the last step (diag, upper, lower | None, source, the start
+    field, the solution and the solver's perf) -- tests/test_assembly.py solves it with the oracle's GAMG."""
+    import torch
+    N, F = case.n_cells, case.n_faces
+    nx = case.dims[0]
+    h = 1.0 / nx
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    E = lambda n: torch.empty(n, dtype=torch.float64, device=dev)
+    asm = eng.Assembly(addr)
+    dirn = box_direction(case)
+    Sf = [t(h * h * (dirn == d)) for d in range(3)]
+    magSf, delta, vol = t(np.full(F, h * h)), t(np.full(F, 1.0 / h)), t(np.full(N, h ** 3))
+    lam = t(np.full(F, 0.5))                                        # linear interpolation weights of the uniform box
+    dt = 1e-4
+    rdt = 1.0 / dt
+    R, T0, p0 = 287.0, 300.0, 1.0e5
+    psi = t(np.full(N, 1.0 / (R * T0)) * (1.0 + 0.01 * (syn.splitmix_uniform(21, N) - 0.5)))          # compressibility rho = psi p
+    p = t(p0 * (1.0 + 1e-3 * (syn.splitmix_uniform(22, N) - 0.5)))
+    rho = psi * p
+    U = [t(20.0 * (d == 0) + 2.0 * (syn.splitmix_uniform(10 + d, N) - 0.5)) for d in range(3)]
+    he = t(1005.0 * T0 * (1.0 + 1e-3 * (syn.splitmix_uniform(23, N) - 0.5)))
+    rho_f = E(F)
+    asm.face_interpolate(lam, rho, rho_f)
+    phi = rho_f * Sf[0] * 20.0 * t(1.0 + 0.05 * (syn.splitmix_uniform(3, F) - 0.5))                    # mass flux, mostly along x
+    muMagSf, alphaMagSf = t(np.full(F, 1.8e-5 * h * h)), t(np.full(F, 2.5e-5 * h * h))
+    UM, EM, PM = eng.Matrix(addr), eng.Matrix(addr), eng.Matrix(addr)
+    G = gamg if gamg is not None else eng.Gamg(addr, box_pair_weights(case), 100)
+    xmin = np.nonzero(np.arange(N) % nx == 0)[0]
+    patch = eng.Patch(ctx, N, xmin)
+    icU, icE, icP = t(np.full(xmin.shape[0], 2.0 * 1.8e-5 * h)), t(np.full(xmin.shape[0], 2.0 * 2.5e-5 * h)), t(np.full(xmin.shape[0], 2.0e-4 * h))
+    wts, cl, cu, cd, lu, ld = E(F), E(F), E(F), E(N), E(F), E(N)
+    dd, ds = E(N), [E(N) for _ in range(3)]
+    ul, uu, ud = E(F), E(F), E(N)
+    el, eu, ed, es, expl, Kf = E(F), E(F), E(N), E(N), E(N), E(F)
+    rAU, rhorAUf, pu, pl, pd, ps, pdd = E(N), E(F), E(F), E(F), E(N), E(N), E(N)
+    ddtc, phiH, divH, fh, pf = E(F), E(F), E(N), E(F), E(F)
+    grad, HbyA, tmpN = [E(N) for _ in range(3)], [E(N) for _ in range(3)], E(N)
+    rho0, p_old = rho.clone(), p.clone()
+    U0 = [u.clone() for u in U]
+    K0 = 0.5 * (U[0] * U[0] + U[1] * U[1] + U[2] * U[2])
+    ev = {}
+
+    class stage:
+        def __init__(self, name): self.name = name
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True); self.b = torch.cuda.Event(enable_timing=True); self.a.record()
+        def __exit__(self, *x):
+            self.b.record(); ev.setdefault(self.name, []).append((self.a, self.b))
+
+    def step():
+        with stage("UEqn: upwind + fvm::div(phi) + fvm::laplacian(muEff) + fvm::ddt(rho, U) x3 + grad(p) source"):
+            asm.upwind_weights(phi, wts); asm.fvm_div(wts, phi, cl, cu, cd); asm.fvm_laplacian(delta, muMagSf, lu, ld)
+            asm.face_interpolate(lam, p, pf); asm.gauss_grad(Sf, pf, None, grad)       # integral of grad p over the cell = V * grad p
+            for d in range(3):
+                asm.fvm_ddt_euler_rho(rdt, rho, rho0, vol, U0[d], dd, ds[d])
+                asm.axpby(1.0, ds[d], -1.0, grad[d], ds[d])                            # UEqn == -fvc::grad(p): source -= V grad(p)
+            asm.axpby(1.0, cl, -1.0, lu, ul); asm.axpby(1.0, cu, -1.0, lu, uu)
+            asm.axpby(1.0, dd, 1.0, cd, ud); asm.axpby(1.0, ud, -1.0, ld, ud)
+            patch.add(icU, ud, 0)
+        with stage("UEqn: relax(0.7) + bind + PBiCG + DILU, 3 components in one batched solve (relTol 0.1)"):
+            asm.relax(0.7, ud, ul, uu, ds[0], U[0])
+            UM.set_coeffs(ud, uu, ul)
+            its = [q["nIterations"] for q in UM.pbicg_multi(U, ds, "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)]
+        with stage("EEqn: fvm::ddt(rho, he) + fvm::div(phi, he) - fvm::laplacian(alphaEff, he) + explicit K / dpdt terms (fvm::Su) + relax + PBiCG"):
+            asm.fvm_ddt_euler_rho(rdt, rho, rho0, vol, he, ed, es)
+            asm.fvm_laplacian(delta, alphaMagSf, lu, ld)
+            asm.axpby(1.0, cl, -1.0, lu, el); asm.axpby(1.0, cu, -1.0, lu, eu)
+            asm.axpby(1.0, ed, 1.0, cd, ed); asm.axpby(1.0, ed, -1.0, ld, ed)
+            patch.add(icE, ed, 0)
+            K = 0.5 * (U[0] * U[0] + U[1] * U[1] + U[2] * U[2])
+            asm.face_interpolate(wts, K, Kf); Kf.mul_(phi)
+            asm.surface_integrate(Kf, vol, expl)                                       # fvc::div(phi, K)
+            expl.add_(rdt * (rho * K - rho0 * K0)).sub_(rdt * (p - p_old))              # + fvc::ddt(rho, K) - dpdt
+            asm.fvm_su(vol, expl, es)                                                  # an explicit term on the left-hand side: source -= V expl (fvmSup.C:34-54)
+            asm.relax(0.9, ed, el, eu, es, he)
+            EM.set_coeffs(ed, eu, el)
+            e_it = EM.pbicg(he, es, "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)["nIterations"]
+            torch.mul(psi, p, out=rho)                                                 # thermo.correct(): rho = psi p
+        with stage("pEqn: rAU, rhorAUf, HbyA = rAU H, fvc::ddtCorr(rho, U, phi)"):
+            torch.div(vol, ud, out=rAU)                                                # 1 / UEqn.A(), A = D / V
+            torch.mul(rho, rAU, out=tmpN); asm.face_interpolate(lam, tmpN, rhorAUf)
+            for d in range(3):
+                UM.H(U[d], HbyA[d]); HbyA[d].add_(ds[d]).div_(vol).mul_(rAU)            # fvMatrix::H = (lduMatrix::H + source) / V
+            asm.ddt_phi_corr(rdt, lam, Sf, U0, rho0, phi, ddtc)
+        if not transonic:
+            with stage("pEqn: phiHbyA + fvc::div(phiHbyA) in one pass, fvm::ddt(psi, p) - fvm::laplacian(rhorAUf, p), bind"):
+                asm.flux_div(lam, Sf, HbyA, phiH, divH, cell_scale=rho, add_a=rhorAUf, add_b=ddtc)
+                rhorAUf.mul_(magSf)
+                asm.fvm_laplacian(delta, rhorAUf, pu, pd)
+                asm.fvm_ddt_euler_rho(rdt, psi, psi, vol, p_old, pdd, ps)
+                asm.axpby(1.0, pdd, -1.0, pd, pd); asm.axpby(-1.0, pu, 0.0, pu, pu)     # ddt - laplacian
+                asm.axpby(1.0, ps, -1.0, divH, ps)                                      # + fvc::div(phiHbyA): source -= V div
+                patch.add(icP, pd, 0)
+                PM.set_coeffs(pd, pu, None)
+        else:
+            with stage("pEqn (transonic): phid, fvm::ddt(psi, p) + fvm::div(phid, p) - fvm::laplacian(rhorAUf, p): asymmetric, bind"):
+                asm.flux_div(lam, Sf, HbyA, phiH, divH)                                  # interpolate(HbyA) & Sf
+                asm.face_interpolate(lam, rho, rho_f); asm.face_interpolate(lam, psi, pf)
+                phiH.add_(rhorAUf * ddtc / rho_f).mul_(pf)                               # phid
+                asm.upwind_weights(phiH, wts); asm.fvm_div(wts, phiH, pl, pu, pd)
+                rhorAUf.mul_(magSf)
+                asm.fvm_laplacian(delta, rhorAUf, lu, ld)
+                asm.fvm_ddt_euler_rho(rdt, psi, psi, vol, p_old, pdd, ps)
+                asm.axpby(1.0, pl, -1.0, lu, pl); asm.axpby(1.0, pu, -1.0, lu, pu)
+                asm.axpby(1.0, pd, 1.0, pdd, pd); asm.axpby(1.0, pd, -1.0, ld, pd)
+                patch.add(icP, pd, 0)
+                PM.set_coeffs(pd, pu, pl)
+        if capture is not None:
+            torch.cuda.synchronize()
+            capture.update(diag=pd.cpu().numpy().copy(), upper=pu.cpu().numpy().copy(), lower=pl.cpu().numpy().copy() if transonic else None,
+                           source=ps.cpu().numpy().copy(), start=p.cpu().numpy().copy())
+        with stage("pEqn: GAMG (relTol 0.05)"):
+            perf = G.solve(PM, p, ps, tolerance=1e-12, relTol=0.05, maxIter=50)
+            cyc = perf["nIterations"]
+        if capture is not None:
+            torch.cuda.synchronize()
+            capture.update(solution=p.cpu().numpy().copy(), perf=perf)
+        with stage("corrector: phi = phiHbyA + pEqn.flux(), U = HbyA - rAU grad(p)"):
+            PM.faceH(p, fh)
+            if not transonic:
+                torch.sub(phiH, fh, out=Kf)                                            # (the step's phi; `phi` itself stays the step's input: same work every step)
+            asm.face_interpolate(lam, p, pf); asm.gauss_grad(Sf, pf, vol, grad)
+            for d in range(3): torch.addcmul(HbyA[d], rAU, grad[d], value=-1.0, out=tmpN)
+        return its, e_it, cyc
+
+    he0 = he.clone()
+
+    def reset():
+        p.copy_(p_old); torch.mul(psi, p, out=rho); he.copy_(he0)
+        for d in range(3): U[d].copy_(U0[d])
+
+    step(); reset(); torch.cuda.synchronize(); ev.clear()
+    wall = 0.0
+    for _ in range(steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        its, e_it, cyc = step()
+        torch.cuda.synchronize(); wall += time.perf_counter() - t0
+        reset()
+    wall /= steps
+    return {"workload": f"BASELINE config 5's solver, per-rank share: one rhoPimpleFoam time step ({'transonic' if transonic else 'non-transonic'} pEqn) on the "
+                        f"{case.dims[0]}x{case.dims[1]}x{case.dims[2]} box -- UEqn (fvm::ddt(rho,U) + upwind fvm::div(phi,U) - fvm::laplacian(muEff,U) == -grad p, relax, "
+                        "batched PBiCG + DILU), EEqn (fvm::ddt(rho,he) + fvm::div - fvm::laplacian + explicit K / dpdt terms, PBiCG + DILU), pEqn "
+                        + ("(fvm::ddt(psi,p) + fvm::div(phid,p) - fvm::laplacian(rhorAUf,p): asymmetric GAMG)" if transonic else
+                           "(fvc::ddtCorr, phiHbyA + its divergence in one pass, fvm::ddt(psi,p) - fvm::laplacian(rhorAUf,p): GAMG)") + ", flux and velocity correction",
+            "ms_per_time_step": 1e3 * wall, "pbicg_iterations_per_component": [int(v) for v in its], "energy_pbicg_iterations": int(e_it), "gamg_cycles": int(cyc),
+            "pressure_matrix": "asymmetric" if transonic else "symmetric",
+            "stages_ms": {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()},
+            "timing": f"mean of {steps} steps after one warm-up step (fields reset between steps: same work every step); stages by HIP events on the engine's stream"}
+
+
 def decomposed_supplements(eng, syn, par, sub, ctx, dev, comms, n_global, cycles=10, steps=3, reduce_max=lambda v: v):
     """BASELINE configs 3 / 4 / 5 as DECOMPOSED workloads, per rank (`bench.py --gpus N` measured diagonal PCG
     only): `sub` is this rank's sub-domain with its processor patches, `comms` the (reduce, halo) communicators the PCG bench
