@@ -468,9 +468,12 @@ def main():
                     return float(tm.item())
                 ok_sup = 1
                 try:
-                    d = workloads.decomposed_supplements(eng, syn, par, wsub, ctx, dev, ws.comms, nx * px * ny * py * nz * pz, reduce_max=rmax)
+                    # (MI_BENCH_DECOMP_CYCLES / _STEPS: shorter supplements for the rehearsals between processes that SHARE a GPU, where every
+                    #  exchange costs a scheduling quantum -- tests/test_bench_contract.py)
+                    dkw = dict(cycles=int(os.environ.get("MI_BENCH_DECOMP_CYCLES", "10")), steps=int(os.environ.get("MI_BENCH_DECOMP_STEPS", "3")))
+                    d = workloads.decomposed_supplements(eng, syn, par, wsub, ctx, dev, ws.comms, nx * px * ny * py * nz * pz, reduce_max=rmax, **dkw)
                     supplements[f"decomposed_{wsub.n_cells}_cells_per_rank"] = d
-                    d2 = workloads.decomposed_supplements(eng, syn, par, sub, ctx, dev, ws.comms, N, reduce_max=rmax)
+                    d2 = workloads.decomposed_supplements(eng, syn, par, sub, ctx, dev, ws.comms, N, reduce_max=rmax, **dkw)
                     supplements[f"decomposed_{sub.n_cells}_cells_per_rank"] = d2
                 except Exception as e:  # a supplement must never cost the headline line (the other ranks' waits are bounded: they end up here too)
                     ok_sup = 0

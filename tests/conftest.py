@@ -34,11 +34,19 @@ def _world_of(item):
     return {"test_transformed_processor_patches_between_engine_ranks": 4, "test_distributed_pcg_real_engine_ragged_graph_random_partition": 3}.get(name, 0)
 
 
+def _uses_windows(item):
+    """ranks of this test wait for each other inside kernels (hipIpc windows, persistent grids): a rank PROCESS that has done
+    that once stays slow for plain-transport jobs too (measured: 60 x, profiles/r05_c_native_solve_timings.tsv), so within one world
+    size the plain-transport tests run first"""
+    p = getattr(getattr(item, "callspec", None), "params", {})
+    return int(bool(p.get("peer", False)) or any(w in item.name for w in ("peer", "window", "persistent")))
+
+
 def pytest_collection_modifyitems(config, items):
     def key(item):
         name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
         rank = _FILE_ORDER.index(name) if name in _FILE_ORDER else _FILE_ORDER.index("test_distributed") - 0.5
-        return (rank, _world_of(item) if name == "test_distributed" else 0)
+        return (rank,) + ((_world_of(item), _uses_windows(item)) if name == "test_distributed" else (0, 0))
     items.sort(key=key)          # stable: apart from the grouping by world size the order inside a file stays the file's
 
 

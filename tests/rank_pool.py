@@ -7,7 +7,8 @@ of `world` processes joins ONE gloo group when it is first asked for and then se
     run_ranks(world, "test_distributed", "_native_body", spec, out_dir, ...)   ->   module.fn(rank, world, *args) on every rank
 
 A job runs with a fresh engine context (the engine reads its MI_* switches when a context is created, so per-job os.environ
-changes take effect; the pool restores the environment afterwards), and everything it created is collected before the next one.
+changes take effect; the pool restores the environment afterwards) and closes what it created before the next one.  ONE pool is
+alive at a time; tests/conftest.py groups the multi-process tests by world size, plain-transport jobs before window jobs.
 A rank that raises, or a job that exceeds its time limit, costs that pool its life (its processes are killed -- by PID -- and the
 next job for that world size starts new ones), so one failing test cannot poison the ones after it.  MI_TEST_POOL=0 goes back to
 fresh processes per call.
@@ -151,8 +152,13 @@ class RankPool:
         self.procs, self.conns = [], []
 
 
-def run_ranks(world, module, fn, *args, timeout=600.0):
-    """module.fn(rank, world, *args) on `world` ranks that share one gloo group; raises AssertionError with the ranks' tracebacks"""
+def run_ranks(world, module, fn, *args, timeout=600.0, fresh=False):
+    """module.fn(rank, world, *args) on `world` ranks that share one gloo group; raises AssertionError with the ranks' tracebacks.
+    fresh: do not reuse rank processes of earlier jobs (a process whose kernels have once waited on another process's windows
+    stays slow -- 60 x on the plain transport, profiles/r05_c_native_solve_timings.tsv; the large plain-transport jobs ask for new ones)"""
+    if fresh:
+        for w in list(_POOLS):
+            _POOLS.pop(w).close()
     if os.environ.get("MI_TEST_POOL", "1") == "0":
         pool = RankPool(world, persistent=False)
         try:

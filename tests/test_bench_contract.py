@@ -87,7 +87,8 @@ def test_two_rank_rehearsal_with_peer_windows_and_the_persistent_kernel():
     history with the five-launch loop's, bare timed repeats, one more sampled batch for the Amul duration -- rehearsed with two
     ranks that share this box's GPU: communicators over the host transport, windows over hipIpc, the two cooperative grids side by
     side (MI_PERSIST_GRID workgroups each)"""
-    env = dict(os.environ, MI_BENCH_BACKEND="gloo", MI_DPCG_DRIVER="native", MI_COMM_TRANSPORT="host", MI_PERSIST_SHARED="1", MI_PERSIST_GRID="96", MI_PEER_POLLS="3000000")
+    env = dict(os.environ, MI_BENCH_BACKEND="gloo", MI_DPCG_DRIVER="native", MI_COMM_TRANSPORT="host", MI_PERSIST_SHARED="1", MI_PERSIST_GRID="96", MI_PEER_POLLS="3000000",
+               MI_BENCH_DECOMP_CYCLES="3", MI_BENCH_DECOMP_STEPS="1")     # (two processes on one GPU: a scheduling quantum per exchange -- short supplements)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
            "--dims", "96", "64", "48", "--no-cpu"]

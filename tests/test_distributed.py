@@ -212,8 +212,11 @@ def _native_body(rank, world, spec, out_dir, rccl=False, peer=False):
     x = pkg.synthetic.splitmix_uniform(3, dm.n_global)[sub.global_cells] - 0.5
     out = torch.empty(sub.n_cells, dtype=torch.float64, device=dname)
     dm.mat.amul(dev(x), out); torch.cuda.synchronize(); res["amul"] = out.cpu().numpy()
+    import time as _time
+    timings = []
     for name, solver, kw in spec["solves"]:
         kw = dict(kw)
+        _t0 = _time.perf_counter()
         if solver == "GAMG":
             kw["face_weights"] = weights[rank]
         if solver == "PBiCG3":   # the components of a vector equation in ONE solve on the attached matrix (mi_pbicg_solve_multi)
@@ -222,10 +225,12 @@ def _native_body(rank, world, spec, out_dir, rccl=False, peer=False):
             torch.cuda.synchronize()
             for c, (q, pf) in enumerate(zip(psis, perfs)):
                 res[f"{name}{c}_psi"] = q.cpu().numpy(); res[f"{name}{c}_hist"] = pf["history"]; res[f"{name}{c}_nit"] = pf["nIterations"]
+            timings.append((name, solver, _time.perf_counter() - _t0, sum(pf["nIterations"] for pf in perfs)))
             continue
         psi = torch.zeros(sub.n_cells, dtype=torch.float64, device=dname)
         perf = dm.solve(solver, psi, dev(sub.source), **kw)
         torch.cuda.synchronize()
+        timings.append((name, solver, _time.perf_counter() - _t0, perf["nIterations"]))
         res[name + "_psi"] = psi.cpu().numpy(); res[name + "_hist"] = perf["history"]; res[name + "_nit"] = perf["nIterations"]
     if any(s[1] == "GAMG" for s in spec["solves"]):
         res["gamg_levels"] = dm._gamg.n_levels
@@ -239,6 +244,22 @@ def _native_body(rank, world, spec, out_dir, rccl=False, peer=False):
         assert ctx.stat(1) > 0, "the persistent distributed kernel did not run"
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
+    if rank == 0:     # where a multi-process test spends its time, solve by solve (gpurun_out/native_solve_timings.tsv)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "native_solve_timings.tsv"), "a") as f:
+                for name, solver, sec, nit in timings:
+                    f.write(f"{sec:8.3f}\t{nit}\t{solver}\t{name}\t{spec['kind']}\tworld={world}\tpeer={peer}\tpersist={persist}\trccl={rccl}\n")
+        except OSError:
+            pass
+    # everything this job created goes before the next one runs in this process (tests/rank_pool.py): the engine's handles have no
+    # finalisers, a rank process that serves many jobs would otherwise keep every context, window and hierarchy of the jobs before
+    if dm._gamg is not None:
+        dm._gamg.close()
+    dm.mat.close(); dm.addr.close()
+    for c in {id(c): c for c in comms}.values():
+        c.close()
+    ctx.close()
 
 
 PBICG3_COMPONENTS = ((1.0, 0.0), (0.5, 0.01), (-0.3, 0.0))   # source of component c = a * source + b
@@ -285,18 +306,19 @@ NATIVE_SPECS = {
                                       ("stab", "PBiCGStab", dict(precond="diagonal", tolerance=1e-10, maxIter=300)),
                                       ("smooth", "smoothSolver", dict(n_sweeps=2, tolerance=1e-4, maxIter=300))]),
     # sub-domains for the persistent distributed kernel: two tiles per workgroup at 2 ranks x 96 workgroups, one at 4 x 48
-    # (short solves: the processes' cooperative grids share one GPU and every exchange waits for the other process's kernel)
+    # (short solves: the processes' cooperative grids share one GPU and every exchange waits for the other process's kernel --
+    #  a scheduling quantum per barrier; one solve of each spec ends by the convergence test INSIDE the kernel)
     "box_2_persist": dict(kind="box", dims=(96, 64, 48), parts=(2, 1, 1), symmetric=True,
-                          solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=60)), ("pcg0", "PCG", dict(precond="none", tolerance=1e-2, maxIter=600))]),
+                          solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=24)), ("pcg0", "PCG", dict(precond="none", tolerance=0.15, maxIter=200))]),
     # ... and five tiles per workgroup (what the 8-GPU share of the benchmark needs) at 2 ranks x 96 workgroups
     "box_2_persist5": dict(kind="box", dims=(128, 96, 80), parts=(1, 2, 1), symmetric=True,
-                           solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=30))]),
+                           solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=16))]),
     # the REAL 8-GPU topology: 2 x 2 x 2, three processor patches per rank, 108 tiles per rank on 24 workgroups = five tiles per
     # workgroup -> k_pcg_persist<5, true> (VERDICT r03 "weak" 1: that topology had never been through the DIST kernel)
     "box_8_persist5": dict(kind="box", dims=(96, 96, 96), parts=(2, 2, 2), symmetric=True,
-                           solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=40)), ("pcg0", "PCG", dict(precond="none", tolerance=1e-3, maxIter=600))]),
+                           solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.0, maxIter=16)), ("pcg0", "PCG", dict(precond="none", tolerance=0.15, maxIter=200))]),
     "box_4_persist": dict(kind="box", dims=(64, 64, 48), parts=(2, 2, 1), symmetric=True,
-                          solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=1e-3, maxIter=600)), ("pcg0", "PCG", dict(precond="none", tolerance=0.0, maxIter=25))]),
+                          solves=[("pcg", "PCG", dict(precond="diagonal", tolerance=0.15, maxIter=200)), ("pcg0", "PCG", dict(precond="none", tolerance=0.0, maxIter=16))]),
     # row f3: cyclicAMI whose halves live on different ranks (AMIInterpolation.C:940-1091): y-slabs, slab 0 holds the y-min side,
     # the last slab the refined and shifted y-max side (different face counts), processor patches between the slabs
     "ami_sym": dict(kind="ami_y", dims=(20, 16, 12), symmetric=True, ami=dict(shift=0.37),
@@ -311,6 +333,27 @@ NATIVE_SPECS = {
 }
 
 
+# Ranks that SHARE a GPU and wait for each other inside kernels (window flags / pairs polled by a tile kernel, the one-shot window
+# all-reduce, the persistent grids) pay one hardware scheduling quantum per exchange: 16 ms per all-reduce measured between two
+# processes on one MI355X (profiles/r05_c_native_solve_timings.tsv: 144 PCG iterations 4.6 s over windows, 0.08 s over gloo; the
+# same to three digits with fresh and with re-used processes).  One rank per device never sees that -- but these tests do, so the
+# window variants run every solver for a FIXED, short number of iterations (histories compared entry by entry as always); the
+# runs to convergence are the gloo-transport variants' (same C++ loops, same collectives).
+_WINDOW_ITERATIONS = {"PCG": 24, "PBiCG": 12, "PBiCGStab": 10, "smoothSolver": 8, "GAMG": 3, "PBiCG3": 8}
+
+
+def _windows_spec(spec):
+    out = dict(spec)
+    out["solves"] = [(name, solver, dict(kw, tolerance=0.0, maxIter=_WINDOW_ITERATIONS[solver])) for name, solver, kw in spec["solves"]]
+    # ... except that the first PCG still ENDS BY ITS TOLERANCE, in the middle of a batch of enqueued iterations: the exchanges of the
+    # iterations behind the converged one must be counted alike by ranks in different window forms (round 4's 4-rank cyclicAMI hang)
+    for k, (name, solver, kw) in enumerate(out["solves"]):
+        if solver == "PCG":
+            out["solves"][k] = (name, solver, dict(kw, tolerance=0.05, maxIter=200))
+            break
+    return out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("peer", [False, "auto"])
 def test_transformed_processor_patches_between_engine_ranks(pkg, orc, tmp_path, peer):
@@ -318,7 +361,7 @@ def test_transformed_processor_patches_between_engine_ranks(pkg, orc, tmp_path, 
     transformCoupleField factor (scale_received after the send/recv exchange; inside k_halo_pull when the halo travels through
     peer windows).  Amul bit-exact across the cuts, PBiCG + DILU / PBiCGStab / smoothSolver histories against the multi-domain
     oracle whose interfaces carry the same factors."""
-    spec = NATIVE_SPECS["box_4_transformed"]
+    spec = NATIVE_SPECS["box_4_transformed"] if not peer else _windows_spec(NATIVE_SPECS["box_4_transformed"])
     run_ranks(4, "test_distributed", "_native_body", spec, str(tmp_path), False, peer)
     _check_native(pkg, orc, spec, 4, str(tmp_path))
 
@@ -356,7 +399,7 @@ def test_native_solvers_with_the_one_shot_peer_allreduce(pkg, orc, tmp_path, nam
     going through the peer windows (mi_comm_peer_window / mi_comm_peer_connect): each rank writes its values + an epoch flag
     into every rank's window and adds the nRanks contributions in rank order.  Here the ranks are processes that share the
     GPU and map each other's windows over hipIpc; halo exchange and the large all-reduces stay on the gloo transport."""
-    spec = NATIVE_SPECS[name]
+    spec = _windows_spec(NATIVE_SPECS[name])
     run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, True)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
@@ -368,7 +411,7 @@ def test_native_solvers_entirely_over_peer_windows(pkg, orc, tmp_path, name, wor
     and, on top of it, the HALO of every attached matrix -- GAMG level matrices included -- through windows (k_halo_push /
     k_halo_pull) and the fused three-launch distributed PCG iteration, between 2, 3 and 4 processes that map each other's
     windows over hipIpc.  Only what does not fit the windows (all-reduces > 8 doubles, the hierarchy build) still uses gloo."""
-    spec = NATIVE_SPECS[name]
+    spec = _windows_spec(NATIVE_SPECS[name])
     run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, "auto")
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
@@ -380,7 +423,7 @@ def test_neighbours_in_different_window_forms(pkg, orc, tmp_path, name, world):
     one-launch form next to ranks in the four-launch form must count the same exchanges -- also in the iterations a batch
     enqueues after the solve has converged, which the one-launch operators used to skip entirely while k_halo_push /
     k_halo_pull went on (round 4: a 4-rank cyclicAMI case ran out of polls exactly there)."""
-    spec = NATIVE_SPECS[name]
+    spec = _windows_spec(NATIVE_SPECS[name])
     run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, "mixed")
     _check_native(pkg, orc, spec, world, str(tmp_path))
 
@@ -396,7 +439,7 @@ def test_cyclic_ami_whose_halves_live_on_different_ranks(pkg, orc, tmp_path, nam
     side's coarse faces from the coarse cells the transport patch receives.  Amul bit-exact across the interface; PCG / DIC-PCG /
     smoothSolver / PBiCG / PBiCGStab / GAMG (ICCG / BICCG on the coarsest level) against the multi-domain oracle (1e-10), over
     the external transport and over peer windows, with low-weight faces and a transformation factor in the asymmetric case."""
-    spec = NATIVE_SPECS[name]
+    spec = _windows_spec(NATIVE_SPECS[name]) if peer else NATIVE_SPECS[name]
     run_ranks(world, "test_distributed", "_native_body", spec, str(tmp_path), False, peer)
     _check_native(pkg, orc, spec, world, str(tmp_path))
 

@@ -184,7 +184,7 @@ def test_config5_eight_engine_ranks_80M_cells(pkg, orc, tmp_path):
     world = 8
     t0 = time.perf_counter()
     if rec:
-        run_ranks(world, "test_gpu_configs", "_config5_body", str(tmp_path), timeout=500.0)
+        run_ranks(world, "test_gpu_configs", "_config5_body", str(tmp_path), timeout=500.0, fresh=True)
         ref = _config5_recorded(rec)
         procs = None
     else:

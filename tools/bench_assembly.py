@@ -45,6 +45,16 @@ def run(tag, addr):
     timeit("negSumDiag (symmetric)", lambda: asm.row_face_op(1, None, fu, fd), 16 * N + 8 * F)
     timeit("fvc::surfaceIntegrate", lambda: asm.surface_integrate(ff, None, y), 8 * N + 8 * F)
     timeit("fvc::grad (Gauss, 3 components)", lambda: asm.gauss_grad(Sf, ff, vol, g3), 8 * N + 32 * F + 24 * N)
+    # round 5: rhoPimpleFoam's phiHbyA = (interpolate(rho HbyA) & Sf) + rhorAUf ddtCorr and its surfaceIntegrate in ONE row pass, and
+    # fvc::ddtCorr(rho, U, phi) in one face pass (algorithmic: every cell / face array once)
+    lam, rho, aA, aB = t(syn.splitmix_uniform(20, F)), t(0.8 + syn.splitmix_uniform(21, N)), t(syn.splitmix_uniform(22, F)), t(syn.splitmix_uniform(23, F))
+    V3 = [t(syn.splitmix_uniform(24 + k, N) - 0.5) for k in range(3)]
+    os.environ["MI_FLUX_FUSED"] = "0"
+    timeit("phiHbyA + fvc::div(phiHbyA) (mi_flux_div: face pass + row sum)", lambda: asm.flux_div(lam, Sf, V3, fl, y, cell_scale=rho, add_a=aA, add_b=aB), 32 * N + 8 * N + (8 + 24 + 16 + 8) * F)
+    os.environ["MI_FLUX_FUSED"] = "1"
+    timeit("phiHbyA + fvc::div(phiHbyA) (MI_FLUX_FUSED=1: one row pass)", lambda: asm.flux_div(lam, Sf, V3, fl, y, cell_scale=rho, add_a=aA, add_b=aB), 32 * N + 8 * N + (8 + 24 + 16 + 8) * F)
+    os.environ["MI_FLUX_FUSED"] = "0"
+    timeit("fvc::ddtCorr(rho, U, phi) (mi_ddt_phi_corr)", lambda: asm.ddt_phi_corr(1e4, lam, Sf, V3, rho, ff, fu), 32 * N + (8 + 24 + 8 + 8) * F)
     out[tag] = rows
 
 run("caller numbering (blocks of 1024 cells; gradient 256)", eng.Addressing(ctx, N, case.lower_addr, case.upper_addr))
