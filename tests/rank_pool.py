@@ -10,8 +10,8 @@ A job runs with a fresh engine context (the engine reads its MI_* switches when 
 changes take effect; the pool restores the environment afterwards) and closes what it created before the next one.  ONE pool is
 alive at a time; tests/conftest.py groups the multi-process tests by world size, plain-transport jobs before window jobs.
 A rank that raises, or a job that exceeds its time limit, costs that pool its life (its processes are killed -- by PID -- and the
-next job for that world size starts new ones), so one failing test cannot poison the ones after it.  MI_TEST_POOL=0 goes back to
-fresh processes per call.
+next job for that world size starts new ones), so one failing test cannot poison the ones after it.  That is MI_TEST_POOL=1; the
+DEFAULT is fresh processes per call (same code path, pool closed after its one job): see run_ranks.
 """
 import atexit
 import importlib
@@ -159,7 +159,11 @@ def run_ranks(world, module, fn, *args, timeout=600.0, fresh=False):
     if fresh:
         for w in list(_POOLS):
             _POOLS.pop(w).close()
-    if os.environ.get("MI_TEST_POOL", "1") == "0":
+    # Default: fresh processes per call.  Re-used processes (MI_TEST_POOL=1) save ~3 s of start-up per test, but jobs that talk through
+    # the host transport (a hipMemcpy per callback) get slower and slower in a process that has served jobs before -- measured on the
+    # GPU box: a 4-rank cyclicAMI case 127 s re-used against ~12 s fresh, a 2-rank one 79 s against 3.3 s
+    # (profiles/r05_c_multiprocess_test_timing.md); the cause was not found within the round's GPU time.
+    if os.environ.get("MI_TEST_POOL", "0") != "1":
         pool = RankPool(world, persistent=False)
         try:
             pool.run(module, fn, *args, timeout=timeout)

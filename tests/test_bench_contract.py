@@ -69,7 +69,7 @@ def test_gamg_mode_line():
 
 @pytest.mark.parametrize("n", [2, 4])
 def test_multi_rank_rehearsal_over_gloo(n):
-    env = dict(os.environ, MI_BENCH_BACKEND="gloo")
+    env = dict(os.environ, MI_BENCH_BACKEND="gloo", MI_BENCH_DECOMP_CYCLES="3", MI_BENCH_DECOMP_STEPS="1")   # (ranks share ONE GPU here: short supplements)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "12", "--warmup", "3",
            "--dims", "40", "32", "24", "--no-cpu"]
@@ -114,7 +114,7 @@ def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
     """`python bench.py --gpus 2` (no torch.distributed.run around it) must not fall back to one GPU silently: it re-executes
     itself under the launcher.  Rehearsed over gloo (two ranks share this box's GPU); over RCCL it refuses when fewer GPUs than
     ranks are visible."""
-    env = dict(os.environ, MI_BENCH_BACKEND="gloo")
+    env = dict(os.environ, MI_BENCH_BACKEND="gloo", MI_BENCH_DECOMP_CYCLES="3", MI_BENCH_DECOMP_STEPS="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--dims", "40", "32", "24", "--no-cpu"],

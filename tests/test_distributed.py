@@ -344,7 +344,9 @@ _WINDOW_ITERATIONS = {"PCG": 24, "PBiCG": 12, "PBiCGStab": 10, "smoothSolver": 8
 
 def _windows_spec(spec):
     out = dict(spec)
-    out["solves"] = [(name, solver, dict(kw, tolerance=0.0, maxIter=_WINDOW_ITERATIONS[solver])) for name, solver, kw in spec["solves"]]
+    # (GAMG keeps a finite tolerance: with directSolveCoarsest = False its coarsest-level ICCG / BICCG inherits it,
+    #  GAMGSolverSolve.C:572-613 -- tolerance 0 there means 1000 coarsest iterations per cycle)
+    out["solves"] = [(name, solver, dict(kw, tolerance=1e-3 if solver == "GAMG" else 0.0, maxIter=_WINDOW_ITERATIONS[solver])) for name, solver, kw in spec["solves"]]
     # ... except that the first PCG still ENDS BY ITS TOLERANCE, in the middle of a batch of enqueued iterations: the exchanges of the
     # iterations behind the converged one must be counted alike by ranks in different window forms (round 4's 4-rank cyclicAMI hang)
     for k, (name, solver, kw) in enumerate(out["solves"]):
