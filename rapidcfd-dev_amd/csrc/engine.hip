@@ -103,6 +103,7 @@ struct mi_ctx_s {
     uint64_t faultEpoch = 0; // faults of the persistent kernel reported on this context so far (fetch_state); a matrix re-zeroes its barrier words when it has missed one
     int winDirect = 1; // MI_WIN_DIRECT: tile operators of attached matrices read neighbour-rank values straight from the halo window (one launch for all tiles) instead of k_halo_pull + a second launch (A/B hook)
     int gamgGraphAttached = 1; // MI_GAMG_GRAPH_ATTACHED: the V-cycle of a decomposed case replays as a hipGraph when every exchange of it is stream work (peer windows)
+    int multiPipe = 1; // MI_MULTI_PIPE: tile_kernel_multi_pipe (multi_pipe.inc) for the multi-vector passes of the Krylov iterations
     int pairAT = 1;    // MI_PBICG_PAIR: PBiCG's A p / A^T pT (and the DILU pair) in one pass over the coefficients (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
     int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1; // MI_* switches, read once per context
@@ -261,6 +262,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->fusePerm = env_int("MI_FUSE_PERM", 1);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->pairAT = env_int("MI_PBICG_PAIR", 1);
+    c->multiPipe = env_int("MI_MULTI_PIPE", 1);   // the multi-vector tile passes of the Krylov iterations as persistent pipelined workgroups (multi_pipe.inc): same bits, three-component PBiCG + DILU iteration 1 812 -> 1 643 us (profiles/r05_f_multi_pipe_ab.md)
     c->winDirect = env_int("MI_WIN_DIRECT", 1); c->gamgGraphAttached = env_int("MI_GAMG_GRAPH_ATTACHED", 1);
     c->pcgPersist = env_int("MI_PCG_PERSIST", 1);
     c->persistGrid = env_int("MI_PERSIST_GRID", 0);
@@ -2329,6 +2331,7 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
     return MI_OK;
 }
 
+#include "multi_pipe.inc"
 #include "multi.inc"
 #include "comm.inc"
 #include "persist.inc"

@@ -506,6 +506,45 @@ def test_native_rccl_loop_self_exchange(pkg, orc, ctx):
     assert torch.equal(t.cpu(), torch.arange(5, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("dims", [(96, 80, 72), (21, 17, 13)])
+def test_pipelined_multi_vector_pass_equals_the_plain_one_bit_for_bit(pkg, dims, monkeypatch):
+    """csrc/multi_pipe.inc (MI_MULTI_PIPE=1): the multi-vector tile passes of the Krylov iterations as persistent workgroups that
+    prefetch their next tile into registers while they walk the current one.  Only WHEN a tile's image is loaded differs from
+    tile_kernel_multi: the three-component PBiCG + DILU / + diagonal solves, the paired single-component solve and PBiCGStab must
+    give the same bits -- histories, iteration counts, solutions -- on a matrix with several tiles per resident workgroup (553 k
+    cells = 540 tiles on 256 workgroups) and on one with two tiles (first-tile staging only)."""
+    syn, eng = pkg.synthetic, pkg.engine
+    case = syn.box_case(*dims, symmetric=False)
+    n = case.n_cells
+    srcs = [case.source, 3.0 * (syn.splitmix_uniform(41, n) - 0.5), syn.splitmix_uniform(42, n) - 0.5]
+    out = {}
+    for pipe in ("0", "1"):
+        monkeypatch.setenv("MI_MULTI_PIPE", pipe)
+        ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+        addr = eng.Addressing(ctx, n, case.lower_addr, case.upper_addr)
+        if dims[0] > 50:
+            assert addr.n_tiles > 2 * 256
+        mat = eng.Matrix(addr)
+        mat.set_coeffs(dev(case.diag), dev(case.upper), dev(case.lower))
+        res = []
+        for precond in ("DILU", "diagonal"):
+            psis = [torch.zeros(n, dtype=torch.float64, device="cuda:0") for _ in range(3)]
+            got = mat.pbicg_multi(psis, [dev(b) for b in srcs], precond, tolerance=0.0, maxIter=9)
+            res += [(g["history"], g["nIterations"], host(q)) for g, q in zip(got, psis)]
+            psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+            g = mat.pbicg(psi, dev(srcs[1]), precond, tolerance=1e-7, maxIter=200)
+            res.append((g["history"], g["nIterations"], host(psi)))
+        psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        g = mat.pbicgstab(psi, dev(srcs[0]), "DILU", tolerance=0.0, maxIter=8)
+        res.append((g["history"], g["nIterations"], host(psi)))
+        out[pipe] = res
+        mat.close(); addr.close(); ctx.close()
+    assert len(out["0"]) == len(out["1"]) == 9
+    for k, ((h0, n0, p0), (h1, n1, p1)) in enumerate(zip(out["0"], out["1"])):
+        assert n0 == n1 and np.array_equal(h0, h1) and np.array_equal(p0, p1), k
+    assert np.all(np.isfinite(out["1"][0][0])) and out["1"][0][0][-1] < out["1"][0][0][0]
+
+
 @pytest.mark.parametrize("name", ["box_asym", "graph_asym", "box_sym"])
 @pytest.mark.parametrize("precond", ["AINV", "diagonal", "none"])
 def test_multi_rhs_pbicg_equals_the_single_solves_bit_for_bit(pkg, orc, ctx, name, precond, monkeypatch):
