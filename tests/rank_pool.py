@@ -87,6 +87,18 @@ def _collect():
 
 class RankPool:
     def __init__(self, world, persistent=True):
+        # the rendezvous port is found free and then bound by rank 0 a moment later: another socket of this busy box (the gloo pairs of
+        # a pool that is just closing, a bench rehearsal's store) can take it in between -- seen twice in 58 pools of one suite run.
+        # Start again with another port instead of failing the test.
+        for attempt in range(4):
+            try:
+                self._start(world, persistent)
+                return
+            except AssertionError as e:
+                if attempt == 3 or "address already in use" not in str(e).lower():
+                    raise
+
+    def _start(self, world, persistent):
         ctx = multiprocessing.get_context("spawn")
         port = free_port()
         self.world, self.procs, self.conns = world, [], []

@@ -31,6 +31,15 @@ def _check(line, n):
     return d
 
 
+def _run_with_port(make_cmd, env, attempts=4):
+    """subprocess.run of a launcher command built for a free rendezvous port; the port is found free and bound a moment later by the
+    launcher's store, so on a busy box another socket can take it in between: try again with another port"""
+    for k in range(attempts):
+        out = subprocess.run(make_cmd(_free_port()), capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        if out.returncode == 0 or "address already in use" not in out.stderr.lower() or k == attempts - 1:
+            return out
+
+
 def test_single_gpu_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--dims", "40", "32", "24", "--cpu-iters", "5"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -70,10 +79,10 @@ def test_gamg_mode_line():
 @pytest.mark.parametrize("n", [2, 4])
 def test_multi_rank_rehearsal_over_gloo(n):
     env = dict(os.environ, MI_BENCH_BACKEND="gloo", MI_BENCH_DECOMP_CYCLES="3", MI_BENCH_DECOMP_STEPS="1")   # (ranks share ONE GPU here: short supplements)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "12", "--warmup", "3",
+    make = lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "12", "--warmup", "3",
            "--dims", "40", "32", "24", "--no-cpu"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    out = _run_with_port(make, env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout                       # rank 0 only
@@ -89,10 +98,10 @@ def test_two_rank_rehearsal_with_peer_windows_and_the_persistent_kernel():
     side (MI_PERSIST_GRID workgroups each)"""
     env = dict(os.environ, MI_BENCH_BACKEND="gloo", MI_DPCG_DRIVER="native", MI_COMM_TRANSPORT="host", MI_PERSIST_SHARED="1", MI_PERSIST_GRID="96", MI_PEER_POLLS="3000000",
                MI_BENCH_DECOMP_CYCLES="3", MI_BENCH_DECOMP_STEPS="1")     # (two processes on one GPU: a scheduling quantum per exchange -- short supplements)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+    make = lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
            "--dims", "96", "64", "48", "--no-cpu"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    out = _run_with_port(make, env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout
