@@ -61,6 +61,30 @@ def test_distributed_pcg_matches_serial_oracle(pkg, orc, tmp_path, parts, kw):
     assert np.max(np.abs(psi - ref_psi)) < 1e-9 * np.max(np.abs(ref_psi))
 
 
+def _sum_ranks_body(rank, world, out_dir):
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), t.numpy())
+
+
+def test_rank_pool_starts_again_when_the_rendezvous_port_is_taken(tmp_path, monkeypatch):
+    """tests/rank_pool.py: the rendezvous port is found free and bound by rank 0 a moment later -- on a busy box another socket can take
+    it in between (round 5: EADDRINUSE in 2 of 58 pools of one GPU-suite run).  With the first port it is offered held by a listening
+    socket, a pool must start again on another port and run its job."""
+    import rank_pool
+    busy = socket.socket()
+    busy.bind(("127.0.0.1", 0)); busy.listen(1)
+    offered = [busy.getsockname()[1]]
+    real = rank_pool.free_port
+    monkeypatch.setattr(rank_pool, "free_port", lambda: offered.pop() if offered else real())
+    try:
+        rank_pool.run_ranks(2, "test_distributed", "_sum_ranks_body", str(tmp_path))
+    finally:
+        busy.close()
+    assert not offered                                                       # the busy port was really the first one tried
+    assert all(float(np.load(tmp_path / f"s{r}.npy")[0]) == 3.0 for r in range(2))
+
+
 def test_direct_subdomain_equals_decomposed_global_case(pkg):
     # bench.py builds every rank's sub-domain directly (an 8 x 216^3 run never forms the 80 M-cell global case):
     # same addressing, coefficients, source, interface order and pairing as decompose_box(box_case(...))
