@@ -195,6 +195,38 @@ def build_v4(pkg, orc):
     return out
 
 
+def v5_inputs(pkg):
+    """fields of the fifth fixture set: a 12 x 10 x 8 box, densities, volumes, face weights / areas, a velocity, old fluxes"""
+    syn = pkg.synthetic
+    case = syn.box_case(12, 10, 8)
+    n, nf = case.n_cells, case.n_faces
+    u = syn.splitmix_uniform
+    return dict(case=case, rho=0.9 + u(501, n), rho0=0.8 + u(502, n), vol=0.5 + u(503, n), psi0=u(504, n) - 0.5, su=u(505, n) - 0.5, sp=u(506, n),
+                susp=u(507, n) - 0.5, vf=u(508, n) - 0.5, lam=u(509, nf), Sf=[u(510 + k, nf) - 0.5 for k in range(3)], U=[u(513 + k, n) - 0.5 for k in range(3)],
+                aA=u(516, nf) - 0.5, aB=u(517, nf), phi0=u(518, nf) - 0.5, rdt=1.0 / 3e-4)
+
+
+def build_v5(pkg, orc):
+    """fifth fixture set (round 5): the compressible operators of rhoPimpleFoam -- fvm::ddt(rho, vf) (EulerDdtScheme.C:403-440), fvm::Su / Sp /
+    SuSp (fvmSup.C:34-214), fvc::ddtCorr(rho, U, phi) (EulerDdtScheme.C:663-720, ddtScheme.C:139-174), the interpolated flux with its
+    surfaceIntegrate (pEqn.H:49-71) -- whole arrays (the case is small)"""
+    q = v5_inputs(pkg)
+    case = q["case"]
+    n, lo, up = case.n_cells, case.lower_addr, case.upper_addr
+    out = {}
+    d, s = orc.fvm_ddt_euler_rho(q["rdt"], q["rho"], q["rho0"], q["vol"], q["psi0"])
+    out["ddt_rho/diag"], out["ddt_rho/source"] = d, s
+    out["su/source"] = orc.fvm_su(q["vol"], q["su"], s)
+    out["sp/diag"] = orc.fvm_sp(q["vol"], q["sp"], d)
+    out["sp_scalar/diag"] = orc.fvm_sp(q["vol"], 0.25, d)
+    out["susp/diag"], out["susp/source"] = orc.fvm_susp(q["vol"], q["susp"], q["vf"], d, s)
+    out["ddtcorr/rho"] = orc.ddt_phi_corr(lo, up, q["rdt"], q["lam"], q["Sf"], q["U"], q["rho0"], q["phi0"])
+    out["ddtcorr/plain"] = orc.ddt_phi_corr(lo, up, q["rdt"], q["lam"], q["Sf"], q["U"], None, q["phi0"])
+    out["fluxdiv/phi"], out["fluxdiv/div"] = orc.flux_div(n, lo, up, q["lam"], q["Sf"], q["U"], scale=q["rho"], add_a=q["aA"], add_b=q["aB"], vol=q["vol"])
+    out["fluxdiv_plain/phi"], out["fluxdiv_plain/div"] = orc.flux_div(n, lo, up, q["lam"], q["Sf"], q["U"])
+    return out
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
@@ -206,5 +238,7 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(here, "golden_v2.npz"), **build_v2(pkg, orc))
     if "--v3" in sys.argv or not os.path.exists(os.path.join(here, "golden_v3.npz")):   # frozen
         np.savez_compressed(os.path.join(here, "golden_v3.npz"), **build_v3(pkg, orc))
-    np.savez_compressed(os.path.join(here, "golden_v4.npz"), **build_v4(pkg, orc))
+    if "--v4" in sys.argv or not os.path.exists(os.path.join(here, "golden_v4.npz")):   # frozen
+        np.savez_compressed(os.path.join(here, "golden_v4.npz"), **build_v4(pkg, orc))
+    np.savez_compressed(os.path.join(here, "golden_v5.npz"), **build_v5(pkg, orc))
     print("written")
