@@ -175,12 +175,11 @@ def main():
     # `python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (one rank per GPU, as the driver's
     # `python -m torch.distributed.run --nproc-per-node N ... bench.py` does) instead of silently measuring one GPU
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # (--standalone: the launcher hosts the rendezvous itself on a port it binds, instead of a port found free here and bound a
+        #  moment later by someone else -- EADDRINUSE was seen in 2 of ~60 such rendezvous in one GPU-suite run of round 5)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--standalone", "--local-addr", "127.0.0.1",
+               os.path.abspath(__file__)] + sys.argv[1:]
         log(f"[bench] --gpus {args.gpus} without a launcher: re-executing under torch.distributed.run")
         raise SystemExit(subprocess.call(cmd))
 
