@@ -19,6 +19,7 @@ import multiprocessing
 import os
 import socket
 import sys
+import tempfile
 import time
 import traceback
 
@@ -33,16 +34,18 @@ def free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, conn, persistent):
+def _rank_main(rank, world, port, store, conn, persistent):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MASTER_PORT"] = str(port)         # (for code that reads them; the group itself meets through a file, below)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # rendezvous through a FileStore: no port that is found free here and bound by rank 0 seconds later (EADDRINUSE in 2 of 58 pools
+        # of one GPU-suite run of round 5); gloo's own pair sockets bind port 0 themselves
+        dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
         conn.send(("ready", None))
     except BaseException:
         conn.send(("error", traceback.format_exc()))
@@ -101,10 +104,13 @@ class RankPool:
     def _start(self, world, persistent):
         ctx = multiprocessing.get_context("spawn")
         port = free_port()
+        fd, store = tempfile.mkstemp(prefix="mi_rank_pool_", suffix=".store")
+        os.close(fd); os.unlink(store)                 # (the FileStore creates it; the name only has to be unique)
+        self.store = store
         self.world, self.procs, self.conns = world, [], []
         for r in range(world):
             a, b = ctx.Pipe()
-            p = ctx.Process(target=_rank_main, args=(r, world, port, b, persistent), daemon=True)
+            p = ctx.Process(target=_rank_main, args=(r, world, port, store, b, persistent), daemon=True)
             p.start()
             b.close()
             self.procs.append(p); self.conns.append(a)
@@ -162,6 +168,10 @@ class RankPool:
         for c in self.conns:
             c.close()
         self.procs, self.conns = [], []
+        try:
+            os.unlink(getattr(self, "store", ""))
+        except OSError:
+            pass
 
 
 def run_ranks(world, module, fn, *args, timeout=600.0, fresh=False):

@@ -67,10 +67,11 @@ def _sum_ranks_body(rank, world, out_dir):
     np.save(os.path.join(out_dir, f"s{rank}.npy"), t.numpy())
 
 
-def test_rank_pool_starts_again_when_the_rendezvous_port_is_taken(tmp_path, monkeypatch):
-    """tests/rank_pool.py: the rendezvous port is found free and bound by rank 0 a moment later -- on a busy box another socket can take
-    it in between (round 5: EADDRINUSE in 2 of 58 pools of one GPU-suite run).  With the first port it is offered held by a listening
-    socket, a pool must start again on another port and run its job."""
+def test_rank_pool_does_not_depend_on_a_free_rendezvous_port(tmp_path, monkeypatch):
+    """tests/rank_pool.py: a rendezvous port that is found free and bound by rank 0 seconds later can be taken in between on a busy box
+    (round 5: EADDRINUSE in 2 of 58 pools of one GPU-suite run).  The ranks therefore meet through a FileStore; with the port they are
+    handed (MASTER_PORT, for code that reads it) held by a listening socket, a pool must still come up and run its job -- and a pool that
+    does fail with "address already in use" is started again (RankPool.__init__)."""
     import rank_pool
     busy = socket.socket()
     busy.bind(("127.0.0.1", 0)); busy.listen(1)
