@@ -260,7 +260,7 @@ int mi_vec_from_engine(mi_addr_t addr, const double *x_engine_dev, double *x_cal
 /* ---- SpMV family, caller order (lduMatrix::Amul/Tmul lduMatrixATmul.C:183-342,
  *      sumA :345-395, residual :397-496, H1 :533-554, H lduMatrixOperations.C:130-154,
  *      faceH lduMatrixTemplates.C:110-148) ----
- * Interface (halo) terms use ext values previously placed with mi_set_ext (single
+ * Interface (halo) terms use ext values previously placed with mi_matrix_set_ext (single
  * process: none).  On an addressing that permutes (mi_addr_create) these run the tile pass straight on the caller's arrays:
  * x is gathered through the cell permutation while a tile is staged, y (and source) are addressed through it in the row
  * loop -- no separate permutation passes (mi_amul 173 us against 146 in engine order on the 216^3 box); with ordered
@@ -486,6 +486,53 @@ int mi_flux_div(mi_addr_t addr, const double *lambda_dev, const double *sfx_dev,
 int mi_ddt_phi_corr(mi_addr_t addr, double r_delta_t, const double *lambda_dev, const double *sfx_dev, const double *sfy_dev,
                     const double *sfz_dev, const double *ux_old_dev, const double *uy_old_dev, const double *uz_old_dev,
                     const double *rho_old_dev_or_null, const double *phi_old_dev, double *out_dev);
+/* ---- fused matrix assembly (round 6) ----
+ * mi_fvm_assemble: the matrix of   [fvm::ddt(rho, vf)] + [fvm::div(flux, vf)] - [fvm::laplacian(gamma, vf)] [+- fvm::Sp(sp, vf)] [+- su ...]
+ * written ONCE by one row pass -- the expression every transport equation of simpleFoam / pisoFoam / rhoPimpleFoam has
+ * (UEqn.H, EEqn.H, pEqn.H) and that the reference evaluates scheme by scheme (gaussConvectionScheme.C:74-115, gaussLaplacianScheme.C:44-88,
+ * EulerDdtScheme.C:371-440, fvmSup.C:34-214) and then combines array by array with fvMatrix::operator+ / - / == (fvMatrix.C:1693-2030 ->
+ * lduMatrix::operator+= / -=, lduMatrixOperations.C:235-396).  The outputs equal that sequence BIT FOR BIT, because every intermediate is
+ * rounded where the sequence rounds it:
+ *   per face    lB = -w*flux, uB = lB + flux (w = div_weights, or pos(flux) when div_weights_dev is NULL: upwind);  uL = deltaCoeffs*gammaMagSf
+ *               lower = lB - uL, upper = uB - uL   (a term that is absent drops out of the expression; no convection: upper = -uL, the
+ *               matrix stays symmetric and lower_out_dev may be NULL)
+ *   per cell    sumB = negSumDiag of (lB, uB), sumL = negSumDiag of (uL, uL)   (lduMatrixOperations.C:61-83: own faces ascending, then losort order)
+ *               diag = (((rDeltaT*rho)*V + sumB) - sumL) [+- V*sp]
+ *               source[r] = ((rDeltaT*rho_old)*psi_old[r])*V, then  -= V*su[k][r] (su_sign[k] > 0: the term stands on the left, `+ su`)
+ *               or += V*su[k][r] (su_sign[k] < 0: `== su`), k ascending      (fvMatrix.C:1850-1905 operator+/-(fvMatrix, volField), :1741 operator==)
+ * rho_dev NULL: the constant rho_value (fvm::ddt(vf): 1).  su_dev holds n_su * n_rhs device pointers, su_dev[k * n_rhs + r]; su_sign
+ * n_su host doubles.  n_rhs <= 4 right-hand sides share the coefficients (the components of a vector equation, fvMatrixSolve.C:103-225),
+ * n_su <= 4.  sum_mag_off_diag_out_dev (may be NULL): lduMatrix::sumMagOffDiag of the FINAL coefficients from the same pass -- what
+ * fvMatrix::relax needs (mi_relax_multi takes it).  Boundary coefficients stay with the caller (mi_patch_add), as in the reference.
+ * Coefficient outputs must not alias inputs (faces cut by a block boundary are recomputed from the inputs).                          */
+typedef struct mi_fvm_terms {
+    int32_t ddt;                                   /* != 0: Euler time derivative present */
+    double r_delta_t, rho_value;
+    const double *rho_dev, *rho_old_dev;           /* both NULL (constant rho_value) or both given */
+    const double *vol_dev;                         /* needed with ddt, sp or su */
+    const double *div_flux_dev, *div_weights_dev;  /* flux NULL: no convection term */
+    const double *lap_delta_coeffs_dev, *lap_gamma_magsf_dev;   /* delta NULL: no diffusion term */
+    const double *sp_dev; double sp_sign;          /* sp NULL: none; sign > 0: diag += V*sp, < 0: diag -= V*sp */
+    int32_t n_rhs; const double *const *psi_old_dev;   /* n_rhs old-time fields (read when ddt != 0) */
+    int32_t n_su; const double *const *su_dev; const double *su_sign;
+} mi_fvm_terms;
+int mi_fvm_assemble(mi_addr_t addr, const mi_fvm_terms *terms, double *lower_out_dev_or_null, double *upper_out_dev, double *diag_out_dev,
+                    double *const *source_out_dev, double *sum_mag_off_diag_out_dev_or_null);
+/* fvMatrix::setReference (src/finiteVolume/fvMatrices/fvMatrix/fvMatrix.C:964-981; icoFoam.C:89, simpleFoam/pEqn.H:21: the pressure level of a
+ * closed domain): source[celli] += diag[celli]*value; diag[celli] += diag[celli].  celli < 0 (the rank does not hold the cell): no-op. */
+int mi_fvm_set_reference(mi_addr_t addr, int32_t celli, double value, double *diag_dev, double *source_dev);
+/* fvMatrix::setValues (fvMatrix.C:454-656, functors :352-452; fvOptions constraints, wall-function cells): psi[cell] = value,
+ * source[cell] = value*diag[cell]; the source of every OTHER row is corrected for its set neighbours; the coefficients that couple a
+ * set row to its neighbours and the boundary coefficients of its patch faces are cleared.
+ * upstream_semantics == 0, the REFERENCE's behaviour (it deviates from upstream OpenFOAM, SURVEY appendix B style): the correction uses
+ * the transposed coefficient (lower[face] for an own face, upper[face] for a neighbour-side face), upper is cleared where the OWNER is
+ * set and lower where the NEIGHBOUR is set, and a symmetric matrix comes out asymmetric (the reference's non-const lower() copies
+ * upper) -- hence lower_out_dev is always written (lower_in_dev NULL: symmetric input).  != 0: upstream OpenFOAM's
+ * (source[nei] -= lower*value, source[own] -= upper*value, both triangles cleared at every face of a set cell).  Outputs may alias inputs. */
+int mi_fvm_set_values(mi_addr_t addr, int32_t n_set, const int32_t *cell_labels_dev, const double *values_dev, int32_t upstream_semantics,
+                      double *psi_dev, const double *diag_dev, double *source_dev, const double *upper_in_dev, const double *lower_in_dev_or_null,
+                      double *upper_out_dev, double *lower_out_dev, int32_t n_patches, const mi_patch_t *patches,
+                      double *const *internal_coeffs_dev, double *const *boundary_coeffs_dev);
 /* out = x / y element-wise (fvMatrix::A = D/V, fvMatrix::H /= V; fvMatrix.C:1424-1506); out may alias x */
 int mi_vec_div(mi_ctx_t ctx, int64_t n, const double *x_dev, const double *y_dev, double *out_dev);
 /* Non-orthogonal correction of fvm::laplacian (row a22): gaussLaplacianScheme<Type, scalar>::fvmLaplacian with a `corrected`
@@ -519,7 +566,14 @@ int mi_patch_add_product(mi_patch_t patch, const double *pf_dev, const double *q
  * The internal-face part of flux() is mi_faceH.                                                                      */
 int mi_patch_flux(mi_patch_t patch, const double *internal_coeffs_dev, const double *boundary_coeffs_dev,
                   const double *psi_dev, const double *patch_neighbour_field_dev_or_null, double *flux_dev);
-/* fvMatrix<scalar>::relax(alpha): coupled[p] != 0 marks processor-like patches */
+/* fvMatrix<scalar>::relax(alpha) (fvMatrix.C:1087-1345, functors :983-1084): coupled[p] != 0 marks processor-like patches.
+ * mi_relax_multi: the same for an equation with n_rhs sources / solution components that share the diagonal (fvMatrix<vector>::relax:
+ * S += (D - D0)*psi per component); sum_mag_off_diag_dev_or_null: lduMatrix::sumMagOffDiag of the coefficients if the caller already
+ * has it (mi_fvm_assemble's by-product; lower / upper may then be NULL) -- completed IN PLACE with the coupled patches' |boundaryCoeffs|. */
+int mi_relax_multi(mi_addr_t addr, double alpha, double *diag_dev, const double *lower_dev, const double *upper_dev,
+                   double *sum_mag_off_diag_dev_or_null, int32_t n_rhs, double *const *source_dev, const double *const *psi_dev,
+                   int32_t n_patches, const mi_patch_t *patches, const double *const *internal_coeffs_dev,
+                   const double *const *boundary_coeffs_dev, const int32_t *coupled);
 int mi_relax(mi_addr_t addr, double alpha, double *diag_dev, const double *lower_dev, const double *upper_dev,
              double *source_dev, const double *psi_dev, int32_t n_patches, const mi_patch_t *patches,
              const double *const *internal_coeffs_dev, const double *const *boundary_coeffs_dev,

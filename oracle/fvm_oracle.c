@@ -1,7 +1,15 @@
 /*
- * fvm_oracle.c -- CPU ORACLE for the fvMatrix assembly sweeps (test infrastructure, NOT product
- * code; PARITY UNPINNED, see ldu_oracle.c).  Scalar fields.  Paths relative to
- * /root/reference/src/ .
+ * fvm_oracle.c -- CPU ORACLE for the fvMatrix assembly sweeps (test infrastructure, NOT product code: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it).  Scalar fields.  Paths relative to /root/reference/src/ .
+ * PINNED by the reference's own functors: every loop below whose reference form is a device functor (patch add / boundary source /
+ * relax functors of fvMatrix.C, surfaceIntegrate, the face interpolate, gaussGrad, faceH, the limitedLinear limiter and weights,
+ * setValues) is reproduced BIT FOR BIT against those functors compiled from /root/reference on the reference's own Vector / Scalar
+ * primitives (oracle/ref_shim/ref_fvm_tu.cpp -> oracle/_ref/libref_fvm.so; frozen in tests/golden/golden_ref_fvm.npz;
+ * tests/test_oracle.py).  Rounding rule the compiled functors show (LLVM -- the code generator family of the reference's nvcc; g++ agrees on
+ * all but the limitedLinear weights functor, see oracle/Makefile): inside ONE functor a*b + c is one fma,
+ * and of a sum of two products the FIRST is fused and the second rounded -- a*b + c*d = fma(a, b, c*d), a*b - c*d = fma(a, b, -(c*d)),
+ * x*x' + y*y' + z*z' = fma(z, z', fma(x, x', y*y')); operations the reference spells as separate FIELD operations (gpuField
+ * operators = one thrust::transform each, fields/Fields/gpuField/gpuFieldFunctionsM.C:283-340) round separately.
  *   negSumDiag / sumDiag / sumMagOffDiag  OpenFOAM/matrices/lduMatrix/lduMatrix/lduMatrixOperations.C:36-106
  *                                          (row order of lduAddressingFunctors.H:10-64: own faces, then losort)
  *   fvm::laplacian (uncorrected)          finiteVolume/finiteVolume/laplacianSchemes/gaussLaplacianScheme/gaussLaplacianScheme.C:44-88
@@ -81,14 +89,12 @@ void orc_patch_add(label nPatchFaces, const label *faceCells, const scalar *pf, 
     }
 }
 
-/* relax, scalar Type.  coupled[p] != 0: processor-like patch. */
-/* coupled part of fvMatrix::addBoundarySource (fvMatrix.C:318-346): cmptMultiply(pbc, pnf) is a rounded temporary field,
- * then addToInternalField adds it face by face */
+/* coupled part of fvMatrix::addBoundarySource (fvMatrix.C:245-286,318-346): fvMatrixAddBoundarySourceFunctor's
+ * out += cmptMultiply(pbc[face], pnf[face]) per patch face in ascending order -- one fma inside the functor (pinned) */
 void orc_patch_add_product(label nPatchFaces, const label *faceCells, const scalar *pf, const scalar *q, int fn, scalar *intf)
 {
     for (label i = 0; i < nPatchFaces; i++) {
-        volatile scalar v = pf[i] * q[i];
-        intf[faceCells[i]] += fn == 0 ? v : -v;
+        intf[faceCells[i]] = fn == 0 ? fma(pf[i], q[i], intf[faceCells[i]]) : fma(-pf[i], q[i], intf[faceCells[i]]);
     }
 }
 
@@ -106,6 +112,7 @@ void orc_patch_flux(label nPatchFaces, const label *faceCells, const scalar *ic,
     }
 }
 
+/* relax, scalar Type.  coupled[p] != 0: processor-like patch. */
 void orc_relax(label n, label nf, const label *lo, const label *up, scalar alpha, scalar *diag,
                const scalar *lowerC, const scalar *upperC, scalar *source, const scalar *psi, int nPatches,
                const label *patchSizes, const label *const *faceCells, const scalar *const *iCoeffs,
@@ -131,7 +138,8 @@ void orc_relax(label n, label nf, const label *lo, const label *up, scalar alpha
         if (!patchSizes[p]) continue;
         orc_patch_add(patchSizes[p], faceCells[p], iCoeffs[p], 1, n, diag); /* -component0 | -cmptMin */
     }
-    for (label c = 0; c < n; c++) source[c] = fma(diag[c] - D0[c], psi[c], source[c]);
+    /* S += (D - D0)*psi_.internalField()  (fvMatrix.C:1344): three field operations, three roundings */
+    for (label c = 0; c < n; c++) { const scalar dd = diag[c] - D0[c]; const scalar t = dd * psi[c]; source[c] = source[c] + t; }
     free(D0); free(sumOff);
 }
 
@@ -201,8 +209,8 @@ void orc_fvm_susp(label n, const scalar *vol, const scalar *susp, const scalar *
 
 /* ---- face flux of an interpolated cell vector, internal faces:  phi[f] = Sf[f] & linear.interpolate(V)[f]  with V = U or
  *      V = rho*U (a cell field: the product is rounded per cell, as rhoU0 = rho.oldTime()*U.oldTime() is, EulerDdtScheme.C:683-686);
- *      the interpolate one fma per component (surfaceInterpolationScheme.C:275-280), a & b = ax*bx + ay*by + az*bz contracted left to
- *      right; optionally  + addA[f]*addB[f]  (a rounded field product, e.g. rhorAUf*fvc::ddtCorr(rho, U, phi), pEqn.H:49-56) or
+ *      the interpolate one fma per component (surfaceInterpolationScheme.C:275-280), a & b = ax*bx + ay*by + az*bz = fma(az, bz, fma(ax, bx, ay*by))
+ *      (the first of two products fused, as the compiled reference shows); optionally  + addA[f]*addB[f]  (a rounded field product, e.g. rhorAUf*fvc::ddtCorr(rho, U, phi), pEqn.H:49-56) or
  *      + addA[f]                                                                                                           */
 static scalar flux_face(label f, const label *lo, const label *up, const scalar *lambda, const scalar *sx, const scalar *sy, const scalar *sz,
                         const scalar *vx, const scalar *vy, const scalar *vz, const scalar *sc, const scalar *addA, const scalar *addB)
@@ -211,7 +219,7 @@ static scalar flux_face(label f, const label *lo, const label *up, const scalar 
     scalar px = vx[P], py = vy[P], pz = vz[P], nx = vx[N], ny = vy[N], nz = vz[N];
     if (sc) { px = sc[P] * px; py = sc[P] * py; pz = sc[P] * pz; nx = sc[N] * nx; ny = sc[N] * ny; nz = sc[N] * nz; }
     const scalar ix = fma(lambda[f], px - nx, nx), iy = fma(lambda[f], py - ny, ny), iz = fma(lambda[f], pz - nz, nz);
-    scalar d = fma(iz, sz[f], fma(iy, sy[f], ix * sx[f]));
+    scalar d = fma(iz, sz[f], fma(ix, sx[f], iy * sy[f]));   /* Vector operator& (VectorI.H:129-132) as compiled: pinned */
     if (addA) d = d + (addB ? addA[f] * addB[f] : addA[f]);
     return d;
 }
@@ -267,7 +275,7 @@ void orc_limited_linear_weights(label nf, const label *lo, const label *up, scal
         const scalar gradf = phi[N] - phi[P];
         const scalar dx = Cx[N] - Cx[P], dy = Cy[N] - Cy[P], dz = Cz[N] - Cz[P];
         const label c = faceFlux[f] > 0 ? P : N;
-        const scalar gradcf = fma(dz, gz[c], fma(dy, gy[c], dx * gx[c]));
+        const scalar gradcf = fma(dz, gz[c], fma(dx, gx[c], dy * gy[c]));
         scalar r;
         if (fabs(gradcf) >= 1000 * fabs(gradf)) r = 2 * 1000 * sgn(gradcf) * sgn(gradf) - 1;
         else r = fma(2.0, gradcf / gradf, -1.0);
@@ -309,7 +317,7 @@ void orc_axpby(label n, scalar a, const scalar *x, scalar b, const scalar *y, sc
 /* ---- non-orthogonal correction of fvm::laplacian (gaussLaplacianSchemes.C:64-90, correctedSnGrad.C:45-65):
  *   flux[f] = gammaMagSf[f] * ( corrVec[f] & (lambda[f]*(grad[P] - grad[N]) + grad[N]) )        internal faces
  * the interpolate is one fma per component (surfaceInterpolationScheme.C:275-280), the dot product ax*bx + ay*by + az*bz
- * contracted left to right, the product with gammaMagSf a separate (rounded) field operation.                       */
+ * = fma(az, bz, fma(ax, bx, ay*by)), the product with gammaMagSf a separate (rounded) field operation.                       */
 void orc_sngrad_correction_flux(label nf, const label *lo, const label *up, const scalar *cvx, const scalar *cvy, const scalar *cvz,
                                 const scalar *lambda, const scalar *gx, const scalar *gy, const scalar *gz, const scalar *gammaMagSf,
                                 scalar *flux)
@@ -317,7 +325,7 @@ void orc_sngrad_correction_flux(label nf, const label *lo, const label *up, cons
     for (label f = 0; f < nf; f++) {
         const label P = lo[f], N = up[f];
         const scalar fx = fma(lambda[f], gx[P] - gx[N], gx[N]), fy = fma(lambda[f], gy[P] - gy[N], gy[N]), fz = fma(lambda[f], gz[P] - gz[N], gz[N]);
-        const scalar corr = fma(cvz[f], fz, fma(cvy[f], fy, cvx[f] * fx));
+        const scalar corr = fma(cvz[f], fz, fma(cvx[f], fx, cvy[f] * fy));
         flux[f] = gammaMagSf ? gammaMagSf[f] * corr : corr;
     }
 }
@@ -333,7 +341,7 @@ void orc_patch_sngrad_correction_flux(label n, const label *faceCells, const sca
         const scalar ax = w[i] * gx[c], ay = w[i] * gy[c], az = w[i] * gz[c];
         const scalar bx = m * nx[i], by = m * ny[i], bz = m * nz[i];
         const scalar fx = ax + bx, fy = ay + by, fz = az + bz;
-        const scalar corr = fma(cvz[i], fz, fma(cvy[i], fy, cvx[i] * fx));
+        const scalar corr = fma(cvz[i], fz, fma(cvx[i], fx, cvy[i] * fy));
         flux[i] = gammaMagSf ? gammaMagSf[i] * corr : corr;
     }
 }
@@ -341,4 +349,65 @@ void orc_patch_sngrad_correction_flux(label n, const label *faceCells, const sca
 void orc_submul(label n, const scalar *x, const scalar *y, scalar *io)
 {
     for (label i = 0; i < n; i++) { const scalar t = x[i] * y[i]; io[i] -= t; }
+}
+
+/* ---- fvMatrix::setReference (fvMatrices/fvMatrix/fvMatrix.C:964-981): source[celli] += diag[celli]*value; diag[celli] *= 2
+ *      -- two host-side get/set pairs in the reference (source().set(celli, source().get(celli) + diag().get(celli)*value)): HOST
+ *      code of the reference, built for baseline x86-64 (wmake/rules/linux64Nvcc/c++: -m64, no -march), which has no fma
+ *      instruction: the product is rounded, then added                                                                         */
+void orc_set_reference(label celli, scalar value, scalar *diag, scalar *source)
+{
+    if (celli < 0) return;
+    { const scalar t = diag[celli] * value; source[celli] = source[celli] + t; }
+    diag[celli] = 2 * diag[celli];
+}
+
+/* ---- fvMatrix::setValues (fvMatrix.C:454-656, setValuesFromList; functors :352-452 pinned by oracle/_ref/libref_fvm.so):
+ *   psi[cellLabels[i]] = values[i];  source[cellLabels[i]] = values[i]*diag[cellLabels[i]]
+ *   every row that is NOT set:  source -= lower[face]*value[nei]   over its own faces whose neighbour is set (ascending),
+ *                               source -= upper[face]*value[own]   over its neighbour-side faces (losort order) whose owner is set
+ *                               (each one fma inside the functor)
+ *   upper[face] = 0 where the OWNER is set;  lower[face] = 0 where the NEIGHBOUR is set -- the non-const lower() of the reference
+ *   makes a symmetric matrix asymmetric here, so lower is always an output (lowerIn NULL: a copy of upperIn is the input);
+ *   internalCoeffs / boundaryCoeffs of every patch face whose cell is set = 0.
+ * upstreamSemantics != 0: upstream OpenFOAM's fvMatrix::setValuesFromList instead (the reference deviates from it: it uses the
+ * TRANSPOSED coefficient in both source sums and clears only the set row's triangle, leaving the other rows coupled to the set
+ * cell although their source was corrected -- SURVEY appendix B style quirk): source[nei] -= lower*value for a set owner,
+ * source[own] -= upper*value for a set neighbour (face order per row as above), and BOTH triangles cleared at every face that
+ * touches a set cell.                                                                                                          */
+void orc_set_values(label n, label nf, const label *lo, const label *up, label nSet, const label *cellLabels, const scalar *values,
+                    int upstreamSemantics, scalar *psi, const scalar *diag, scalar *source, const scalar *upperIn, const scalar *lowerIn,
+                    scalar *upperOut, scalar *lowerOut, int nPatches, const label *patchSizes, const label *const *faceCells,
+                    scalar *const *iCoeffs, scalar *const *bCoeffs)
+{
+    unsigned char *mask = (unsigned char *)calloc((size_t)(n ? n : 1), 1);
+    scalar *val = (scalar *)calloc((size_t)(n ? n : 1), sizeof(scalar));
+    const scalar *L = lowerIn ? lowerIn : upperIn;
+    for (label i = 0; i < nSet; i++) {
+        const label c = cellLabels[i];
+        psi[c] = values[i];
+        source[c] = values[i] * diag[c];
+        mask[c] = 1; val[c] = values[i];
+    }
+    tables t = mk(n, nf, lo, up);
+    for (label c = 0; c < n; c++) {
+        if (mask[c]) continue;
+        scalar out = source[c];
+        for (label j = t.os[c]; j < t.os[c + 1]; j++)
+            if (mask[up[j]]) out = fma(-(upstreamSemantics ? upperIn[j] : L[j]), val[up[j]], out);
+        for (label j = t.ls[c]; j < t.ls[c + 1]; j++) {
+            const label g = t.losort[j];
+            if (mask[lo[g]]) out = fma(-(upstreamSemantics ? L[g] : upperIn[g]), val[lo[g]], out);
+        }
+        source[c] = out;
+    }
+    for (label f = 0; f < nf; f++) {
+        const int oSet = mask[lo[f]], nSetF = mask[up[f]];
+        upperOut[f] = (upstreamSemantics ? (oSet || nSetF) : oSet) ? 0.0 : upperIn[f];
+        lowerOut[f] = (upstreamSemantics ? (oSet || nSetF) : nSetF) ? 0.0 : L[f];
+    }
+    for (int p = 0; p < nPatches; p++)
+        for (label i = 0; i < patchSizes[p]; i++)
+            if (mask[faceCells[p][i]]) { iCoeffs[p][i] = 0.0; bCoeffs[p][i] = 0.0; }
+    rel(t); free(mask); free(val);
 }

@@ -445,7 +445,7 @@ void orc_faceH(const orc_system *s, int d, const scalar *psi, scalar *faceH)
     const orc_domain *m = &s->dom[d]; label f;
     const scalar *x = psi + m->offset;
     for (f = 0; f < m->nFaces; f++)
-        faceH[f] = m->upperC[f] * x[m->upper[f]] - m->lowerC[f] * x[m->lower[f]];
+        faceH[f] = fma(m->upperC[f], x[m->upper[f]], -(m->lowerC[f] * x[m->lower[f]]));   /* lduMatrixfaceHFunctor as compiled (oracle/_ref/libref_fvm.so) */
 }
 
 /* sumDiag / negSumDiag / sumMagOffDiag: lduMatrixOperations.C:36-106       */

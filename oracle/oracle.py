@@ -871,3 +871,163 @@ def submul(x, y, inout):
     io = _d(inout).copy()
     lib().orc_submul(C.c_int32(io.shape[0]), _p(_d(x), C.c_double), _p(_d(y), C.c_double), _p(io, C.c_double))
     return io
+
+
+
+def set_reference(celli, value, diag, source):
+    """fvMatrix::setReference (fvMatrix.C:964-981) -> (diag, source)"""
+    d, s = _d(diag).copy(), _d(source).copy()
+    lib().orc_set_reference(C.c_int32(celli), C.c_double(value), _p(d, C.c_double), _p(s, C.c_double))
+    return d, s
+
+
+def set_values(n_cells, lower_addr, upper_addr, cell_labels, values, psi, diag, source, upper, lower=None, face_cells=(), icoeffs=(), bcoeffs=(),
+               upstream=False):
+    """fvMatrix::setValues (fvMatrix.C:454-656) -> dict(psi, source, upper, lower, icoeffs, bcoeffs)"""
+    lo, up = _i(lower_addr), _i(upper_addr)
+    cl, v = _i(cell_labels), _d(values)
+    ps, s = _d(psi).copy(), _d(source).copy()
+    U = _d(upper); Lw = None if lower is None else _d(lower)
+    uo, lw = np.empty(lo.shape[0]), np.empty(lo.shape[0])
+    n = len(face_cells)
+    fcs = [_i(f) for f in face_cells]
+    ics = [_d(a).copy() for a in icoeffs]
+    bcs = [_d(a).copy() for a in bcoeffs]
+    sizes = (C.c_int32 * max(n, 1))(*[f.shape[0] for f in fcs])
+    fp = (C.POINTER(C.c_int32) * max(n, 1))(*[_p(f, C.c_int32) for f in fcs])
+    ip = (C.POINTER(C.c_double) * max(n, 1))(*[_p(a, C.c_double) for a in ics])
+    bp = (C.POINTER(C.c_double) * max(n, 1))(*[_p(a, C.c_double) for a in bcs])
+    lib().orc_set_values(C.c_int32(n_cells), C.c_int32(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), C.c_int32(cl.shape[0]), _p(cl, C.c_int32),
+                         _p(v, C.c_double), C.c_int(int(upstream)), _p(ps, C.c_double), _p(_d(diag), C.c_double), _p(s, C.c_double), _p(U, C.c_double),
+                         None if Lw is None else _p(Lw, C.c_double), _p(uo, C.c_double), _p(lw, C.c_double), n, sizes, fp, ip, bp)
+    return dict(psi=ps, source=s, upper=uo, lower=lw, icoeffs=ics, bcoeffs=bcs)
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle/_ref/libref_fvm.so: the REFERENCE's fvMatrix-assembly functors (fvMatrix.C, fvcSurfaceIntegrate.C, gaussGrad.C,
+# surfaceInterpolationScheme.C, limitedSurfaceInterpolationScheme.C, LimitedScheme.C + NVDTVD.H / limitedLinear.H,
+# lduMatrixTemplates.C) on the reference's own primitives, host-compiled (oracle/ref_shim/ref_fvm_tu.cpp)
+# ---------------------------------------------------------------------------------------------
+REF_FVM_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_fvm.so")
+REF_FVM_PATCH_KINDS = {"add": 0, "subtract": 1, "boundarySource": 2, "relaxComponentZero": 3, "relaxMagComponentZero": 4,
+                       "relaxMaxComponentMag": 5, "relaxNegComponentZero": 6, "relaxNegComponentMin": 7, "surfaceIntegratePatch": 8}
+
+
+def ref_fvm_available() -> bool:
+    return os.path.exists(REF_FVM_LIB)
+
+
+def patch_sort_tables(face_cells):
+    """lduAddressing::patchSortCells / patchSortAddr / patchSortStartAddr (lduAddressing.C:373-400): the patch's unique cells ascending,
+    its faces stably sorted by cell, the start of every cell's segment"""
+    fc = _i(face_cells)
+    sort = np.argsort(fc, kind="stable").astype(np.int32)
+    cells, counts = np.unique(fc, return_counts=True)
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return np.ascontiguousarray(cells.astype(np.int32)), start, sort
+
+
+def ref_fvm_patch_rows(kind, face_cells, pf, field, q=None):
+    """field[cell] = F(field[cell], patch faces of the cell in ascending order) for every unique patch cell, F one of the reference's
+    patch functors (REF_FVM_PATCH_KINDS)"""
+    L = C.CDLL(REF_FVM_LIB)
+    cells, start, sort = patch_sort_tables(face_cells)
+    out = _d(field).copy()
+    qq = None if q is None else _d(q)
+    L.ref_fvm_patch_rows(C.c_int(REF_FVM_PATCH_KINDS[kind]), C.c_int(cells.shape[0]), _p(cells, C.c_int32), _p(start, C.c_int32), _p(sort, C.c_int32),
+                         _p(_d(pf), C.c_double), None if qq is None else _p(qq, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def ref_fvm_relax_dominance(diag, sum_off):
+    L = C.CDLL(REF_FVM_LIB)
+    out = _d(diag).copy()
+    L.ref_fvm_relax_dominance(C.c_int(out.shape[0]), _p(_d(sum_off), C.c_double), _p(out, C.c_double))
+    return out
+
+
+def _ldu_row_tables(n, lower_addr, upper_addr):
+    lo, up = _i(lower_addr), _i(upper_addr)
+    losort = np.argsort(up, kind="stable").astype(np.int32)
+    own_start = np.searchsorted(lo, np.arange(n + 1)).astype(np.int32)
+    los_start = np.searchsorted(up[losort], np.arange(n + 1)).astype(np.int32)
+    return lo, up, own_start, los_start, losort
+
+
+def ref_surface_integrate_rows(n_cells, lower_addr, upper_addr, ssf, integrate=True):
+    L = C.CDLL(REF_FVM_LIB)
+    lo, up, os_, ls_, losort = _ldu_row_tables(n_cells, lower_addr, upper_addr)
+    out = np.empty(n_cells)
+    L.ref_surface_integrate_rows(C.c_int(int(integrate)), C.c_int(n_cells), _p(_d(ssf), C.c_double), _p(os_, C.c_int32), _p(ls_, C.c_int32),
+                                 _p(lo, C.c_int32), _p(up, C.c_int32), _p(losort, C.c_int32), _p(out, C.c_double))
+    return out
+
+
+def ref_face_interpolate(lower_addr, upper_addr, lam, vf):
+    """scalar vf[N] -> [F]; vector vf[N, 3] -> [F, 3]"""
+    L = C.CDLL(REF_FVM_LIB)
+    lo, up = _i(lower_addr), _i(upper_addr)
+    v = _d(vf)
+    out = np.empty((lo.shape[0],) + v.shape[1:])
+    fn = L.ref_face_interpolate if v.ndim == 1 else L.ref_face_interpolate_vector
+    fn(C.c_int(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(_d(lam), C.c_double), _p(v, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def ref_face_dot(a3, b3):
+    L = C.CDLL(REF_FVM_LIB)
+    a, b = _d(a3), _d(b3)
+    out = np.empty(a.shape[0])
+    L.ref_face_dot(C.c_int(a.shape[0]), _p(a, C.c_double), _p(b, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def ref_gauss_grad_rows(n_cells, lower_addr, upper_addr, sf3, ssf):
+    L = C.CDLL(REF_FVM_LIB)
+    lo, up, os_, ls_, losort = _ldu_row_tables(n_cells, lower_addr, upper_addr)
+    out = np.empty((n_cells, 3))
+    L.ref_gauss_grad_rows(C.c_int(n_cells), _p(_d(sf3), C.c_double), _p(_d(ssf), C.c_double), _p(os_, C.c_int32), _p(ls_, C.c_int32),
+                          _p(lo, C.c_int32), _p(up, C.c_int32), _p(losort, C.c_int32), _p(out, C.c_double))
+    return out
+
+
+def ref_gauss_grad_patch_rows(face_cells, psf3, pssf, grad3):
+    L = C.CDLL(REF_FVM_LIB)
+    cells, start, sort = patch_sort_tables(face_cells)
+    out = _d(grad3).copy()
+    L.ref_gauss_grad_patch_rows(C.c_int(cells.shape[0]), _p(cells, C.c_int32), _p(start, C.c_int32), _p(sort, C.c_int32), _p(_d(psf3), C.c_double),
+                                _p(_d(pssf), C.c_double), _p(out, C.c_double))
+    return out
+
+
+def ref_faceH(lower_addr, upper_addr, lower, upper, psi):
+    L = C.CDLL(REF_FVM_LIB)
+    lo, up = _i(lower_addr), _i(upper_addr)
+    out = np.empty(lo.shape[0])
+    L.ref_faceH(C.c_int(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(_d(lower), C.c_double), _p(_d(upper), C.c_double), _p(_d(psi), C.c_double),
+                _p(out, C.c_double))
+    return out
+
+
+def ref_limited_linear(lower_addr, upper_addr, k, cd_weights, face_flux, phi, grad3, centres3):
+    """-> (limiter, weights) of limitedLinear(k) on the internal faces"""
+    L = C.CDLL(REF_FVM_LIB)
+    lo, up = _i(lower_addr), _i(upper_addr)
+    lim, w = np.empty(lo.shape[0]), np.empty(lo.shape[0])
+    L.ref_limited_linear(C.c_int(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), C.c_double(k), _p(_d(cd_weights), C.c_double), _p(_d(face_flux), C.c_double),
+                         _p(_d(phi), C.c_double), _p(_d(grad3), C.c_double), _p(_d(centres3), C.c_double), _p(lim, C.c_double), _p(w, C.c_double))
+    return lim, w
+
+
+def ref_set_values_source(n_cells, lower_addr, upper_addr, cell_mask, cell_values, upper, lower, source):
+    """fvMatrix::setValuesFromList's row functor + clear-faces functor -> (source, upper, lower | None)"""
+    L = C.CDLL(REF_FVM_LIB)
+    lo, up, os_, ls_, losort = _ldu_row_tables(n_cells, lower_addr, upper_addr)
+    s = _d(source).copy()
+    U = _d(upper); Lw = U if lower is None else _d(lower)
+    uo = np.empty(lo.shape[0]); lw = None if lower is None else np.empty(lo.shape[0])
+    m = np.ascontiguousarray(cell_mask, dtype=np.uint8)
+    L.ref_set_values_source(C.c_int(n_cells), C.c_int(lo.shape[0]), _p(lo, C.c_int32), _p(up, C.c_int32), _p(os_, C.c_int32), _p(ls_, C.c_int32),
+                            _p(losort, C.c_int32), _p(m, C.c_uint8), _p(_d(cell_values), C.c_double), _p(U, C.c_double), _p(Lw, C.c_double),
+                            _p(s, C.c_double), _p(uo, C.c_double), None if lw is None else _p(lw, C.c_double))
+    return s, uo, lw

@@ -124,6 +124,7 @@ struct mi_addr_s {
     DevBuf<uint32_t> row16; DevBuf<uint16_t> losort16; DevBuf<int32_t> rowEsc, rowEscStart; // their block-local 16-bit form (assembly.inc: R16)
     struct RowPlan { bool tiles = false; int bs = 256, blocks = 0, maxFaces = 0, capForced = 0; } rowPlan[2]; // blocks of the assembly row passes: [0] sums / fused schemes, [1] gradient (assembly.inc)
     DevBuf<double> relaxD0, relaxSumOff;
+    DevBuf<uint8_t> setMask; DevBuf<double> setVal;   // fvMatrix::setValues scratch (assembly.inc)
     std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
     int32_t nInterior = 0, nBoundary = 0, nLocalPatches = 0;
     std::vector<char> patchIsLocal; // [nPatches] cyclic (local) coupled patch: no exchange

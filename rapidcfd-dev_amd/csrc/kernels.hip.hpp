@@ -753,7 +753,7 @@ __global__ void k_faceH(const double* __restrict__ psi, const int32_t* __restric
 {
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nFaces; f += gridDim.x * blockDim.x) {
         const int k = faceSlot[f];
-        out[f] = upE[k] * psi[up[f]] - lowE[k] * psi[lo[f]];
+        out[f] = fma(upE[k], psi[up[f]], -(lowE[k] * psi[lo[f]]));   // lduMatrixfaceHFunctor (lduMatrixTemplates.C:38-48) as the compiled reference rounds it
     }
 }
 

@@ -887,6 +887,14 @@ class Patch:
             self.h = C.c_void_p()
 
 
+class FvmTerms(C.Structure):
+    """mi_fvm_terms (include/mi_ldu.h)"""
+    _fields_ = [("ddt", C.c_int32), ("r_delta_t", C.c_double), ("rho_value", C.c_double), ("rho_dev", C.c_void_p), ("rho_old_dev", C.c_void_p),
+                ("vol_dev", C.c_void_p), ("div_flux_dev", C.c_void_p), ("div_weights_dev", C.c_void_p), ("lap_delta_coeffs_dev", C.c_void_p),
+                ("lap_gamma_magsf_dev", C.c_void_p), ("sp_dev", C.c_void_p), ("sp_sign", C.c_double), ("n_rhs", C.c_int32),
+                ("psi_old_dev", C.POINTER(C.c_void_p)), ("n_su", C.c_int32), ("su_dev", C.POINTER(C.c_void_p)), ("su_sign", C.POINTER(C.c_double))]
+
+
 class Assembly:
     """fvm::div / fvm::laplacian / negSumDiag / relax ... on caller-order arrays of an Addressing."""
 
@@ -962,6 +970,64 @@ class Assembly:
 
     def axpby(self, a, x, b, y, out):
         _chk(lib().mi_vec_axpby(self.addr.ctx.h, C.c_int64(x.numel()), C.c_double(a), _ptr(x), C.c_double(b), _ptr(y), _ptr(out)))
+
+    def assemble(self, upper_out, diag_out, lower_out=None, sources_out=(), ddt=None, div=None, laplacian=None, sp=None, su=(), sum_mag_out=None):
+        """[fvm::ddt] + [fvm::div] - [fvm::laplacian] [+- fvm::Sp] [+- su] in one row pass (mi_fvm_assemble).
+        ddt = dict(r_delta_t=, vol=, psi_old=[...], rho=None | tensor, rho_old=None | tensor, rho_value=1.0); div = dict(flux=, weights=None (upwind) | tensor);
+        laplacian = dict(delta_coeffs=, gamma_magsf=); sp = (field, sign); su = [(sign, [field per rhs]), ...]; vol is taken from ddt or the `vol` key of sp / su
+        through ddt["vol"] (pass ddt=dict(vol=...) with r_delta_t omitted for no time derivative)."""
+        t = FvmTerms()
+        n_rhs = len(sources_out)
+        keep = []
+        if ddt is not None and "r_delta_t" in ddt:
+            t.ddt = 1; t.r_delta_t = float(ddt["r_delta_t"]); t.rho_value = float(ddt.get("rho_value", 1.0))
+            t.rho_dev = _ptr(ddt.get("rho")).value; t.rho_old_dev = _ptr(ddt.get("rho_old")).value
+            po = (C.c_void_p * max(n_rhs, 1))(*[_ptr(x) for x in ddt["psi_old"]]); keep.append(po)
+            t.psi_old_dev = C.cast(po, C.POINTER(C.c_void_p))
+        if ddt is not None:
+            t.vol_dev = _ptr(ddt.get("vol")).value
+        if div is not None:
+            t.div_flux_dev = _ptr(div["flux"]).value; t.div_weights_dev = _ptr(div.get("weights")).value
+        if laplacian is not None:
+            t.lap_delta_coeffs_dev = _ptr(laplacian["delta_coeffs"]).value; t.lap_gamma_magsf_dev = _ptr(laplacian["gamma_magsf"]).value
+        if sp is not None:
+            t.sp_dev = _ptr(sp[0]).value; t.sp_sign = float(sp[1])
+        t.n_rhs = n_rhs; t.n_su = len(su)
+        if su:
+            sd = (C.c_void_p * (len(su) * n_rhs))(*[_ptr(f) for _, fields in su for f in fields]); keep.append(sd)
+            sg = (C.c_double * len(su))(*[float(sign) for sign, _ in su]); keep.append(sg)
+            t.su_dev = C.cast(sd, C.POINTER(C.c_void_p)); t.su_sign = C.cast(sg, C.POINTER(C.c_double))
+        so = (C.c_void_p * max(n_rhs, 1))(*[_ptr(x) for x in sources_out])
+        _chk(lib().mi_fvm_assemble(self.addr.h, C.byref(t), _ptr(lower_out), _ptr(upper_out), _ptr(diag_out), so, _ptr(sum_mag_out)))
+
+    def set_reference(self, celli, value, diag, source):
+        """fvMatrix::setReference (fvMatrix.C:964-981)"""
+        _chk(lib().mi_fvm_set_reference(self.addr.h, C.c_int32(celli), C.c_double(value), _ptr(diag), _ptr(source)))
+
+    def set_values(self, cell_labels, values, psi, diag, source, upper_in, lower_in, upper_out, lower_out, patches=(), internal_coeffs=(), boundary_coeffs=(),
+                   upstream=False):
+        """fvMatrix::setValues (fvMatrix.C:454-656); cell_labels: int32 device tensor"""
+        n = len(patches)
+        ph = (C.c_void_p * max(n, 1))(*[p.h for p in patches])
+        ic = (C.c_void_p * max(n, 1))(*[_ptr(t) for t in internal_coeffs])
+        bc = (C.c_void_p * max(n, 1))(*[_ptr(t) for t in boundary_coeffs])
+        assert cell_labels.is_contiguous() and cell_labels.element_size() == 4
+        _chk(lib().mi_fvm_set_values(self.addr.h, C.c_int32(cell_labels.numel()), C.c_void_p(cell_labels.data_ptr()), _ptr(values), C.c_int32(int(upstream)),
+                                     _ptr(psi), _ptr(diag), _ptr(source), _ptr(upper_in), _ptr(lower_in), _ptr(upper_out), _ptr(lower_out),
+                                     C.c_int32(n), ph, ic, bc))
+
+    def relax_multi(self, alpha, diag, lower, upper, sources, psis, sum_mag=None, patches=(), internal_coeffs=(), boundary_coeffs=(), coupled=()):
+        """fvMatrix<Type>::relax for n_rhs components sharing the diagonal; sum_mag: mi_fvm_assemble's sumMagOffDiag by-product (completed in place)"""
+        n = len(patches)
+        ph = (C.c_void_p * max(n, 1))(*[p.h for p in patches])
+        ic = (C.c_void_p * max(n, 1))(*[_ptr(t) for t in internal_coeffs])
+        bc = (C.c_void_p * max(n, 1))(*[_ptr(t) for t in boundary_coeffs])
+        cp = (C.c_int32 * max(n, 1))(*[int(v) for v in coupled])
+        m = len(sources)
+        sp = (C.c_void_p * max(m, 1))(*[_ptr(t) for t in sources])
+        pp = (C.c_void_p * max(m, 1))(*[_ptr(t) for t in psis])
+        _chk(lib().mi_relax_multi(self.addr.h, C.c_double(alpha), _ptr(diag), _ptr(lower), _ptr(upper), _ptr(sum_mag), C.c_int32(m), sp, pp,
+                                  C.c_int32(n), ph, ic, bc, cp))
 
     def relax(self, alpha, diag, lower, upper, source, psi, patches=(), internal_coeffs=(), boundary_coeffs=(), coupled=()):
         n = len(patches)

@@ -6,10 +6,13 @@ window.  tests/golden/make_full_size.py runs the oracle ON THE CPU BOX and write
   * residual histories, iteration counts, flags and normFactor (small arrays, stored whole),
   * sha256 of the result BITS of every operator that is compared bit for bit,
   * of every solution vector: its values at SAMPLE positions (sample_idx: a fixed multiplicative walk over the cells), its
-    max |.|, its sum and its sum of magnitudes,
-  * sha256 of the oracle's C sources and of the case generator's OUTPUT on small reference cases, so that a fixture older than
-    the code it restates fails a CPU test (tests/test_full_size_fixture.py) instead of passing silently; that file also RE-DERIVES a sample of the records
-    with the live oracle.
+    max |.|, its sum and its sum of magnitudes, and the sum / sum of magnitudes of each of N_CHUNKS contiguous chunks of it (so that
+    an error confined to one tile or one processor-patch strip cannot hide in the whole-vector sums),
+  * per section, sha256 of what the section was derived from: the oracle's C sources and its ctypes wrapper (by text), the
+    section's own generator function (by text), the case generator's OUTPUT on small reference cases and -- for the assembly
+    section, whose ordered variant runs on the mesh renumbered into the engine's tile order -- the tile layout's OUTPUT on
+    reference cases; a fixture older than the code it restates fails a CPU test (tests/test_full_size_fixture.py) instead of
+    passing silently; that file also RE-DERIVES a sample of the records with the live oracle.
 
 The GPU tests (test_gpu_full_size.py, test_gpu_configs.py) compare the engine against these records with the bars they had
 against the live oracle.  With MI_LIVE_ORACLE=1 they run the oracle in-process again (the pre-r05 behaviour).
@@ -23,6 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 FIXTURE = os.path.join(HERE, "golden", "full_size_v1.npz")
 N_SAMPLE = 4096
+N_CHUNKS = 4096
 PERF_KEYS = ("nIterations", "converged", "singular")
 PERF_REALS = ("normFactor", "initialResidual", "finalResidual")
 
@@ -73,13 +77,34 @@ def synthetic_fingerprint():
     return h.hexdigest()
 
 
-def source_hashes():
-    """what the records were derived from: the oracle's C sources (by text) and the synthetic case generator (by output)"""
+ASSEMBLY_SECTIONS = ("assembly216",)
+
+
+def source_hashes(section=None, generator=None):
+    """what a section's records were derived from: the oracle's C sources and ctypes wrapper (by text), the synthetic case
+    generator (by output), the section's generator function in make_full_size.py (by text; `generator` = that function, looked up
+    in make_full_size.SECTIONS when omitted) and, for the assembly section, the assembly case module (by text) and the tile layout
+    (by output: the ordered variant runs on the mesh renumbered into the engine's tile order)"""
+    import inspect
     h = {}
-    for rel in ("oracle/ldu_oracle.c", "oracle/gamg_oracle.c", "oracle/ldu_oracle.h"):
+    rels = ["oracle/ldu_oracle.c", "oracle/ldu_oracle.h", "oracle/oracle.py"]
+    rels += ["oracle/fvm_oracle.c", "tests/assembly_full_size.py"] if section in ASSEMBLY_SECTIONS else ["oracle/gamg_oracle.c"]
+    for rel in rels:
         with open(os.path.join(ROOT, rel), "rb") as f:
             h[rel] = hashlib.sha256(f.read()).hexdigest()
     h["synthetic.py outputs"] = synthetic_fingerprint()
+    if section is not None:
+        if generator is None:
+            import sys
+            sys.path.insert(0, os.path.join(HERE, "golden"))
+            import make_full_size
+            generator = make_full_size.SECTIONS[section]
+        h["generator"] = hashlib.sha256(inspect.getsource(generator).encode()).hexdigest()
+    if section in ASSEMBLY_SECTIONS:
+        import sys
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import source_fingerprint
+        h["tile layout outputs"] = source_fingerprint.layout_fingerprint()
     return h
 
 
@@ -94,6 +119,13 @@ def pack_solution(out, key, psi):
     psi = np.asarray(psi)
     out[key + "/psi_sample"] = psi[sample_idx(psi.shape[0])].copy()
     out[key + "/psi_stats"] = np.array([np.max(np.abs(psi)), psi.sum(), np.abs(psi).sum(), psi.shape[0]], dtype=np.float64)
+    out[key + "/psi_chunks"] = chunk_sums(psi)
+
+
+def chunk_sums(psi):
+    """[2, N_CHUNKS]: sum and sum of magnitudes of each of N_CHUNKS contiguous chunks (np.array_split boundaries)"""
+    b = np.linspace(0, psi.shape[0], N_CHUNKS + 1).astype(np.int64)[:-1]
+    return np.stack([np.add.reduceat(psi, b), np.add.reduceat(np.abs(psi), b)])
 
 
 def pack_sha(out, key, a):
@@ -124,15 +156,17 @@ class Records:
         return str(self.z[key + "/sha256"])
 
     def solution(self, key):
-        return SolutionRecord(self.z[key + "/psi_sample"], self.z[key + "/psi_stats"])
+        return SolutionRecord(self.z[key + "/psi_sample"], self.z[key + "/psi_stats"], self.z[key + "/psi_chunks"] if key + "/psi_chunks" in self.z.files else None)
 
 
 class SolutionRecord:
     """stands in for the oracle's solution vector: check(psi, tol) is the test's  max|psi - ref| < tol * max|ref|  on the sample
-    positions plus the vector's sum and sum of magnitudes to the same tolerance (of the sum of magnitudes)"""
+    positions plus the vector's sum and sum of magnitudes to the same tolerance (of the sum of magnitudes), and the same two sums of
+    every one of N_CHUNKS contiguous chunks to tol * max|ref| * chunk length"""
 
-    def __init__(self, sample, stats):
+    def __init__(self, sample, stats, chunks=None):
         self.sample = sample
+        self.chunks = chunks
         self.maxabs, self.sum, self.abssum, self.n = float(stats[0]), float(stats[1]), float(stats[2]), int(stats[3])
 
     def deviation(self, psi):
@@ -145,6 +179,9 @@ class SolutionRecord:
         assert self.deviation(psi) < tol
         assert abs(float(psi.sum()) - self.sum) < tol * self.abssum
         assert abs(float(np.abs(psi).sum()) - self.abssum) < tol * self.abssum
+        if self.chunks is not None:
+            bar = tol * self.maxabs * np.diff(np.linspace(0, self.n, N_CHUNKS + 1).astype(np.int64))
+            assert np.all(np.abs(chunk_sums(psi) - self.chunks) <= bar), "a chunk of the solution deviates"
 
 
 def check_solution(psi, ref, tol):

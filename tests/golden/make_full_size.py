@@ -1,4 +1,5 @@
-"""Writes tests/golden/full_size_v1.npz: the CPU oracle's results for the full-size GPU tests (216^3, 108^3, 640x250x250, 432^3).
+"""Writes tests/golden/full_size_v1.npz: the CPU oracle's results for the full-size GPU tests (216^3, 108^3, 640x250x250, 432^3; section
+assembly216: every fvMatrix-assembly operator at 216^3 in the caller's numbering and under ordered addressing).
 
 Run on the CPU box from the repo root (tens of minutes, ~45 GB of RAM for the 80 M-cell section):
 
@@ -127,7 +128,23 @@ def config5(pkg, orc, out):
         del S, subs, rp, src
 
 
-SECTIONS = dict(box216_sym=box216_sym, box216_asym=box216_asym, persist108=persist108, config4=config4, config5=config5)
+def assembly216(pkg, orc, out):
+    """the fvMatrix-assembly operators at 216^3 on both meshes (tests/assembly_full_size.py): sha256 of every result's bits, a sample of
+    each in the clear, and the sha256 of the renumbered addressing the `ordered` records belong to"""
+    import assembly_full_size as afs
+    for variant in afs.VARIANTS:
+        M = afs.mesh(pkg, variant)
+        q = afs.inputs(pkg, M)
+        fs.pack_sha(out, f"assembly216/{variant}/lowerAddr", M["lo"]); fs.pack_sha(out, f"assembly216/{variant}/upperAddr", M["up"])
+        res = afs.oracle_run(pkg, orc, M, q)
+        out[f"assembly216/{variant}/names"] = np.array(sorted(res))
+        for name, a in res.items():
+            fs.pack_sha(out, f"assembly216/{variant}/{name}", a)
+            out[f"assembly216/{variant}/{name}/sample"] = a[fs.sample_idx(a.shape[0], 256)].copy()
+        del res, q, M
+
+
+SECTIONS = dict(assembly216=assembly216, box216_sym=box216_sym, box216_asym=box216_asym, persist108=persist108, config4=config4, config5=config5)
 
 
 def main():
@@ -142,7 +159,9 @@ def main():
             del out[key]
         SECTIONS[name](pkg, orc, out)
         out[f"seconds/{name}"] = np.array(time.perf_counter() - t0)
-        for rel, h in fs.source_hashes().items():
+        for key in [q for q in out if q.startswith(f"sources/{name}/")]:
+            del out[key]
+        for rel, h in fs.source_hashes(name, SECTIONS[name]).items():
             out[f"sources/{name}/{rel}"] = np.array(h)
         np.savez_compressed(fs.FIXTURE, **out)       # after every section: a killed run keeps what it finished
         print(f"{name}: {time.perf_counter() - t0:.0f} s", flush=True)

@@ -4,7 +4,7 @@ coarse-cell maps are frozen in tests/golden/golden_ref_pair.npz; its PCG::solve 
 PBiCG.C, PBiCGStab.C, smoothSolver.C + the functor headers, oracle/_ref/libref_solvers.so) run on the oracle's primitives and their psi and
 solverPerformance are frozen in tests/golden/golden_ref_solvers.npz; its GAMGSolver::solve / Vcycle / initVcycle /
 solveCoarsestLevel (GAMGSolverSolve.C, oracle/_ref/libref_gamg.so) run on the oracle's hierarchy and primitives ->
-tests/golden/golden_ref_gamg.npz.  Needs the reference tree:
+tests/golden/golden_ref_gamg.npz; its fvMatrix-assembly functors (oracle/_ref/libref_fvm.so) -> tests/golden/golden_ref_fvm.npz.  Needs the reference tree:
     python tests/golden/make_golden_ref.py
 """
 import os
@@ -246,6 +246,82 @@ def build_gamg_scale(pkg, orc):
     return out
 
 
+def fvm_cases(pkg):
+    from conftest import random_graph_case
+    syn = pkg.synthetic
+    return {"box_asym": syn.box_case(10, 9, 8, symmetric=False), "box_sym": syn.box_case(9, 7, 6), "graph_asym": random_graph_case(pkg, 600, extra=3.0, symmetric=False)}
+
+
+def fvm_inputs(pkg, case):
+    """seeded fields for the assembly functors: face fields, cell fields, AoS vectors, one ragged patch with repeated cells"""
+    u = pkg.synthetic.splitmix_uniform
+    n, nf = case.n_cells, case.n_faces
+    npf = 240
+    return dict(ssf=u(1, nf) - 0.5, lam=u(2, nf), phi=u(3, n) - 0.5, sf3=u(4, nf * 3).reshape(nf, 3) - 0.5, psi=u(5, n) - 0.5, v3=u(6, n * 3).reshape(n, 3) - 0.5,
+                cdw=0.3 + 0.4 * u(7, nf), flux=u(8, nf) - 0.5, g3=u(9, n * 3).reshape(n, 3) - 0.5, C3=u(10, n * 3).reshape(n, 3),
+                fc=(u(11, npf) * n).astype(np.int32), pf=u(12, npf) - 0.5, q=u(13, npf) - 0.5, fld=u(14, n) - 0.5, psf3=u(15, npf * 3).reshape(npf, 3) - 0.5,
+                sumOff=np.abs(u(16, n)), set_cells=np.unique((u(17, 25) * n).astype(np.int32)), set_vals=u(18, 25) - 0.5)
+
+
+def build_fvm(pkg, orc):
+    """outputs of the REFERENCE's fvMatrix-assembly functors (fvMatrix.C, fvcSurfaceIntegrate.C, gaussGrad.C, surfaceInterpolationScheme.C,
+    limitedSurfaceInterpolationScheme.C, LimitedScheme.C + NVDTVD.H / limitedLinear.H, lduMatrixTemplates.C on the reference's own primitives,
+    oracle/_ref/libref_fvm.so)"""
+    out = {}
+    for name, case in fvm_cases(pkg).items():
+        q = fvm_inputs(pkg, case)
+        n, lo, up = case.n_cells, case.lower_addr, case.upper_addr
+        lower = case.upper if case.lower is None else case.lower
+        out[f"{name}/surfaceIntegrate"] = orc.ref_surface_integrate_rows(n, lo, up, q["ssf"], True)
+        out[f"{name}/surfaceSum"] = orc.ref_surface_integrate_rows(n, lo, up, q["ssf"], False)
+        out[f"{name}/interpolate"] = orc.ref_face_interpolate(lo, up, q["lam"], q["phi"])
+        iv = orc.ref_face_interpolate(lo, up, q["lam"], q["v3"])
+        out[f"{name}/interpolate_vector"] = iv
+        out[f"{name}/Sf_dot_interpolate"] = orc.ref_face_dot(q["sf3"], iv)
+        out[f"{name}/gaussGrad"] = orc.ref_gauss_grad_rows(n, lo, up, q["sf3"], q["ssf"])
+        out[f"{name}/gaussGrad_patch"] = orc.ref_gauss_grad_patch_rows(q["fc"], q["psf3"], q["pf"], out[f"{name}/gaussGrad"])
+        out[f"{name}/faceH"] = orc.ref_faceH(lo, up, lower, case.upper, q["psi"])
+        for k in (1.0, 0.33):
+            out[f"{name}/limitedLinear_{k}/limiter"], out[f"{name}/limitedLinear_{k}/weights"] = orc.ref_limited_linear(lo, up, k, q["cdw"], q["flux"], q["phi"], q["g3"], q["C3"])
+        for kind in orc.REF_FVM_PATCH_KINDS:
+            out[f"{name}/patch/{kind}"] = orc.ref_fvm_patch_rows(kind, q["fc"], q["pf"], q["fld"], q["q"] if kind == "boundarySource" else None)
+        out[f"{name}/relaxDominance"] = orc.ref_fvm_relax_dominance(q["fld"], q["sumOff"])
+        mask = np.zeros(n, np.uint8); mask[q["set_cells"]] = 1
+        vals = np.zeros(n); vals[q["set_cells"]] = q["set_vals"][:q["set_cells"].shape[0]]
+        s, uo, lw = orc.ref_set_values_source(n, lo, up, mask, vals, case.upper, lower, case.source)
+        out[f"{name}/setValues/source"], out[f"{name}/setValues/upper"], out[f"{name}/setValues/lower"] = s, uo, lw
+        out[f"{name}/relax/diag"], out[f"{name}/relax/source"] = reference_relax(orc, case, q, 0.7)
+    return out
+
+
+def relax_patches(q):
+    """two patches for relax: the first coupled (processor-like), the second not"""
+    h = q["fc"].shape[0] // 2
+    return [q["fc"][:h], q["fc"][h:]], [q["pf"][:h], q["pf"][h:]], [q["q"][:h], q["q"][h:]], [1, 0]
+
+
+def reference_relax(orc, case, q, alpha):
+    """fvMatrix<scalar>::relax(alpha) (fvMatrix.C:1087-1345) composed of the REFERENCE's pieces in its order: sumMagOffDiag of
+    lduMatrixOperations.C (libref_ldu_ops.so), the patch functors and the dominance functor of fvMatrix.C (libref_fvm.so); the field
+    operations between them (D /= alpha, S += (D - D0)*psi: one rounding each) in numpy"""
+    fcs, ics, bcs, coupled = relax_patches(q)
+    D = case.diag.copy(); D0 = D.copy()
+    sumOff = orc.ref_ldu_ops(case, "sumMagOffDiag")
+    for fc, ic, bc, cpl in zip(fcs, ics, bcs, coupled):
+        if cpl:
+            D = orc.ref_fvm_patch_rows("relaxComponentZero", fc, ic, D)
+            sumOff = orc.ref_fvm_patch_rows("relaxMagComponentZero", fc, bc, sumOff)
+        else:
+            D = orc.ref_fvm_patch_rows("relaxMaxComponentMag", fc, ic, D)
+    D = orc.ref_fvm_relax_dominance(D, sumOff)
+    D = D / alpha
+    for fc, ic, bc, cpl in zip(fcs, ics, bcs, coupled):
+        D = orc.ref_fvm_patch_rows("relaxNegComponentZero" if cpl else "relaxNegComponentMin", fc, ic, D)
+    t = D - D0
+    t = t * q["psi"]
+    return D, case.source + t
+
+
 if __name__ == "__main__":
     graft.build()
     pkg = graft.load_package()
@@ -266,4 +342,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_atmul.npz"), **build_atmul(pkg, orc))
     assert orc.ref_ldu_ops_available(), "oracle/_ref/libref_ldu_ops.so missing"
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_ldu_ops.npz"), **build_ldu_ops(pkg, orc))
+    assert orc.ref_fvm_available(), "oracle/_ref/libref_fvm.so missing"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_ref_fvm.npz"), **build_fvm(pkg, orc))
     print("written")

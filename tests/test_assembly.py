@@ -243,7 +243,7 @@ def test_compressible_operators_oracle_against_plain_numpy(pkg, orc):
         for f in range(nf):
             P, N = lo[f], up[f]
             i = [fma(lam[f], V[k][P] - V[k][N], V[k][N]) for k in range(3)]
-            out[f] = fma(i[2], Sf[2][f], fma(i[1], Sf[1][f], i[0] * Sf[0][f]))
+            out[f] = fma(i[2], Sf[2][f], fma(i[0], Sf[0][f], i[1] * Sf[1][f]))   # Vector operator& as the compiled reference rounds it
         return out
     phi, div = orc.flux_div(n, lo, up, lam, Sf, U, scale=rho0, add_a=aA, add_b=aB, vol=vol)
     ref = flux(rho0) + aA * aB
@@ -461,6 +461,67 @@ def test_engine_scheme_front_end_bit_exact(pkg, orc, dims):
     assert np.array_equal(host(out), orc.axpby(1.0, x, -0.75, y))
     xd = dev(x); A.axpby(2.0, xd, 1.0, dev(y), xd)           # in place
     assert np.array_equal(host(xd), orc.axpby(2.0, x, 1.0, y))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fixed256", "fixed1024", "tiles", "tiles_unstaged"])
+@pytest.mark.parametrize("name", ["box", "graph"])
+def test_fused_assembly_equals_the_unfused_sequence_bit_for_bit(pkg, orc, monkeypatch, name, mode):
+    """mi_fvm_assemble -- [fvm::ddt] + [fvm::div] - [fvm::laplacian] [+- fvm::Sp] [+- explicit terms] in ONE row pass -- against (a) the
+    oracle's unfused sequence (tests/assembly_full_size.py: oracle_assemble) and (b) the engine's own scheme-by-scheme calls combined
+    with mi_vec_axpby the way fvMatrix::operator+ / - combine them (fvMatrix.C:1693-2030), for three systems (momentum-like with three
+    right-hand sides, upwind convection, Sp and two explicit terms; pressure-like symmetric; convection with given weights), in every
+    block shape of the row passes; plus fvMatrix<vector>::relax fed with the pass's sumMagOffDiag, setValues (reference and upstream
+    semantics) and setReference."""
+    import torch
+    import assembly_full_size as afs
+    from conftest import random_graph_case
+    eng, syn = pkg.engine, pkg.synthetic
+    ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to("cuda:0")
+    host = lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1]
+    case = syn.box_case(31, 23, 19, symmetric=False) if name == "box" else random_graph_case(pkg, 9000, extra=3.0, seed=5, symmetric=False)
+    if mode.startswith("tiles"):
+        a0 = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+        case = syn.renumber(case, a0.cell_perm())
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr, ordered=True, tile_cell_start=a0.tile_starts())
+        assert addr.is_ordered
+    else:
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+    monkeypatch.setenv("MI_ROW_BS", "1024" if mode == "fixed1024" else "256")
+    if mode.endswith("unstaged"):
+        monkeypatch.setenv("MI_ROW_CAP", "64")
+    M = dict(n=case.n_cells, nf=case.n_faces, lo=case.lower_addr, up=case.upper_addr, dims=(1, 1, 1))
+    q = afs.inputs(pkg, M)
+    got = afs.engine_run(pkg, ctx, addr, M, q)
+    ref = afs.oracle_run(pkg, orc, M, q)
+    assert sorted(got) == sorted(ref)
+    for k in sorted(ref):
+        assert np.array_equal(got[k], ref[k]), k
+    # (b) the engine's own unfused sequence for the momentum-like system
+    n, nf = M["n"], M["nf"]
+    asm = eng.Assembly(addr)
+    E = lambda m: torch.empty(m, dtype=torch.float64, device="cuda:0")
+    wts, cl, cu, cd, lu, ld, dd, ds = E(nf), E(nf), E(nf), E(n), E(nf), E(n), E(n), [E(n) for _ in range(3)]
+    flux, vol = dev(q["flux"]), dev(q["vol"])
+    asm.upwind_weights(flux, wts); asm.fvm_div(wts, flux, cl, cu, cd); asm.fvm_laplacian(dev(q["delta"]), dev(q["gamma"]), lu, ld)
+    for r in range(3):
+        asm.fvm_ddt_euler_rho(q["rdt"], dev(q["rho"]), dev(q["rho0"]), vol, dev(q["V"][r]), dd, ds[r])
+        asm.fvm_su(vol, dev(q["su"][r]), ds[r])                                   # + su: source -= V*su
+        t = vol * dev(q["g"][r]); ds[r].add_(t)                                   # == g: source += V*g
+    asm.axpby(1.0, cl, -1.0, lu, cl); asm.axpby(1.0, cu, -1.0, lu, cu)
+    asm.axpby(1.0, dd, 1.0, cd, dd); asm.axpby(1.0, dd, -1.0, ld, dd)
+    t = vol * dev(q["sp"]); dd.sub_(t)
+    for key, t in (("lower", cl), ("upper", cu), ("diag", dd), ("source0", ds[0]), ("source1", ds[1]), ("source2", ds[2])):
+        assert np.array_equal(host(t), got["assemble_momentum/" + key]), key
+    # upstream semantics of setValues against the oracle
+    sv = orc.set_values(n, M["lo"], M["up"], q["set_cells"], q["set_vals"], q["psi"], q["Dc"], q["src"], q["Uc"], None, upstream=True)
+    ps, sr, uo, lo_o = dev(q["psi"]), dev(q["src"]), E(nf), E(nf)
+    asm.set_values(torch.from_numpy(q["set_cells"]).to("cuda:0"), dev(q["set_vals"]), ps, dev(q["Dc"]), sr, dev(q["Uc"]), None, uo, lo_o, upstream=True)
+    assert np.array_equal(host(sr), sv["source"]) and np.array_equal(host(uo), sv["upper"]) and np.array_equal(host(lo_o), sv["lower"]) and np.array_equal(host(ps), sv["psi"])
+    assert np.array_equal(sv["upper"], sv["lower"])          # upstream: a symmetric matrix stays symmetric
+    with pytest.raises(eng.MiError):
+        asm.assemble(flux, dd, lower_out=cl, sources_out=[], div=dict(flux=flux))       # a coefficient output aliasing an input
 
 
 # ---- non-orthogonal correction of fvm::laplacian (SURVEY.md 8a row a22; gaussLaplacianSchemes.C:64-90) --------------------

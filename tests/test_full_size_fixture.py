@@ -1,8 +1,9 @@
 """CPU: tests/golden/full_size_v1.npz (the oracle's results at the BASELINE sizes, which the GPU tests compare the engine
 against -- tests/full_size_ref.py) cannot drift from the oracle unseen:
 
-  * every section carries the sha256 of the oracle's C sources and of the case generator it was derived from; they must be the
-    current ones (a change of oracle/*.c or synthetic.py => re-run tests/golden/make_full_size.py);
+  * every section carries the sha256 of what it was derived from -- the oracle's C sources and ctypes wrapper, its own generator
+    function, the case generator's outputs (assembly section: also tests/assembly_full_size.py and the tile layout's outputs);
+    they must be the current ones (a change => re-run tests/golden/make_full_size.py <section>);
   * a sample of the records is RE-DERIVED here with the live oracle, bit for bit: the 108^3 persistent-kernel reference solve
     (300 iterations, whole history and the solution sample) and, at 216^3, the Amul result (sha256 + sample) and the first
     iterations of the diagonal-PCG history (PCG.C:133-204).
@@ -12,7 +13,7 @@ import pytest
 
 import full_size_ref as fs
 
-SECTIONS = ("box216_sym", "box216_asym", "persist108", "config4", "config5")
+SECTIONS = ("assembly216", "box216_sym", "box216_asym", "persist108", "config4", "config5")
 
 
 @pytest.fixture(scope="module")
@@ -21,8 +22,8 @@ def rec():
 
 
 def test_every_section_was_derived_from_the_current_oracle_sources(rec):
-    now = fs.source_hashes()
     for name in SECTIONS:
+        now = fs.source_hashes(name)
         for rel, h in now.items():
             assert str(rec.scalar(f"sources/{name}/{rel}")) == h, f"section {name} is older than {rel}: re-run tests/golden/make_full_size.py {name}"
 
@@ -63,3 +64,21 @@ def test_rederive_amul_and_the_first_pcg_iterations_at_216_cubed(pkg, orc, rec):
     _, perf = S.pcg(np.zeros(case.n_cells), case.source, "diagonal", tolerance=0.0, maxIter=5)
     ref = rec.perf("box216_sym/pcg_diagonal_120")
     assert np.array_equal(perf["history"], ref["history"][:perf["history"].shape[0]]) and perf["normFactor"] == ref["normFactor"]
+
+
+def test_rederive_assembly_records_on_a_slab_of_the_same_generators(pkg, orc, rec):
+    """the assembly section's generators (tests/assembly_full_size.py) run here on a small box on both meshes: every operator name the
+    216^3 record holds is produced, and the unfused oracle sequence of the fused assembly agrees with plain numpy on the diagonal"""
+    import assembly_full_size as afs
+    for variant in afs.VARIANTS:
+        M = afs.mesh(pkg, variant, dims=(20, 12, 9))
+        q = afs.inputs(pkg, M)
+        res = afs.oracle_run(pkg, orc, M, q)
+        assert sorted(res) == list(rec.scalar(f"assembly216/{variant}/names"))
+        for name, a in res.items():
+            assert np.all(np.isfinite(a)), name
+            assert len(rec.sha(f"assembly216/{variant}/{name}")) == 64
+        m = res["assemble_momentum/diag"]
+        dA = (q["rdt"] * q["rho"]) * q["vol"]
+        assert np.array_equal(m, ((dA + orc.fvm_div(M["n"], M["lo"], M["up"], orc.upwind_weights(q["flux"]), q["flux"])[2])
+                                  - res["laplacian/diag"]) - q["vol"] * q["sp"])

@@ -317,3 +317,44 @@ def test_persistent_pcg_kernel_at_its_design_point_108_cubed(pkg, orc, rec, form
         assert d_all < HIST_RTOL and d_first < HIST_RTOL
         assert late < 1e-9                                  # per-workgroup sum grouping: rounding-level drift late in the solve (seen: 1.1e-12 at a residual of 1e-8)
         check_solution(got, ref_psi, 1e-8)
+
+
+@pytest.mark.parametrize("variant", ["caller", "ordered"])
+def test_assembly_bit_exact_at_10M_cells(pkg, orc, ctx, rec, variant):
+    """VERDICT r05 "next" 1b: every fvMatrix-assembly operator of the C ABI at 216^3 -- row sums, fvm::laplacian, fvm::div,
+    surfaceIntegrate, the face interpolate, Gauss grad, limitedLinear weights, fvc::ddtCorr, flux + divergence, the non-orthogonal
+    correction flux, relax (with a coupled and a plain patch), faceH, setValues, setReference, and the FUSED assembly
+    (ddt + div - laplacian - Sp + explicit terms: momentum-like with three right-hand sides, pressure-like symmetric, convection with
+    given weights) followed by the vector relax fed with the pass's sumMagOffDiag -- sha256 of the result BITS against the oracle's
+    (tests/golden/full_size_v1.npz section assembly216, written on the CPU box by tests/assembly_full_size.py's oracle_run), in the
+    caller's numbering (fixed 1024-cell blocks) and under ordered addressing (one block = one tile of the layout: 9 842 blocks,
+    16-bit row tables with escape lists, cut faces recomputed from the schemes' inputs)."""
+    import assembly_full_size as afs
+    eng = pkg.engine
+    M = afs.mesh(pkg, "caller")
+    if variant == "ordered":
+        addr = eng.Addressing(ctx, M["n"], M["lo"], M["up"], adopt=True)
+        M = dict(M, lo=addr.lower_addr, up=addr.upper_addr)
+        assert addr.is_ordered and addr.n_tiles > 9000
+    else:
+        addr = eng.Addressing(ctx, M["n"], M["lo"], M["up"])
+        assert not addr.is_ordered
+    q = afs.inputs(pkg, M)
+    if rec is not None:      # the records belong to exactly this addressing (a changed tile layout renumbers the ordered mesh)
+        assert fs.sha(M["lo"]) == rec.sha(f"assembly216/{variant}/lowerAddr") and fs.sha(M["up"]) == rec.sha(f"assembly216/{variant}/upperAddr")
+    got = afs.engine_run(pkg, ctx, addr, M, q)
+    if rec is None:
+        ref = afs.oracle_run(pkg, orc, M, q)
+        assert sorted(ref) == sorted(got)
+        for name in sorted(ref):
+            assert np.array_equal(got[name], ref[name]), name
+        return
+    assert sorted(got) == list(rec.scalar(f"assembly216/{variant}/names"))
+    bad = []
+    for name in sorted(got):
+        a = got[name]
+        if fs.sha(a) != rec.sha(f"assembly216/{variant}/{name}"):
+            s = rec.scalar(f"assembly216/{variant}/{name}/sample")
+            d = np.abs(a[fs.sample_idx(a.shape[0], 256)] - s)
+            bad.append((name, float(d.max()), int(np.count_nonzero(d))))
+    assert not bad, bad

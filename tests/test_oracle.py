@@ -472,3 +472,54 @@ def test_arbitrarily_partitioned_system_matches_serial(pkg, orc):
         assert abs(p1["nIterations"] - p2["nIterations"]) <= 1
         k = min(len(p1["history"]), len(p2["history"]))
         assert np.max(np.abs(p1["history"][:k] - p2["history"][:k])) < 1e-9 * p1["history"][0]
+
+
+def test_assembly_oracle_equals_the_reference_functors_run_on_the_host(pkg, orc):
+    """The reference's fvMatrix-assembly functors -- fvMatrixPatchAddFunctor, fvMatrixAddBoundarySourceFunctor, the relax functors and
+    the setValues functors of fvMatrix.C, surfaceIntegrateFunctor / surfaceIntegratePatchFunctor (fvcSurfaceIntegrate.C),
+    surfaceInterpolationSchemeInterpolateFunctor (scalar and vector), gaussGradFunctor / gaussGradPatchFunctor, lduMatrixfaceHFunctor,
+    LimitedSchemeCalcLimiterFunctor with limitedLinearLimiter<NVDTVD> and limitedSurfaceInterpolationSchemeWeightsFunctor -- compiled
+    from /root/reference on the reference's own Vector / Scalar primitives (oracle/ref_shim/ref_fvm_tu.cpp -> oracle/_ref/libref_fvm.so)
+    produced tests/golden/golden_ref_fvm.npz.  oracle/fvm_oracle.c (and faceH of ldu_oracle.c) must give the reference's BITS for every
+    one of them, including fvMatrix::relax composed of the reference's own pieces; where the reference tree is present the record is
+    re-derived live."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_ref as mg
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_ref_fvm.npz"))
+    cols = lambda a: [np.ascontiguousarray(a[:, k]) for k in range(3)]
+    fn_of = {"add": 0, "subtract": 1, "relaxComponentZero": 0, "relaxMagComponentZero": 2, "relaxMaxComponentMag": 2, "relaxNegComponentZero": 1,
+             "relaxNegComponentMin": 1, "surfaceIntegratePatch": 0}
+    for name, case in mg.fvm_cases(pkg).items():
+        q = mg.fvm_inputs(pkg, case)
+        n, lo, up = case.n_cells, case.lower_addr, case.upper_addr
+        eq = lambda got, key: np.array_equal(got, G[f"{name}/{key}"])
+        assert eq(orc.surface_integrate(n, lo, up, q["ssf"]), "surfaceIntegrate")
+        assert eq(orc.face_interpolate(lo, up, q["lam"], q["phi"]), "interpolate")
+        assert eq(np.stack([orc.face_interpolate(lo, up, q["lam"], v) for v in cols(q["v3"])], 1), "interpolate_vector")
+        assert eq(orc.flux_div(n, lo, up, q["lam"], cols(q["sf3"]), cols(q["v3"]), want_div=False), "Sf_dot_interpolate")
+        g = orc.gauss_grad(n, lo, up, cols(q["sf3"]), q["ssf"])
+        assert eq(np.stack(g, 1), "gaussGrad")
+        gp = [orc.patch_add_product(q["fc"], psf, q["pf"], gk, 0) for psf, gk in zip(cols(q["psf3"]), g)]   # out += Sf[face]*issf[face]: one fma
+        assert eq(np.stack(gp, 1), "gaussGrad_patch")
+        assert eq(orc.System([case]).faceH(q["psi"]), "faceH")
+        for k in (1.0, 0.33):
+            w, lim = orc.limited_linear_weights(lo, up, k, q["cdw"], q["flux"], q["phi"], cols(q["g3"]), cols(q["C3"]))
+            assert eq(lim, f"limitedLinear_{k}/limiter") and eq(w, f"limitedLinear_{k}/weights")
+        for kind, fn in fn_of.items():
+            assert eq(orc.patch_add(q["fc"], q["pf"], q["fld"], fn), f"patch/{kind}"), kind
+        assert eq(orc.patch_add_product(q["fc"], q["pf"], q["q"], q["fld"], 0), "patch/boundarySource")
+        assert eq(np.maximum(np.abs(q["fld"]), q["sumOff"]), "relaxDominance")
+        fcs, ics, bcs, coupled = mg.relax_patches(q)
+        d, s = orc.relax(n, lo, up, 0.7, case.diag, case.lower, case.upper, case.source, q["psi"], fcs, ics, bcs, coupled)
+        assert eq(d, "relax/diag") and eq(s, "relax/source")
+        sv = orc.set_values(n, lo, up, q["set_cells"], q["set_vals"][:q["set_cells"].shape[0]], q["psi"], case.diag, case.source, case.upper, case.lower)
+        keep = np.ones(n, bool); keep[q["set_cells"]] = False
+        assert np.array_equal(sv["source"][keep], G[f"{name}/setValues/source"][keep])
+        assert np.array_equal(sv["source"][~keep], q["set_vals"][:q["set_cells"].shape[0]] * case.diag[q["set_cells"]])
+        assert eq(sv["upper"], "setValues/upper") and eq(sv["lower"], "setValues/lower")
+    if orc.ref_fvm_available():
+        now = mg.build_fvm(pkg, orc)
+        assert set(now) == set(G.files)
+        for k in G.files:
+            assert np.array_equal(now[k], G[k]), k

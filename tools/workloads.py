@@ -122,8 +122,8 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
     xmin = np.nonzero(np.arange(N) % nx == 0)[0]
     patch = eng.Patch(ctx, N, xmin)
     icU, icP = t(np.full(xmin.shape[0], 2.0 * 1e-3 * h)), t(np.full(xmin.shape[0], -2.0 * h))
-    wts, cl, cu, cd, lu, ld = E(F), E(F), E(F), E(N), E(F), E(N)
-    dd, ds = E(N), [E(N) for _ in range(3)]
+    lam = t(np.full(F, 0.5))                     # linear interpolation weights of the uniform box
+    ds, smag = [E(N) for _ in range(3)], E(N)
     ul, uu, ud = E(F), E(F), E(N)
     rAU, rAUf, pu, pd, psrc = E(N), E(F), E(F), E(N), E(N)
     fh, grad = E(F), [E(N) for _ in range(3)]
@@ -139,17 +139,14 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
             self.b.record(); ev.setdefault(self.name, []).append((self.a, self.b))
 
     def step():
-        with stage("momentum: upwind weights + fvm::div + fvm::laplacian"):
-            asm.upwind_weights(phi, wts); asm.fvm_div(wts, phi, cl, cu, cd); asm.fvm_laplacian(delta, nuMagSf, lu, ld)
-        with stage("momentum: fvm::ddt x3 + UEqn = ddt + div - laplacian + boundary diag"):
-            for d in range(3): asm.fvm_ddt_euler(1.0 / 1e-3, 1.0, vol, U[d], dd, ds[d])
-            asm.axpby(1.0, cl, -1.0, lu, ul); asm.axpby(1.0, cu, -1.0, lu, uu)
-            asm.axpby(1.0, dd, 1.0, cd, ud); asm.axpby(1.0, ud, -1.0, ld, ud)
+        with stage("momentum: UEqn = fvm::ddt(U) + fvm::div(phi, U) [upwind] - fvm::laplacian(nu, U), three sources, in ONE pass (mi_fvm_assemble) + boundary diag"):
+            asm.assemble(uu, ud, lower_out=ul, sources_out=ds, ddt=dict(r_delta_t=1.0 / 1e-3, vol=vol, psi_old=U), div=dict(flux=phi),
+                         laplacian=dict(delta_coeffs=delta, gamma_magsf=nuMagSf), sum_mag_out=smag)
             patch.add(icU, ud, 0)
             if cpl:
                 for q in cpl: q["patch"].add(q["dU"], ud, 0)
-        with stage("momentum: relax(0.7) + bind coefficients"):
-            asm.relax(0.7, ud, ul, uu, ds[0], U[0])
+        with stage("momentum: relax(0.7), three components (sumMagOffDiag from the assembly pass) + bind coefficients"):
+            asm.relax_multi(0.7, ud, None, None, ds, U, sum_mag=smag)
             UM.set_coeffs(ud, uu, ul)
             if cpl:
                 for k, q in enumerate(cpl): UM.set_interface_coeffs(k, q["bU"], q["bU"])
@@ -160,7 +157,7 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
                 its = [UM.pbicg(U[d], ds[d], "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)["nIterations"] for d in range(3)]
         with stage("pressure: rAU, interpolate, fvm::laplacian(rAUf), bind, div(phi) source"):
             torch.reciprocal(ud, out=rAU); rAU.mul_(vol)
-            asm.face_interpolate(wts, rAU, rAUf); rAUf.mul_(magSf)
+            asm.face_interpolate(lam, rAU, rAUf); rAUf.mul_(magSf)
             asm.fvm_laplacian(delta, rAUf, pu, pd); patch.add(icP, pd, 0)
             if cpl:
                 for q in cpl: q["patch"].add(q["dP"], pd, 0)
@@ -173,7 +170,7 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
             cyc = G.solve(PM, p, psrc, tolerance=1e-12, relTol=0.05, maxIter=50)["nIterations"]
         with stage("corrector: flux (faceH), fvc::grad(p), U -= rAU grad p"):
             PM.faceH(p, fh); phi.sub_(fh * 0.0)
-            asm.face_interpolate(wts, p, rAUf); asm.gauss_grad(Sf, rAUf, vol, grad)
+            asm.face_interpolate(lam, p, rAUf); asm.gauss_grad(Sf, rAUf, vol, grad)
             for d in range(3): asm.axpby(1.0, U[d], -1e-3, grad[d], U[d])
         return its, cyc
 
@@ -184,7 +181,7 @@ def timestep_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=5, batc
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps
     return {"workload": f"BASELINE configs 4/5, per-rank share: one PISO-like time step on the {case.dims[0]}x{case.dims[1]}x{case.dims[2]} box "
-                        "(fvm::ddt + upwind fvm::div - fvm::laplacian, relax, PBiCG + DILU x 3 components, pressure assembly, GAMG, flux + Gauss gradient correction), "
+                        "(fvm::ddt + upwind fvm::div - fvm::laplacian assembled in one pass, relax, PBiCG + DILU x 3 components, pressure assembly, GAMG, flux + Gauss gradient correction), "
                         "every stage through the C ABI",
             "ms_per_time_step": 1e3 * wall, "pbicg_iterations_per_component": [int(v) for v in its], "gamg_cycles": int(cyc),
             "momentum_solve": "one batched 3-right-hand-side PBiCG" if batched else "three segregated PBiCG solves",
@@ -239,8 +236,8 @@ def rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=3, tra
     xmin = np.nonzero(np.arange(N) % nx == 0)[0]
     patch = eng.Patch(ctx, N, xmin)
     icU, icE, icP = t(np.full(xmin.shape[0], 2.0 * 1.8e-5 * h)), t(np.full(xmin.shape[0], 2.0 * 2.5e-5 * h)), t(np.full(xmin.shape[0], 2.0e-4 * h))
-    wts, cl, cu, cd, lu, ld = E(F), E(F), E(F), E(N), E(F), E(N)
-    dd, ds = E(N), [E(N) for _ in range(3)]
+    wts, lu, ld = E(F), E(F), E(N)
+    ds, smag = [E(N) for _ in range(3)], E(N)
     ul, uu, ud = E(F), E(F), E(N)
     el, eu, ed, es, expl, Kf = E(F), E(F), E(N), E(N), E(N), E(F)
     rAU, rhorAUf, pu, pl, pd, ps, pdd = E(N), E(F), E(F), E(F), E(N), E(N), E(N)
@@ -259,31 +256,24 @@ def rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=3, tra
             self.b.record(); ev.setdefault(self.name, []).append((self.a, self.b))
 
     def step():
-        with stage("UEqn: upwind + fvm::div(phi) + fvm::laplacian(muEff) + fvm::ddt(rho, U) x3 + grad(p) source"):
-            asm.upwind_weights(phi, wts); asm.fvm_div(wts, phi, cl, cu, cd); asm.fvm_laplacian(delta, muMagSf, lu, ld)
-            asm.face_interpolate(lam, p, pf); asm.gauss_grad(Sf, pf, None, grad)       # integral of grad p over the cell = V * grad p
-            for d in range(3):
-                asm.fvm_ddt_euler_rho(rdt, rho, rho0, vol, U0[d], dd, ds[d])
-                asm.axpby(1.0, ds[d], -1.0, grad[d], ds[d])                            # UEqn == -fvc::grad(p): source -= V grad(p)
-            asm.axpby(1.0, cl, -1.0, lu, ul); asm.axpby(1.0, cu, -1.0, lu, uu)
-            asm.axpby(1.0, dd, 1.0, cd, ud); asm.axpby(1.0, ud, -1.0, ld, ud)
+        with stage("UEqn: fvc::grad(p), then fvm::ddt(rho, U) + fvm::div(phi, U) [upwind] - fvm::laplacian(muEff, U) == -grad(p) in ONE pass (mi_fvm_assemble)"):
+            asm.face_interpolate(lam, p, pf); asm.gauss_grad(Sf, pf, vol, grad)
+            asm.assemble(uu, ud, lower_out=ul, sources_out=ds, ddt=dict(r_delta_t=rdt, vol=vol, psi_old=U0, rho=rho, rho_old=rho0), div=dict(flux=phi),
+                         laplacian=dict(delta_coeffs=delta, gamma_magsf=muMagSf), su=[(1.0, grad)], sum_mag_out=smag)   # == -grad(p): source -= V grad(p)
             patch.add(icU, ud, 0)
         with stage("UEqn: relax(0.7) + bind + PBiCG + DILU, 3 components in one batched solve (relTol 0.1)"):
-            asm.relax(0.7, ud, ul, uu, ds[0], U[0])
+            asm.relax_multi(0.7, ud, None, None, ds, U, sum_mag=smag)
             UM.set_coeffs(ud, uu, ul)
             its = [q["nIterations"] for q in UM.pbicg_multi(U, ds, "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)]
         with stage("EEqn: fvm::ddt(rho, he) + fvm::div(phi, he) - fvm::laplacian(alphaEff, he) + explicit K / dpdt terms (fvm::Su) + relax + PBiCG"):
-            asm.fvm_ddt_euler_rho(rdt, rho, rho0, vol, he, ed, es)
-            asm.fvm_laplacian(delta, alphaMagSf, lu, ld)
-            asm.axpby(1.0, cl, -1.0, lu, el); asm.axpby(1.0, cu, -1.0, lu, eu)
-            asm.axpby(1.0, ed, 1.0, cd, ed); asm.axpby(1.0, ed, -1.0, ld, ed)
-            patch.add(icE, ed, 0)
             K = 0.5 * (U[0] * U[0] + U[1] * U[1] + U[2] * U[2])
-            asm.face_interpolate(wts, K, Kf); Kf.mul_(phi)
+            asm.upwind_weights(phi, wts); asm.face_interpolate(wts, K, Kf); Kf.mul_(phi)
             asm.surface_integrate(Kf, vol, expl)                                       # fvc::div(phi, K)
             expl.add_(rdt * (rho * K - rho0 * K0)).sub_(rdt * (p - p_old))              # + fvc::ddt(rho, K) - dpdt
-            asm.fvm_su(vol, expl, es)                                                  # an explicit term on the left-hand side: source -= V expl (fvmSup.C:34-54)
-            asm.relax(0.9, ed, el, eu, es, he)
+            asm.assemble(eu, ed, lower_out=el, sources_out=[es], ddt=dict(r_delta_t=rdt, vol=vol, psi_old=[he], rho=rho, rho_old=rho0), div=dict(flux=phi),
+                         laplacian=dict(delta_coeffs=delta, gamma_magsf=alphaMagSf), su=[(1.0, [expl])], sum_mag_out=smag)   # the explicit terms stand on the left: source -= V expl
+            patch.add(icE, ed, 0)
+            asm.relax_multi(0.9, ed, None, None, [es], [he], sum_mag=smag)
             EM.set_coeffs(ed, eu, el)
             e_it = EM.pbicg(he, es, "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)["nIterations"]
             torch.mul(psi, p, out=rho)                                                 # thermo.correct(): rho = psi p
@@ -295,12 +285,10 @@ def rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=3, tra
             asm.ddt_phi_corr(rdt, lam, Sf, U0, rho0, phi, ddtc)
         if not transonic:
             with stage("pEqn: phiHbyA + fvc::div(phiHbyA) in one pass, fvm::ddt(psi, p) - fvm::laplacian(rhorAUf, p), bind"):
-                asm.flux_div(lam, Sf, HbyA, phiH, divH, cell_scale=rho, add_a=rhorAUf, add_b=ddtc)
+                asm.flux_div(lam, Sf, HbyA, phiH, divH, cell_scale=rho, add_a=rhorAUf, add_b=ddtc, vol=vol)
                 rhorAUf.mul_(magSf)
-                asm.fvm_laplacian(delta, rhorAUf, pu, pd)
-                asm.fvm_ddt_euler_rho(rdt, psi, psi, vol, p_old, pdd, ps)
-                asm.axpby(1.0, pdd, -1.0, pd, pd); asm.axpby(-1.0, pu, 0.0, pu, pu)     # ddt - laplacian
-                asm.axpby(1.0, ps, -1.0, divH, ps)                                      # + fvc::div(phiHbyA): source -= V div
+                asm.assemble(pu, pd, sources_out=[ps], ddt=dict(r_delta_t=rdt, vol=vol, psi_old=[p_old], rho=psi, rho_old=psi),
+                             laplacian=dict(delta_coeffs=delta, gamma_magsf=rhorAUf), su=[(1.0, [divH])])   # ddt(psi, p) + fvc::div(phiHbyA) - laplacian in one pass
                 patch.add(icP, pd, 0)
                 PM.set_coeffs(pd, pu, None)
         else:
@@ -308,12 +296,9 @@ def rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=3, tra
                 asm.flux_div(lam, Sf, HbyA, phiH, divH)                                  # interpolate(HbyA) & Sf
                 asm.face_interpolate(lam, rho, rho_f); asm.face_interpolate(lam, psi, pf)
                 phiH.add_(rhorAUf * ddtc / rho_f).mul_(pf)                               # phid
-                asm.upwind_weights(phiH, wts); asm.fvm_div(wts, phiH, pl, pu, pd)
                 rhorAUf.mul_(magSf)
-                asm.fvm_laplacian(delta, rhorAUf, lu, ld)
-                asm.fvm_ddt_euler_rho(rdt, psi, psi, vol, p_old, pdd, ps)
-                asm.axpby(1.0, pl, -1.0, lu, pl); asm.axpby(1.0, pu, -1.0, lu, pu)
-                asm.axpby(1.0, pd, 1.0, pdd, pd); asm.axpby(1.0, pd, -1.0, ld, pd)
+                asm.assemble(pu, pd, lower_out=pl, sources_out=[ps], ddt=dict(r_delta_t=rdt, vol=vol, psi_old=[p_old], rho=psi, rho_old=psi), div=dict(flux=phiH),
+                             laplacian=dict(delta_coeffs=delta, gamma_magsf=rhorAUf))               # ddt(psi, p) + div(phid, p) [upwind] - laplacian in one pass
                 patch.add(icP, pd, 0)
                 PM.set_coeffs(pd, pu, pl)
         if capture is not None:
