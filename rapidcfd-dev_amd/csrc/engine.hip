@@ -106,7 +106,7 @@ struct mi_ctx_s {
     int multiPipe = 1; // MI_MULTI_PIPE: tile_kernel_multi_pipe (multi_pipe.inc) for the multi-vector passes of the Krylov iterations
     int pairAT = 1;    // MI_PBICG_PAIR: PBiCG's A p / A^T pT (and the DILU pair) in one pass over the coefficients (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
-    int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1; // MI_* switches, read once per context
+    int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1, gamgFuse = 1; // MI_* switches, read once per context
     std::set<const void*> ldsAttrSet;                         // kernels whose dynamic-LDS limit has been raised on THIS device
     std::map<std::pair<const void*, size_t>, int> occCache;  // (kernel, LDS bytes) -> resident workgroups per CU on this device
 };
@@ -271,7 +271,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
     c->amulBS = env_int("MI_AMUL_BS", 0); // 0 = choose per launch from the LDS footprint
     c->pcgBatch = env_int("MI_PCG_BATCH", 16); c->pcgGraph = env_int("MI_PCG_GRAPH", -1); c->pbicgHostStepped = env_int("MI_PBICG_HOST_STEPPED", 0);
-    c->gamgDeviceInvert = env_int("MI_GAMG_DEVICE_INVERT", -1); c->gamgAlwaysAgglomerate = env_int("MI_GAMG_ALWAYS_AGGLOMERATE", 0); c->gamgGraph = env_int("MI_GAMG_GRAPH", 1);
+    c->gamgDeviceInvert = env_int("MI_GAMG_DEVICE_INVERT", -1); c->gamgAlwaysAgglomerate = env_int("MI_GAMG_ALWAYS_AGGLOMERATE", 0); c->gamgGraph = env_int("MI_GAMG_GRAPH", 1); c->gamgFuse = env_int("MI_GAMG_FUSE", 1);
     if (c->amulBS != 256 && c->amulBS != 512 && c->amulBS != 1024) c->amulBS = 0;
     *out = c;
     return MI_OK;
@@ -905,6 +905,50 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
         return launch_tile_bs<OP, true, false, false>(m, t, nTiles, lds);
     }
     return launch_tile_bs<OP, false, false, false>(m, t, nTiles, lds);
+}
+
+// tile pass with the operand formed in the staging (tile_kernel_fx; kernels.hip.hpp: TileArgs::fx*): every tile, engine order, no
+// coupled patches (the operand of a halo cell is formed from the same arrays as an own cell's), plain row entries
+struct FxArgs {
+    const int32_t* map = nullptr; const double* coarse = nullptr; double* out = nullptr;
+    const double *field = nullptr, *acf = nullptr, *src = nullptr, *scal = nullptr, *add = nullptr;
+    unsigned int* foldCounter = nullptr; double* foldOut = nullptr;
+};
+inline bool tile_fx_usable(const mi_matrix_s* m) { return m->bound && !m->addr->compact && m->addr->L.nExt == 0 && m->addr->ami.empty() && !m->callerY && !m->gateDone; }
+template <int OP, int XMODE>
+int launch_tile_fx(mi_matrix_s* m, const FxArgs& fx, const double* b, double* y, double omega, double* dotPartial = nullptr, double* dotPartial2 = nullptr)
+{
+    mi_addr_s* a = m->addr;
+    if (!tile_fx_usable(m)) return fail(MI_ERR_STATE, "launch_tile_fx: matrix not eligible");
+    TileArgs t;
+    t.tileCellStart = a->tileCellStart.p; t.tileSlotStart = a->tileSlotStart.p; t.tileIfaceSlot0 = a->tileIfaceSlot0.p; t.tileHaloStart = a->tileHaloStart.p;
+    t.haloCell = a->haloCell.p; t.tileSliceStart = a->tileSliceStart.p; t.sliceEntryStart = a->sliceEntryStart.p;
+    t.entries = a->entries.p; t.entries16 = nullptr; t.sliceEntryStart16 = nullptr; t.slotBase = nullptr; t.tileSbStart = nullptr;
+    t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
+    t.x = nullptr; t.b = b; t.rD = nullptr; t.y = y; t.omega = omega; t.dotPartial = dotPartial; t.dotPartial2 = dotPartial2; t.flags = a->ctx->tileFlags;
+    t.fxMap = fx.map; t.fxCoarse = fx.coarse; t.fxOut = fx.out; t.fxField = fx.field; t.fxAcf = fx.acf; t.fxSrc = fx.src; t.fxScal = fx.scal; t.fxAdd = fx.add;
+    t.foldCounter = fx.foldCounter; t.foldOut = fx.foldOut;
+    size_t lds = lds_bytes(a->L, m->asym, false, &t.offLow, &t.offX, &t.offRD, &t.offSB);
+    if (lds > 159 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 159 KiB of LDS");
+    if (fx.foldOut) lds = std::max(lds, (size_t)(2 * RG + 2 * (RB / 64) + 2) * sizeof(double));   // the folding workgroup's scratch
+    const int nTiles = a->L.nTiles;
+    t.tileList = nullptr; t.nPos = nTiles; t.done = nullptr;
+    if (nTiles <= 0) return MI_OK;
+    mi_ctx_s* cx = a->ctx;
+    hipStream_t s = cx->stream;
+    int bs = cx->amulBS;
+    if (bs == 0) bs = (lds > 53 * 1024) ? 1024 : (a->L.maxCells <= 256 ? 256 : 512);
+#define MI_LAUNCH_FX(ASYM, BS)                                                                                           \
+    {                                                                                                                   \
+        const void* fn = (const void*)tile_kernel_fx<OP, ASYM, BS, XMODE>;                                              \
+        if (!cx->ldsAttrSet.count(fn)) { HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); cx->ldsAttrSet.insert(fn); } \
+        tile_kernel_fx<OP, ASYM, BS, XMODE><<<nTiles, BS, lds, s>>>(t);                                                 \
+    }
+    if (m->asym) { if (bs == 1024) MI_LAUNCH_FX(true, 1024) else if (bs == 512) MI_LAUNCH_FX(true, 512) else MI_LAUNCH_FX(true, 256) }
+    else { if (bs == 1024) MI_LAUNCH_FX(false, 1024) else if (bs == 512) MI_LAUNCH_FX(false, 512) else MI_LAUNCH_FX(false, 256) }
+#undef MI_LAUNCH_FX
+    HIPCHK(hipGetLastError());
+    return MI_OK;
 }
 
 int ensure_rD(mi_matrix_s* m)

@@ -127,7 +127,20 @@ struct TileArgs {
     double omega;
     int32_t offLow, offX, offRD, offSB; // LDS offsets in doubles
     int32_t flags;               // bit0: non-temporal coefficient loads, bit1: non-temporal entry loads, bit2: nt result stores, bit3: nt diagonal loads (Amul)
+    // XMODE launches (tile_kernel_fx; GAMG, gamg_engine.inc): the operand x is FORMED while it is staged instead of read --
+    //   1: x[c] = fxCoarse[fxMap[c]]                                    (GAMGAgglomeration::prolongField, GAMGAgglomerationTemplates.C:273-308),
+    //      written to fxOut for the own cells when fxOut != nullptr
+    //   2: x[c] = sf*fxField[c] + (fxSrc[c] - sf*fxAcf[c])/diag[c],  sf = num / stabilise(den)   (GAMGSolver::scale, GAMGSolverScale.C:59-171),
+    //      {num, den} = fxScal[0..1]
+    //   3: x[c] = fxAdd[c] + the value of 2                               (psi += finestCorrection, GAMGSolverSolve.C:130-138)
+    // -- the prolongation kernel and the scaling pass of a level disappear into the tile pass that consumes their result, same arithmetic.
+    const int32_t* fxMap = nullptr; const double* fxCoarse = nullptr; double* fxOut = nullptr;
+    const double *fxField = nullptr, *fxAcf = nullptr, *fxSrc = nullptr, *fxScal = nullptr, *fxAdd = nullptr;
+    // Amul with both fused sums (dotPartial, dotPartial2): the LAST workgroup to finish adds the per-tile partials in the order
+    // k_fold_partials2 + sum_partials add them and stores {sum of dotPartial2, sum of dotPartial} = {num, den} to foldOut
+    unsigned int* foldCounter = nullptr; double* foldOut = nullptr;
 };
+constexpr double FX_VSMALL = 1e-300;   // SP_VSMALL (below)
 
 // cooperative global -> LDS staging, 4 loads in flight per lane
 template <bool NT, class T>
@@ -194,7 +207,9 @@ __device__ __forceinline__ void stage_dma8(const double* __restrict__ src, doubl
 }
 
 // one tile: position p of the launch (p indexes tileList / dotPartial)
-template <int OP, bool ASYM, bool TRANS, int BS, bool C16, bool PERM = false, int EXTWIN = 0>
+template <int BS>
+__device__ __forceinline__ void fold_two_partials(const double* pA, const double* pB, int n, double* lds, double* out);
+template <int OP, bool ASYM, bool TRANS, int BS, bool C16, bool PERM = false, int EXTWIN = 0, int XMODE = 0>
 __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double* __restrict__ smem)
 {
     double* cU = smem;
@@ -227,7 +242,34 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
         if (ASYM) stage_dma16<BS>(reinterpret_cast<const double2*>(a.low + s0), reinterpret_cast<double2*>(cL), ns >> 1, tid >> 6, tid & 63);
     }
     if (NEEDX) {
-        if (PERM) { // the permutation of the caller-order entry points, folded into the staging
+        if (XMODE != 0) { // GAMG: prolongation / correction scaling folded into the staging (see TileArgs)
+            double sf = 0.0;
+            if (XMODE >= 2) { const double num = a.fxScal[0], den = a.fxScal[1]; sf = num / (den >= 0 ? den + FX_VSMALL : den - FX_VSMALL); }
+            auto fx = [&](int c) -> double {
+                if (XMODE == 1) return a.fxCoarse[a.fxMap[c]];
+                const double v = fma(sf, a.fxField[c], fma(-sf, a.fxAcf[c], a.fxSrc[c]) / a.diag[c]);
+                return XMODE == 3 ? a.fxAdd[c] + v : v;
+            };
+            if (XMODE == 1) {
+                // own and halo cells in ONE index space, four per lane at a time: all cell indices, then all parents, then all coarse values --
+                // three rounds of independent loads instead of a dependent chain per cell (the staging is latency-bound: nothing else is in
+                // flight before the barrier)
+                for (int k0 = 0; k0 < nc + nh; k0 += 4 * BS) {
+                    int cc[4]; double vv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int k = k0 + j * BS + tid; cc[j] = k < nc ? c0 + k : (k < nc + nh ? a.haloCell[h0 + k - nc] : -1); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cc[j] = cc[j] >= 0 ? a.fxMap[cc[j]] : -1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vv[j] = cc[j] >= 0 ? a.fxCoarse[cc[j]] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int k = k0 + j * BS + tid; if (k < nc + nh) { xs[k] = vv[j]; if (a.fxOut && k < nc) a.fxOut[c0 + k] = vv[j]; } }
+                }
+            } else {
+            for (int k = tid; k < nc; k += BS) xs[k] = fx(c0 + k);
+            for (int k = tid; k < nh; k += BS) xs[nc + k] = fx(a.haloCell[h0 + k]);
+            }
+        } else if (PERM) { // the permutation of the caller-order entry points, folded into the staging
             stage_gather<BS>(a.x, a.perm + c0, xs, nc, tid);
             for (int k = tid; k < nh; k += BS) { const int src = a.haloSrc[h0 + k]; xs[nc + k] = src >= 0 ? a.x[src] : a.xExt[-1 - src]; }
         } else {
@@ -392,10 +434,28 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     if ((OP == OP_AMUL || OP == OP_AINV || OP == OP_RESIDUAL) && a.dotPartial) { // fused gSumProd(wA, pA), PCG.C:166 / gSumProd(wA, rA), PCG.C:142 / gSumMag(rA)
         __shared__ double red[BS / 64];
         const double tsum = block_sum<BS>(dot, red);
-        if (tid == 0) a.dotPartial[p] = tsum;
+        if (XMODE != 0 && a.foldOut) { if (tid == 0) __hip_atomic_store(a.dotPartial + p, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else if (tid == 0) a.dotPartial[p] = tsum;
         if (OP == OP_AMUL && a.dotPartial2) {
             const double t2 = block_sum<BS>(dot2, red);
-            if (tid == 0) a.dotPartial2[p] = t2;
+            if (XMODE != 0 && a.foldOut) { if (tid == 0) __hip_atomic_store(a.dotPartial2 + p, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else if (tid == 0) a.dotPartial2[p] = t2;
+        }
+        if (XMODE != 0 && OP == OP_AMUL && a.foldOut) {   // the last workgroup to arrive folds the partials of all tiles
+            __shared__ unsigned int lastOne;
+            // no agent-scope fence here: an agent-scope acquire / release invalidates / writes back the whole L2 of the XCD under the tiles
+            // that are still computing (first version: 3.7 x slower).  The partials were written with agent-scope (write-through) stores and
+            // are read with agent-scope loads; the arrival only has to be ORDERED behind this workgroup's two stores (persist.inc: grid_barrier)
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                lastOne = (__hip_atomic_fetch_add(a.foldCounter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.nPos - 1u) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (lastOne) {
+                fold_two_partials<BS>(a.dotPartial2, a.dotPartial, a.nPos, smem, a.foldOut);
+                if (tid == 0) __hip_atomic_store(a.foldCounter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -438,6 +498,55 @@ __global__ __launch_bounds__(BS) void tile_kernel_perm(const TileArgs a)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x, per = gridDim.x >> 3;
     tile_body<OP, ASYM, TRANS, BS, false, true>(a, (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b, smem);
+}
+
+// tile pass whose operand is formed while it is staged (XMODE, see TileArgs): GAMG's prolongation and correction scaling fused
+// into the Amul / Jacobi pass that consumes them.  Separate instantiations (the solver loops' kernels keep their registers).
+template <int OP, bool ASYM, int BS, int XMODE>
+__global__ __launch_bounds__(BS, (BS >= 512 && !ASYM) ? 8 : 1) void tile_kernel_fx(const TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, per = gridDim.x >> 3;
+    tile_body<OP, ASYM, false, BS, false, false, 0, XMODE>(a, (b < (per << 3)) ? (b & 7) * per + (b >> 3) : b, smem);
+}
+// {out[0], out[1]} = the sums of pA[0..n) and pB[0..n) in exactly the order the two-launch path adds them: k_fold_partials2 (only
+// when n > RG: slot t = sum of entries t, t + 1024, ...) and then sum_partials on RB threads (thread t: slots t, t + RB, ...;
+// wavefront butterflies; the wavefronts' results in order) -- emulated on a workgroup of BS threads; lds: 2 * (RG + RB/64) doubles.
+// Entries are read with agent-scope loads (other workgroups of the same launch wrote them with agent-scope stores).
+template <int BS>
+__device__ __forceinline__ void fold_two_partials(const double* pA, const double* pB, int n, double* lds, double* out)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* lA = lds; double* lB = lds + RG; double* rA = lds + 2 * RG; double* rB = rA + RB / 64;
+    __syncthreads();
+    for (int t = tid; t < RG; t += BS) {               // both arrays in one sweep: the loads of a slot are independent
+        double va = 0.0, vb = 0.0;
+        if (n > RG) {
+            for (int k = t; k < n; k += 1024) {
+                va += __hip_atomic_load(pA + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vb += __hip_atomic_load(pB + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (t < n) {                            // slots >= n were zeroed once and are never written
+            va = __hip_atomic_load(pA + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vb = __hip_atomic_load(pB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lA[t] = va; lB[t] = vb;
+    }
+    __syncthreads();
+    for (int vw = wave; vw < RB / 64; vw += BS / 64) {
+        double va = 0.0, vb = 0.0;
+#pragma unroll
+        for (int k = 0; k < RG / RB; ++k) { va += lA[vw * 64 + lane + k * RB]; vb += lB[vw * 64 + lane + k * RB]; }
+        va = wave_sum(va); vb = wave_sum(vb);
+        if (lane == 0) { rA[vw] = va; rB[vw] = vb; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double ta = rA[0], tb = rB[0];
+#pragma unroll
+        for (int w = 1; w < RB / 64; ++w) { ta += rA[w]; tb += rB[w]; }
+        out[0] = ta; out[1] = tb;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -956,6 +1065,7 @@ struct PcgState {
 };
 
 constexpr double SP_SMALL = 1e-20, SP_VSMALL = 1e-300, SP_GREAT = 1e20; // SolverPerformance.H:269-275
+static_assert(FX_VSMALL == SP_VSMALL, "tile_body's scaling factor uses GAMGSolver::scale's stabilise(den, VSMALL)");
 
 __device__ __forceinline__ bool sp_converged(const PcgState* st, double res)
 {

@@ -665,6 +665,41 @@ def test_cycle_graph_replay_equals_eager_cycles(pkg, orc, kw, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [("box_sym", dict()), ("box_sym", dict(nFinestSweeps=1)), ("box_sym", dict(nFinestSweeps=3, nPostSweeps=1)), ("box_asym", dict(scaleCorrection=1)),
+                                     ("box_asym", dict()), ("graph_sym", dict()), ("box_big", dict())])
+def test_fused_transfers_equal_the_separate_kernels_bit_for_bit(pkg, orc, name, kw, monkeypatch):
+    """Round 6: the prolongation of a level is formed in the staging of the tile pass that consumes it (the Amul of the correction
+    scaling, or the first smoothing sweep where a level is not scaled), the scaling pass in the staging of the first smoothing sweep,
+    psi += finestCorrection in the staging of the first finest sweep; the two sums of the scaling factor are folded by the last
+    workgroup of the Amul in the order k_fold_partials2 + sum_partials add them (MI_GAMG_FUSE, default on).  Same arithmetic, same
+    summation order: residual history AND solution are bit-identical to the cycle of separate kernels, for symmetric and asymmetric
+    matrices, ragged graphs, odd sweep counts, and a matrix with more tiles than reduction slots (box_big: 2 304 tiles > 1 024)."""
+    import torch
+    from conftest import random_graph_case
+    eng = pkg.engine
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    if name == "graph_sym":
+        case = random_graph_case(pkg, 6000, extra=2.0, seed=11); w = 0.5 + pkg.synthetic.splitmix_uniform(3, case.n_faces)
+    else:
+        dims = (160, 120, 120) if name == "box_big" else (40, 32, 24)
+        case = pkg.synthetic.box_case(*dims, symmetric=name != "box_asym"); w = orc.box_face_weights(case)
+    args = dict(tolerance=1e-9, maxIter=12); args.update(kw)
+    got = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MI_GAMG_FUSE", fuse)
+        ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+        addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr)
+        if name == "box_big":
+            assert addr.n_tiles > 1024
+        mat = eng.Matrix(addr); mat.set_coeffs(dev(case.diag), dev(case.upper), None if case.lower is None else dev(case.lower))
+        G = eng.Gamg(addr, w, 10)
+        psi = torch.zeros(case.n_cells, dtype=torch.float64, device="cuda:0")
+        perf = G.solve(mat, psi, dev(case.source), **args)
+        got[fuse] = (perf["history"], psi.cpu().numpy(), perf["nIterations"])
+    assert got["1"][2] == got["0"][2] and np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+
+
+@pytest.mark.gpu
 def test_cycle_graph_is_not_replayed_across_a_symmetric_to_asymmetric_rebind(pkg, orc):
     """the cached V-cycle graph captured tile kernels of the SYMMETRIC matrix; re-binding the same matrix
     handle with asymmetric coefficients (same hierarchy, same vectors, explicit scaleCorrection so that nothing else in the key
