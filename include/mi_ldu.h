@@ -158,11 +158,21 @@ int mi_addr_set_ami_patch(mi_addr_t addr, int32_t patch, int32_t nbr_patch, cons
  * received value is meant (finest level: the partner's face number; < n_partner_faces <= size of the transport patch).
  * The interpolation runs after the halo exchange of the operator (such a matrix exchanges first and runs all tiles in one
  * launch).  GAMG: as for a local cyclicAMI patch; the partner side's coarse faces follow from the coarse cells the transport
- * patch receives on every level, no further talk between the ranks.  An AMI side that is ITSELF split over several ranks
- * (address entries on different partner ranks) is not handled: one partner rank per cyclicAMI patch.                      */
+ * patch receives on every level, no further talk between the ranks.
+ * mi_addr_set_ami_patch_remote_multi (round 6): the partner SIDE is itself split over several ranks -- what decomposePar makes of
+ * any cyclicAMI patch larger than one rank's share; the reference: calcProcMap (AMIInterpolation.C:940-1091) builds a map that
+ * brings every target face a rank's source faces overlap, from whichever rank holds it, into one list numbered rank by rank
+ * (AMIInterpolationParallelOps.C).  Here: ONE transport patch per partner piece (as above, each between this rank and the rank
+ * that holds the piece), and address[k] numbers the pieces' faces CONCATENATED in the order of transport_patches: piece q =
+ * [n_partner_faces[0] + ... + n_partner_faces[q-1], + n_partner_faces[q]), its face j = face j of transport patch q.  A face's
+ * weighted sum may take terms from several pieces; they are added in address order, as on one rank.  GAMG: every piece's coarse
+ * faces are derived from what ITS transport patch receives, piece by piece (each rank agglomerates its own piece).          */
 int mi_addr_set_ami_patch_remote(mi_addr_t addr, int32_t patch, int32_t transport_patch, int32_t n_partner_faces,
                                  const int32_t *start_host, const int32_t *address_host, const double *weights_host,
                                  const uint8_t *low_weight_host_or_null);
+int mi_addr_set_ami_patch_remote_multi(mi_addr_t addr, int32_t patch, int32_t n_transports, const int32_t *transport_patches_host,
+                                       const int32_t *n_partner_faces_host, const int32_t *start_host, const int32_t *address_host,
+                                       const double *weights_host, const uint8_t *low_weight_host_or_null);
 /* face areas |Sf| of a cyclicAMI patch's faces (AMIInterpolation::srcMagSf / tgtMagSf), read by the GAMG agglomeration only */
 int mi_addr_set_ami_face_areas(mi_addr_t addr, int32_t patch, const double *mag_sf_host);
 /* ORDERED addressing -- the caller's numbering is kept: engine order == caller order, mi_addr_cell_perm is the identity and the

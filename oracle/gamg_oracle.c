@@ -34,6 +34,7 @@
 /* from ldu_oracle.c */
 orc_system *orc_sys_create(int nDomains);
 void orc_sys_set_iface_ami(orc_system *s, int d, int p, const label *start, const label *addr, const scalar *w, const unsigned char *low);
+void orc_sys_set_iface_ami_parts(orc_system *s, int d, int p, int nParts, const label *partDomain, const label *partPatch);
 void orc_sys_set_iface_transform(orc_system *s, int d, int p, scalar factor);
 int orc_sys_add_interface(orc_system *s, int d, label nbrDomain, label nbrPatch, label nFaces, const label *faceCells,
                           const scalar *bouCoeffs, const scalar *intCoeffs);
@@ -684,6 +685,23 @@ gamg_sys_hier *orc_gamg_build_sys_merged(const orc_system *S, const scalar *face
             for (int p = 0; p < m->nIfaces; p++) if (fAs[d][p]) {
                 const int nd = m->ifaces[p].nbrDomain, np = m->ifaces[p].nbrPatch;
                 gamg_patch *P = &H->patch[d][l][p];
+                const orc_iface *me = &m->ifaces[p];
+                if (me->nAmiParts > 0) {
+                    /* partner side split over several domains: addresses number the pieces' faces concatenated, on the fine level
+                     * and -- piece by piece, every piece with the coarse faces ITS domain built -- on the coarse level */
+                    label nFineTgt = 0, nCoarseTgt = 0;
+                    for (int q = 0; q < me->nAmiParts; q++) nFineTgt += pn[me->amiPartDomain[q]][me->amiPartPatch[q]];
+                    label *tgtR = (label *)malloc(sizeof(label) * (size_t)(nFineTgt ? nFineTgt : 1));
+                    label at = 0;
+                    for (int q = 0; q < me->nAmiParts; q++) {
+                        const int dq = me->amiPartDomain[q], pq = me->amiPartPatch[q];
+                        const gamg_patch *T = &H->patch[dq][l][pq];
+                        for (label j = 0; j < pn[dq][pq]; j++) tgtR[at++] = nCoarseTgt + T->faceRestrict[j];
+                        nCoarseTgt += T->nCoarse;
+                    }
+                    ami_agglomerate(pn[d][p], fAs[d][p], fAa[d][p], fAw[d][p], fAm[d][p], P->faceRestrict, tgtR, P->nCoarse, P);
+                    free(tgtR);
+                } else
                 ami_agglomerate(pn[d][p], fAs[d][p], fAa[d][p], fAw[d][p], fAm[d][p], P->faceRestrict, H->patch[nd][l][np].faceRestrict, P->nCoarse, P);
             }
         }
@@ -807,6 +825,11 @@ static orc_system *coarse_system(const gamg_sys_hier *H, int l, const orc_system
             orc_sys_set_iface_transform(C, d, p, fm->ifaces[p].factor);                               /* doTransform_/rank_ are the fine interface's (cyclicAMIGAMGInterfaceField.C:63-68) */
             free(cb); free(ci);
         }
+    }
+    for (int d = 0; d < D; d++) {      /* split partner sides: the same pieces, with the coarse interfaces' face counts */
+        const orc_domain *fm = &F->dom[d];
+        for (int p = 0; p < fm->nIfaces; p++)
+            if (fm->ifaces[p].nAmiParts > 0) orc_sys_set_iface_ami_parts(C, d, p, fm->ifaces[p].nAmiParts, fm->ifaces[p].amiPartDomain, fm->ifaces[p].amiPartPatch);
     }
     return C;
 }

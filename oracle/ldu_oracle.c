@@ -143,6 +143,7 @@ int orc_sys_add_interface(orc_system *s, int d, label nbrDomain, label nbrPatch,
     p->bouCoeffs = (scalar *)dupmem(bouCoeffs, sizeof(scalar) * (size_t)nFaces);
     p->intCoeffs = (scalar *)dupmem(intCoeffs, sizeof(scalar) * (size_t)nFaces);
     p->amiStart = p->amiAddr = NULL; p->amiW = NULL; p->amiLow = NULL; p->amiMagSf = NULL; p->factor = 1.0;
+    p->nAmiParts = 0; p->amiPartDomain = p->amiPartPatch = p->amiPartStart = NULL;
     return m->nIfaces++;
 }
 
@@ -155,6 +156,20 @@ void orc_sys_set_iface_ami(orc_system *s, int d, int p, const label *start, cons
     q->amiAddr = (label *)dupmem(addr, sizeof(label) * (size_t)(na ? na : 1));
     q->amiW = (scalar *)dupmem(w, sizeof(scalar) * (size_t)(na ? na : 1));
     q->amiLow = low ? (unsigned char *)dupmem(low, (size_t)(n ? n : 1)) : NULL;
+}
+/* the partner side of cyclicAMI interface p is split over nParts interfaces (every domain's interfaces must have been added): its
+ * addresses number their faces concatenated in this order */
+void orc_sys_set_iface_ami_parts(orc_system *s, int d, int p, int nParts, const label *partDomain, const label *partPatch)
+{
+    orc_iface *q = &s->dom[d].ifaces[p];
+    int k;
+    free(q->amiPartDomain); free(q->amiPartPatch); free(q->amiPartStart);
+    q->nAmiParts = nParts;
+    q->amiPartDomain = (label *)dupmem(partDomain, sizeof(label) * (size_t)nParts);
+    q->amiPartPatch = (label *)dupmem(partPatch, sizeof(label) * (size_t)nParts);
+    q->amiPartStart = (label *)malloc(sizeof(label) * (size_t)(nParts + 1));
+    q->amiPartStart[0] = 0;
+    for (k = 0; k < nParts; k++) q->amiPartStart[k + 1] = q->amiPartStart[k] + s->dom[partDomain[k]].ifaces[partPatch[k]].nFaces;
 }
 void orc_sys_set_iface_magsf(orc_system *s, int d, int p, const scalar *magSf)
 {
@@ -179,6 +194,7 @@ void orc_sys_destroy(orc_system *s)
         for (i = 0; i < m->nIfaces; i++) {
             free(m->ifaces[i].faceCells); free(m->ifaces[i].bouCoeffs); free(m->ifaces[i].intCoeffs);
             free(m->ifaces[i].amiStart); free(m->ifaces[i].amiAddr); free(m->ifaces[i].amiW); free(m->ifaces[i].amiLow); free(m->ifaces[i].amiMagSf);
+            free(m->ifaces[i].amiPartDomain); free(m->ifaces[i].amiPartPatch); free(m->ifaces[i].amiPartStart);
         }
         free(m->ifaces);
     }
@@ -220,7 +236,9 @@ static void update_interfaces(const orc_system *s, int d, int useIntCoeffs,
                 else {
                     label k; pn = 0.0;
                     for (k = me->amiStart[i]; k < me->amiStart[i + 1]; k++) {
-                        const scalar t = me->factor * psiN[ot->faceCells[me->amiAddr[k]]];
+                        int dq; label fq;
+                        const orc_iface *pq = orc_ami_partner(s, me, me->amiAddr[k], &dq, &fq);   /* the one partner, or the split side's piece */
+                        const scalar t = me->factor * psiAll[s->dom[dq].offset + pq->faceCells[fq]];
                         pn = fma(me->amiW[k], t, pn);
                     }
                 }

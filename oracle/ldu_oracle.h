@@ -19,6 +19,11 @@ typedef struct {
     scalar *amiW;
     unsigned char *amiLow;
     scalar *amiMagSf;  /* [nFaces] face areas of this side (srcMagSf / tgtMagSf): only the GAMG agglomeration of the AMI reads them */
+    /* cyclicAMI whose partner SIDE is split over several domains (the reference's distributed AMI, singlePatchProc_ == -1,
+     * AMIInterpolation.C:940-1091: the faces a rank needs arrive from all ranks and are numbered [from rank 0][from rank 1]...):
+     * nAmiParts > 0: amiAddr numbers the concatenation of the faces of interfaces (amiPartDomain[q], amiPartPatch[q]), q ascending;
+     * partner q covers [amiPartStart[q], amiPartStart[q+1]).  nAmiParts == 0: the one partner (nbrDomain, nbrPatch).            */
+    int nAmiParts; label *amiPartDomain, *amiPartPatch, *amiPartStart;
     scalar factor;     /* transformCoupleField: pow(diag(forwardT).component(cmpt), rank); 1 = no transformation */
 } orc_iface;
 
@@ -39,5 +44,15 @@ typedef struct {
     int64_t nTotal;
     int accurate_sums; /* 1: long double reductions (parity), 0: plain double (timing) */
 } orc_system;
+
+/* (domain, interface, face) behind address j of a cyclicAMI interface */
+static inline const orc_iface *orc_ami_partner(const orc_system *s, const orc_iface *me, label j, int *domOut, label *faceOut)
+{
+    if (me->nAmiParts == 0) { *domOut = me->nbrDomain; *faceOut = j; return &s->dom[me->nbrDomain].ifaces[me->nbrPatch]; }
+    int q = 0;
+    while (q + 1 < me->nAmiParts && j >= me->amiPartStart[q + 1]) q++;
+    *domOut = me->amiPartDomain[q]; *faceOut = j - me->amiPartStart[q];
+    return &s->dom[me->amiPartDomain[q]].ifaces[me->amiPartPatch[q]];
+}
 
 #endif

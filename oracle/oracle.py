@@ -92,6 +92,9 @@ class System:
                     low = None if itf.ami_low is None else np.ascontiguousarray(itf.ami_low, dtype=np.uint8)
                     L.orc_sys_set_iface_ami(self.h, d, p, _p(_i(itf.ami_start), C.c_int32), _p(_i(itf.ami_addr), C.c_int32),
                                             _p(_d(itf.ami_w), C.c_double), _p(low, C.c_uint8))
+                if getattr(itf, "ami_parts", None):      # partner side split over several domains: [(domain, interface), ...], addresses concatenated
+                    pd, pp = _i([q[0] for q in itf.ami_parts]), _i([q[1] for q in itf.ami_parts])
+                    L.orc_sys_set_iface_ami_parts(self.h, d, p, C.c_int(len(itf.ami_parts)), _p(pd, C.c_int32), _p(pp, C.c_int32))
                 if getattr(itf, "ami_magsf", None) is not None:
                     L.orc_sys_set_iface_magsf(self.h, d, p, _p(_d(itf.ami_magsf), C.c_double))
                 if getattr(itf, "transform", 1.0) != 1.0:

@@ -136,6 +136,7 @@ struct mi_addr_s {
     // interpolated locally from the partner patch's cells before every operator that reads them
     struct AmiPatch {
         int32_t patch = 0, nbrPatch = 0, n = 0, extOff = 0;
+        std::vector<int32_t> transports, partCount;   // partner SIDE split over several ranks: one transport patch per piece, faces per piece (transport == transports[0], nPartner == their sum)
         int32_t transport = -1, nPartner = 0;   // cyclicAMI whose partner patch lives on ANOTHER rank: the processor patch that carries the partner's internal field; partner patch size
         DevBuf<int32_t> start, cellE, ownE; DevBuf<double> w; bool hasLow = false;
         std::vector<int32_t> hStart, hAddr; std::vector<double> hW, hMagSf; // host copies: the GAMG builder agglomerates them
@@ -629,31 +630,42 @@ extern "C" int mi_addr_set_ami_patch(mi_addr_t a, int32_t patch, int32_t nbr_pat
 // interpolation then reads the transport patch's ext region: address[k] = index of the transport-patch face whose received
 // value is the k-th contribution (finest level: the partner's face number).  Everything else -- weights, low-weight faces,
 // transformCoupleField factor, agglomeration per GAMG level -- as mi_addr_set_ami_patch.
-extern "C" int mi_addr_set_ami_patch_remote(mi_addr_t a, int32_t patch, int32_t transport_patch, int32_t n_partner_faces, const int32_t* start,
-                                            const int32_t* address, const double* weights, const uint8_t* low_weight)
+// the general form: the partner SIDE is split over several ranks (AMIInterpolation.C:940-1091 calcProcMap: what a rank needs arrives from
+// all ranks and is numbered rank by rank) -- one transport patch per partner piece; address k names a received value as (slot of the
+// transport in `transports`, face of that transport patch).  hAddrConcat: the same addresses in the concatenated numbering of the
+// pieces (kept for the GAMG builder).
+int ami_remote_impl(mi_addr_s* a, int32_t patch, const std::vector<int32_t>& transports, const std::vector<int32_t>& partCount, const int32_t* start,
+                    const int32_t* addrSlot, const int32_t* addrFace, const int32_t* hAddrConcat, const double* weights, const uint8_t* low_weight)
 {
-    if (!a || patch < 0 || patch >= a->L.nPatches || transport_patch < 0 || transport_patch >= a->L.nPatches || patch == transport_patch || !start || !address || !weights)
-        return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: bad argument");
-    if (a->patchIsLocal[(size_t)patch] || a->patchIsLocal[(size_t)transport_patch])
-        return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: both patches must be created without neighbour cells (ext regions); the transport patch stays a processor patch");
+    const char* me = "mi_addr_set_ami_patch_remote";
+    if (!a || patch < 0 || patch >= a->L.nPatches || transports.empty() || transports.size() != partCount.size() || !start || !weights) return fail(MI_ERR_ARG, std::string(me) + ": bad argument");
+    if (a->patchIsLocal[(size_t)patch]) return fail(MI_ERR_ARG, std::string(me) + ": the cyclicAMI patch must be created without neighbour cells (an ext region)");
+    int32_t total = 0;
+    for (size_t q = 0; q < transports.size(); ++q) {
+        const int32_t t = transports[q];
+        if (t < 0 || t >= a->L.nPatches || t == patch || a->patchIsLocal[(size_t)t]) return fail(MI_ERR_ARG, std::string(me) + ": a transport patch must be a processor patch of this addressing (created without neighbour cells)");
+        for (size_t r = 0; r < q; ++r) if (transports[r] == t) return fail(MI_ERR_ARG, std::string(me) + ": a transport patch is listed twice");
+        const int32_t nT = a->L.patchOffset[(size_t)t + 1] - a->L.patchOffset[(size_t)t];
+        if (partCount[q] < 0 || partCount[q] > nT) return fail(MI_ERR_ARG, std::string(me) + ": a transport patch is smaller than the partner piece it carries");
+        total += partCount[q];
+    }
     HIPCHK(hipSetDevice(a->ctx->device));
     const std::vector<int32_t>& mine = a->patchFaceCellsHost[(size_t)patch];
     const int32_t n = (int32_t)mine.size();
-    const int32_t nT = a->L.patchOffset[(size_t)transport_patch + 1] - a->L.patchOffset[(size_t)transport_patch];
-    if (n_partner_faces < 0 || n_partner_faces > nT) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: the transport patch is smaller than the partner patch");
-    if (start[0] != 0) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: start[0] must be 0");
-    for (int32_t i = 0; i < n; ++i) if (start[i + 1] < start[i]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: start must be non-decreasing");
+    if (start[0] != 0) return fail(MI_ERR_ARG, std::string(me) + ": start[0] must be 0");
+    for (int32_t i = 0; i < n; ++i) if (start[i + 1] < start[i]) return fail(MI_ERR_ARG, std::string(me) + ": start must be non-decreasing");
     const int32_t na = start[n];
     std::vector<int32_t> st(start, start + n + 1), ce((size_t)na), own;
-    const int32_t src0 = a->L.nCells + a->L.patchOffset[(size_t)transport_patch];   // engine vectors: ext region behind the owned cells
     for (int32_t k = 0; k < na; ++k) {
-        if (address[k] < 0 || address[k] >= nT) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote: address outside the transport patch");
-        ce[(size_t)k] = src0 + address[k];
+        const int32_t q = addrSlot[k];
+        if (q < 0 || q >= (int32_t)transports.size() || addrFace[k] < 0 || addrFace[k] >= a->L.patchOffset[(size_t)transports[(size_t)q] + 1] - a->L.patchOffset[(size_t)transports[(size_t)q]])
+            return fail(MI_ERR_ARG, std::string(me) + ": address outside its transport patch");
+        ce[(size_t)k] = a->L.nCells + a->L.patchOffset[(size_t)transports[(size_t)q]] + addrFace[k];   // engine vectors: ext region behind the owned cells
     }
     mi_addr_s::AmiPatch* q = new mi_addr_s::AmiPatch();
-    q->patch = patch; q->nbrPatch = transport_patch; q->n = n; q->extOff = a->L.patchOffset[(size_t)patch];
-    q->transport = transport_patch; q->nPartner = n_partner_faces;
-    q->hStart = st; q->hW.assign(weights, weights + na); q->hAddr.assign(address, address + na);
+    q->patch = patch; q->nbrPatch = transports[0]; q->n = n; q->extOff = a->L.patchOffset[(size_t)patch];
+    q->transport = transports[0]; q->nPartner = total; q->transports = transports; q->partCount = partCount;
+    q->hStart = st; q->hW.assign(weights, weights + na); q->hAddr.assign(hAddrConcat, hAddrConcat + na);
     if (low_weight) {
         own.assign((size_t)n, -1);
         for (int32_t i = 0; i < n; ++i) if (low_weight[i]) { own[i] = a->L.c2e[(size_t)mine[i]]; q->hasLow = true; }
@@ -666,10 +678,36 @@ extern "C" int mi_addr_set_ami_patch_remote(mi_addr_t a, int32_t patch, int32_t 
     if (r != MI_OK) { delete q; return r; }
     HIPCHK(hipStreamSynchronize(s));
     a->ami.push_back(q);
-    a->patchIsLocal[(size_t)patch] = 2;   // no exchange for the AMI patch itself: its values are interpolated from the transport patch's
+    a->patchIsLocal[(size_t)patch] = 2;   // no exchange for the AMI patch itself: its values are interpolated from the transport patches'
     a->nLocalPatches++;
     a->amiRemote = true;
     return MI_OK;
+}
+// addresses in the concatenated numbering of the partner pieces: piece q = faces [sum of n_partner_faces[0..q), + n_partner_faces[q]),
+// its face j travelling as face j of transport patch q
+extern "C" int mi_addr_set_ami_patch_remote_multi(mi_addr_t a, int32_t patch, int32_t n_transports, const int32_t* transport_patches, const int32_t* n_partner_faces,
+                                                  const int32_t* start, const int32_t* address, const double* weights, const uint8_t* low_weight)
+{
+    if (!a || patch < 0 || patch >= a->L.nPatches || n_transports < 1 || !transport_patches || !n_partner_faces || !start || !address || !weights)
+        return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote_multi: bad argument");
+    const int32_t n = (int32_t)a->patchFaceCellsHost[(size_t)patch].size();
+    std::vector<int32_t> tr(transport_patches, transport_patches + n_transports), cnt(n_partner_faces, n_partner_faces + n_transports), off((size_t)n_transports + 1, 0);
+    for (int32_t q = 0; q < n_transports; ++q) { if (cnt[(size_t)q] < 0) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote_multi: negative partner face count"); off[(size_t)q + 1] = off[(size_t)q] + cnt[(size_t)q]; }
+    for (int32_t i = 0; i < n; ++i) if (start[i + 1] < start[i]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote_multi: start must be non-decreasing");
+    const int32_t na = n > 0 || start ? start[n] : 0;
+    std::vector<int32_t> slot((size_t)na), face((size_t)na);
+    for (int32_t k = 0; k < na; ++k) {
+        if (address[k] < 0 || address[k] >= off[(size_t)n_transports]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote_multi: address outside the partner pieces");
+        int32_t q = 0;
+        while (address[k] >= off[(size_t)q + 1]) ++q;
+        slot[(size_t)k] = q; face[(size_t)k] = address[k] - off[(size_t)q];
+    }
+    return ami_remote_impl(a, patch, tr, cnt, start, slot.data(), face.data(), address, weights, low_weight);
+}
+extern "C" int mi_addr_set_ami_patch_remote(mi_addr_t a, int32_t patch, int32_t transport_patch, int32_t n_partner_faces, const int32_t* start,
+                                            const int32_t* address, const double* weights, const uint8_t* low_weight)
+{
+    return mi_addr_set_ami_patch_remote_multi(a, patch, 1, &transport_patch, &n_partner_faces, start, address, weights, low_weight);
 }
 
 extern "C" int mi_addr_set_ami_face_areas(mi_addr_t a, int32_t patch, const double* mag_sf)

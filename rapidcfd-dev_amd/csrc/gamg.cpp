@@ -315,14 +315,21 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
         const GamgCoupling::Ami& A = pami[(size_t)p];
         if (A.nbrPatch < 0 || A.nbrPatch >= nPatches || A.start.size() != pfc[p].size() + 1 || A.magSf.size() != pfc[p].size())
             return "cyclicAMI patch without complete AMI tables / face areas (mi_addr_set_ami_face_areas)";
-        if (A.transport >= 0 && (A.transport >= nPatches || cpl->isLocal[(size_t)A.transport] != 0 || A.nPartner > (int32_t)pfc[(size_t)A.transport].size()))
-            return "cyclicAMI patch with a partner on another rank: its transport patch must be a processor patch at least as large as the partner patch";
+        if (A.transport >= 0) {
+            if (A.transports.empty()) { pami[(size_t)p].transports.assign(1, A.transport); pami[(size_t)p].partCount.assign(1, A.nPartner); }
+            const GamgCoupling::Ami& B = pami[(size_t)p];
+            for (size_t q = 0; q < B.transports.size(); ++q)
+                if (B.transports[q] < 0 || B.transports[q] >= nPatches || cpl->isLocal[(size_t)B.transports[q]] != 0 || B.partCount[q] > (int32_t)pfc[(size_t)B.transports[q]].size())
+                    return "cyclicAMI patch with a partner on another rank: its transport patches must be processor patches at least as large as the partner pieces";
+        }
     }
     // partner on another rank: transport-patch face that carries the value behind partner face J, on the current fine level
-    std::vector<std::vector<int32_t>> amiSrc((size_t)nPatches);
+    // (a partner side split over several ranks: partner faces numbered piece by piece, amiSlot = the piece = which transport patch)
+    std::vector<std::vector<int32_t>> amiSrc((size_t)nPatches), amiSlot((size_t)nPatches);
     for (int32_t p = 0; p < nPatches; ++p) if (cpl && cpl->isLocal[p] == 2 && pami[(size_t)p].transport >= 0) {
-        amiSrc[(size_t)p].resize((size_t)pami[(size_t)p].nPartner);
-        for (int32_t j = 0; j < pami[(size_t)p].nPartner; ++j) amiSrc[(size_t)p][(size_t)j] = j;
+        const GamgCoupling::Ami& A = pami[(size_t)p];
+        for (size_t q = 0; q < A.transports.size(); ++q)
+            for (int32_t j = 0; j < A.partCount[q]; ++j) { amiSrc[(size_t)p].push_back(j); amiSlot[(size_t)p].push_back((int32_t)q); }
     }
     int nPairLevels = 0;
     while ((int)H.levels.size() < maxLevels - 1) {
@@ -415,24 +422,29 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                 const GamgCoupling::Ami& F = pami[(size_t)p];
                 GamgPatchHost& P = L.patches[p];
                 const std::vector<int32_t>& srcR = P.faceRestrict;
-                std::vector<int32_t> remoteR, nextSrc;
+                std::vector<int32_t> remoteR, nextSrc, nextSlot, nextCount;
                 if (F.transport >= 0) {
                     // The partner's face restrict map, derived here: its coarse faces are its distinct coarse cells in order of
                     // first appearance over its faces (cyclicAMIGAMGInterface.C:47-165 -- what the partner rank builds for its
                     // own side), and the coarse cell behind partner face J is what the transport patch received for its face
                     // amiSrc[J] (theirs[transport]).  nextSrc: the coarse transport face that carries each new partner face.
-                    const std::vector<int32_t>& th = theirs[(size_t)F.transport];
-                    const std::vector<int32_t>& trR = L.patches[(size_t)F.transport].faceRestrict;
+                    // A partner side split over several ranks: every piece is agglomerated by ITS rank, so the first-appearance rule runs
+                    // piece by piece (the pieces' faces are numbered one after the other, on every level).
                     const std::vector<int32_t>& src = amiSrc[(size_t)p];
-                    std::unordered_map<int32_t, int32_t> cellToFace;
+                    const std::vector<int32_t>& slot = amiSlot[(size_t)p];
+                    std::unordered_map<uint64_t, int32_t> cellToFace;
                     remoteR.resize(src.size());
+                    nextCount.assign(F.transports.size(), 0);
                     for (size_t J = 0; J < src.size(); ++J) {
-                        const int32_t cc = th[(size_t)src[J]];
-                        auto it = cellToFace.find(cc);
+                        const int32_t q = slot[J], T = F.transports[(size_t)q];
+                        const int32_t cc = theirs[(size_t)T][(size_t)src[J]];
+                        const uint64_t key = ((uint64_t)(uint32_t)q << 32) | (uint32_t)cc;
+                        auto it = cellToFace.find(key);
                         if (it == cellToFace.end()) {
                             const int32_t k = (int32_t)nextSrc.size();
-                            cellToFace.emplace(cc, k);
-                            nextSrc.push_back(trR[(size_t)src[J]]);
+                            cellToFace.emplace(key, k);
+                            nextSrc.push_back(L.patches[(size_t)T].faceRestrict[(size_t)src[J]]);
+                            nextSlot.push_back(q); ++nextCount[(size_t)q];
                             remoteR[J] = k;
                         } else remoteR[J] = it->second;
                     }
@@ -465,8 +477,8 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                 }
                 GamgCoupling::Ami& N = next[(size_t)p];
                 N.nbrPatch = F.nbrPatch; N.start = P.amiStart; N.addr = P.amiAddr; N.w = P.amiW; N.magSf = P.amiMagSf;
-                N.transport = F.transport; N.nPartner = (int32_t)nextSrc.size();
-                if (F.transport >= 0) { P.amiSrcFace = nextSrc; amiSrc[(size_t)p].swap(nextSrc); }
+                N.transport = F.transport; N.nPartner = (int32_t)nextSrc.size(); N.transports = F.transports; N.partCount = nextCount;
+                if (F.transport >= 0) { P.amiSrcFace = nextSrc; P.amiSrcSlot = nextSlot; P.amiPartCount = nextCount; amiSrc[(size_t)p].swap(nextSrc); amiSlot[(size_t)p].swap(nextSlot); }
             }
             for (int32_t p = 0; p < nPatches; ++p) if (cpl->isLocal[p] == 2) pami[(size_t)p] = std::move(next[(size_t)p]);
         }

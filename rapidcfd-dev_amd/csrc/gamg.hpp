@@ -32,6 +32,9 @@ struct GamgPatchHost {
     // partner coarse cells in order of first appearance); amiSrcFace[J] = face of this level's TRANSPORT patch whose received
     // value is the coarse cell behind partner face J (what mi_addr_set_ami_patch_remote takes as address)
     std::vector<int32_t> amiSrcFace;
+    // partner SIDE split over several ranks: amiSrcSlot[J] = which of the patch's transport patches carries it (all 0 for one partner),
+    // amiPartCount[q] = partner coarse faces that arrive through transport q (partner faces are numbered piece by piece)
+    std::vector<int32_t> amiSrcSlot, amiPartCount;
 };
 
 // (the per-face tables are written completely by threaded passes: a resize() that zeroes 100+ MB on one thread first is time)
@@ -61,7 +64,9 @@ struct GamgCoupling {
     std::vector<char> isLocal;                     // per patch: 0 processor, 1 cyclic (nbrCells), 2 cyclicAMI (ami tables)
     // transport >= 0: the partner patch lives on another rank; `transport` is the processor patch of THIS domain that carries the
     // partner's patch-internal field (same size on both ranks), nPartner the partner patch's face count, addr numbers its faces
-    struct Ami { int32_t nbrPatch = -1; std::vector<int32_t> start, addr; std::vector<double> w, magSf; int32_t transport = -1, nPartner = 0; };
+    // transports / partCount: the partner SIDE is split over several ranks -- one transport patch per piece, addr numbers the pieces' faces
+    // concatenated (transport == transports[0], nPartner == the sum of partCount)
+    struct Ami { int32_t nbrPatch = -1; std::vector<int32_t> start, addr; std::vector<double> w, magSf; int32_t transport = -1, nPartner = 0; std::vector<int32_t> transports, partCount; };
     std::vector<Ami> ami;                          // per patch (nbrPatch < 0: not an AMI patch); finest level
     bool (*allAnd)(void* user, bool v) = nullptr;
     // in: send[p] = local coarse ids of patch p's cells (processor patches only); out: recv[p] same length

@@ -338,6 +338,18 @@ class Addressing:
                                                 w.ctypes.data_as(C.POINTER(C.c_double)),
                                                 lw.ctypes.data_as(C.POINTER(C.c_uint8)) if lw is not None else C.POINTER(C.c_uint8)()))
 
+    def set_ami_patch_remote_multi(self, patch: int, transport_patches, n_partner_faces, start, address, weights, low_weight=None):
+        """cyclicAMI patch whose partner SIDE is split over several ranks: one transport patch per partner piece, addresses numbering the
+        pieces' faces concatenated (mi_addr_set_ami_patch_remote_multi)"""
+        tp = np.ascontiguousarray(transport_patches, dtype=np.int32); nf = np.ascontiguousarray(n_partner_faces, dtype=np.int32)
+        st = np.ascontiguousarray(start, dtype=np.int32); ad = np.ascontiguousarray(address, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        lw = None if low_weight is None else np.ascontiguousarray(low_weight, dtype=np.uint8)
+        I32 = C.POINTER(C.c_int32)
+        _chk(lib().mi_addr_set_ami_patch_remote_multi(self.h, C.c_int32(patch), C.c_int32(tp.shape[0]), tp.ctypes.data_as(I32), nf.ctypes.data_as(I32),
+                                                      st.ctypes.data_as(I32), ad.ctypes.data_as(I32), w.ctypes.data_as(C.POINTER(C.c_double)),
+                                                      lw.ctypes.data_as(C.POINTER(C.c_uint8)) if lw is not None else C.POINTER(C.c_uint8)()))
+
     def set_ami_face_areas(self, patch: int, mag_sf):
         """face areas of a cyclicAMI patch (srcMagSf / tgtMagSf): the GAMG hierarchy agglomerates the AMI with them"""
         a = np.ascontiguousarray(mag_sf, dtype=np.float64)

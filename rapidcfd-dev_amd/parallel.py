@@ -365,18 +365,28 @@ class DistributedMatrix:
         patches = [np.asarray(i.face_cells, dtype=np.int32) for i in sub.interfaces]
         self.patch_rank = [i.nbr_domain for i in sub.interfaces]
         self.patch_nbr_patch = [i.nbr_patch for i in sub.interfaces]
-        transport = {}
+        transport, transports = {}, {}
         for k, itf in enumerate(sub.interfaces):
             if getattr(itf, "ami_transport_nbr_patch", None) is not None:
                 transport[k] = len(patches)
                 patches.append(np.resize(np.asarray(itf.face_cells, dtype=np.int32), max(len(itf.face_cells), int(itf.ami_partner_size))))
                 self.patch_rank.append(itf.nbr_domain); self.patch_nbr_patch.append(int(itf.ami_transport_nbr_patch))
+            elif getattr(itf, "ami_parts", None):
+                # the partner SIDE is split over several ranks: one transport patch per partner piece (mi_addr_set_ami_patch_remote_multi),
+                # each of the larger of the two pieces' sizes (both ranks create it with the same size)
+                transports[k] = []
+                for (q, _), nq, tq in zip(itf.ami_parts, itf.ami_part_sizes, itf.ami_transport_nbr_patches):
+                    transports[k].append(len(patches))
+                    patches.append(np.resize(np.asarray(itf.face_cells, dtype=np.int32), max(len(itf.face_cells), int(nq))))
+                    self.patch_rank.append(int(q)); self.patch_nbr_patch.append(int(tq))
         self.addr = eng.Addressing(ctx, sub.n_cells, sub.lower_addr, sub.upper_addr, patches)
         for k, itf in enumerate(sub.interfaces):
             if getattr(itf, "ami_start", None) is None:
                 continue
             if k in transport:
                 self.addr.set_ami_patch_remote(k, transport[k], int(itf.ami_partner_size), itf.ami_start, itf.ami_addr, itf.ami_w, itf.ami_low)
+            elif k in transports:
+                self.addr.set_ami_patch_remote_multi(k, transports[k], itf.ami_part_sizes, itf.ami_start, itf.ami_addr, itf.ami_w, itf.ami_low)
             else:
                 self.addr.set_ami_patch(k, itf.nbr_patch, itf.ami_start, itf.ami_addr, itf.ami_w, itf.ami_low)
             if itf.ami_magsf is not None:
@@ -388,7 +398,7 @@ class DistributedMatrix:
             self.mat.set_interface_coeffs(p, t(itf.bou_coeffs), None if sub.lower is None else t(itf.int_coeffs))
             if getattr(itf, "transform", 1.0) != 1.0:       # processorCyclic / cyclicAMI: transformCoupleField factor
                 self.mat.set_patch_transform(p, itf.transform)
-        for k, p in transport.items():
+        for p in list(transport.values()) + [p for ps in transports.values() for p in ps]:
             z = t(np.zeros(len(patches[p])))
             self.mat.set_interface_coeffs(p, z, None if sub.lower is None else z)
         if n_global is None:

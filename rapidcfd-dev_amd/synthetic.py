@@ -69,6 +69,13 @@ class Interface:
     # engine's transport patch, the index that patch has in the partner rank's engine patch list
     ami_partner_size: Optional[int] = None
     ami_transport_nbr_patch: Optional[int] = None
+    # cyclicAMI whose partner SIDE is split over several domains (decompose_cyclic_ami_split; the reference's distributed AMI,
+    # AMIInterpolation.C:940-1091): ami_addr numbers the faces of the interfaces ami_parts[q] = (domain, interface) concatenated
+    # in this order, piece q holding ami_part_sizes[q] faces; the engine gets one transport patch per piece, whose index in the
+    # PARTNER rank's engine patch list is ami_transport_nbr_patches[q]
+    ami_parts: Optional[list] = None
+    ami_part_sizes: Optional[list] = None
+    ami_transport_nbr_patches: Optional[list] = None
 
 
 @dataclass
@@ -412,6 +419,74 @@ def decompose_cyclic_ami_y(base: LduCase, py: int, **ami_kw) -> List[LduCase]:
     ia.ami_transport_nbr_patch = nb + 1
     ib.ami_transport_nbr_patch = na + 1
     first.interfaces.append(ia); last.interfaces.append(ib)
+    return subs
+
+
+def decompose_cyclic_ami_split(base: LduCase, px: int, **ami_kw) -> List[LduCase]:
+    """The box with the non-conformal y-min / y-max interface of add_cyclic_ami_y, cut into px x 2 blocks in x and y: BOTH sides of
+    the cyclicAMI pair are split over px ranks each (ranks 0 .. px-1 hold the pieces of the y-min side, px .. 2 px - 1 those of the
+    y-max side), and -- the y-max side being shifted and periodic in x -- every piece overlaps faces of SEVERAL partner pieces:
+    the reference's distributed AMI in full (singlePatchProc_ == -1, AMIInterpolation.C:940-1091 calcProcMap: a rank's source
+    faces interpolate from target faces that arrive from all ranks, numbered rank by rank).  Every sub-domain: processor interfaces
+    first (as decompose_box orders them), its piece of the AMI patch last, with
+        ami_parts       the partner pieces it addresses, as (domain, interface index), ascending in domain,
+        ami_addr        numbering those pieces' faces concatenated in that order (a piece's faces keep the global face order),
+        ami_part_sizes  their face counts.
+    The multi-domain oracle takes the list as it is; the engine adds one transport patch per partner piece
+    (parallel.DistributedMatrix, mi_addr_set_ami_patch_remote_multi).  Partner lists are symmetric: piece P lists piece Q when P
+    addresses Q or Q addresses P (a transport patch carries both directions)."""
+    import copy
+    full = add_cyclic_ami_y(base, **ami_kw)
+    bare = copy.copy(full); bare.interfaces = []
+    subs = decompose_box(bare, (px, 2, 1))
+    sides = full.interfaces                                   # [y-min side, y-max side]
+    n_dom = len(subs)
+    owner = np.empty(base.n_cells, dtype=np.int64); local = np.empty(base.n_cells, dtype=np.int64)
+    for d, sub in enumerate(subs):
+        owner[sub.global_cells] = d; local[sub.global_cells] = np.arange(sub.n_cells)
+    # pieces: faces of a side held by each domain, in global face order
+    piece_faces = [dict(), dict()]                            # side -> {domain: global face ids}
+    face_dom, face_pos = [None, None], [None, None]
+    for sd, itf in enumerate(sides):
+        fd = owner[itf.face_cells]
+        face_dom[sd] = fd
+        pos = np.empty(len(fd), dtype=np.int64)
+        for d in sorted(set(fd.tolist())):
+            ids = np.nonzero(fd == d)[0]
+            piece_faces[sd][d] = ids; pos[ids] = np.arange(len(ids))
+        face_pos[sd] = pos
+    n_proc = [len(sub.interfaces) for sub in subs]            # the AMI piece of domain d is its interface number n_proc[d]
+    # who talks to whom (symmetric)
+    talks = {d: set() for d in range(n_dom)}
+    for sd, itf in enumerate(sides):
+        other = 1 - sd
+        for d, ids in piece_faces[sd].items():
+            for i in ids:
+                for k in range(itf.ami_start[i], itf.ami_start[i + 1]):
+                    q = int(face_dom[other][itf.ami_addr[k]])
+                    talks[d].add(q); talks[q].add(d)
+    partners = {d: sorted(talks[d]) for d in range(n_dom)}
+    for sd, itf in enumerate(sides):
+        other = 1 - sd
+        for d, ids in piece_faces[sd].items():
+            parts = partners[d]
+            sizes = [len(piece_faces[other][q]) for q in parts]
+            start_of = dict(zip(parts, np.concatenate([[0], np.cumsum(sizes)])[:-1].tolist()))
+            st, ad, ww = [0], [], []
+            for i in ids:
+                for k in range(itf.ami_start[i], itf.ami_start[i + 1]):
+                    j = int(itf.ami_addr[k])
+                    ad.append(start_of[int(face_dom[other][j])] + int(face_pos[other][j])); ww.append(itf.ami_w[k])
+                st.append(len(ad))
+            piece = Interface(nbr_domain=parts[0], nbr_patch=n_proc[parts[0]], face_cells=local[itf.face_cells[ids]].astype(np.int32),
+                              bou_coeffs=itf.bou_coeffs[ids].copy(), int_coeffs=itf.int_coeffs[ids].copy(), ami_start=np.array(st, np.int32),
+                              ami_addr=np.array(ad, np.int32), ami_w=np.array(ww, np.float64), ami_low=None if itf.ami_low is None else itf.ami_low[ids].copy(),
+                              ami_magsf=None if itf.ami_magsf is None else itf.ami_magsf[ids].copy(), transform=itf.transform)
+            piece.ami_parts = [(q, n_proc[q]) for q in parts]
+            piece.ami_part_sizes = sizes
+            # engine patch list of a rank: processor interfaces, the AMI piece, then one transport per partner (ascending rank)
+            piece.ami_transport_nbr_patches = [n_proc[q] + 1 + partners[q].index(d) for q in parts]
+            subs[d].interfaces.append(piece)
     return subs
 
 

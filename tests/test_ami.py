@@ -372,3 +372,46 @@ def test_oracle_with_the_ami_sides_in_different_domains_agrees_with_the_single_d
         assert r["nIterations"] == r1["nIterations"], (name, r["nIterations"], r1["nIterations"])
         assert np.max(np.abs(r["history"] - r1["history"])) < 1e-10 * r1["history"][0], name
         assert np.max(np.abs(p - p1[cells])) < 1e-8 * np.max(np.abs(p1))
+
+
+@pytest.mark.parametrize("symmetric,kw,px", [(True, dict(shift=0.37), 2), (False, dict(shift=1.61, low_weight_every=7, transform=0.6), 2), (True, dict(shift=2.3), 3)])
+def test_oracle_split_sides_equal_the_single_domain_interface(pkg, orc, symmetric, kw, px):
+    """CPU: the multi-domain oracle with BOTH cyclicAMI sides split over px domains each (orc_sys_set_iface_ami_parts: addresses
+    numbering the partner pieces' faces concatenated) against the single-domain interface, which the reference's own
+    AMIInterpolationF.H pins (tests/test_oracle.py): every piece addresses several partner pieces; Amul / Tmul agree BIT FOR BIT on
+    every row that no processor patch touches (those rows add a processor-interface term where the single domain adds a face term:
+    another summation order, rounding-level difference), PCG / PBiCG histories and the GAMG solve agree to rounding."""
+    import copy
+    syn = pkg.synthetic
+    base = syn.box_case(12, 8, 5, symmetric=symmetric)
+    full = syn.add_cyclic_ami_y(base, **kw)
+    subs = syn.decompose_cyclic_ami_split(base, px, **kw)
+    assert len(subs) == 2 * px and all(len(s.interfaces[-1].ami_parts) >= 2 for s in subs)      # every piece talks to several partner pieces
+    for s in subs:
+        itf = s.interfaces[-1]
+        assert itf.ami_addr.max() < sum(itf.ami_part_sizes) and len(set(q for q, _ in itf.ami_parts)) == len(itf.ami_parts)
+    S1, SN = orc.System([full]), orc.System(subs)
+    glob = np.concatenate([s.global_cells for s in subs])
+    x = syn.splitmix_uniform(3, base.n_cells) - 0.5
+    touched, off = set(), 0
+    for s in subs:
+        for itf in s.interfaces[:-1]:
+            touched |= set((off + itf.face_cells).tolist())
+        off += s.n_cells
+    clean = np.array(sorted(set(range(base.n_cells)) - touched))
+    for op in ("amul", "tmul"):
+        y1, yn = getattr(S1, op)(x)[glob], getattr(SN, op)(x[glob])
+        assert np.array_equal(y1[clean], yn[clean]) and np.max(np.abs(y1 - yn)) < 4e-16 * np.max(np.abs(y1))
+    ami_rows, off = set(), 0
+    for s in subs:
+        ami_rows |= set((off + s.interfaces[-1].face_cells).tolist()); off += s.n_cells
+    assert len(ami_rows - touched) > 20                       # ... and most cyclicAMI rows are among the bit-exact ones
+    src = np.concatenate([s.source for s in subs])
+    z = np.zeros(base.n_cells)
+    solve = (lambda S, b: S.pcg(z, b, "diagonal", tolerance=1e-10, maxIter=400)) if symmetric else (lambda S, b: S.pbicg(z, b, "diagonal", tolerance=1e-10, maxIter=300))   # (DILU is block-local on a decomposed case: another preconditioner)
+    (p1, f1), (pn, fn) = solve(S1, full.source), solve(SN, src)
+    assert abs(f1["nIterations"] - fn["nIterations"]) <= 1 and np.max(np.abs(p1[glob] - pn)) < 1e-8 * np.max(np.abs(p1))
+    b0 = copy.copy(full); b0.interfaces = []
+    g1 = orc.GamgSysHierarchy(S1, [orc.box_face_weights(b0)], 6).solve(z, full.source, tolerance=1e-9, maxIter=80, directSolveCoarsest=False)
+    gn = orc.GamgSysHierarchy(SN, [orc.box_face_weights(s) for s in subs], 6).solve(z, src, tolerance=1e-9, maxIter=80, directSolveCoarsest=False)
+    assert gn[1]["converged"] and g1[1]["converged"] and np.max(np.abs(g1[0][glob] - gn[0])) < 1e-7 * np.max(np.abs(g1[0]))
