@@ -158,6 +158,45 @@ def bench_gamg(args, eng, syn, ctx, dev, json_fd):
     os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
+def negotiate_peer_path(solver, make_solver, trial, persist_launches, all_ok, any_rank, set_persist, force_rccl):
+    """The trial + fallback chain of the multi-GPU bench (persistent kernel over peer windows -> five launches over peer windows -> RCCL),
+    as a function of its collaborators so that tests/test_bench_contract.py can drive it between real ranks on the CPU with stand-ins:
+      trial(solver) -> (came through on THIS rank, history | None)     a few iterations
+      persist_launches() -> counter of persistent-kernel launches on this rank
+      all_ok(flag) / any_rank(flag) -> the MIN / MAX of flag over the ranks (collectives: every rank must call them in the same order)
+      set_persist(0 | 1), force_rccl(), make_solver() -> a fresh solver (after force_rccl: on RCCL)
+    Returns (solver, note): the solver the timed region runs on and why it is not the first choice ("" if it is).  Every rank takes the same
+    branch at every step -- each decision is made from values that were reduced over the ranks -- so the ranks issue the same collectives."""
+    note = ""
+    before = persist_launches()
+    ok, h_persist = trial(solver)
+    # the sub-domain fits the persistent kernel (csrc/persist.inc): decided from ALL ranks' counters -- a rank whose trial
+    # threw before its launch was counted would otherwise issue a different sequence of collectives below (ADVICE r03)
+    persistent = any_rank(persist_launches() > before)
+    good = all_ok(ok)
+    if persistent:
+        # the same 12 iterations through the five-launch loop: the persistent kernel must reproduce them
+        set_persist(0)
+        ok5, h5 = trial(solver) if good else (0, None)
+        same = int(bool(good and ok5 and h_persist is not None and h5 is not None and float(np.max(np.abs(h_persist - h5))) < 1e-10 * float(h5[0])))
+        if all_ok(same):
+            set_persist(1)
+        else:
+            note = " (the persistent kernel's trial did not reproduce the five-launch loop on every rank: five launches)"
+            if not good:                                   # windows possibly out of step after a timed-out wait: once more from scratch
+                del solver
+                solver = make_solver()
+                good = all_ok(trial(solver)[0])
+            else:
+                good = all_ok(ok5)
+    if not good:
+        force_rccl()
+        del solver
+        solver = make_solver()
+        note = " (the peer-window trial did not come through on every rank: RCCL)"
+    return solver, note
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,12 +372,12 @@ def main():
         # came through (no wait ran out of polls, iteration count right); unless all did, every rank rebuilds on RCCL.
         peer_note = ""
         if world > 1 and getattr(solver.comms[0] if solver.comms else None, "peer_mode", False):
-            def trial():
+            def trial(sv):
                 """12 iterations; (came through on THIS rank, history)"""
                 try:
-                    solver.begin(tolerance=0.0, max_iter=64)
-                    solver.iterate(12)
-                    st = solver.end()
+                    sv.begin(tolerance=0.0, max_iter=64)
+                    sv.iterate(12)
+                    st = sv.end()
                     return int(st["nIterations"] == 12 and bool(np.all(np.isfinite(st["history"][:13])))), np.array(st["history"][:13])
                 except Exception as e:  # MiError: a window wait / a grid barrier ran out of polls
                     log(f"[bench] rank {rank}: peer-window trial failed: {e}")
@@ -354,32 +393,11 @@ def main():
                 dist.all_reduce(v, op=dist.ReduceOp.MAX)
                 return int(v.item()) == 1
 
-            before = ctx.stat(1)
-            ok, h_persist = trial()
-            # the sub-domain fits the persistent kernel (csrc/persist.inc): decided from ALL ranks' counters -- a rank whose trial
-            # threw before its launch was counted would otherwise issue a different sequence of collectives below
-            persistent = any_rank(ctx.stat(1) > before)
-            good = all_ok(ok)
-            if persistent:
-                # the same 12 iterations through the five-launch loop: the persistent kernel must reproduce them
-                ctx.set_option("pcg_persist", 0)
-                ok5, h5 = trial() if good else (0, None)
-                same = int(bool(good and ok5 and h_persist is not None and h5 is not None and float(np.max(np.abs(h_persist - h5))) < 1e-10 * float(h5[0])))
-                if all_ok(same):
-                    ctx.set_option("pcg_persist", 1)
-                else:
-                    peer_note = " (the persistent kernel's trial did not reproduce the five-launch loop on every rank: five launches)"
-                    if not good:                                   # windows possibly out of step after a timed-out wait: once more from scratch
-                        del solver
-                        solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
-                        good = all_ok(trial()[0])
-                    else:
-                        good = all_ok(ok5)
-            if not good:
+            def force_rccl():
                 os.environ["MI_ALLREDUCE"] = "rccl"
-                del solver
-                solver = par.DistributedPCG(ctx, sub, dev, precond=args.precond)
-                peer_note = " (the peer-window trial did not come through on every rank: RCCL)"
+
+            solver, peer_note = negotiate_peer_path(solver, lambda: par.DistributedPCG(ctx, sub, dev, precond=args.precond), trial, lambda: ctx.stat(1),
+                                                    all_ok, any_rank, lambda v: ctx.set_option("pcg_persist", v), force_rccl)
         host_loop = {"native": "C++ loop over RCCL (mi_dpcg_comm_iterate)", "torch": "torch.distributed loop (parallel.py)"}[solver.driver]
         solver.begin(tolerance=0.0, max_iter=W + (R + 1) * K + 8)
         before = ctx.stat(1)

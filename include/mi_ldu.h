@@ -475,9 +475,7 @@ int mi_vec_axpby(mi_ctx_t ctx, int64_t n, double a, const double *x_dev, double 
  *   div = fvc::surfaceIntegrate(phi) [/ vol] in one call -- pEqn.H:49-71's
  *   phiHbyA = (fvc::interpolate(rho*HbyA) & mesh.Sf()) + rhorAUf*fvc::ddtCorr(rho, U, phi) followed by fvc::div(phiHbyA)
  *   (finiteVolume/fvc/fvcSurfaceIntegrate.C:40-96), which the reference computes with seven field passes: here one face pass
- *   (rho*HbyA, the three interpolates, the dot product, the product and the sum at once) + the row sum.  MI_FLUX_FUSED=1: ONE row
- *   pass (every workgroup keeps the flux of its own faces in LDS for the row sums and recomputes the faces cut by its boundary;
- *   measured slower: eight scattered gathers per cut face).  lambda = the
+ *   (rho*HbyA, the three interpolates, the dot product, the product and the sum at once) + the row sum.  lambda = the
  *   interpolation weights (surfaceInterpolationScheme.C:275-280); boundary faces: mi_patch_add on div as the reference adds them.
  * mi_ddt_phi_corr: fvc::ddtCorr(rho, U, phi) on the internal faces, EulerDdtScheme<Type>::fvcDdtPhiCorr(rho, U, phi)
  *   (EulerDdtScheme.C:663-720, first branch; rho_old NULL: fvcDdtPhiCorr(U, phi) :523-551) with ddtScheme<Type>::fvcDdtPhiCoeff

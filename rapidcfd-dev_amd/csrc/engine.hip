@@ -2041,6 +2041,11 @@ int pbicg_solve_device(mi_matrix_s* m, double* psi_io, const double* source, con
 }
 } // namespace
 
+extern "C" int mi_pbicg_solve_multi(mi_matrix_t m, int32_t nrhs, const double* const* diag_dev, double* const* psi_io, const double* const* source,
+                                    const mi_solver_controls* ctl, int precond, mi_solver_perf* perf, double* hist_host, int32_t hist_len);
+namespace {
+bool pbicg_single_via_multi(const mi_matrix_s* m);   // multi.inc
+}
 extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* source, const mi_solver_controls* ctl,
                               int precond, mi_solver_perf* perf, double* hist_host, int32_t hist_len)
 {
@@ -2049,8 +2054,14 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
     if (m->addr->ctx->session) return fail(MI_ERR_STATE, "mi_pbicg_solve: a PCG session (mi_pcg_begin) is active on this context; call mi_pcg_end first");
     mi_addr_s* a = m->addr;
     HIPCHK(hipSetDevice(a->ctx->device));
-    if (m->addr->ctx->pbicgHostStepped == 0)   // also with a communicator attached: the loop all-reduces its sums on the device (globalize)
+    if (m->addr->ctx->pbicgHostStepped == 0) { // also with a communicator attached: the loop all-reduces its sums on the device (globalize)
+        // round 6: one right-hand side through the multi-vector solver -- its prologue forms A psi, A^T psi and both residuals in ONE pass over
+        // the coefficients (here: two tile passes and two vector passes; a one-iteration energy-equation solve spent half its time there),
+        // its iterations are the same pipelined passes.  Same arithmetic per operand.  (mi_pbicg_solve_multi hands matrices it cannot take
+        // -- attached with cyclicAMI patches / compact entries, MI_PBICG_MULTI=0 -- back to pbicg_solve_device below.)
+        if (pbicg_single_via_multi(m)) return mi_pbicg_solve_multi(m, 1, nullptr, &psi_io, &source, ctl, precond, perf, hist_host, hist_len);
         return pbicg_solve_device(m, psi_io, source, ctl, precond, perf, hist_host, hist_len);
+    }
     hipStream_t s = a->ctx->stream;
     const int64_t n = a->L.nCells;
     double *psi, *src, *pA, *wA, *rA, *pT, *wT, *rT;

@@ -34,12 +34,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, store, conn, persistent):
+def _rank_main(rank, world, store, conn, persistent):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)         # (for code that reads them; the group itself meets through a file, below)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"       # (no MASTER_PORT: the group meets through a file, below; a job body that opens a TCPStore or an
+    os.environ.pop("MASTER_PORT", None)           #  nccl group of its own picks its port when it needs it -- test_distributed.py / test_gpu_configs.py do)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         import torch.distributed as dist
@@ -90,9 +90,8 @@ def _collect():
 
 class RankPool:
     def __init__(self, world, persistent=True):
-        # the rendezvous port is found free and then bound by rank 0 a moment later: another socket of this busy box (the gloo pairs of
-        # a pool that is just closing, a bench rehearsal's store) can take it in between -- seen twice in 58 pools of one suite run.
-        # Start again with another port instead of failing the test.
+        # The ranks meet through a FileStore (no rendezvous port that is found free here and bound a moment later -- round 5's
+        # EADDRINUSE, 2 of 58 pools).  gloo's own pair sockets can still fail to bind on a busy box: start again instead of failing the test.
         for attempt in range(4):
             try:
                 self._start(world, persistent)
@@ -103,18 +102,21 @@ class RankPool:
 
     def _start(self, world, persistent):
         ctx = multiprocessing.get_context("spawn")
-        port = free_port()
         fd, store = tempfile.mkstemp(prefix="mi_rank_pool_", suffix=".store")
         os.close(fd); os.unlink(store)                 # (the FileStore creates it; the name only has to be unique)
         self.store = store
         self.world, self.procs, self.conns = world, [], []
         for r in range(world):
             a, b = ctx.Pipe()
-            p = ctx.Process(target=_rank_main, args=(r, world, port, store, b, persistent), daemon=True)
+            p = ctx.Process(target=_rank_main, args=(r, world, store, b, persistent), daemon=True)
             p.start()
             b.close()
             self.procs.append(p); self.conns.append(a)
-        self._gather(180.0, "ready")
+        try:
+            self._gather(180.0, "ready")
+        except BaseException:
+            self._unlink_store()           # (kill() ran inside _gather; a rank that died before it could be killed leaves the file)
+            raise
 
     def _gather(self, timeout, want):
         deadline = time.monotonic() + timeout
@@ -168,6 +170,9 @@ class RankPool:
         for c in self.conns:
             c.close()
         self.procs, self.conns = [], []
+        self._unlink_store()
+
+    def _unlink_store(self):
         try:
             os.unlink(getattr(self, "store", ""))
         except OSError:

@@ -193,13 +193,12 @@ def test_row_passes_bit_exact_for_every_block_shape(pkg, orc, monkeypatch, name,
     V = [syn.splitmix_uniform(31 + k, n) - 0.5 for k in range(3)]
     rho, aA, aB = 0.8 + syn.splitmix_uniform(35, n), syn.splitmix_uniform(36, nf) - 0.5, syn.splitmix_uniform(37, nf)
     po, dv = E(nf), E(n)
-    for fused, kw in [(f, k) for f in ("0", "1") for k in (dict(), dict(scale=rho), dict(scale=rho, add_a=aA, add_b=aB, vol=vol), dict(add_a=aA))]:
-        monkeypatch.setenv("MI_FLUX_FUSED", fused)      # the face pass + row sum (default) and the one-pass form: same bits
+    for kw in (dict(), dict(scale=rho), dict(scale=rho, add_a=aA, add_b=aB, vol=vol), dict(add_a=aA)):
         asm.flux_div(dev(lam), [dev(x) for x in Sf], [dev(x) for x in V], po, dv, cell_scale=dev(kw["scale"]) if "scale" in kw else None,
                      add_a=dev(kw["add_a"]) if "add_a" in kw else None, add_b=dev(kw["add_b"]) if "add_b" in kw else None,
                      vol=dev(kw["vol"]) if "vol" in kw else None)
         rp, rd = orc.flux_div(n, lo, up, lam, Sf, V, **kw)
-        assert np.array_equal(host(po), rp) and np.array_equal(host(dv), rd), (fused, sorted(kw))
+        assert np.array_equal(host(po), rp) and np.array_equal(host(dv), rd), sorted(kw)
     # the fused passes recompute cut faces from their inputs: an output aliasing an input is refused
     d = dev(delta)
     with pytest.raises(eng.MiError):

@@ -139,3 +139,4 @@ def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dims", "40", "32", "24", "--no-cpu"],
                              capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
         assert out.returncode != 0 and "GPU(s) visible" in out.stderr
+

@@ -69,21 +69,21 @@ def _sum_ranks_body(rank, world, out_dir):
 
 def test_rank_pool_does_not_depend_on_a_free_rendezvous_port(tmp_path, monkeypatch):
     """tests/rank_pool.py: a rendezvous port that is found free and bound by rank 0 seconds later can be taken in between on a busy box
-    (round 5: EADDRINUSE in 2 of 58 pools of one GPU-suite run).  The ranks therefore meet through a FileStore; with the port they are
-    handed (MASTER_PORT, for code that reads it) held by a listening socket, a pool must still come up and run its job -- and a pool that
-    does fail with "address already in use" is started again (RankPool.__init__)."""
+    (round 5: EADDRINUSE in 2 of 58 pools of one GPU-suite run).  The ranks therefore meet through a FileStore and are handed NO port at
+    all (round 6, ADVICE r05: a job body that wants a TCPStore picks its own); a pool comes up and runs its job with MASTER_PORT of the
+    parent pointing at a port that is taken, and leaves no store file behind."""
+    import glob, tempfile
     import rank_pool
     busy = socket.socket()
     busy.bind(("127.0.0.1", 0)); busy.listen(1)
-    offered = [busy.getsockname()[1]]
-    real = rank_pool.free_port
-    monkeypatch.setattr(rank_pool, "free_port", lambda: offered.pop() if offered else real())
+    monkeypatch.setenv("MASTER_PORT", str(busy.getsockname()[1]))
+    before = set(glob.glob(os.path.join(tempfile.gettempdir(), "mi_rank_pool_*.store")))
     try:
         rank_pool.run_ranks(2, "test_distributed", "_sum_ranks_body", str(tmp_path))
     finally:
         busy.close()
-    assert not offered                                                       # the busy port was really the first one tried
     assert all(float(np.load(tmp_path / f"s{r}.npy")[0]) == 3.0 for r in range(2))
+    assert set(glob.glob(os.path.join(tempfile.gettempdir(), "mi_rank_pool_*.store"))) <= before
 
 
 def test_direct_subdomain_equals_decomposed_global_case(pkg):
@@ -381,6 +381,12 @@ _WINDOW_ITERATIONS = {"PCG": 24, "PBiCG": 12, "PBiCGStab": 10, "smoothSolver": 8
 
 
 def _windows_spec(spec):
+    # With ONE DEVICE PER RANK (MI_TEST_DEVICE_PER_RANK=1: tools/first_lease.sh on a multi-GPU node) nothing shares a scheduler, an
+    # exchange costs microseconds, and the window variants run the SAME solves as the plain transport -- to their tight tolerances,
+    # hundreds of iterations: late-iteration epoch / parity / flag-reuse errors (round 4's cyclicAMI hang was of that kind) would show
+    # there.  On the shared GPU of the default suite they stay short (below).
+    if os.environ.get("MI_TEST_DEVICE_PER_RANK") == "1":
+        return dict(spec)
     out = dict(spec)
     # (GAMG keeps a finite tolerance: with directSolveCoarsest = False its coarsest-level ICCG / BICCG inherits it,
     #  GAMGSolverSolve.C:572-613 -- tolerance 0 there means 1000 coarsest iterations per cycle)

@@ -34,7 +34,7 @@ echo "[first_lease] RCCL one-device-per-rank tests: rc=$? ($(tail -n 1 $O/tests_
 # ---- 2b. the window tests with ONE DEVICE PER RANK (host transport gloo, halo / all-reduce / gather windows across xGMI): every
 # solver over windows, neighbours in different window forms, cyclicAMI across ranks, the persistent distributed kernel
 MI_TEST_DEVICE_PER_RANK=1 timeout 2400 python -m pytest tests/test_distributed.py -q \
-    -k "entirely_over_peer_windows or different_window_forms or cyclic_ami_whose or persistent_distributed or transformed_processor" > $O/tests_windows_per_device.log 2>&1
+    -k "entirely_over_peer_windows or different_window_forms or cyclic_ami_whose or cyclic_ami_side_split or persistent_distributed or transformed_processor" > $O/tests_windows_per_device.log 2>&1
 echo "[first_lease] window tests, one device per rank: rc=$? ($(tail -n 1 $O/tests_windows_per_device.log))" | tee -a $O/selftests.log
 
 # ---- 3. bench.py per forced path

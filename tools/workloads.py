@@ -243,6 +243,7 @@ def rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=3, tra
     rAU, rhorAUf, pu, pl, pd, ps, pdd = E(N), E(F), E(F), E(F), E(N), E(N), E(N)
     ddtc, phiH, divH, fh, pf = E(F), E(F), E(N), E(F), E(F)
     grad, HbyA, tmpN = [E(N) for _ in range(3)], [E(N) for _ in range(3)], E(N)
+    K = E(N)
     rho0, p_old = rho.clone(), p.clone()
     U0 = [u.clone() for u in U]
     K0 = 0.5 * (U[0] * U[0] + U[1] * U[1] + U[2] * U[2])
@@ -266,10 +267,11 @@ def rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=3, tra
             UM.set_coeffs(ud, uu, ul)
             its = [q["nIterations"] for q in UM.pbicg_multi(U, ds, "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)]
         with stage("EEqn: fvm::ddt(rho, he) + fvm::div(phi, he) - fvm::laplacian(alphaEff, he) + explicit K / dpdt terms (fvm::Su) + relax + PBiCG"):
-            K = 0.5 * (U[0] * U[0] + U[1] * U[1] + U[2] * U[2])
+            torch.mul(U[0], U[0], out=K); K.addcmul_(U[1], U[1]).addcmul_(U[2], U[2]).mul_(0.5)
             asm.upwind_weights(phi, wts); asm.face_interpolate(wts, K, Kf); Kf.mul_(phi)
             asm.surface_integrate(Kf, vol, expl)                                       # fvc::div(phi, K)
-            expl.add_(rdt * (rho * K - rho0 * K0)).sub_(rdt * (p - p_old))              # + fvc::ddt(rho, K) - dpdt
+            torch.mul(rho, K, out=tmpN); tmpN.addcmul_(rho0, K0, value=-1.0).sub_(p).add_(p_old)
+            expl.add_(tmpN, alpha=rdt)                                                  # + fvc::ddt(rho, K) - dpdt  (= rdt (rho K - rho0 K0 - (p - p_old)))
             asm.assemble(eu, ed, lower_out=el, sources_out=[es], ddt=dict(r_delta_t=rdt, vol=vol, psi_old=[he], rho=rho, rho_old=rho0), div=dict(flux=phi),
                          laplacian=dict(delta_coeffs=delta, gamma_magsf=alphaMagSf), su=[(1.0, [expl])], sum_mag_out=smag)   # the explicit terms stand on the left: source -= V expl
             patch.add(icE, ed, 0)
