@@ -498,6 +498,24 @@ void fvScalarMatrix::relax(scalar alpha, const scalargpuField& psi)
     miCheck(mi_relax(lduAddr().handle(), alpha, diag().data(), asymmetric() ? lower().data() : nullptr, upper().data(), source_.data(), psi.data(),
                      (label)ph.size(), ph.data(), ic.data(), bc.data(), cp.data()), "fvMatrix::relax");
 }
+void fvScalarMatrix::setReference(label celli, scalar value)
+{
+    miCheck(mi_fvm_set_reference(lduAddr().handle(), celli, value, diag().data(), source_.data()), "fvMatrix::setReference");
+}
+void fvScalarMatrix::setValues(const labelgpuList& cellLabels, const scalargpuField& values, scalargpuField& psi)
+{
+    std::vector<mi_patch_t> ph; std::vector<double*> ic, bc;
+    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p) {
+        ph.push_back(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]));
+        ic.push_back(internalCoeffs_[p].data()); bc.push_back(boundaryCoeffs_[p].data());
+    }
+    const bool wasSym = !asymmetric();
+    const scalargpuField upperIn(upper());            // (the non-const lower() below copies upper, as the reference's does)
+    scalargpuField& lo = lower();
+    miCheck(mi_fvm_set_values(lduAddr().handle(), cellLabels.size(), cellLabels.data(), values.data(), 0, psi.data(), diag().data(), source_.data(),
+                              upperIn.data(), wasSym ? nullptr : lo.data(), upper().data(), lo.data(), (label)ph.size(), ph.data(), ic.data(), bc.data()),
+            "fvMatrix::setValues");
+}
 solverPerformance fvScalarMatrix::solve(scalargpuField& psi, const dictionary& solverControls)
 {
     // fvScalarMatrix.C:142-192: saveDiag; addBoundaryDiag; totalSource = source + boundary; solver::New()->solve; restore
@@ -686,6 +704,19 @@ fvScalarMatrix& fvScalarMatrix::operator*=(scalar s)
 void fvm::ddt(fvScalarMatrix& M, scalar rDeltaT, scalar rho, const scalargpuField& V, const scalargpuField& psiOld)
 {
     miCheck(mi_fvm_ddt_euler(miEngine::New().ctx, V.size(), rDeltaT, rho, V.data(), psiOld.data(), M.diag().data(), M.source().data()), "fvm::ddt");
+}
+void fvm::assemble(fvScalarMatrix& M, scalar rDeltaT, scalar rho, const scalargpuField& V, const scalargpuField& psiOld, const scalargpuField* faceFlux,
+                   const scalargpuField* weights, const scalargpuField* deltaCoeffs, const scalargpuField* gammaMagSf, const scalargpuField* su)
+{
+    mi_fvm_terms t{};
+    t.ddt = 1; t.r_delta_t = rDeltaT; t.rho_value = rho; t.vol_dev = V.data();
+    t.div_flux_dev = faceFlux ? faceFlux->data() : nullptr; t.div_weights_dev = weights ? weights->data() : nullptr;
+    t.lap_delta_coeffs_dev = deltaCoeffs ? deltaCoeffs->data() : nullptr; t.lap_gamma_magsf_dev = gammaMagSf ? gammaMagSf->data() : nullptr;
+    const double* po[1] = {psiOld.data()}; t.n_rhs = 1; t.psi_old_dev = po;
+    const double* sd[1] = {su ? su->data() : nullptr}; const double sg[1] = {1.0};
+    if (su) { t.n_su = 1; t.su_dev = sd; t.su_sign = sg; }
+    double* so[1] = {M.source().data()};
+    miCheck(mi_fvm_assemble(M.lduAddr().handle(), &t, faceFlux ? M.lower().data() : nullptr, M.upper().data(), M.diag().data(), so, nullptr), "fvm::assemble");
 }
 void fvc::grad(vectorgpuField& g, const lduAddressing& a, const vectorgpuField& Sf, const scalargpuField& ssf, const scalargpuField& V)
 {

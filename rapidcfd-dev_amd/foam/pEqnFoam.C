@@ -133,6 +133,28 @@ int main(int argc, char** argv)
                 for (scalar v : Hphi.asHost()) { sh += v; mh = std::max(mh, std::fabs(v)); }
                 Info << "H(Ux) coupled sum max: " << sh << " " << mh << std::endl;
             }
+            {   // the same UEqn written ONCE by the fused assembly (fvm::assemble -> mi_fvm_assemble): bit-identical to ddt; += conv; -= laplacian
+                fvScalarMatrix FEqn("Ux", addr, patches, std::vector<bool>(6, false));
+                scalarField ones(nf, 1.0), phiF(nf), dl(nf, 1.0 / h);
+                for (label f = 0; f < nf; ++f) phiF[f] = dir[f] == 0 ? 0.3 * h * h : 0.0;
+                scalargpuField V(scalarField(n, h * h * h)), zero(n), w(ones), ph(phiF), dlt(dl), gm(gam);
+                fvm::assemble(FEqn, 1.0 / 1e-3, 1.0, V, zero, &ph, &w, &dlt, &gm);
+                const bool same = FEqn.lower().asHost() == UEqn.lower().asHost() && FEqn.upper().asHost() == UEqn.upper().asHost() && FEqn.diag().asHost() == UEqn.diag().asHost();
+                Info << "fvm::assemble equals the operator sequence: " << (same ? 1 : 0) << std::endl;
+                // fvMatrix::setReference (closed domains: icoFoam.C:89, simpleFoam/pEqn.H:21) and setValues on copies of it
+                FEqn.source() = src;
+                FEqn.setReference(7, 0.5);
+                std::vector<scalar> d = FEqn.diag().asHost(), so = FEqn.source().asHost();
+                Info << "setReference cell 7: " << d[7] << " " << so[7] << std::endl;
+                labelList cells{3, 11, 40}; scalarField vals{0.25, -0.5, 1.5};
+                scalargpuField psiF(src);
+                FEqn.setValues(labelgpuList(cells), scalargpuField(vals), psiF);
+                scalar ss = 0, su = 0, sl = 0;
+                for (scalar v : FEqn.source().asHost()) ss += v;
+                for (scalar v : FEqn.upper().asHost()) su += v;
+                for (scalar v : FEqn.lower().asHost()) sl += v;
+                Info << "setValues sums source upper lower psi11: " << ss << " " << su << " " << sl << " " << psiF.asHost()[11] << std::endl;
+            }
             scalargpuField psi(n);
             UEqn.relax(0.7, psi);
             UEqn.solve(psi, dictionary{{"solver", "PBiCG"}, {"preconditioner", "diagonal"}, {"tolerance", "1e-10"}, {"relTol", "0"}});

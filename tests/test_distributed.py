@@ -491,8 +491,8 @@ def test_cyclic_ami_whose_halves_live_on_different_ranks(pkg, orc, tmp_path, nam
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("peer", [False, "auto"])
-@pytest.mark.parametrize("name,world", [("ami_split_sym", 4), ("ami_split_asym", 4), ("ami_split_sym", 6)])
+@pytest.mark.parametrize("name,world,peer", [("ami_split_sym", 4, False), ("ami_split_sym", 4, "auto"), ("ami_split_asym", 4, False), ("ami_split_asym", 4, "auto"),
+                                             ("ami_split_sym", 6, "auto")])   # (6 ranks over the plain transport: 157 s on the shared GPU -- the callbacks' hipMemcpy per exchange; windows: 12 s)
 def test_cyclic_ami_side_split_over_ranks(pkg, orc, tmp_path, name, world, peer):
     """Row f3 (round 6; VERDICT r05 "missing" 1): BOTH sides of the non-conformal interface split over several ranks (px x 2 blocks:
     ranks 0 .. px-1 hold the pieces of the y-min side, the others the pieces of the refined, shifted, x-periodic y-max side), every

@@ -88,6 +88,16 @@ def test_pEqnFoam_matches_oracle(pkg, orc):
     m = re.search(r"H\(Ux\) coupled sum max: (\S+) (\S+)", out.stdout)
     assert m, out.stdout
     assert abs(float(m.group(1)) - hc.sum()) < 1e-9 * np.abs(hc).sum() and abs(float(m.group(2)) - np.max(np.abs(hc))) < 1e-13 * np.max(np.abs(hc))
+    # round 6: the fused assembly writes the same matrix bit for bit; setReference / setValues of the mirror against the oracle
+    assert "fvm::assemble equals the operator sequence: 1" in out.stdout, out.stdout
+    rdg, rsc = orc.set_reference(7, 0.5, ud, src)
+    m = re.search(r"setReference cell 7: (\S+) (\S+)", out.stdout)
+    assert m and abs(float(m.group(1)) - rdg[7]) < 1e-5 * abs(rdg[7]) and abs(float(m.group(2)) - rsc[7]) < 1e-5 * max(abs(rsc[7]), 1e-30), out.stdout   # (printed with 6 digits)
+    sv = orc.set_values(n, case.lower_addr, case.upper_addr, np.array([3, 11, 40], np.int32), np.array([0.25, -0.5, 1.5]), src, rdg, rsc, uu, ul)
+    m = re.search(r"setValues sums source upper lower psi11: (\S+) (\S+) (\S+) (\S+)", out.stdout)
+    assert m, out.stdout
+    for got_v, ref_v in zip(map(float, m.groups()), (sv["source"].sum(), sv["upper"].sum(), sv["lower"].sum(), -0.5)):
+        assert abs(got_v - ref_v) < 2e-5 * max(abs(ref_v), 1e-12), (got_v, ref_v)
     rd, rs = orc.relax(n, case.lower_addr, case.upper_addr, 0.7, ud, ul, uu, src, z, [xmin], [np.full(xmin.shape[0], 2.0 * h)],
                        [np.zeros(xmin.shape[0])], [0])
     rd_solve = orc.patch_add(xmin, np.full(xmin.shape[0], 2.0 * h), rd, 0)

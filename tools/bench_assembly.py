@@ -49,11 +49,15 @@ def run(tag, addr):
     # fvc::ddtCorr(rho, U, phi) in one face pass (algorithmic: every cell / face array once)
     lam, rho, aA, aB = t(syn.splitmix_uniform(20, F)), t(0.8 + syn.splitmix_uniform(21, N)), t(syn.splitmix_uniform(22, F)), t(syn.splitmix_uniform(23, F))
     V3 = [t(syn.splitmix_uniform(24 + k, N) - 0.5) for k in range(3)]
-    os.environ["MI_FLUX_FUSED"] = "0"
     timeit("phiHbyA + fvc::div(phiHbyA) (mi_flux_div: face pass + row sum)", lambda: asm.flux_div(lam, Sf, V3, fl, y, cell_scale=rho, add_a=aA, add_b=aB), 32 * N + 8 * N + (8 + 24 + 16 + 8) * F)
-    os.environ["MI_FLUX_FUSED"] = "1"
-    timeit("phiHbyA + fvc::div(phiHbyA) (MI_FLUX_FUSED=1: one row pass)", lambda: asm.flux_div(lam, Sf, V3, fl, y, cell_scale=rho, add_a=aA, add_b=aB), 32 * N + 8 * N + (8 + 24 + 16 + 8) * F)
-    os.environ["MI_FLUX_FUSED"] = "0"
+    # round 6: a whole transport equation in one row pass (mi_fvm_assemble) -- momentum-like: ddt(rho, U) + div(phi, U) [upwind] - laplacian(mu, U),
+    # three sources and sumMagOffDiag (algorithmic: flux, delta, gamma in, lower, upper out = 40F; rho, rho0, V, 3 psi0 in, diag, sumMag, 3 sources out = 88N)
+    srcs, mag = [E(N) for _ in range(3)], E(N)
+    timeit("ddt + div - laplacian, 3 sources (mi_fvm_assemble)", lambda: asm.assemble(fu, fd, lower_out=fl, sources_out=srcs, ddt=dict(r_delta_t=1e4, vol=vol, psi_old=V3, rho=rho, rho_old=rho),
+                                                                                 div=dict(flux=ff), laplacian=dict(delta_coeffs=fw, gamma_magsf=aB), sum_mag_out=mag), 40 * F + 88 * N)
+    ps = E(N)
+    timeit("ddt - laplacian, symmetric (mi_fvm_assemble)", lambda: asm.assemble(fu, fd, sources_out=[ps], ddt=dict(r_delta_t=1e4, vol=vol, psi_old=[V3[0]], rho=rho, rho_old=rho),
+                                                                           laplacian=dict(delta_coeffs=fw, gamma_magsf=aB)), 24 * F + 48 * N)
     timeit("fvc::ddtCorr(rho, U, phi) (mi_ddt_phi_corr)", lambda: asm.ddt_phi_corr(1e4, lam, Sf, V3, rho, ff, fu), 32 * N + (8 + 24 + 8 + 8) * F)
     out[tag] = rows
 
