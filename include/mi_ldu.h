@@ -541,6 +541,13 @@ int mi_fvm_set_values(mi_addr_t addr, int32_t n_set, const int32_t *cell_labels_
                       double *psi_dev, const double *diag_dev, double *source_dev, const double *upper_in_dev, const double *lower_in_dev_or_null,
                       double *upper_out_dev, double *lower_out_dev, int32_t n_patches, const mi_patch_t *patches,
                       double *const *internal_coeffs_dev, double *const *boundary_coeffs_dev);
+/* fvc::div(faceFlux, vf) -- gaussConvectionScheme<Type>::fvcDiv (src/finiteVolume/finiteVolume/convectionSchemes/gaussConvectionScheme/
+ * gaussConvectionScheme.C:117-140): fvc::surfaceIntegrate(faceFlux*interpolate(faceFlux, vf)) on the internal faces; EEqn.H:9's fvc::div(phi, K).
+ * weights NULL: upwind (pos(faceFlux)).  face_out receives faceFlux*interpolate (gaussConvectionScheme::flux, :62-70); div_out the row sums
+ * [/ vol].  One face pass + one row pass (the reference: weights, interpolate, product, surfaceIntegrate = four field passes); boundary
+ * faces: mi_patch_add on div_out as the reference adds them.                                                                           */
+int mi_fvc_div(mi_addr_t addr, const double *face_flux_dev, const double *weights_dev_or_null, const double *vf_dev,
+               const double *vol_dev_or_null, double *face_out_dev, double *div_out_dev);
 /* out = x / y element-wise (fvMatrix::A = D/V, fvMatrix::H /= V; fvMatrix.C:1424-1506); out may alias x */
 int mi_vec_div(mi_ctx_t ctx, int64_t n, const double *x_dev, const double *y_dev, double *out_dev);
 /* Non-orthogonal correction of fvm::laplacian (row a22): gaussLaplacianScheme<Type, scalar>::fvmLaplacian with a `corrected`

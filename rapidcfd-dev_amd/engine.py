@@ -44,7 +44,7 @@ SYMBOLS = [
     "mi_addr_set_ami_patch", "mi_addr_set_ami_patch_remote", "mi_addr_set_ami_face_areas", "mi_matrix_set_patch_transform",
     "mi_comm_peer_window", "mi_comm_peer_connect", "mi_comm_peer_status", "mi_gamg_create_dummy", "mi_gamg_host_build_ami",
     "mi_addr_create_adopted", "mi_layout_adopt_host", "mi_pbicg_solve_multi", "mi_comm_peer_auto", "mi_comm_peer_selftest", "mi_comm_peer_enable", "mi_matrix_peer_halo_auto", "mi_matrix_peer_halo_status",
-    "mi_pcg_iterate_sampled", "mi_addr_set_ami_patch_remote_multi", "mi_fvm_assemble", "mi_fvm_set_reference", "mi_fvm_set_values", "mi_relax_multi",
+    "mi_pcg_iterate_sampled", "mi_addr_set_ami_patch_remote_multi", "mi_fvm_assemble", "mi_fvm_set_reference", "mi_fvm_set_values", "mi_relax_multi", "mi_fvc_div",
     "mi_fvm_ddt_euler", "mi_fvm_ddt_euler_rho", "mi_fvm_su", "mi_fvm_sp", "mi_fvm_susp", "mi_flux_div", "mi_ddt_phi_corr", "mi_upwind_weights", "mi_limited_linear_weights", "mi_gauss_grad", "mi_vec_axpby", "mi_vec_div",
     "mi_comm_unique_id", "mi_comm_create", "mi_comm_destroy", "mi_comm_allreduce_sum", "mi_dpcg_comm_begin",
     "mi_dpcg_comm_iterate", "mi_gamg_create_coupled", "mi_matrix_attach_comm", "mi_matrix_detach_comm", "mi_matrix_patch_neighbour_field",
@@ -1011,6 +1011,10 @@ class Assembly:
             t.su_dev = C.cast(sd, C.POINTER(C.c_void_p)); t.su_sign = C.cast(sg, C.POINTER(C.c_double))
         so = (C.c_void_p * max(n_rhs, 1))(*[_ptr(x) for x in sources_out])
         _chk(lib().mi_fvm_assemble(self.addr.h, C.byref(t), _ptr(lower_out), _ptr(upper_out), _ptr(diag_out), so, _ptr(sum_mag_out)))
+
+    def fvc_div(self, face_flux, weights, vf, vol, face_out, div_out):
+        """fvc::div(faceFlux, vf) (gaussConvectionScheme.C:117-140); weights None: upwind"""
+        _chk(lib().mi_fvc_div(self.addr.h, _ptr(face_flux), _ptr(weights), _ptr(vf), _ptr(vol), _ptr(face_out), _ptr(div_out)))
 
     def set_reference(self, celli, value, diag, source):
         """fvMatrix::setReference (fvMatrix.C:964-981)"""

@@ -513,6 +513,13 @@ def test_fused_assembly_equals_the_unfused_sequence_bit_for_bit(pkg, orc, monkey
     t = vol * dev(q["sp"]); dd.sub_(t)
     for key, t in (("lower", cl), ("upper", cu), ("diag", dd), ("source0", ds[0]), ("source1", ds[1]), ("source2", ds[2])):
         assert np.array_equal(host(t), got["assemble_momentum/" + key]), key
+    # fvc::div(faceFlux, vf) (gaussConvectionScheme::fvcDiv): upwind and given weights, against the oracle's interpolate -> product -> surfaceIntegrate
+    Kf, dv = E(nf), E(n)
+    for wname in (None, "w"):
+        asm.fvc_div(flux, None if wname is None else dev(q[wname]), dev(q["psi"]), vol, Kf, dv)
+        wts_h = orc.upwind_weights(q["flux"]) if wname is None else q[wname]
+        ref_f = q["flux"] * orc.face_interpolate(M["lo"], M["up"], wts_h, q["psi"])
+        assert np.array_equal(host(Kf), ref_f) and np.array_equal(host(dv), orc.surface_integrate(n, M["lo"], M["up"], ref_f, q["vol"])), wname
     # upstream semantics of setValues against the oracle
     sv = orc.set_values(n, M["lo"], M["up"], q["set_cells"], q["set_vals"], q["psi"], q["Dc"], q["src"], q["Uc"], None, upstream=True)
     ps, sr, uo, lo_o = dev(q["psi"]), dev(q["src"]), E(nf), E(nf)

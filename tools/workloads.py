@@ -268,8 +268,7 @@ def rhopimple_supplement(eng, syn, case, addr, ctx, dev, gamg=None, steps=3, tra
             its = [q["nIterations"] for q in UM.pbicg_multi(U, ds, "DILU", tolerance=1e-12, relTol=0.1, maxIter=50)]
         with stage("EEqn: fvm::ddt(rho, he) + fvm::div(phi, he) - fvm::laplacian(alphaEff, he) + explicit K / dpdt terms (fvm::Su) + relax + PBiCG"):
             torch.mul(U[0], U[0], out=K); K.addcmul_(U[1], U[1]).addcmul_(U[2], U[2]).mul_(0.5)
-            asm.upwind_weights(phi, wts); asm.face_interpolate(wts, K, Kf); Kf.mul_(phi)
-            asm.surface_integrate(Kf, vol, expl)                                       # fvc::div(phi, K)
+            asm.fvc_div(phi, None, K, vol, Kf, expl)                                   # fvc::div(phi, K), upwind: one face pass + the row sum
             torch.mul(rho, K, out=tmpN); tmpN.addcmul_(rho0, K0, value=-1.0).sub_(p).add_(p_old)
             expl.add_(tmpN, alpha=rdt)                                                  # + fvc::ddt(rho, K) - dpdt  (= rdt (rho K - rho0 K0 - (p - p_old)))
             asm.assemble(eu, ed, lower_out=el, sources_out=[es], ddt=dict(r_delta_t=rdt, vol=vol, psi_old=[he], rho=rho, rho_old=rho0), div=dict(flux=phi),
