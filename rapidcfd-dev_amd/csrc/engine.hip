@@ -125,23 +125,23 @@ struct mi_addr_s {
     struct RowPlan { bool tiles = false; int bs = 256, blocks = 0, maxFaces = 0, capForced = 0; } rowPlan[2]; // blocks of the assembly row passes: [0] sums / fused schemes, [1] gradient (assembly.inc)
     DevBuf<double> relaxD0, relaxSumOff;
     DevBuf<uint8_t> setMask; DevBuf<double> setVal;   // fvMatrix::setValues scratch (assembly.inc)
-    std::vector<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
+    Table<int32_t> lowerHost, upperHost; // kept for the lazily-built faceH tables
     int32_t nInterior = 0, nBoundary = 0, nLocalPatches = 0;
-    std::vector<char> patchIsLocal; // [nPatches] cyclic (local) coupled patch: no exchange
+    Table<char> patchIsLocal; // [nPatches] cyclic (local) coupled patch: no exchange
     DevBuf<int32_t> ifaceNbrCaller; // [nExt] caller cell across every LOCAL interface face, -1 for remote faces (lazy)
     DevBuf<int32_t> haloSrc;        // [nHaloTot] caller cell of every halo entry, or -1-k for ext value k (lazy; caller-order tile launches)
-    std::vector<std::vector<int32_t>> patchFaceCellsHost, patchNbrCellsHost; // caller order (GAMG interface agglomeration)
+    Table<Table<int32_t>> patchFaceCellsHost, patchNbrCellsHost; // caller order (GAMG interface agglomeration)
     int64_t nEntries = 0, nHaloTot = 0;
     // cyclicAMI patches (mi_addr_set_ami_patch): declared like processor patches (ext region), their neighbour values are
     // interpolated locally from the partner patch's cells before every operator that reads them
     struct AmiPatch {
         int32_t patch = 0, nbrPatch = 0, n = 0, extOff = 0;
-        std::vector<int32_t> transports, partCount;   // partner SIDE split over several ranks: one transport patch per piece, faces per piece (transport == transports[0], nPartner == their sum)
+        Table<int32_t> transports, partCount;   // partner SIDE split over several ranks: one transport patch per piece, faces per piece (transport == transports[0], nPartner == their sum)
         int32_t transport = -1, nPartner = 0;   // cyclicAMI whose partner patch lives on ANOTHER rank: the processor patch that carries the partner's internal field; partner patch size
         DevBuf<int32_t> start, cellE, ownE; DevBuf<double> w; bool hasLow = false;
-        std::vector<int32_t> hStart, hAddr; std::vector<double> hW, hMagSf; // host copies: the GAMG builder agglomerates them
+        Table<int32_t> hStart, hAddr; Table<double> hW, hMagSf; // host copies: the GAMG builder agglomerates them
     };
-    std::vector<AmiPatch*> ami;
+    Table<AmiPatch*> ami;
     bool amiRemote = false;   // some cyclicAMI patch interpolates from a transport patch: interpolate AFTER the halo exchange
     ~mi_addr_s() { for (AmiPatch* q : ami) delete q; }
     bool identity = false; // engine order == caller order (ordered addressing, or a mesh whose numbering happens to be tile-contiguous)
@@ -155,9 +155,9 @@ struct mi_matrix_s {
     mi_dpcg_s dp; // buffers of a distributed PCG session (owned by the caller)
     DevBuf<double> diagE, upE, lowE, rD, sumAE; // sumAE: lduMatrix::sumA of the bound coefficients (normFactor), kept per binding
     bool asym = false, bound = false, rDValid = false, sumAValid = false;
-    std::vector<double> patchFactor; // transformCoupleField factor of every coupled patch (empty: none set, all 1)
+    Table<double> patchFactor; // transformCoupleField factor of every coupled patch (empty: none set, all 1)
     uint64_t epoch = 0; // bumped whenever coefficients are (re)bound: lets a GAMG hierarchy keep its level matrices between solves
-    std::vector<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
+    Table<DevBuf<double>*> work; // engine-order vectors (n_cells + n_ext)
     DevBuf<double> hist, tilePartial;
     DevBuf<PcgState> mstate; DevBuf<double> mpartial, mhist, mtilePartial; PcgState* mhostState = nullptr;   // multi-right-hand-side solves (multi.inc): one state / partial block / history per component
     DevBuf<double> persistScratch;   // per-workgroup partials + the grid barrier of the persistent PCG kernel (persist.inc)
@@ -167,7 +167,7 @@ struct mi_matrix_s {
     // running PCG session (mi_pcg_begin/iterate/end)
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
     bool pcgActive = false;
-    std::vector<hipEvent_t> evPool;
+    Table<hipEvent_t> evPool;
     // hipGraph of one batch of device-resident PCG iterations (launch-bound regime: small meshes, coarse ranks)
     hipGraphExec_t pcgGraph = nullptr;
     struct { int precond = -1, batch = 0, histLen = 0; const void* hist = nullptr; const void* psi = nullptr; } pcgGraphKey;
@@ -368,9 +368,9 @@ extern "C" int mi_addr_create_ordered(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
 // into upper-triangular order of the new numbering -- what polyMesh::renumber / renumberMesh.C do with a manual cell map.
 namespace {
 struct AdoptedMesh {
-    std::vector<int32_t> cellMap, faceMap, lower, upper, tileStart;   // new -> old cell / face; addressing of the renumbered mesh
-    std::vector<uint8_t> flipped;                                      // new face f has owner and neighbour swapped w.r.t. old face faceMap[f]
-    std::vector<std::vector<int32_t>> patchFaceCells, patchNbrCells;   // renumbered
+    Table<int32_t> cellMap, faceMap, lower, upper, tileStart;   // new -> old cell / face; addressing of the renumbered mesh
+    Table<uint8_t> flipped;                                      // new face f has owner and neighbour swapped w.r.t. old face faceMap[f]
+    Table<Table<int32_t>> patchFaceCells, patchNbrCells;   // renumbered
 };
 std::string adopt_engine_order(int32_t n_cells, int32_t n_faces, const int32_t* lower, const int32_t* upper, int32_t n_patches, const int32_t* patch_sizes,
                                const int32_t* const* patch_face_cells, const int32_t* const* patch_nbr_cells, AdoptedMesh& M)
@@ -384,15 +384,15 @@ std::string adopt_engine_order(int32_t n_cells, int32_t n_faces, const int32_t* 
     const std::string err = build_tile_layout(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, prm, L, patch_nbr_cells);
     if (!err.empty()) return err;
     M.cellMap = L.e2c; M.tileStart = L.tileCellStart;
-    const std::vector<int32_t>& o2n = L.c2e;
-    std::vector<int32_t> lo((size_t)n_faces), up((size_t)n_faces);
-    std::vector<uint8_t> fl((size_t)n_faces);
+    const Table<int32_t>& o2n = L.c2e;
+    Table<int32_t> lo((size_t)n_faces), up((size_t)n_faces);
+    Table<uint8_t> fl((size_t)n_faces);
     for (int32_t f = 0; f < n_faces; ++f) {
         const int32_t a = o2n[(size_t)lower[f]], b = o2n[(size_t)upper[f]];
         fl[(size_t)f] = a > b; lo[(size_t)f] = a < b ? a : b; up[(size_t)f] = a < b ? b : a;
     }
     // owner-sorted, then by neighbour, ties in old face order (two counting-sort passes: stable)
-    std::vector<int32_t> byUp((size_t)n_faces), cnt((size_t)n_cells + 1, 0);
+    Table<int32_t> byUp((size_t)n_faces), cnt((size_t)n_cells + 1, 0);
     for (int32_t f = 0; f < n_faces; ++f) cnt[(size_t)up[(size_t)f] + 1]++;
     for (int32_t c = 0; c < n_cells; ++c) cnt[(size_t)c + 1] += cnt[(size_t)c];
     for (int32_t f = 0; f < n_faces; ++f) byUp[(size_t)cnt[(size_t)up[(size_t)f]]++] = f;
@@ -442,7 +442,7 @@ extern "C" int mi_addr_create_adopted(mi_ctx_t ctx, int32_t n_cells, int32_t n_f
     AdoptedMesh M;
     const std::string err = adopt_engine_order(n_cells, n_faces, lower, upper, n_patches, patch_sizes, patch_face_cells, patch_nbr_cells, M);
     if (!err.empty()) return fail(MI_ERR_LIMIT, "mi_addr_create_adopted: " + err);
-    std::vector<const int32_t*> pfc((size_t)n_patches), pnb((size_t)n_patches, nullptr);
+    Table<const int32_t*> pfc((size_t)n_patches), pnb((size_t)n_patches, nullptr);
     bool anyNbr = false;
     for (int32_t p = 0; p < n_patches; ++p) {
         pfc[(size_t)p] = M.patchFaceCells[(size_t)p].data();
@@ -558,11 +558,11 @@ static int addr_create_impl(mi_ctx_t ctx, int32_t n_cells, int32_t n_faces, cons
     }
     // drop the big host tables that only the device needs (their memory goes back to the system on another thread)
     {
-        std::vector<int32_t> slotFace, faceSlot;
+        Table<int32_t> slotFace, faceSlot;
         if (!ctx->keepSlotTables) { slotFace.swap(L.slotFace); faceSlot.swap(L.faceSlot); }
         mi::free_in_background(L.entries, L.entries16, L.sliceEntryStart16, L.slotBase, slotFace, L.haloCell, L.sliceEntryStart, faceSlot);
-        L.entries = std::vector<uint32_t>(); L.entries16 = std::vector<uint32_t>(); L.sliceEntryStart16 = std::vector<int32_t>(); L.slotBase = std::vector<uint16_t>();
-        L.haloCell = std::vector<int32_t>(); L.sliceEntryStart = std::vector<int32_t>();
+        L.entries = Table<uint32_t>(); L.entries16 = Table<uint32_t>(); L.sliceEntryStart16 = Table<int32_t>(); L.slotBase = Table<uint16_t>();
+        L.haloCell = Table<int32_t>(); L.sliceEntryStart = Table<int32_t>();
     }
 #ifdef MI_TIMING
     ta_tick("host copies + frees");
@@ -581,11 +581,11 @@ extern "C" int mi_addr_set_ami_patch(mi_addr_t a, int32_t patch, int32_t nbr_pat
     if (a->patchIsLocal[(size_t)patch]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: the patch must be created without neighbour cells (ext region), once");
     if ((start || address || weights) && !(start && address && weights)) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: start, address and weights go together");
     HIPCHK(hipSetDevice(a->ctx->device));
-    const std::vector<int32_t>& mine = a->patchFaceCellsHost[(size_t)patch];
-    const std::vector<int32_t>& theirs = a->patchFaceCellsHost[(size_t)nbr_patch];
+    const Table<int32_t>& mine = a->patchFaceCellsHost[(size_t)patch];
+    const Table<int32_t>& theirs = a->patchFaceCellsHost[(size_t)nbr_patch];
     const int32_t n = (int32_t)mine.size(), nn = (int32_t)theirs.size();
-    std::vector<int32_t> st((size_t)n + 1, 0), ce, own;
-    std::vector<double> w;
+    Table<int32_t> st((size_t)n + 1, 0), ce, own;
+    Table<double> w;
     if (!start) { // one face to one face with unit weight: a cyclic patch that needs its transformation factor
         if (n != nn) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch: one-to-one coupling needs patches of equal size");
         ce.resize((size_t)n); w.assign((size_t)n, 1.0);
@@ -634,7 +634,7 @@ extern "C" int mi_addr_set_ami_patch(mi_addr_t a, int32_t patch, int32_t nbr_pat
 // all ranks and is numbered rank by rank) -- one transport patch per partner piece; address k names a received value as (slot of the
 // transport in `transports`, face of that transport patch).  hAddrConcat: the same addresses in the concatenated numbering of the
 // pieces (kept for the GAMG builder).
-int ami_remote_impl(mi_addr_s* a, int32_t patch, const std::vector<int32_t>& transports, const std::vector<int32_t>& partCount, const int32_t* start,
+int ami_remote_impl(mi_addr_s* a, int32_t patch, const Table<int32_t>& transports, const Table<int32_t>& partCount, const int32_t* start,
                     const int32_t* addrSlot, const int32_t* addrFace, const int32_t* hAddrConcat, const double* weights, const uint8_t* low_weight)
 {
     const char* me = "mi_addr_set_ami_patch_remote";
@@ -650,12 +650,12 @@ int ami_remote_impl(mi_addr_s* a, int32_t patch, const std::vector<int32_t>& tra
         total += partCount[q];
     }
     HIPCHK(hipSetDevice(a->ctx->device));
-    const std::vector<int32_t>& mine = a->patchFaceCellsHost[(size_t)patch];
+    const Table<int32_t>& mine = a->patchFaceCellsHost[(size_t)patch];
     const int32_t n = (int32_t)mine.size();
     if (start[0] != 0) return fail(MI_ERR_ARG, std::string(me) + ": start[0] must be 0");
     for (int32_t i = 0; i < n; ++i) if (start[i + 1] < start[i]) return fail(MI_ERR_ARG, std::string(me) + ": start must be non-decreasing");
     const int32_t na = start[n];
-    std::vector<int32_t> st(start, start + n + 1), ce((size_t)na), own;
+    Table<int32_t> st(start, start + n + 1), ce((size_t)na), own;
     for (int32_t k = 0; k < na; ++k) {
         const int32_t q = addrSlot[k];
         if (q < 0 || q >= (int32_t)transports.size() || addrFace[k] < 0 || addrFace[k] >= a->L.patchOffset[(size_t)transports[(size_t)q] + 1] - a->L.patchOffset[(size_t)transports[(size_t)q]])
@@ -691,11 +691,11 @@ extern "C" int mi_addr_set_ami_patch_remote_multi(mi_addr_t a, int32_t patch, in
     if (!a || patch < 0 || patch >= a->L.nPatches || n_transports < 1 || !transport_patches || !n_partner_faces || !start || !address || !weights)
         return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote_multi: bad argument");
     const int32_t n = (int32_t)a->patchFaceCellsHost[(size_t)patch].size();
-    std::vector<int32_t> tr(transport_patches, transport_patches + n_transports), cnt(n_partner_faces, n_partner_faces + n_transports), off((size_t)n_transports + 1, 0);
+    Table<int32_t> tr(transport_patches, transport_patches + n_transports), cnt(n_partner_faces, n_partner_faces + n_transports), off((size_t)n_transports + 1, 0);
     for (int32_t q = 0; q < n_transports; ++q) { if (cnt[(size_t)q] < 0) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote_multi: negative partner face count"); off[(size_t)q + 1] = off[(size_t)q] + cnt[(size_t)q]; }
     for (int32_t i = 0; i < n; ++i) if (start[i + 1] < start[i]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote_multi: start must be non-decreasing");
     const int32_t na = n > 0 || start ? start[n] : 0;
-    std::vector<int32_t> slot((size_t)na), face((size_t)na);
+    Table<int32_t> slot((size_t)na), face((size_t)na);
     for (int32_t k = 0; k < na; ++k) {
         if (address[k] < 0 || address[k] >= off[(size_t)n_transports]) return fail(MI_ERR_ARG, "mi_addr_set_ami_patch_remote_multi: address outside the partner pieces");
         int32_t q = 0;
@@ -1184,7 +1184,7 @@ int caller_op(mi_matrix_s* m, bool trans, const double* x, const double* b, doub
         // (The ext tail, if the mesh has coupled patches whose values the caller placed with mi_matrix_set_ext, lives in work 0.)
         MICHK(m->vec(0, &v0));
         if (a->haloSrc.n != a->haloCell.n) {
-            std::vector<int32_t> hc(a->haloCell.n), src(a->haloCell.n);
+            Table<int32_t> hc(a->haloCell.n), src(a->haloCell.n);
             HIPCHK(hipMemcpy(hc.data(), a->haloCell.p, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost));
             for (size_t h = 0; h < hc.size(); ++h) src[h] = hc[h] < a->L.nCells ? a->L.e2c[(size_t)hc[h]] : -1 - (hc[h] - a->L.nCells);
             MICHK(a->haloSrc.upload(src, s));
@@ -1922,7 +1922,7 @@ struct HostPerf {
     bool checkSingularity(double v) { singular = (v < SP_VSMALL); return singular != 0; }
 };
 
-int finish_host(mi_matrix_s* m, const HostPerf& hp, const std::vector<double>& hist, double* psi_e, double* psi_out,
+int finish_host(mi_matrix_s* m, const HostPerf& hp, const Table<double>& hist, double* psi_e, double* psi_out,
                 mi_solver_perf* perf, double* hist_host, int hist_len)
 {
     mi_addr_s* a = m->addr;
@@ -1938,7 +1938,7 @@ int finish_host(mi_matrix_s* m, const HostPerf& hp, const std::vector<double>& h
 }
 
 int host_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* psi_e, const double* src_e,
-                  double* wA, double* rA, double* tmp, HostPerf& hp, std::vector<double>& hist)
+                  double* wA, double* rA, double* tmp, HostPerf& hp, Table<double>& hist)
 {
     MICHK(solve_prologue(m, ctl, psi_e, src_e, wA, rA, tmp, 1));
     MICHK(fetch_state(m->addr->ctx));
@@ -2069,7 +2069,7 @@ extern "C" int mi_pbicg_solve(mi_matrix_t m, double* psi_io, const double* sourc
     MICHK(m->vec(8, &pT)); MICHK(m->vec(9, &wT)); MICHK(m->vec(10, &rT));
     k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->perm(), psi, a->L.nCells);
     k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
-    HostPerf hp; std::vector<double> hist;
+    HostPerf hp; Table<double> hist;
     MICHK(host_prologue(m, ctl, psi, src, wA, rA, pA, hp, hist));
     MICHK(tile_op<OP_AMUL>(m, true, psi, nullptr, nullptr, wT, 0.0));
     k_sub<<<RG, RB, 0, s>>>(rT, src, wT, n);
@@ -2195,7 +2195,7 @@ extern "C" int mi_pbicgstab_solve(mi_matrix_t m, double* psi_io, const double* s
     MICHK(m->vec(13, &res1));
     k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->perm(), psi, a->L.nCells);
     k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
-    HostPerf hp; std::vector<double> hist;
+    HostPerf hp; Table<double> hist;
     MICHK(host_prologue(m, ctl, psi, src, yA, rA, pA, hp, hist));
     if (hp.minIter > 0 || !hp.checkConvergence()) {
         HIPCHK(hipMemcpyAsync(rA0, rA, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
@@ -2258,7 +2258,7 @@ extern "C" int mi_smooth_solve(mi_matrix_t m, double* psi_io, const double* sour
     MICHK(m->vec(8, &psi2));
     k_gather_perm<<<RG, RB, 0, s>>>(psi_io, a->perm(), psi, a->L.nCells);
     k_gather_perm<<<RG, RB, 0, s>>>(source, a->perm(), src, a->L.nCells);
-    HostPerf hp; std::vector<double> hist;
+    HostPerf hp; Table<double> hist;
     hp.tolerance = ctl->tolerance; hp.relTol = ctl->relTol; hp.maxIter = ctl->maxIter; hp.minIter = ctl->minIter;
     double *cur = psi, *nxt = psi2;
     auto sweeps = [&](int cnt) -> int {
@@ -2382,7 +2382,7 @@ extern "C" int mi_layout_inherit_tiles(int32_t n_fine, const int32_t* restrict_m
                                        int32_t* part_out, int32_t* n_parts_out)
 {
     if (!restrict_map || !fine_tile_of_cell || !part_out || !n_parts_out) return fail(MI_ERR_ARG, "mi_layout_inherit_tiles: bad argument");
-    std::vector<int32_t> part;
+    Table<int32_t> part;
     int32_t nParts = 0;
     const std::string err = inherit_tiles(n_fine, restrict_map, fine_tile_of_cell, n_fine_tiles, n_coarse, n_coarse_faces, c_lower, c_upper, 0, nullptr, nullptr,
                                           cell_cap > 0 ? cell_cap : 1024, slot_cap > 0 ? slot_cap : 4094, part, nParts);

@@ -24,7 +24,7 @@ namespace {
 // ascending.  Upper-triangular order (lduAddressing; the coarse levels built here as well) has the owners ascending, so the owner
 // side is a RANGE of faces and needs no list (oF empty).
 struct CellFaces {
-    std::vector<int32_t> uS, oS; IndexList uF, oF;
+    Table<int32_t> uS, oS; IndexList uF, oF;
     template <class Fn> void for_each_other(int32_t c, Fn fn) const { for (int32_t j = uS[(size_t)c]; j < uS[(size_t)c + 1]; ++j) fn(uF[(size_t)j]); }
     template <class Fn> void for_each_owned(int32_t c, Fn fn) const
     {
@@ -35,7 +35,7 @@ struct CellFaces {
     int32_t degree(int32_t c) const { return uS[(size_t)c + 1] - uS[(size_t)c] + oS[(size_t)c + 1] - oS[(size_t)c]; }
 };
 // owner side as ranges (false: the owners are not ascending -- lists instead)
-bool owner_ranges(int32_t nFine, int32_t nFaces, const int32_t* lower, std::vector<int32_t>& oS)
+bool owner_ranges(int32_t nFine, int32_t nFaces, const int32_t* lower, Table<int32_t>& oS)
 {
     std::atomic<bool> unsorted{false};
     parallel_blocks(nFaces, 1 << 18, [&](int64_t b, int64_t e, int) { bool u = false; for (int64_t f = std::max<int64_t>(b, 1); f < e; ++f) u |= lower[f] < lower[f - 1]; if (u) unsorted = true; });
@@ -57,14 +57,14 @@ void cell_faces(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32
 // all.  They are only missed by the cells that find no free neighbour and JOIN across their heaviest face: those are collected,
 // their neighbour-side faces bucketed in one pass over the faces, and the joins resolved in visiting order afterwards (a join
 // reads the coarse cell of its target, which was paired, or joined at an earlier turn: the same value at either time).
-int32_t match_pairs_forward_owned(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32_t* upper, const std::vector<int32_t>& oS,
-                                  const double* w, std::vector<int32_t>& coarseOf)
+int32_t match_pairs_forward_owned(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32_t* upper, const Table<int32_t>& oS,
+                                  const double* w, Table<int32_t>& coarseOf)
 {
     (void)lower;
     coarseOf.assign((size_t)nFine, -1);
     int32_t nCoarse = 0;
     const double NEG = -1e20;
-    std::vector<int32_t> joiners;
+    Table<int32_t> joiners;
     for (int32_t c = 0; c < nFine; ++c) {
         if (coarseOf[c] >= 0) continue;
         int32_t pick = -1; double best = NEG;
@@ -73,7 +73,7 @@ int32_t match_pairs_forward_owned(int32_t nFine, int32_t nFaces, const int32_t* 
         else joiners.push_back(c);
     }
     if (!joiners.empty()) {
-        std::vector<int32_t> jIndex((size_t)nFine, -1), jS; IndexList jF;
+        Table<int32_t> jIndex((size_t)nFine, -1), jS; IndexList jF;
         for (size_t k = 0; k < joiners.size(); ++k) jIndex[(size_t)joiners[k]] = (int32_t)k;
         bucket_items(nFaces, (int32_t)joiners.size(), [&](int64_t f) { return jIndex[(size_t)upper[f]]; }, jS, jF);
         for (size_t k = 0; k < joiners.size(); ++k) {
@@ -93,7 +93,7 @@ int32_t match_pairs_forward_owned(int32_t nFine, int32_t nFaces, const int32_t* 
 // is still to come can be free: on a forward sweep those are across the faces the cell OWNS, on a backward sweep across the
 // others, and the other half of the list is skipped without a look at its state (same picks: it never held a free cell).
 int32_t match_pairs_sequential(int32_t nFine, const int32_t* lower, const int32_t* upper, const CellFaces& F,
-                               const double* w, bool forward, bool laterOnly, std::vector<int32_t>& coarseOf)
+                               const double* w, bool forward, bool laterOnly, Table<int32_t>& coarseOf)
 {
     coarseOf.assign((size_t)nFine, -1);
     int32_t nCoarse = 0;
@@ -140,7 +140,7 @@ struct PairGraph {   // the cell graph of one level for greedy_match_parallel (h
 // the cell whose turn made it, a cell that joined gets the coarse cell across its heaviest face (which that cell had at that
 // moment: it was paired, or had joined at an earlier turn), singletons come last.
 int32_t match_pairs(int32_t nFine, int32_t nFaces, const int32_t* lower, const int32_t* upper,
-                    const double* w, bool forward, std::vector<int32_t>& coarseOf)
+                    const double* w, bool forward, Table<int32_t>& coarseOf)
 {
 #ifdef MI_TIMING
     auto t__ = std::chrono::steady_clock::now();
@@ -167,17 +167,17 @@ int32_t match_pairs(int32_t nFine, int32_t nFaces, const int32_t* lower, const i
     if (!parallel) { const int32_t nc = match_pairs_sequential(nFine, lower, upper, F, w, forward, laterOnly, coarseOf); sub("the sequential loop"); return nc; }
     // per list entry: the cell across and the weight (the decisions are taken in wavefront order, not in index order: every
     // indirection less is a cache miss less)
-    std::vector<int32_t> start((size_t)nFine + 1, 0);
+    Table<int32_t> start((size_t)nFine + 1, 0);
     parallel_for(nFine, 1 << 18, [&](int64_t c) { start[(size_t)c + 1] = F.degree((int32_t)c); });
     parallel_inclusive_scan(start.data() + 1, (int64_t)nFine);
-    std::vector<int32_t> nbr((size_t)start[(size_t)nFine]);
-    std::vector<double> wj((size_t)start[(size_t)nFine]);
+    Table<int32_t> nbr((size_t)start[(size_t)nFine]);
+    Table<double> wj((size_t)start[(size_t)nFine]);
     parallel_for(nFine, 1 << 16, [&](int64_t c) {
         int32_t o = start[(size_t)c];
         F.for_each((int32_t)c, [&](int32_t f) { nbr[(size_t)o] = upper[f] == (int32_t)c ? lower[f] : upper[f]; wj[(size_t)o] = w[(size_t)f]; ++o; });
     });
     PairGraph g{nFine, forward, start.data(), nbr.data(), wj.data()};
-    std::vector<int32_t> mate; std::vector<uint8_t> proposer;
+    Table<int32_t> mate; Table<uint8_t> proposer;
     greedy_match_parallel(g, mate, proposer);
     // the cell across the heaviest face (first maximum in list order), or -1: where an unmatched cell joins
     auto join_target = [&](int32_t c) {
@@ -186,12 +186,12 @@ int32_t match_pairs(int32_t nFine, int32_t nFaces, const int32_t* lower, const i
         return join;
     };
     // ranks in visiting order: pairs by the cell whose turn made them, then the singletons
-    std::vector<int32_t> rank((size_t)nFine);
+    Table<int32_t> rank((size_t)nFine);
     auto cell_at = [&](int64_t k) { return forward ? (int32_t)k : nFine - 1 - (int32_t)k; };
     parallel_for(nFine, 1 << 18, [&](int64_t k) { rank[(size_t)k] = proposer[(size_t)cell_at(k)]; });
     parallel_inclusive_scan(rank.data(), (int64_t)nFine);
     const int32_t nPairs = nFine > 0 ? rank[(size_t)nFine - 1] : 0;
-    std::vector<int32_t> single((size_t)nFine);
+    Table<int32_t> single((size_t)nFine);
     parallel_for(nFine, 1 << 16, [&](int64_t k) { const int32_t c = cell_at(k); single[(size_t)k] = (mate[(size_t)c] == c && join_target(c) < 0) ? 1 : 0; });
     parallel_inclusive_scan(single.data(), (int64_t)nFine);
     const int32_t nCoarse = nPairs + (nFine > 0 ? single[(size_t)nFine - 1] : 0);
@@ -229,7 +229,7 @@ void build_coarse_faces(GamgLevelHost& L, const int32_t* lower, const int32_t* u
     sub("allocate");
     // cut faces bucketed by owner (= smaller coarse cell), ascending fine face inside a bucket (bucket_items: the stable counting
     // sort, threaded); flat arrays and per-owner work only, so the owners are processed by the host threads independently
-    std::vector<int32_t> oStart; IndexList oFace;
+    Table<int32_t> oStart; IndexList oFace;
     parallel_for(nF, 1 << 16, [&](int64_t f) {   // interior: -(coarse cell + 1); cut: for now the owner
         const int32_t ru = L.restrictMap[(size_t)upper[f]], rl = L.restrictMap[(size_t)lower[f]];
         L.faceRestrict[(size_t)f] = ru == rl ? -(ru + 1) : std::min(ru, rl);
@@ -240,9 +240,9 @@ void build_coarse_faces(GamgLevelHost& L, const int32_t* lower, const int32_t* u
     sub("bucket cut faces by owner");
     // distinct neighbours of every owner in order of first appearance: per cut face its position in that list (and the flip:
     // the fine lower -> upper direction runs against the coarse owner -> neighbour one when the UPPER cell is in the owner) ...
-    std::vector<int32_t> base((size_t)nC + 1, 0); IndexList oAt(oFace.size()), oNei(oFace.size());
+    Table<int32_t> base((size_t)nC + 1, 0); IndexList oAt(oFace.size()), oNei(oFace.size());
     parallel_blocks(nC, 32768, [&](int64_t b, int64_t e, int) {
-        std::vector<int32_t> seen;
+        Table<int32_t> seen;
         for (int32_t c = (int32_t)b; c < (int32_t)e; ++c) {
             seen.clear();
             for (int32_t j = oStart[c]; j < oStart[(size_t)c + 1]; ++j) {
@@ -281,7 +281,7 @@ void build_coarse_faces(GamgLevelHost& L, const int32_t* lower, const int32_t* u
 }
 
 template <class Vec>
-void segment(int32_t nTargets, const Vec& target, std::vector<int32_t>& start, std::vector<int32_t>& child)
+void segment(int32_t nTargets, const Vec& target, Table<int32_t>& start, Table<int32_t>& child)
 {
     // children of target t = all i with target[i] == t, ascending i (the stable counting sort, threaded); negatives skipped
     bucket_items((int64_t)target.size(), nTargets, [&](int64_t i) { return target[(size_t)i]; }, start, child);
@@ -307,8 +307,8 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
     int32_t nFine = nCells, nF = nFaces;
     const int32_t *lo = lower, *up = upper;
     const int32_t nPatches = cpl ? cpl->nPatches : 0;
-    std::vector<std::vector<int32_t>> pfc, pnb; // patch faceCells / local neighbour cells of the current fine level
-    std::vector<GamgCoupling::Ami> pami;        // AMI tables of the current fine level (cyclicAMI patches)
+    Table<Table<int32_t>> pfc, pnb; // patch faceCells / local neighbour cells of the current fine level
+    Table<GamgCoupling::Ami> pami;        // AMI tables of the current fine level (cyclicAMI patches)
     if (cpl) { pfc = cpl->faceCells; pnb = cpl->nbrCells; pami = cpl->ami; pami.resize((size_t)nPatches); }
     for (int32_t p = 0; p < nPatches; ++p) if (cpl->isLocal[p] == 2) {
         if (mergeLevels != 1) return "cyclicAMI patches are agglomerated with mergeLevels 1 only";
@@ -325,7 +325,7 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
     }
     // partner on another rank: transport-patch face that carries the value behind partner face J, on the current fine level
     // (a partner side split over several ranks: partner faces numbered piece by piece, amiSlot = the piece = which transport patch)
-    std::vector<std::vector<int32_t>> amiSrc((size_t)nPatches), amiSlot((size_t)nPatches);
+    Table<Table<int32_t>> amiSrc((size_t)nPatches), amiSlot((size_t)nPatches);
     for (int32_t p = 0; p < nPatches; ++p) if (cpl && cpl->isLocal[p] == 2 && pami[(size_t)p].transport >= 0) {
         const GamgCoupling::Ami& A = pami[(size_t)p];
         for (size_t q = 0; q < A.transports.size(); ++q)
@@ -357,7 +357,7 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
         }
         if (nPatches > 0) {
             // coarse-cell ids on both sides of every coupled patch face
-            std::vector<std::vector<int32_t>> mine((size_t)nPatches), theirs((size_t)nPatches), send((size_t)nPatches);
+            Table<Table<int32_t>> mine((size_t)nPatches), theirs((size_t)nPatches), send((size_t)nPatches);
             bool anyRemote = false;
             for (int32_t p = 0; p < nPatches; ++p) {
                 mine[p].resize(pfc[p].size());
@@ -370,7 +370,7 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
             }
             if (anyRemote) {
                 if (!cpl->nbrRestrict) return "processor patches need the nbrRestrict callback";
-                std::vector<std::vector<int32_t>> recv((size_t)nPatches);
+                Table<Table<int32_t>> recv((size_t)nPatches);
                 if (!cpl->nbrRestrict(cpl->user, (int)H.levels.size(), send, recv)) return "exchange of the restrict addressing failed";
                 for (int32_t p = 0; p < nPatches; ++p) if (!cpl->isLocal[p]) {
                     if (recv[p].size() != mine[p].size()) return "exchange of the restrict addressing returned a wrong size";
@@ -417,12 +417,12 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
             // the coarse AMI of every cyclicAMI patch: fine faces in order, their addresses in order; an address whose coarse
             // target is already listed adds fineArea*weight, a new one is appended; then every list is divided by its sum
             // (normaliseWeights with conformal = true).  Host arithmetic of the reference: product, then addition.
-            std::vector<GamgCoupling::Ami> next((size_t)nPatches);
+            Table<GamgCoupling::Ami> next((size_t)nPatches);
             for (int32_t p = 0; p < nPatches; ++p) if (cpl->isLocal[p] == 2) {
                 const GamgCoupling::Ami& F = pami[(size_t)p];
                 GamgPatchHost& P = L.patches[p];
-                const std::vector<int32_t>& srcR = P.faceRestrict;
-                std::vector<int32_t> remoteR, nextSrc, nextSlot, nextCount;
+                const Table<int32_t>& srcR = P.faceRestrict;
+                Table<int32_t> remoteR, nextSrc, nextSlot, nextCount;
                 if (F.transport >= 0) {
                     // The partner's face restrict map, derived here: its coarse faces are its distinct coarse cells in order of
                     // first appearance over its faces (cyclicAMIGAMGInterface.C:47-165 -- what the partner rank builds for its
@@ -430,8 +430,8 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                     // amiSrc[J] (theirs[transport]).  nextSrc: the coarse transport face that carries each new partner face.
                     // A partner side split over several ranks: every piece is agglomerated by ITS rank, so the first-appearance rule runs
                     // piece by piece (the pieces' faces are numbered one after the other, on every level).
-                    const std::vector<int32_t>& src = amiSrc[(size_t)p];
-                    const std::vector<int32_t>& slot = amiSlot[(size_t)p];
+                    const Table<int32_t>& src = amiSrc[(size_t)p];
+                    const Table<int32_t>& slot = amiSlot[(size_t)p];
                     std::unordered_map<uint64_t, int32_t> cellToFace;
                     remoteR.resize(src.size());
                     nextCount.assign(F.transports.size(), 0);
@@ -449,15 +449,15 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
                         } else remoteR[J] = it->second;
                     }
                 }
-                const std::vector<int32_t>& tgtR = F.transport >= 0 ? remoteR : L.patches[(size_t)F.nbrPatch].faceRestrict;
+                const Table<int32_t>& tgtR = F.transport >= 0 ? remoteR : L.patches[(size_t)F.nbrPatch].faceRestrict;
                 const size_t nc = P.faceCells.size();
-                std::vector<std::vector<int32_t>> el(nc);
-                std::vector<std::vector<double>> wl(nc);
+                Table<Table<int32_t>> el(nc);
+                Table<Table<double>> wl(nc);
                 P.amiMagSf.assign(nc, 0.0);
                 for (size_t i = 0; i < srcR.size(); ++i) P.amiMagSf[(size_t)srcR[i]] += F.magSf[i];
                 for (size_t i = 0; i < srcR.size(); ++i) {
-                    std::vector<int32_t>& e = el[(size_t)srcR[i]];
-                    std::vector<double>& ww = wl[(size_t)srcR[i]];
+                    Table<int32_t>& e = el[(size_t)srcR[i]];
+                    Table<double>& ww = wl[(size_t)srcR[i]];
                     const double fineArea = F.magSf[i];
                     for (int32_t k = F.start[i]; k < F.start[i + 1]; ++k) {
                         const int32_t K = tgtR[(size_t)F.addr[(size_t)k]];
@@ -551,9 +551,9 @@ __attribute__((target("avx2"))) static bool invert_dense_avx2(int n, double* A, 
 #endif
 static bool invert_dense_base(int n, double* A, double* I) { return invert_dense_impl<0>(n, A, I); }
 
-bool invert_dense(int n, std::vector<double>& A)
+bool invert_dense(int n, Table<double>& A)
 {
-    std::vector<double> I((size_t)n * n, 0.0);
+    Table<double> I((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) I[(size_t)i * n + i] = 1.0;
     bool ok;
 #if defined(__x86_64__)

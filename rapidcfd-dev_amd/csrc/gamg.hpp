@@ -20,36 +20,36 @@ namespace mi {
 // one coarse interface face per distinct (local coarse cell, neighbour coarse cell) pair, in order of first
 // appearance among the fine patch faces -- both sides visit matching faces in the same order, so they agree)
 struct GamgPatchHost {
-    std::vector<int32_t> faceCells;     // [nCoarseIfaceFaces] coarse cell on this side
-    std::vector<int32_t> nbrCells;      // [nCoarseIfaceFaces] coarse cell on the other side (its owner's numbering)
-    std::vector<int32_t> faceRestrict;  // [nFineIfaceFaces] -> coarse interface face
-    std::vector<int32_t> childStart, child; // fine patch faces of every coarse interface face, ascending
+    Table<int32_t> faceCells;     // [nCoarseIfaceFaces] coarse cell on this side
+    Table<int32_t> nbrCells;      // [nCoarseIfaceFaces] coarse cell on the other side (its owner's numbering)
+    Table<int32_t> faceRestrict;  // [nFineIfaceFaces] -> coarse interface face
+    Table<int32_t> childStart, child; // fine patch faces of every coarse interface face, ascending
     // cyclicAMI patch (cyclicAMIGAMGInterface.C:47-165): one coarse face per distinct LOCAL coarse cell; the AMI of the coarse
     // side is the fine one agglomerated over both sides' face maps (AMIInterpolation::agglomerate, AMIInterpolation.C:279-540)
-    std::vector<int32_t> amiStart, amiAddr; // [nCoarse+1], coarse face of the neighbour patch
-    std::vector<double> amiW, amiMagSf;     // weights normalised per coarse face; agglomerated face areas
+    Table<int32_t> amiStart, amiAddr; // [nCoarse+1], coarse face of the neighbour patch
+    Table<double> amiW, amiMagSf;     // weights normalised per coarse face; agglomerated face areas
     // cyclicAMI whose partner patch lives on another rank: amiAddr numbers the PARTNER's coarse faces (its own order: distinct
     // partner coarse cells in order of first appearance); amiSrcFace[J] = face of this level's TRANSPORT patch whose received
     // value is the coarse cell behind partner face J (what mi_addr_set_ami_patch_remote takes as address)
-    std::vector<int32_t> amiSrcFace;
+    Table<int32_t> amiSrcFace;
     // partner SIDE split over several ranks: amiSrcSlot[J] = which of the patch's transport patches carries it (all 0 for one partner),
     // amiPartCount[q] = partner coarse faces that arrive through transport q (partner faces are numbered piece by piece)
-    std::vector<int32_t> amiSrcSlot, amiPartCount;
+    Table<int32_t> amiSrcSlot, amiPartCount;
 };
 
 // (the per-face tables are written completely by threaded passes: a resize() that zeroes 100+ MB on one thread first is time)
 template <class T> using HostVec = std::vector<T, NoInitAlloc<T>>;
 struct GamgLevelHost {
     int32_t nFine = 0, nFineFaces = 0, nCoarse = 0, nCoarseFaces = 0;
-    std::vector<int32_t> restrictMap;    // [nFine] -> coarse cell
+    Table<int32_t> restrictMap;    // [nFine] -> coarse cell
     HostVec<int32_t> faceRestrict;       // [nFineFaces] coarse face or -(coarseCell+1)
     HostVec<uint8_t> faceFlip;           // [nFineFaces]
     HostVec<int32_t> cLower, cUpper;     // coarse addressing
     // segmented children (ascending fine index inside every segment = the reference's stable sort)
-    std::vector<int32_t> cellChildStart, cellChild;   // children cells of every coarse cell
-    std::vector<int32_t> faceChildStart, faceChild;   // fine faces mapped onto every coarse face
-    std::vector<int32_t> diagChildStart, diagChild;   // fine faces interior to every coarse cell
-    std::vector<GamgPatchHost> patches;               // coupled patches of the COARSE side of this level
+    Table<int32_t> cellChildStart, cellChild;   // children cells of every coarse cell
+    Table<int32_t> faceChildStart, faceChild;   // fine faces mapped onto every coarse face
+    Table<int32_t> diagChildStart, diagChild;   // fine faces interior to every coarse cell
+    Table<GamgPatchHost> patches;               // coupled patches of the COARSE side of this level
 };
 
 // The two places where the ranks of a decomposed case have to talk while the hierarchy is built:
@@ -59,23 +59,23 @@ struct GamgLevelHost {
 // Local (cyclic) patches are resolved by the builder itself; processor patches go through the callbacks.
 struct GamgCoupling {
     int32_t nPatches = 0;
-    std::vector<std::vector<int32_t>> faceCells;   // finest level, per patch
-    std::vector<std::vector<int32_t>> nbrCells;    // finest level, per patch; empty vector = processor patch
-    std::vector<char> isLocal;                     // per patch: 0 processor, 1 cyclic (nbrCells), 2 cyclicAMI (ami tables)
+    Table<Table<int32_t>> faceCells;   // finest level, per patch
+    Table<Table<int32_t>> nbrCells;    // finest level, per patch; empty vector = processor patch
+    Table<char> isLocal;                     // per patch: 0 processor, 1 cyclic (nbrCells), 2 cyclicAMI (ami tables)
     // transport >= 0: the partner patch lives on another rank; `transport` is the processor patch of THIS domain that carries the
     // partner's patch-internal field (same size on both ranks), nPartner the partner patch's face count, addr numbers its faces
     // transports / partCount: the partner SIDE is split over several ranks -- one transport patch per piece, addr numbers the pieces' faces
     // concatenated (transport == transports[0], nPartner == the sum of partCount)
-    struct Ami { int32_t nbrPatch = -1; std::vector<int32_t> start, addr; std::vector<double> w, magSf; int32_t transport = -1, nPartner = 0; std::vector<int32_t> transports, partCount; };
-    std::vector<Ami> ami;                          // per patch (nbrPatch < 0: not an AMI patch); finest level
+    struct Ami { int32_t nbrPatch = -1; Table<int32_t> start, addr; Table<double> w, magSf; int32_t transport = -1, nPartner = 0; Table<int32_t> transports, partCount; };
+    Table<Ami> ami;                          // per patch (nbrPatch < 0: not an AMI patch); finest level
     bool (*allAnd)(void* user, bool v) = nullptr;
     // in: send[p] = local coarse ids of patch p's cells (processor patches only); out: recv[p] same length
-    bool (*nbrRestrict)(void* user, int level, const std::vector<std::vector<int32_t>>& send, std::vector<std::vector<int32_t>>& recv) = nullptr;
+    bool (*nbrRestrict)(void* user, int level, const Table<Table<int32_t>>& send, Table<Table<int32_t>>& recv) = nullptr;
     void* user = nullptr;
 };
 
 struct GamgHierarchyHost {
-    std::vector<GamgLevelHost> levels;
+    Table<GamgLevelHost> levels;
     bool forwardOut = true;
     // Called (when set, mergeLevels == 1) as soon as a level's coarse addressing and patches are final -- BEFORE the pair
     // matching of the next level starts; levels is reserved up front, so &levels[level] stays valid.  The engine uses it to
@@ -98,6 +98,6 @@ std::string build_gamg_hierarchy(int32_t nCells, int32_t nFaces, const int32_t* 
 // of the LAST pair step is kept, the earlier ones are dropped -- the reference's behaviour, reproduced as is).
 
 // dense inverse by Gauss-Jordan with partial pivoting (coarsest level); returns false if singular
-bool invert_dense(int n, std::vector<double>& A);
+bool invert_dense(int n, Table<double>& A);
 
 } // namespace mi

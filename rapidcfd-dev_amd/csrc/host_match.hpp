@@ -55,21 +55,21 @@ struct TeamBarrier {
 // Result: mate[v] = partner of v, or v itself when v left the pool alone; proposer[v] = 1 for the vertex of a pair whose turn
 // made the pair (the one visited first).
 template <class G>
-void greedy_match_parallel(const G& g, std::vector<int32_t>& mate, std::vector<uint8_t>& proposer)
+void greedy_match_parallel(const G& g, Table<int32_t>& mate, Table<uint8_t>& proposer)
 {
     const int32_t n = g.n;
     const bool fwd = g.forward;
     auto before = [fwd](int32_t a, int32_t b) { return fwd ? a < b : a > b; };
     mate.assign((size_t)n, -1);
     proposer.assign((size_t)n, 0);
-    std::vector<int32_t> pending((size_t)n);   // earlier neighbours that have not had their turn yet
-    std::vector<uint8_t> done((size_t)n, 0);
+    Table<int32_t> pending((size_t)n);   // earlier neighbours that have not had their turn yet
+    Table<uint8_t> done((size_t)n, 0);
     // work lists: the round's list is ONE array (threads take blocks of it through a cursor); what a round activates goes to the
     // activating thread's own list (no shared counter in the hot path) and is gathered into the array between the rounds
     const int nt = host_threads();
-    std::vector<int32_t> cur((size_t)n);
-    std::vector<std::vector<int32_t>> mine((size_t)nt);
-    std::vector<int64_t> offset((size_t)nt + 1, 0);
+    Table<int32_t> cur((size_t)n);
+    Table<Table<int32_t>> mine((size_t)nt);
+    Table<int64_t> offset((size_t)nt + 1, 0);
     std::atomic<int64_t> cursor{0};
     int64_t nCur = 0;
     int32_t* M = mate.data();
@@ -86,14 +86,14 @@ void greedy_match_parallel(const G& g, std::vector<int32_t>& mate, std::vector<u
         });
         nCur = k0.load();
     }
-    auto resolve = [&](int32_t x, std::vector<int32_t>& out) {   // x has had its turn (or was taken): its later neighbours lose one pending vertex
+    auto resolve = [&](int32_t x, Table<int32_t>& out) {   // x has had its turn (or was taken): its later neighbours lose one pending vertex
         __atomic_store_n(D + x, (uint8_t)1, __ATOMIC_RELEASE);
         for (int64_t j = g.begin(x); j < g.end(x); ++j) {
             const int32_t y = g.other(x, j);
             if (before(x, y) && __atomic_fetch_sub(&pending[(size_t)y], 1, __ATOMIC_ACQ_REL) == 1) out.push_back(y);
         }
     };
-    auto process = [&](int32_t v, std::vector<int32_t>& out) {
+    auto process = [&](int32_t v, Table<int32_t>& out) {
         if (__atomic_load_n(M + v, __ATOMIC_ACQUIRE) >= 0) return;   // taken before its turn: resolved by the vertex that took it
         typename G::Weight best = G::none();
         int32_t pick = -1;
@@ -125,7 +125,7 @@ void greedy_match_parallel(const G& g, std::vector<int32_t>& mate, std::vector<u
     // between two rounds (run by the last thread to finish its copy): the next list is complete; short rounds are run here
     auto between = [&] {
         nCur = total.load(std::memory_order_relaxed);
-        std::vector<int32_t> a, b;
+        Table<int32_t> a, b;
         while (nCur > 0 && nCur <= small) {
             a.assign(cur.begin(), cur.begin() + nCur);
             while (!a.empty() && (int64_t)a.size() <= small) { b.clear(); for (int32_t v : a) process(v, b); a.swap(b); }
@@ -139,7 +139,7 @@ void greedy_match_parallel(const G& g, std::vector<int32_t>& mate, std::vector<u
     total.store(nCur);
     between();
     auto team = [&](int tid) {
-        std::vector<int32_t>& out = mine[(size_t)tid];
+        Table<int32_t>& out = mine[(size_t)tid];
         while (!finished) {
             const int64_t m = nCur;
             for (;;) {
@@ -155,7 +155,7 @@ void greedy_match_parallel(const G& g, std::vector<int32_t>& mate, std::vector<u
             bar.wait(between);                            // the next round's list is published
         }
     };
-    std::vector<std::thread> pool;
+    Table<std::thread> pool;
     for (int t = 1; t < nt; ++t) pool.emplace_back(team, t);
     team(0);
     for (auto& t : pool) t.join();

@@ -12,6 +12,8 @@
 #include <utility>
 #include <vector>
 
+#include "host_tables.hpp"
+
 namespace mi {
 // Host threads for the one-time layout build: plain std::thread workers pulling blocks of `grain` indices from an atomic
 // counter (no OpenMP runtime to clash with the caller's).  Everything built under it is independent per index, so the
@@ -130,22 +132,16 @@ void parallel_inclusive_scan(T* v, int64_t n)
 // the items of bucket b in ASCENDING item order -- what the sequential count / prefix / fill passes produce.  Threads fill
 // the buckets through atomic cursors in whatever order they run, then every bucket is sorted (they are short: the faces of a
 // cell, the children of a coarse cell).
-// (List: std::vector<int32_t>, or IndexList whose resize() does not zero what the fill pass writes anyway)
-template <class T>
-struct NoInitAlloc : std::allocator<T> {
-    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
-    template <class U, class... A> void construct(U* p, A&&... a) { if (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...); }
-};
-typedef std::vector<int32_t, NoInitAlloc<int32_t>> IndexList;
+// (List: Table<int32_t>, or IndexList whose resize() does not zero what the fill pass writes anyway)
 template <class Key, class List>
-void bucket_items(int64_t n, int32_t nBuckets, Key key, std::vector<int32_t>& start, List& list)
+void bucket_items(int64_t n, int32_t nBuckets, Key key, Table<int32_t>& start, List& list)
 {
     start.assign((size_t)nBuckets + 1, 0);
     if (host_threads() == 1 || n < (1 << 16)) {
         for (int64_t i = 0; i < n; ++i) { const int32_t k = key(i); if (k >= 0) ++start[(size_t)k + 1]; }
         for (int32_t b = 0; b < nBuckets; ++b) start[(size_t)b + 1] += start[(size_t)b];
         list.resize((size_t)start[(size_t)nBuckets]);
-        std::vector<int32_t> fill(start.begin(), start.end() - 1);
+        Table<int32_t> fill(start.begin(), start.end() - 1);
         for (int64_t i = 0; i < n; ++i) { const int32_t k = key(i); if (k >= 0) list[(size_t)fill[(size_t)k]++] = (int32_t)i; }
         return;
     }
@@ -154,7 +150,7 @@ void bucket_items(int64_t n, int32_t nBuckets, Key key, std::vector<int32_t>& st
     const int64_t nChunks = std::min<int64_t>(4 * (int64_t)host_threads(), (n + (1 << 16) - 1) >> 16);
     if ((int64_t)nBuckets * nChunks <= 2 * n) {
         const int64_t per = (n + nChunks - 1) / nChunks;
-        std::vector<int32_t> hist((size_t)(nBuckets * nChunks), 0);
+        Table<int32_t> hist((size_t)(nBuckets * nChunks), 0);
         parallel_for(nChunks, 1, [&](int64_t c) {
             int32_t* h = hist.data() + (size_t)c * (size_t)nBuckets;
             for (int64_t i = c * per, e = std::min(n, (c + 1) * per); i < e; ++i) { const int32_t k = key(i); if (k >= 0) ++h[k]; }

@@ -29,12 +29,12 @@ namespace {
 // One level of the multilevel clustering graph (CSR, undirected, both directions stored).
 struct Graph {
     int32_t n = 0;
-    std::vector<int64_t> xadj;
+    Table<int64_t> xadj;
     std::vector<int32_t, NoInitAlloc<int32_t>> adj;
     std::vector<int32_t, NoInitAlloc<int32_t>> ew;   // edge weight = number of mesh faces between the clusters
-    std::vector<int32_t> vw;   // cells in cluster
-    std::vector<int32_t> vinc; // face incidences of the cluster's cells (internal counted twice)
-    std::vector<int32_t> vint; // faces internal to the cluster
+    Table<int32_t> vw;   // cells in cluster
+    Table<int32_t> vinc; // face incidences of the cluster's cells (internal counted twice)
+    Table<int32_t> vint; // faces internal to the cluster
 };
 
 struct ClusterGraph {   // one level of the clustering graph for greedy_match_parallel (host_match.hpp)
@@ -57,16 +57,16 @@ struct ClusterGraph {   // one level of the clustering graph for greedy_match_pa
 // Heavy-edge matching with size caps; returns number of coarse vertices and cmap.
 // Large levels: the same decisions taken by the host threads (host_match.hpp); coarse vertex ids are the ranks of the vertices
 // whose turn made a pair or that stayed alone, in index order.
-int32_t match_level(const Graph& g, int32_t cellCap, int32_t slotCap, std::vector<int32_t>& cmap, std::vector<int32_t>& match)
+int32_t match_level(const Graph& g, int32_t cellCap, int32_t slotCap, Table<int32_t>& cmap, Table<int32_t>& match)
 {
     const int32_t n = g.n;
     match.resize((size_t)n);
     cmap.resize((size_t)n);
     if (host_threads() > 1 && n >= (1 << 15) && env_int_host("MI_MATCH_PARALLEL", 0) != 0) {
         ClusterGraph cg{n, true, &g, cellCap, slotCap};
-        std::vector<uint8_t> proposer;
+        Table<uint8_t> proposer;
         greedy_match_parallel(cg, match, proposer);
-        std::vector<int32_t> rank((size_t)n);
+        Table<int32_t> rank((size_t)n);
         parallel_for(n, 1 << 18, [&](int64_t v) { rank[(size_t)v] = (proposer[(size_t)v] || match[(size_t)v] == (int32_t)v) ? 1 : 0; });
         parallel_inclusive_scan(rank.data(), (int64_t)n);
         parallel_for(n, 1 << 18, [&](int64_t v) {
@@ -98,12 +98,12 @@ int32_t match_level(const Graph& g, int32_t cellCap, int32_t slotCap, std::vecto
     return nc;
 }
 
-void coarsen(const Graph& g, const std::vector<int32_t>& cmap, const std::vector<int32_t>& match, int32_t nc, Graph& c)
+void coarsen(const Graph& g, const Table<int32_t>& cmap, const Table<int32_t>& match, int32_t nc, Graph& c)
 {
     c.n = nc;
     c.vw.resize(nc); c.vinc.resize(nc); c.vint.resize(nc);
     // members of each coarse vertex (1 or 2): the vertex that was visited first (the smaller one) and its partner
-    std::vector<int32_t> first(nc, -1), second(nc, -1);
+    Table<int32_t> first(nc, -1), second(nc, -1);
     parallel_for(g.n, 1 << 16, [&](int64_t v) {
         const int32_t u = match[(size_t)v];
         if (u < (int32_t)v) return;
@@ -119,8 +119,8 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, const std::vector
     auto t__ = std::chrono::steady_clock::now();
 #endif
     c.xadj.assign((size_t)nc + 1, 0);
-    std::vector<int32_t> vintAdd((size_t)nc, 0);
-    auto build_row = [&](int32_t cv, std::vector<std::pair<int32_t, int32_t>>& tmp, int32_t& internal) {
+    Table<int32_t> vintAdd((size_t)nc, 0);
+    auto build_row = [&](int32_t cv, Table<std::pair<int32_t, int32_t>>& tmp, int32_t& internal) {
         tmp.clear(); internal = 0;
         for (int k = 0; k < 2; ++k) {
             const int32_t v = k ? second[cv] : first[cv];
@@ -140,7 +140,7 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, const std::vector
         tmp.resize(w);
     };
     parallel_blocks(nc, 16384, [&](int64_t b, int64_t e, int) {
-        std::vector<std::pair<int32_t, int32_t>> tmp;
+        Table<std::pair<int32_t, int32_t>> tmp;
         int32_t internal;
         for (int32_t cv = (int32_t)b; cv < (int32_t)e; ++cv) { build_row(cv, tmp, internal); c.xadj[(size_t)cv + 1] = (int64_t)tmp.size(); vintAdd[(size_t)cv] = internal; }
     });
@@ -150,7 +150,7 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, const std::vector
     c.adj.resize((size_t)c.xadj[nc]); c.ew.resize((size_t)c.xadj[nc]);
     MI_T("    coarsen: prefix+alloc");
     parallel_blocks(nc, 16384, [&](int64_t b, int64_t e, int) {
-        std::vector<std::pair<int32_t, int32_t>> tmp;
+        Table<std::pair<int32_t, int32_t>> tmp;
         int32_t internal;
         for (int32_t cv = (int32_t)b; cv < (int32_t)e; ++cv) {
             build_row(cv, tmp, internal);
@@ -163,22 +163,22 @@ void coarsen(const Graph& g, const std::vector<int32_t>& cmap, const std::vector
 // Reverse Cuthill-McKee ordering of the cell graph (new -> old): components started from their lowest-degree cell, neighbours
 // appended in order of increasing degree (ties by cell index: deterministic).  Host, sequential, only for meshes whose
 // numbering has no locality.
-void cuthill_mckee(int32_t n, const std::vector<int32_t>& ownStart, const std::vector<int32_t>& neiStart, const IndexList& ownFaces,
-                   const IndexList& neiFaces, const int32_t* lower, const int32_t* upper, std::vector<int32_t>& order)
+void cuthill_mckee(int32_t n, const Table<int32_t>& ownStart, const Table<int32_t>& neiStart, const IndexList& ownFaces,
+                   const IndexList& neiFaces, const int32_t* lower, const int32_t* upper, Table<int32_t>& order)
 {
-    std::vector<int32_t> deg((size_t)n);
+    Table<int32_t> deg((size_t)n);
     int32_t maxDeg = 0;
     for (int32_t c = 0; c < n; ++c) { deg[c] = (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]); maxDeg = std::max(maxDeg, deg[c]); }
-    std::vector<int32_t> byDeg((size_t)n); // cells by (degree, index): counting sort
+    Table<int32_t> byDeg((size_t)n); // cells by (degree, index): counting sort
     {
-        std::vector<int32_t> cnt((size_t)maxDeg + 2, 0);
+        Table<int32_t> cnt((size_t)maxDeg + 2, 0);
         for (int32_t c = 0; c < n; ++c) cnt[(size_t)deg[c] + 1]++;
         for (int32_t d = 0; d <= maxDeg; ++d) cnt[(size_t)d + 1] += cnt[d];
         for (int32_t c = 0; c < n; ++c) byDeg[(size_t)cnt[deg[c]]++] = c;
     }
-    std::vector<char> seen((size_t)n, 0);
+    Table<char> seen((size_t)n, 0);
     order.clear(); order.reserve((size_t)n);
-    std::vector<int32_t> nb;
+    Table<int32_t> nb;
     for (int32_t s = 0; s < n; ++s) {
         const int32_t start = byDeg[s];
         if (seen[start]) continue;
@@ -227,7 +227,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     // owner side: faces with lower==c ascending (ownerStartAddr); neighbour side:
     // faces with upper==c in losort order (stable sort by upper) -- lduAddressing.C:169-344
     // (threaded: buckets filled through atomic cursors, then sorted -- ascending face id inside a cell as the stable passes give)
-    std::vector<int32_t> ownStart, neiStart;
+    Table<int32_t> ownStart, neiStart;
     IndexList ownFaces, neiFaces, ownPos((size_t)nFaces); // ownPos: rank of f among its owner's faces
     if (lowerUnsorted) bucket_items(nFaces, nCells, [&](int64_t f) { return lower[f]; }, ownStart, ownFaces);
     else {
@@ -241,7 +241,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     bucket_items(nFaces, nCells, [&](int64_t f) { return upper[f]; }, neiStart, neiFaces);
     parallel_for(nCells, 1 << 16, [&](int64_t c) { for (int32_t j = ownStart[(size_t)c]; j < ownStart[(size_t)c + 1]; ++j) ownPos[(size_t)ownFaces[(size_t)j]] = j - ownStart[(size_t)c]; });
     // patch faces per cell (patch order, then face order)
-    std::vector<int32_t> pfStart((size_t)nCells + 1, 0), pfList((size_t)L.nExt);
+    Table<int32_t> pfStart((size_t)nCells + 1, 0), pfList((size_t)L.nExt);
     for (int32_t p = 0; p < nPatches; ++p)
         for (int32_t i = 0; i < patchSizes[p]; ++i) {
             const int32_t c = patchFaceCells[p][i];
@@ -250,14 +250,14 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         }
     for (int32_t c = 0; c < nCells; ++c) pfStart[(size_t)c + 1] += pfStart[c];
     {
-        std::vector<int32_t> cp(pfStart.begin(), pfStart.end() - 1);
+        Table<int32_t> cp(pfStart.begin(), pfStart.end() - 1);
         for (int32_t p = 0; p < nPatches; ++p)
             for (int32_t i = 0; i < patchSizes[p]; ++i)
                 pfList[(size_t)cp[patchFaceCells[p][i]]++] = L.patchOffset[p] + i;
     }
 
     // local coupled patches (cyclic): caller cell on the other side of every interface face, or -1 (ext region)
-    std::vector<int32_t> ifaceLocalNbr((size_t)L.nExt, -1);
+    Table<int32_t> ifaceLocalNbr((size_t)L.nExt, -1);
     if (patchNbrCells)
         for (int32_t p = 0; p < nPatches; ++p)
             if (patchNbrCells[p])
@@ -269,15 +269,15 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
 
     MI_T("face lists");
     // ---- multilevel heavy-edge clustering ------------------------------------
-    std::vector<int32_t> part((size_t)nCells);
+    Table<int32_t> part((size_t)nCells);
     std::iota(part.begin(), part.end(), 0);
     int32_t nClusters = nCells;
-    std::vector<int32_t> cmOrder, cmRank; // Cuthill-McKee ordering (new -> old) and its inverse, when the clustering runs on it
+    Table<int32_t> cmOrder, cmRank; // Cuthill-McKee ordering (new -> old) and its inverse, when the clustering runs on it
     if (prm.givenPart) {
         // given partition: checked against the caps (cells; slots = face incidences + patch faces - faces inside the tile)
         const int32_t nP = prm.nGivenParts;
         if (nP <= 0) return "given partition: no tiles";
-        std::vector<int32_t> cells((size_t)nP, 0), inc((size_t)nP, 0), internal((size_t)nP, 0);
+        Table<int32_t> cells((size_t)nP, 0), inc((size_t)nP, 0), internal((size_t)nP, 0);
         std::atomic<bool> bad{false};
         parallel_for(nCells, 1 << 16, [&](int64_t c) {
             const int32_t t = prm.givenPart[c];
@@ -368,7 +368,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         if (tooMany) return "a single cell has more faces than a tile can hold";
         if (reorder) for (int32_t c = 0; c < nCells; ++c) part[c] = cmRank[(size_t)c];
         // multi-edges (two faces between the same cell pair) are legal in LDU addressing; merge them
-        std::vector<int32_t> cmap, partner;
+        Table<int32_t> cmap, partner;
         for (int level = 0; level < 64; ++level) {
             const int32_t nc = match_level(g, prm.tileCells, prm.slotCap, cmap, partner);
             MI_T("  match");
@@ -389,12 +389,12 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     L.nTiles = nT;
     const bool byRank = !cmRank.empty(); // tiles and the cells inside them follow the ordering the clustering ran on
     {
-        std::vector<int32_t> tileMin((size_t)nT, INT32_MAX);   // smallest vertex of every tile (a minimum: any order of visits)
+        Table<int32_t> tileMin((size_t)nT, INT32_MAX);   // smallest vertex of every tile (a minimum: any order of visits)
         parallel_for(nCells, 1 << 16, [&](int64_t v) { atomic_min_i32(&tileMin[(size_t)part[(size_t)(byRank ? cmOrder[(size_t)v] : (int32_t)v)]], (int32_t)v); });
-        std::vector<int32_t> order((size_t)nT);
+        Table<int32_t> order((size_t)nT);
         std::iota(order.begin(), order.end(), 0);
         std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return tileMin[a] < tileMin[b]; });
-        std::vector<int32_t> rank((size_t)nT);
+        Table<int32_t> rank((size_t)nT);
         for (int32_t i = 0; i < nT; ++i) rank[order[i]] = i;
         parallel_for(nCells, 1 << 18, [&](int64_t c) { part[(size_t)c] = rank[(size_t)part[(size_t)c]]; });
     }
@@ -433,23 +433,27 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     // Every tile is built on its own (OpenMP over tiles: nothing a tile writes depends on another tile) into local tables;
     // a sequential pass then lays them end to end.  A cut face gets its faceSlot from the tile of its OWNER cell (both
     // tiles hold the coefficient), so the result does not depend on the order tiles are visited in.
+    // (their storage: the building thread's BumpArena, csrc/host_tables.hpp -- reserved to the sizes known before a tile is filled)
     struct TileOut {
-        std::vector<int32_t> slotFace, haloCell, sliceEntryStart, sliceEntryStart16;   // slice starts relative to the tile's first entry
-        std::vector<uint32_t> entries, entries16;
-        std::vector<uint16_t> slotBase;
-        std::vector<std::pair<int32_t, int32_t>> extSlot, faceSlot;                    // (ext / face id, local slot)
+        ArenaVec<int32_t> slotFace, haloCell, sliceEntryStart, sliceEntryStart16;   // slice starts relative to the tile's first entry
+        ArenaVec<uint32_t> entries, entries16;
+        ArenaVec<uint16_t> slotBase;
+        ArenaVec<std::pair<int32_t, int32_t>> extSlot, faceSlot;                    // (ext / face id, local slot)
         int32_t ifaceSlot0 = 0, nSlots = 0, nHalo = 0, nc = 0;
         bool boundary = false, fits16 = true;
         std::string err;
     };
-    std::vector<TileOut> outs((size_t)nT);
+    Table<TileOut> outs((size_t)nT);
     const bool wantCompact = prm.compact;
-    parallel_blocks(nT, 8, [&](int64_t tBegin, int64_t tEnd, int) {
+    Table<std::unique_ptr<BumpArena>> arenas((size_t)host_threads());
+    for (auto& a : arenas) { a.reset(new BumpArena()); a->chunk = std::min<size_t>((size_t)16 << 20, std::max<size_t>((size_t)64 << 10, (size_t)96 * (size_t)nCells / (size_t)host_threads())); }
+    parallel_blocks(nT, 8, [&](int64_t tBegin, int64_t tEnd, int worker) {
+    struct UseArena { explicit UseArena(BumpArena* a) { tile_arena_of_this_thread() = a; } ~UseArena() { tile_arena_of_this_thread() = nullptr; } } useArena(arenas[(size_t)worker].get());
     // per-block scratch: halo lookup by engine cell (open addressing, rebuilt per tile)
-    std::vector<RowEnt> rowEnt;          // entries of the rows of the current tile, row-major
-    std::vector<int32_t> rowEntStart, sbLocal, haloCnt, sbHalo;
-    std::vector<Pending> cutList, ifaceList;
-    std::vector<int32_t> hKey, hVal;      // hash table
+    Table<RowEnt> rowEnt;          // entries of the rows of the current tile, row-major
+    Table<int32_t> rowEntStart, sbLocal, haloCnt, sbHalo;
+    Table<Pending> cutList, ifaceList;
+    Table<int32_t> hKey, hVal;      // hash table
     auto hash_reset = [&](size_t want) { size_t cap = 64; while (cap < 2 * want) cap <<= 1; hKey.assign(cap, -1); hVal.assign(cap, 0); };
     for (int32_t t = (int32_t)tBegin; t < (int32_t)tEnd; ++t) {
         TileOut& O = outs[(size_t)t];
@@ -468,6 +472,23 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
             incid += (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]) + (pfStart[(size_t)c + 1] - pfStart[c]);
         }
         const int32_t nLocal = sbLocal[nc];
+        {   // sizes known now: the slots are at most one per incidence (+ the zero slot, + the pad), the entries exactly the slices' widths
+            O.slotFace.reserve((size_t)incid + 3); O.faceSlot.reserve((size_t)nLocal); O.haloCell.reserve((size_t)incid / 8 + 32);
+            size_t nEnt = 0, nEnt16 = 0, nPf = 0;
+            const int32_t nSl0 = (nc + 63) / 64;
+            for (int32_t sl = 0; sl < nSl0; ++sl) {
+                int32_t width = 0;
+                for (int32_t e = cs + sl * 64; e < std::min(ce, cs + sl * 64 + 64); ++e) {
+                    const int32_t c = L.e2c[e];
+                    width = std::max(width, (ownStart[(size_t)c + 1] - ownStart[c]) + (neiStart[(size_t)c + 1] - neiStart[c]) + (pfStart[(size_t)c + 1] - pfStart[c]));
+                    nPf += (size_t)(pfStart[(size_t)c + 1] - pfStart[c]);
+                }
+                nEnt += (size_t)width * 64; nEnt16 += (size_t)((width + 1) / 2) * 64;
+            }
+            O.entries.reserve(nEnt); O.extSlot.reserve(nPf);
+            if (wantCompact) O.entries16.reserve(nEnt16);
+            O.sliceEntryStart.reserve((size_t)nSl0 + 1); O.sliceEntryStart16.reserve((size_t)nSl0 + 1);
+        }
         hash_reset((size_t)incid + 8);
         const size_t hMask = hKey.size() - 1;
         auto halo_of = [&](int32_t engineCell) -> int32_t {
@@ -544,6 +565,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
         if ((O.slotFace.size() & 1u) != 0) O.slotFace.push_back(-1);
         // slot bases: local rows, halo cells, the pad cell (-> zero slot)
         if (wantCompact) {
+            O.slotBase.reserve((size_t)nc + (size_t)nHalo + 2);
             for (int32_t i = 0; i < nc; ++i) O.slotBase.push_back((uint16_t)sbLocal[i]);
             for (int32_t h = 0; h < nHalo; ++h) O.slotBase.push_back((uint16_t)sbHalo[h]);
             O.slotBase.push_back((uint16_t)nSlots);
@@ -597,7 +619,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
     }
     {
         // offsets of every tile (sequential: nT additions), then the copies and the face / ext slot scatters by the host threads
-        std::vector<size_t> sAt((size_t)nT + 1, 0), eAt((size_t)nT + 1, 0), e16At((size_t)nT + 1, 0), hAt((size_t)nT + 1, 0), sbAt((size_t)nT + 1, 0), slAt((size_t)nT + 1, 0);
+        Table<size_t> sAt((size_t)nT + 1, 0), eAt((size_t)nT + 1, 0), e16At((size_t)nT + 1, 0), hAt((size_t)nT + 1, 0), sbAt((size_t)nT + 1, 0), slAt((size_t)nT + 1, 0);
         for (int32_t t = 0; t < nT; ++t) {
             const TileOut& O = outs[(size_t)t];
             sAt[(size_t)t + 1] = sAt[(size_t)t] + O.slotFace.size(); eAt[(size_t)t + 1] = eAt[(size_t)t] + O.entries.size(); hAt[(size_t)t + 1] = hAt[(size_t)t] + O.haloCell.size();
@@ -631,13 +653,12 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
                 }
                 for (const auto& q : O.extSlot) L.extSlot[(size_t)q.first] = (int32_t)(sAt[(size_t)t] + (size_t)q.second);
                 for (const auto& q : O.faceSlot) L.faceSlot[(size_t)q.first] = (int32_t)(sAt[(size_t)t] + (size_t)q.second);
-                TileOut().slotFace.swap(O.slotFace); std::vector<uint32_t>().swap(O.entries); std::vector<uint32_t>().swap(O.entries16); // free as we go
             }
         });
     }
-    free_in_background(outs, ownStart, neiStart, ownFaces, neiFaces, ownPos, pfStart, pfList, part, ifaceLocalNbr);
+    free_in_background(outs, arenas, ownStart, neiStart, ownFaces, neiFaces, ownPos, pfStart, pfList, part, ifaceLocalNbr);
     MI_T("slots / halos / entries");
-    if (!L.compact) { std::vector<uint32_t>().swap(L.entries16); std::vector<int32_t>().swap(L.sliceEntryStart16); }
+    if (!L.compact) { Table<uint32_t>().swap(L.entries16); Table<int32_t>().swap(L.sliceEntryStart16); }
     L.nSlices = L.tileSliceStart[nT];
     L.totalSlots = (int64_t)L.slotFace.size();
     return std::string();
@@ -646,15 +667,15 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
 std::string inherit_tiles(int32_t nFine, const int32_t* restrictMap, const int32_t* fineTileOfCell, int32_t nFineTiles,
                           int32_t nCoarse, int32_t nCoarseFaces, const int32_t* cLower, const int32_t* cUpper,
                           int32_t nPatches, const int32_t* patchSizes, const int32_t* const* patchFaceCells,
-                          int32_t cellCap, int32_t slotCap, std::vector<int32_t>& part, int32_t& nParts)
+                          int32_t cellCap, int32_t slotCap, Table<int32_t>& part, int32_t& nParts)
 {
     if (nFine <= 0 || nCoarse <= 0 || nFineTiles <= 0) return "inherit_tiles: bad argument";
     const int32_t nT = nFineTiles;
     // a coarse cell goes where its first (smallest) child is
-    std::vector<int32_t> firstChild((size_t)nCoarse, INT32_MAX);
+    Table<int32_t> firstChild((size_t)nCoarse, INT32_MAX);
     parallel_for(nFine, 1 << 16, [&](int64_t fc) { atomic_min_i32(&firstChild[(size_t)restrictMap[fc]], (int32_t)fc); });
     part.resize((size_t)nCoarse);
-    std::vector<int32_t> vw((size_t)nT, 0), vinc((size_t)nT, 0), vint((size_t)nT, 0);
+    Table<int32_t> vw((size_t)nT, 0), vinc((size_t)nT, 0), vint((size_t)nT, 0);
     std::atomic<bool> bad{false};
     parallel_for(nCoarse, 1 << 16, [&](int64_t c) {
         if (firstChild[(size_t)c] == INT32_MAX) { bad = true; return; }
@@ -666,7 +687,7 @@ std::string inherit_tiles(int32_t nFine, const int32_t* restrictMap, const int32
     if (bad) return "inherit_tiles: a coarse cell without children, or a fine tile id out of range";
     for (int32_t p = 0; p < nPatches; ++p) for (int32_t i = 0; i < patchSizes[p]; ++i) ++vinc[(size_t)part[(size_t)patchFaceCells[p][i]]];
     // tile graph: faces between two tiles counted per unordered pair (thread-local tables, merged)
-    struct EdgeMap { std::vector<uint64_t> key; std::vector<int32_t> val; size_t mask = 0, used = 0;
+    struct EdgeMap { Table<uint64_t> key; Table<int32_t> val; size_t mask = 0, used = 0;
         void init(size_t cap) { size_t c = 64; while (c < cap) c <<= 1; key.assign(c, ~0ull); val.assign(c, 0); mask = c - 1; used = 0; }
         void grow() { EdgeMap g; g.init(key.size() * 2); for (size_t i = 0; i < key.size(); ++i) if (key[i] != ~0ull) g.add(key[i], val[i]); *this = std::move(g); }
         void add(uint64_t k, int32_t v) { if (2 * (used + 1) > key.size()) grow(); size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & mask; while (key[h] != ~0ull && key[h] != k) h = (h + 1) & mask; if (key[h] == ~0ull) { key[h] = k; ++used; } val[h] += v; } };
@@ -686,15 +707,15 @@ std::string inherit_tiles(int32_t nFine, const int32_t* restrictMap, const int32
         for (size_t i = 0; i < local.key.size(); ++i) if (local.key[i] != ~0ull) all.add(local.key[i], local.val[i]);
     });
     // sorted edge list (tile pairs ascending): deterministic whatever order the blocks were merged in
-    std::vector<std::pair<uint64_t, int32_t>> edges;
+    Table<std::pair<uint64_t, int32_t>> edges;
     edges.reserve(all.used);
     for (size_t i = 0; i < all.key.size(); ++i) if (all.key[i] != ~0ull) edges.push_back({all.key[i], all.val[i]});
     std::sort(edges.begin(), edges.end());
     // rounds of pairwise merges: tiles in index order take the free neighbour across the heaviest common boundary that fits
-    std::vector<int32_t> rep((size_t)nT);
+    Table<int32_t> rep((size_t)nT);
     std::iota(rep.begin(), rep.end(), 0);
     for (int round = 0; round < 4; ++round) {
-        std::vector<std::pair<uint64_t, int32_t>> cur;
+        Table<std::pair<uint64_t, int32_t>> cur;
         cur.reserve(edges.size());
         for (const auto& q : edges) {
             const int32_t a = rep[(size_t)(q.first >> 32)], b = rep[(size_t)(uint32_t)q.first];
@@ -704,17 +725,17 @@ std::string inherit_tiles(int32_t nFine, const int32_t* restrictMap, const int32
         size_t w = 0;
         for (size_t i = 0; i < cur.size(); ++i) { if (w > 0 && cur[w - 1].first == cur[i].first) cur[w - 1].second += cur[i].second; else cur[w++] = cur[i]; }
         cur.resize(w);
-        std::vector<int32_t> start((size_t)nT + 1, 0);
+        Table<int32_t> start((size_t)nT + 1, 0);
         for (const auto& q : cur) { ++start[(size_t)(q.first >> 32) + 1]; ++start[(size_t)(uint32_t)q.first + 1]; }
         for (int32_t t = 0; t < nT; ++t) start[(size_t)t + 1] += start[(size_t)t];
-        std::vector<int32_t> nbr((size_t)start[(size_t)nT]), wgt((size_t)start[(size_t)nT]), fill(start.begin(), start.end() - 1);
+        Table<int32_t> nbr((size_t)start[(size_t)nT]), wgt((size_t)start[(size_t)nT]), fill(start.begin(), start.end() - 1);
         for (const auto& q : cur) {   // (ascending pairs: every tile's list comes out ascending by neighbour)
             const int32_t a = (int32_t)(q.first >> 32), b = (int32_t)(uint32_t)q.first;
             nbr[(size_t)fill[(size_t)a]] = b; wgt[(size_t)fill[(size_t)a]++] = q.second;
             nbr[(size_t)fill[(size_t)b]] = a; wgt[(size_t)fill[(size_t)b]++] = q.second;
         }
-        std::vector<char> used((size_t)nT, 0);
-        std::vector<int32_t> into((size_t)nT, -1);
+        Table<char> used((size_t)nT, 0);
+        Table<int32_t> into((size_t)nT, -1);
         int merged = 0;
         for (int32_t t = 0; t < nT; ++t) {
             if (rep[(size_t)t] != t || used[(size_t)t] || vw[(size_t)t] == 0) continue;
@@ -734,7 +755,7 @@ std::string inherit_tiles(int32_t nFine, const int32_t* restrictMap, const int32
         for (int32_t k = 0; k < nT; ++k) { const int32_t r = rep[(size_t)k]; if (into[(size_t)r] >= 0) rep[(size_t)k] = into[(size_t)r]; }
     }
     // compact ids (tiles that hold cells), caps
-    std::vector<int32_t> id((size_t)nT, -1);
+    Table<int32_t> id((size_t)nT, -1);
     nParts = 0;
     for (int32_t t = 0; t < nT; ++t) if (rep[(size_t)t] == t && vw[(size_t)t] > 0) {
         if (vw[(size_t)t] > cellCap || vinc[(size_t)t] - vint[(size_t)t] > slotCap) return "inherit_tiles: an inherited tile exceeds the caps";

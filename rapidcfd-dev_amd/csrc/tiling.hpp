@@ -21,36 +21,37 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include "host_tables.hpp"
 
 namespace mi {
 
 struct TileLayout {
     int32_t nCells = 0, nFaces = 0, nExt = 0, nTiles = 0, nSlices = 0;
     int32_t nPatches = 0;
-    std::vector<int32_t> e2c, c2e;        // engine<->caller cell permutation
-    std::vector<int32_t> tileCellStart;   // [nTiles+1] engine cell range
-    std::vector<int32_t> tileSlotStart;   // [nTiles+1] slot range (starts are even)
-    std::vector<int32_t> tileIfaceSlot0;  // [nTiles] local slot index of the first interface slot (they follow the face slots)
-    std::vector<int32_t> tileHaloStart;   // [nTiles+1]
-    std::vector<int32_t> haloCell;        // engine index; >= nCells means ext cell
-    std::vector<int32_t> tileSliceStart;  // [nTiles+1]
-    std::vector<int32_t> sliceEntryStart; // [nSlices+1]
-    std::vector<uint32_t> entries;        // other | slot<<16 | isLower<<31
+    Table<int32_t> e2c, c2e;        // engine<->caller cell permutation
+    Table<int32_t> tileCellStart;   // [nTiles+1] engine cell range
+    Table<int32_t> tileSlotStart;   // [nTiles+1] slot range (starts are even)
+    Table<int32_t> tileIfaceSlot0;  // [nTiles] local slot index of the first interface slot (they follow the face slots)
+    Table<int32_t> tileHaloStart;   // [nTiles+1]
+    Table<int32_t> haloCell;        // engine index; >= nCells means ext cell
+    Table<int32_t> tileSliceStart;  // [nTiles+1]
+    Table<int32_t> sliceEntryStart; // [nSlices+1]
+    Table<uint32_t> entries;        // other | slot<<16 | isLower<<31
     // compact form (half the bytes), usable when every tile has <= 4095 cells+halo and no cell owns more than 8 faces
     // of one tile: 16-bit entries {other:12 | k:3 | rule:1}, two per word.  The slot is implied by the slot ORDER of a
     // tile: rule 0 (the row owns the face; always the leading entries of a row) slot = slotBase[row] + position in row;
     // rule 1 (the other cell owns the face, or an interface) slot = slotBase[other] + k.
     bool compact = false;
-    std::vector<uint32_t> entries16;        // [pair][lane] per slice
-    std::vector<int32_t> sliceEntryStart16; // [nSlices+1], in words
-    std::vector<uint16_t> slotBase;         // per tile: nc + nh + 1 values (the last one is the zero slot), padded to an even count
-    std::vector<int32_t> tileSbStart;       // [nTiles+1] start of a tile's slotBase segment, in 32-bit words
-    std::vector<int32_t> slotFace;        // caller face id; -1 = padding; <= -2 : interface slot -(2+ext)
-    std::vector<int32_t> extSlot;         // [nExt] slot of each interface face
-    std::vector<int32_t> interiorTiles, boundaryTiles;
-    std::vector<int32_t> patchOffset;     // [nPatches+1]
-    std::vector<int32_t> patchFaceCellsE; // [nExt] engine cell of each patch face
-    std::vector<int32_t> faceSlot;        // [nFaces] a slot that holds caller face f (for faceH)
+    Table<uint32_t> entries16;        // [pair][lane] per slice
+    Table<int32_t> sliceEntryStart16; // [nSlices+1], in words
+    Table<uint16_t> slotBase;         // per tile: nc + nh + 1 values (the last one is the zero slot), padded to an even count
+    Table<int32_t> tileSbStart;       // [nTiles+1] start of a tile's slotBase segment, in 32-bit words
+    Table<int32_t> slotFace;        // caller face id; -1 = padding; <= -2 : interface slot -(2+ext)
+    Table<int32_t> extSlot;         // [nExt] slot of each interface face
+    Table<int32_t> interiorTiles, boundaryTiles;
+    Table<int32_t> patchOffset;     // [nPatches+1]
+    Table<int32_t> patchFaceCellsE; // [nExt] engine cell of each patch face
+    Table<int32_t> faceSlot;        // [nFaces] a slot that holds caller face f (for faceH)
     int32_t maxCells = 0, maxSlots = 0, maxHalo = 0;
     int64_t totalSlots = 0;
 };
@@ -95,7 +96,7 @@ std::string build_tile_layout(int32_t nCells, int32_t nFaces, const int32_t* low
 std::string inherit_tiles(int32_t nFine, const int32_t* restrictMap, const int32_t* fineTileOfCell, int32_t nFineTiles,
                           int32_t nCoarse, int32_t nCoarseFaces, const int32_t* cLower, const int32_t* cUpper,
                           int32_t nPatches, const int32_t* patchSizes, const int32_t* const* patchFaceCells,
-                          int32_t cellCap, int32_t slotCap, std::vector<int32_t>& part, int32_t& nParts);
+                          int32_t cellCap, int32_t slotCap, Table<int32_t>& part, int32_t& nParts);
 // patchNbrCells[p] != nullptr marks patch p as a LOCAL coupled patch (cyclic): face i couples faceCells[i]
 // with the local cell patchNbrCells[p][i] (cyclicLduInterfaceField); nullptr = values arrive in the ext region.
 

@@ -18,11 +18,12 @@ pkg = g.load_package(); eng, syn = pkg.engine, pkg.synthetic
 import workloads
 case = syn.box_case(216, 216, 216)
 ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+w = workloads.box_pair_weights(case)      # the caller's input, generated outside the timed calls
 for rep in range(2):
     print(f"== rep {rep}", file=sys.stderr, flush=True)
     t0 = time.perf_counter(); addr = eng.Addressing(ctx, case.n_cells, case.lower_addr, case.upper_addr); t1 = time.perf_counter()
     print(f"== layout done {t1-t0:.3f}", file=sys.stderr, flush=True)
-    G = eng.Gamg(addr, workloads.box_pair_weights(case), 100); torch.cuda.synchronize(); t2 = time.perf_counter()
+    G = eng.Gamg(addr, w, 100); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"== hierarchy done {t2-t1:.3f}", file=sys.stderr, flush=True)
     del G, addr
 PY
