@@ -316,6 +316,8 @@ def main():
             rep_s.append(time.perf_counter() - t0); rep_amul_ms.append(a_ms)
         perf = mat.pcg_end(None, history_len=W + R * K + 2)
         assert perf["nIterations"] == W + R * K, perf          # every timed step really iterated (no device-side early exit)
+        if ctx.stat(4) > 0:                                      # (csrc/pcg_fused.inc ran: three launches per iteration instead of five)
+            host_loop += ": Amul, fold, then ONE launch for residual update + test + next direction (z = rD o rA stays on the chip)"
         assert np.all(np.isfinite(perf["history"])) and perf["history"][-1] < perf["history"][0]
         n_amul_cells, n_amul_faces = N, F
         # Amul alone, out of the solver loop: rotating vectors (4 input/output pairs = 645 MB > the 256 MiB Infinity Cache),

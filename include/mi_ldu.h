@@ -88,6 +88,9 @@ int mi_ctx_destroy(mi_ctx_t ctx);
 int mi_ctx_synchronize(mi_ctx_t ctx);
 /* run-time switches of a context (the environment variable of the same meaning sets the value a new context starts with):
  *   "pcg_persist" 0 / 1          the persistent PCG kernel for matrices whose tiles fit the CUs' registers (MI_PCG_PERSIST)
+ *   "pcg_fuse_rp" 0 / 1          PCG on one GPU: residual update of an iteration + direction update of the next as one
+ *                                launch that keeps the preconditioned residual on the chip (MI_PCG_FUSE_RP; same bits)
+ *   "pcg_fuse_test" 0..3         tests: workgroups of that launch leave its barrier at once (1: every third, 2: the first)
  *   "win_direct" 0 / 1 / 2       operators of attached matrices as ONE launch whose boundary tiles read the halo window
  *                                (MI_WIN_DIRECT; 2: also between ranks that share a device -- tests)
  *   "gamg_graph_attached" 0 / 1  hipGraph replay of the V-cycle of a decomposed case (MI_GAMG_GRAPH_ATTACHED)             */
@@ -95,11 +98,12 @@ int mi_ctx_set_option(mi_ctx_t ctx, const char *name, int32_t value);
 /* which solver paths ran on this context (diagnostics, tests): launches of the persistent PCG kernel -- one per batch of
  * iterations -- on plain (MI_STAT_PERSIST_PCG) / communicator-attached (MI_STAT_PERSIST_DPCG) matrices; runs of the grid
  * barrier litmus that gates that kernel (MI_STAT_BARRIER_LITMUS); V-cycles of a decomposed case replayed as a hipGraph
- * (MI_STAT_GAMG_GRAPH_ATTACHED) */
+ * (MI_STAT_GAMG_GRAPH_ATTACHED); launches of the fused residual / direction kernel of PCG (MI_STAT_PCG_FUSED_RP) */
 #define MI_STAT_PERSIST_PCG 0
 #define MI_STAT_PERSIST_DPCG 1
 #define MI_STAT_BARRIER_LITMUS 2
 #define MI_STAT_GAMG_GRAPH_ATTACHED 3
+#define MI_STAT_PCG_FUSED_RP 4
 int mi_ctx_stat(mi_ctx_t ctx, int32_t which, int64_t *out);
 const char *mi_last_error(void);
 /* 1 if a usable gfx950 device is visible to this process, else 0 */

@@ -95,8 +95,10 @@ struct mi_ctx_s {
     int fusePerm = 1;  // MI_FUSE_PERM: caller-order operators gather / scatter through e2c inside the tile kernel (A/B hook)
     int deferPsi = 1;  // MI_PCG_DEFER_PSI: psi += alpha pA rides in the next k_pcg_update_p (one vector read less per iteration; A/B hook)
     int fuseFinal = 0; // MI_PCG_FUSE_FINAL: convergence test fused into the next update_p (A/B hook)
+    int pcgFuseTest = 0; // tests ("pcg_fuse_test"): workgroups of the fused launch that leave its barrier at once (pcg_fused.inc)
+    int pcgFuseRP = -1; // MI_PCG_FUSE_RP: residual update + next direction update as one launch (pcg_fused.inc); 0 never, -1 (default) once the device has been asked
     int pcgPersist = 1; // MI_PCG_PERSIST: 0 never, 1 (default) whenever the tiles fit the CUs' registers (persist.inc)
-    int64_t stats[4] = {0, 0, 0, 0}; // mi_ctx_stat
+    int64_t stats[5] = {0, 0, 0, 0, 0}; // mi_ctx_stat
     int persistGrid = 0; // MI_PERSIST_GRID: workgroups of the persistent kernel (0: one per CU); MI_PERSIST_SHARED=1 lets ranks that share a device use it -- tests only: their grids must fit the device TOGETHER
     int persistShared = 0;
     int persistCoop = -1; // cooperative launch of the persistent kernel possible on this device AND its barrier litmus clean (-1: not asked yet)
@@ -167,6 +169,9 @@ struct mi_matrix_s {
     // running PCG session (mi_pcg_begin/iterate/end)
     int pcgIt = 0, pcgPrecond = MI_PRECOND_DIAGONAL;
     bool pcgActive = false;
+    bool pcgPReady = false;            // pA of iteration pcgIt has been formed already (by the fused launch of the previous iteration, pcg_fused.inc)
+    DevBuf<unsigned int> fusedBar;     // its barrier words, the generation of its last launch, the fault epoch the words were zeroed in
+    unsigned int fusedGen = 0;
     Table<hipEvent_t> evPool;
     // hipGraph of one batch of device-resident PCG iterations (launch-bound regime: small meshes, coarse ranks)
     hipGraphExec_t pcgGraph = nullptr;
@@ -267,6 +272,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->multiPipe = env_int("MI_MULTI_PIPE", 1);   // the multi-vector tile passes of the Krylov iterations as persistent pipelined workgroups (multi_pipe.inc): same bits, three-component PBiCG + DILU iteration 1 812 -> 1 643 us (profiles/r05_f_multi_pipe_ab.md)
     c->winDirect = env_int("MI_WIN_DIRECT", 1); c->gamgGraphAttached = env_int("MI_GAMG_GRAPH_ATTACHED", 1);
     c->pcgPersist = env_int("MI_PCG_PERSIST", 1);
+    c->pcgFuseRP = env_int("MI_PCG_FUSE_RP", 1) != 0 ? -1 : 0;
     c->persistGrid = env_int("MI_PERSIST_GRID", 0);
     c->persistShared = env_int("MI_PERSIST_SHARED", 0);
     c->fuseFinal = env_int("MI_PCG_FUSE_FINAL", 0); // measured: no gain (332.0 vs 332.3 us/iter), kept as an option
@@ -310,6 +316,8 @@ extern "C" int mi_ctx_set_option(mi_ctx_t c, const char* name, int32_t value)
 {
     if (!c || !name) return fail(MI_ERR_ARG, "mi_ctx_set_option: bad argument");
     if (std::string(name) == "pcg_persist") { c->pcgPersist = value; return MI_OK; }
+    if (std::string(name) == "pcg_fuse_rp") { c->pcgFuseRP = value != 0 ? -1 : 0; return MI_OK; }
+    if (std::string(name) == "pcg_fuse_test") { c->pcgFuseTest = value; return MI_OK; }
     if (std::string(name) == "win_direct") { c->winDirect = value; return MI_OK; }                     // MI_WIN_DIRECT
     if (std::string(name) == "gamg_graph_attached") { c->gamgGraphAttached = value; return MI_OK; }   // MI_GAMG_GRAPH_ATTACHED
     return fail(MI_ERR_ARG, "mi_ctx_set_option: unknown option");
@@ -319,7 +327,7 @@ extern "C" int mi_ctx_set_option(mi_ctx_t c, const char* name, int32_t value)
 // attached matrices, 2 = grid-barrier litmus runs (persist.inc), 3 = V-cycles of a decomposed case replayed as a hipGraph
 extern "C" int mi_ctx_stat(mi_ctx_t c, int32_t which, int64_t* out)
 {
-    if (!c || !out || which < 0 || which >= 4) return fail(MI_ERR_ARG, "mi_ctx_stat: bad argument");
+    if (!c || !out || which < 0 || which >= 5) return fail(MI_ERR_ARG, "mi_ctx_stat: bad argument");
     *out = c->stats[which];
     return MI_OK;
 }
@@ -1578,6 +1586,8 @@ int globalize(mi_matrix_s* m, double* PA, double* PB = nullptr)
     return MI_OK;
 }
 
+bool pcg_fused_rp_usable(const mi_matrix_s* m, int precond);      // pcg_fused.inc: residual update of iteration it + direction update of it + 1 in one launch
+int pcg_fused_rp_launch(mi_matrix_s* m, int it, int precond);
 bool pcg_persist_usable(const mi_matrix_s* m, int precond);       // persist.inc: the iteration as one persistent cooperative kernel
 int pcg_persist_enqueue(mi_matrix_s* m, int n_iters, int precond);
 // enqueue PCG iteration bodies it0 .. it0+count-1 (no host sync).
@@ -1599,8 +1609,15 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
     const int defer = (c->deferPsi && !fuse) ? 1 : 0; // (the fused convergence test has no per-iteration k_pcg_final to record the added psi term)
     double* psiD = defer ? psi : nullptr;
     struct Gate { mi_matrix_s* m; explicit Gate(mi_matrix_s* mm) : m(mm) { m->gateDone = true; } ~Gate() { m->gateDone = false; } } gate(m);
+    // round 6: k_pcg_update_psi_r(it) + k_pcg_final(it) + k_pcg_update_p(it + 1) as one launch that keeps rD o rA on the chip
+    // (pcg_fused.inc).  Not under graph capture (it0 < 0: the launch carries the iteration number and its barrier generation).
+    bool fusedRP = it0 >= 0 && pcg_fused_rp_usable(m, precond);
+    if (it0 < 0) m->pcgPReady = false;
     for (int k = 0; k < count; ++k) {
         const int it = it0 < 0 ? -1 : it0 + k; // it0 < 0: the iteration counter lives on the device (graph replay)
+        if (m->pcgPReady) {
+            // pA of this iteration came out of the previous iteration's fused launch
+        } else
         if (precond == MI_PRECOND_AINV) {
             // AINV apply with sum wA.rA fused into the tile pass (per-tile partials folded into P1): no separate reduction pass
             MICHK(launch_tile<OP_AINV>(m, false, rA, nullptr, m->rD.p, wA, 0.0, 0, m->tilePartial.p));
@@ -1625,6 +1642,13 @@ int pcg_enqueue(mi_matrix_s* m, int it0, int count, int precond, int evStride) /
         if (rec && !c->attachEvents) HIPCHK(hipEventRecord(m->evPool[ev + 1], s));
         k_fold_partials<<<1, 1024, 0, s>>>(m->tilePartial.p, a->L.nTiles, P2);
         MICHK(globalize(m, P2));
+        m->pcgPReady = false;
+        if (fusedRP) {
+            const int rcF = pcg_fused_rp_launch(m, it, precond);
+            if (rcF == MI_OK) { m->pcgPReady = true; continue; }
+            if (rcF != MI_ERR_UNSUPPORTED) return rcF;
+            fusedRP = false;   // the device does not hold the grid: the separate kernels, here and from now on
+        }
         if (precond == MI_PRECOND_AINV)
             k_pcg_update_psi_r<0><<<RG, RB, 0, s>>>(c->state.p, it, P2, pA, wA, nullptr, psi, rA, n, P3, P1, defer);
         else if (precond == MI_PRECOND_DIAGONAL)
@@ -1681,7 +1705,7 @@ extern "C" int mi_pcg_begin(mi_matrix_t m, const double* psi0, const double* sou
         k_pcg_precond_dot<false><<<RG, RB, 0, s>>>(a->ctx->state.p, nullptr, rA, wA, a->L.nCells, a->ctx->partial.p);
     }
     HIPCHK(hipGetLastError());
-    m->pcgIt = 0; m->pcgPrecond = precond; m->pcgActive = true; a->ctx->session = m;
+    m->pcgIt = 0; m->pcgPrecond = precond; m->pcgActive = true; m->pcgPReady = false; a->ctx->session = m;
     return MI_OK;
 }
 
@@ -2429,6 +2453,7 @@ extern "C" int mi_event_elapsed_ms(mi_matrix_t m, int32_t idx0, int32_t idx1, fl
 #include "multi.inc"
 #include "comm.inc"
 #include "persist.inc"
+#include "pcg_fused.inc"
 #include "gamg_engine.inc"
 #include "assembly.inc"
 

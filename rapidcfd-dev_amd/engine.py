@@ -223,12 +223,12 @@ class Context:
         _chk(lib().mi_ctx_synchronize(self.h))
 
     def set_option(self, name: str, value: int):
-        """mi_ctx_set_option: "pcg_persist", "win_direct", "gamg_graph_attached" 0 / 1"""
+        """mi_ctx_set_option: "pcg_persist", "pcg_fuse_rp", "win_direct", "gamg_graph_attached" 0 / 1"""
         _chk(lib().mi_ctx_set_option(self.h, name.encode(), C.c_int32(int(value))))
 
     def stat(self, which: int) -> int:
         """mi_ctx_stat: 0 = launches of the persistent PCG kernel on plain matrices, 1 = on communicator-attached ones,
-        2 = grid-barrier litmus runs, 3 = V-cycles of a decomposed case replayed as a hipGraph"""
+        2 = grid-barrier litmus runs, 3 = V-cycles of a decomposed case replayed as a hipGraph, 4 = launches of the fused residual / direction kernel of PCG"""
         v = C.c_int64(0)
         _chk(lib().mi_ctx_stat(self.h, C.c_int32(which), C.byref(v)))
         return int(v.value)
