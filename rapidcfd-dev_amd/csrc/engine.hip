@@ -106,6 +106,7 @@ struct mi_ctx_s {
     int winDirect = 1; // MI_WIN_DIRECT: tile operators of attached matrices read neighbour-rank values straight from the halo window (one launch for all tiles) instead of k_halo_pull + a second launch (A/B hook)
     int gamgGraphAttached = 1; // MI_GAMG_GRAPH_ATTACHED: the V-cycle of a decomposed case replays as a hipGraph when every exchange of it is stream work (peer windows)
     int multiPipe = 1; // MI_MULTI_PIPE: tile_kernel_multi_pipe (multi_pipe.inc) for the multi-vector passes of the Krylov iterations
+    int fusePrologue = 1; // MI_FUSE_PROLOGUE: A psi, source - A psi and sumA in one pass over the coefficients, the prologue's sums batched (A/B hook: 0 = the separate passes, same bits)
     int pairAT = 1;    // MI_PBICG_PAIR: PBiCG's A p / A^T pT (and the DILU pair) in one pass over the coefficients (A/B hook)
     struct mi_matrix_s* session = nullptr; // matrix whose mi_pcg_begin/iterate/end session owns this context's solver scratch (partial, scalars, state)
     int pcgBatch = 16, pcgGraph = -1, pbicgHostStepped = 0, gamgDeviceInvert = -1, gamgAlwaysAgglomerate = 0, gamgGraph = 1, gamgFuse = 1; // MI_* switches, read once per context
@@ -177,6 +178,7 @@ struct mi_matrix_s {
     hipGraphExec_t pcgGraph = nullptr;
     struct { int precond = -1, batch = 0, histLen = 0; const void* hist = nullptr; const void* psi = nullptr; } pcgGraphKey;
     bool gateDone = false; // tile launches of a device-resident solver loop read PcgState::done and exit past convergence
+    double *proY2 = nullptr, *proY3 = nullptr; // set around ONE OP_PROLOGUE tile pass (solve_prologue): rA = source - A psi and sumA go out of the same pass
     const double *callerX = nullptr, *callerB = nullptr; double* callerY = nullptr; // set around ONE tile launch: x, b, y are the caller's arrays (permutation folded into the kernel)
     hipEvent_t kevStart = nullptr, kevStop = nullptr; // when set: attached to the next tile-kernel launch (hipExtLaunchKernel)
     struct mi_dpcg_comm_s* dpc = nullptr; // attached RCCL communicators + exchange plan (comm.inc)
@@ -269,6 +271,7 @@ extern "C" int mi_ctx_create(int device, void* hip_stream, mi_ctx_t* out)
     c->fusePerm = env_int("MI_FUSE_PERM", 1);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->nCU = pr.multiProcessorCount; }
     c->pairAT = env_int("MI_PBICG_PAIR", 1);
+    c->fusePrologue = env_int("MI_FUSE_PROLOGUE", 1);
     c->multiPipe = env_int("MI_MULTI_PIPE", 1);   // the multi-vector tile passes of the Krylov iterations as persistent pipelined workgroups (multi_pipe.inc): same bits, three-component PBiCG + DILU iteration 1 812 -> 1 643 us (profiles/r05_f_multi_pipe_ab.md)
     c->winDirect = env_int("MI_WIN_DIRECT", 1); c->gamgGraphAttached = env_int("MI_GAMG_GRAPH_ATTACHED", 1);
     c->pcgPersist = env_int("MI_PCG_PERSIST", 1);
@@ -310,6 +313,7 @@ extern "C" int mi_ctx_synchronize(mi_ctx_t c)
 
 // run-time switches of a context (the environment variables of the same meaning are read once, at mi_ctx_create):
 //   "pcg_persist"  0 / 1: the persistent PCG kernel for matrices that fit the CUs' registers (MI_PCG_PERSIST)
+//   "fuse_prologue" 0 / 1: the solvers' prologue as one tile pass (A psi, source - A psi, sumA) + batched sums (MI_FUSE_PROLOGUE)
 //   "win_direct"   0 / 1: boundary tiles of attached matrices read the halo window themselves (MI_WIN_DIRECT)
 //   "gamg_graph_attached" 0 / 1: hipGraph replay of the V-cycle of a decomposed case (MI_GAMG_GRAPH_ATTACHED)
 extern "C" int mi_ctx_set_option(mi_ctx_t c, const char* name, int32_t value)
@@ -318,6 +322,7 @@ extern "C" int mi_ctx_set_option(mi_ctx_t c, const char* name, int32_t value)
     if (std::string(name) == "pcg_persist") { c->pcgPersist = value; return MI_OK; }
     if (std::string(name) == "pcg_fuse_rp") { c->pcgFuseRP = value != 0 ? -1 : 0; return MI_OK; }
     if (std::string(name) == "pcg_fuse_test") { c->pcgFuseTest = value; return MI_OK; }
+    if (std::string(name) == "fuse_prologue") { c->fusePrologue = value; return MI_OK; }             // MI_FUSE_PROLOGUE
     if (std::string(name) == "win_direct") { c->winDirect = value; return MI_OK; }                     // MI_WIN_DIRECT
     if (std::string(name) == "gamg_graph_attached") { c->gamgGraphAttached = value; return MI_OK; }   // MI_GAMG_GRAPH_ATTACHED
     return fail(MI_ERR_ARG, "mi_ctx_set_option: unknown option");
@@ -907,6 +912,7 @@ int launch_tile(mi_matrix_s* m, bool trans, const double* x, const double* b, co
     t.entries = a->entries.p; t.entries16 = a->entries16.p; t.sliceEntryStart16 = a->sliceEntryStart16.p; t.slotBase = reinterpret_cast<const uint32_t*>(a->slotBase.p); t.tileSbStart = a->tileSbStart.p;
     t.diag = m->diagE.p; t.up = m->upE.p; t.low = m->lowE.p;
     t.x = x; t.b = b; t.rD = rD; t.y = y; t.omega = omega; t.dotPartial = dotPartial; t.dotPartial2 = dotPartial2; t.flags = a->ctx->tileFlags;
+    if (OP == OP_PROLOGUE) { t.y2 = m->proY2; t.y3 = m->proY3; }
 
     const size_t lds = lds_bytes(a->L, m->asym, OP == OP_AINV, &t.offLow, &t.offX, &t.offRD, &t.offSB);
     if (lds > 159 * 1024) return fail(MI_ERR_LIMIT, "tile needs more than 159 KiB of LDS");
@@ -1070,7 +1076,7 @@ template <int OP>
 int tile_op(mi_matrix_s* m, bool trans, const double* x, const double* b, const double* rD, double* y, double omega,
             double* dotPartial = nullptr, double* dotPartial2 = nullptr)
 {
-    constexpr bool readsNbr = (OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_JACOBI);
+    constexpr bool readsNbr = (OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_JACOBI || OP == OP_PROLOGUE);
     mi_addr_s* a = m->addr;
     if (readsNbr && a->amiRemote && comm_remote(m)) {
         // a cyclicAMI patch whose partner lives on another rank interpolates from what its transport patch RECEIVES: whole
@@ -1513,9 +1519,36 @@ int solve_prologue(mi_matrix_s* m, const mi_solver_controls* ctl, const double* 
     h.tolerance = ctl->tolerance; h.relTol = ctl->relTol; h.maxIter = ctl->maxIter; h.minIter = ctl->minIter;
     *c->hostState = h;
     HIPCHK(hipMemcpyAsync(c->state.p, c->hostState, sizeof(PcgState), hipMemcpyHostToDevice, s));
+    (void)tmp;
+    if (c->fusePrologue) {
+        // ONE pass over the coefficients: wA = A psi, rA = source - wA and -- when the coefficients were re-bound since the last solve, as in
+        // every equation of a time step -- sumA (OP_PROLOGUE: the Amul's and the sumA pass's chains side by side, same bits); then the
+        // sum of psi, and normFactor + sum|rA| in one vector pass with gAverage(psi) formed on the device (no host read)
+        const bool needSumA = !m->sumAValid;
+        if (needSumA && m->sumAE.n != (size_t)n) MICHK(m->sumAE.alloc((size_t)n));
+        m->proY2 = rA; m->proY3 = needSumA ? m->sumAE.p : nullptr;
+        const int rc = tile_op<OP_PROLOGUE>(m, false, psi_e, src_e, nullptr, wA, 0.0);
+        m->proY2 = nullptr; m->proY3 = nullptr;
+        MICHK(rc);
+        m->sumAValid = true;
+        double* P = c->partial.p;          // [0, RG): normFactor, [RG, 2 RG): sum|rA|, [2 RG, 3 RG): sum psi
+        k_reduce<RED_SUM><<<RG, RB, 0, s>>>(psi_e, nullptr, n, P + 2 * RG);
+        if (comm_attached(m)) { // gSum(psi), then the two sums are global (lduMatrixSolver.C:182-236, gSumMag)
+            k_reduce_final<<<1, RB, 0, s>>>(P + 2 * RG, c->scalars.p);
+            MICHK(comm_allreduce(m, c->scalars.p, 1));
+            k_normfactor_mag<true><<<RG, RB, 0, s>>>(wA, src_e, m->sumAE.p, c->scalars.p, (double)comm_n_global(m), n, P, P + RG);
+            k_reduce_final2<<<2, RB, 0, s>>>(P, c->scalars.p + 1, P + RG, c->scalars.p + 2);
+            MICHK(comm_allreduce(m, c->scalars.p + 1, 2));
+            k_solve_init<true><<<1, RB, 0, s>>>(c->state.p, c->scalars.p + 1, c->scalars.p + 2, m->hist.p, histLen);
+        } else {
+            k_normfactor_mag<false><<<RG, RB, 0, s>>>(wA, src_e, m->sumAE.p, P + 2 * RG, (double)n, n, P, P + RG);
+            k_solve_init<false><<<1, RB, 0, s>>>(c->state.p, P, P + RG, m->hist.p, histLen);
+        }
+        HIPCHK(hipGetLastError());
+        return MI_OK;
+    }
     MICHK(tile_op<OP_AMUL>(m, false, psi_e, nullptr, nullptr, wA, 0.0));
     k_sub<<<RG, RB, 0, s>>>(rA, src_e, wA, n);
-    (void)tmp;
     if (!m->sumAValid) { // sumA depends on the coefficients only: once per binding, not once per solve
         if (m->sumAE.n != (size_t)n) MICHK(m->sumAE.alloc((size_t)n));
         MICHK(launch_tile<OP_SUMA>(m, false, nullptr, nullptr, nullptr, m->sumAE.p, 0.0, 0));

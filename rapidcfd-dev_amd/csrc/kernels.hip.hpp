@@ -84,7 +84,11 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ partia
 // ---------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------
-enum { OP_AMUL = 0, OP_SUMA = 1, OP_RESIDUAL = 2, OP_H = 3, OP_H1 = 4, OP_AINV = 5, OP_JACOBI = 6 };
+enum { OP_AMUL = 0, OP_SUMA = 1, OP_RESIDUAL = 2, OP_H = 3, OP_H1 = 4, OP_AINV = 5, OP_JACOBI = 6,
+       // the start of every solver in ONE pass over the coefficients (PCG.C:91-121 and siblings, lduMatrixSolver.C:182-236):
+       // y = A x (the Amul's fma chain), y2 = b - y, y3 = lduMatrix::sumA (the sumA pass's chain of additions) -- both chains
+       // term by term, so every output bit equals the separate passes'
+       OP_PROLOGUE = 7 };
 
 struct TileArgs {
     const int32_t* tileCellStart;
@@ -122,6 +126,8 @@ struct TileArgs {
     const double* b;  // source (residual, Jacobi)
     const double* rD; // AINV
     double* y;
+    double* y2 = nullptr; // OP_PROLOGUE: b - y (rA = source - A psi), or nullptr
+    double* y3 = nullptr; // OP_PROLOGUE: sumA, or nullptr (valid from an earlier solve on the same coefficients)
     double* dotPartial; // per-workgroup partial fused into the pass, or nullptr: Amul sum(y*x) (gSumProd), AINV sum(w*r), residual sum|r| (gSumMag)
     double* dotPartial2; // Amul only: per-workgroup partial of sum(b*x) with b = the `b` vector (GAMG scale: gSumProd(source, field)), or nullptr
     double omega;
@@ -226,6 +232,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
     uint16_t* sb = reinterpret_cast<uint16_t*>(smem + a.offSB);
     constexpr bool NEEDX = (OP != OP_SUMA && OP != OP_H1);
     static_assert(!PERM || OP == OP_AMUL || OP == OP_RESIDUAL || OP == OP_H || OP == OP_SUMA || OP == OP_H1, "caller-order form: ops with a caller-order entry point only");
+    static_assert(OP != OP_PROLOGUE || XMODE == 0, "the solver prologue reads its operand");
 
     // ---- stage: coefficients (16-byte coalesced), psi, halo -------------------
     // All global loads of a phase are issued before the first LDS store (4-deep
@@ -374,7 +381,8 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
         const double xi = (NEEDX && live) ? xs[i] : 0.0;
         double acc, accI = 0.0;
         if (OP == OP_JACOBI) accI = a.b[gi];
-        if (OP == OP_AMUL) acc = ((a.flags & 8) ? __builtin_nontemporal_load(a.diag + gi) : a.diag[gi]) * xi;
+        if (OP == OP_PROLOGUE) { accI = a.diag[gi]; acc = accI * xi; }   // accI: the row's sumA
+        else if (OP == OP_AMUL) acc = ((a.flags & 8) ? __builtin_nontemporal_load(a.diag + gi) : a.diag[gi]) * xi;
         else if (OP == OP_SUMA) acc = a.diag[gi];
         else if (OP == OP_RESIDUAL) acc = a.b[go] - a.diag[gi] * xi;
         else acc = 0.0;
@@ -385,6 +393,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
             if (OP == OP_JACOBI) { // coupled patches go to bPrime, faces to the row sum (JacobiSmoother.C:75-93, JacobiSmootherF.H)
                 if (sl >= ifs0) accI = fma(-c, xs[o], accI); else acc = fma(c, xs[o], acc);
             } else if (OP == OP_AMUL) acc = fma(c, xs[o], acc);
+            else if (OP == OP_PROLOGUE) { acc = fma(c, xs[o], acc); accI += c; }
             else if (OP == OP_SUMA) acc += c;
             else if (OP == OP_RESIDUAL) acc = fma(-c, xs[o], acc);
             else if (OP == OP_H) { if (sl < ifs0) acc = fma(-c, xs[o], acc); }   // lduMatrix::H / H1 are face sums only
@@ -422,6 +431,10 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
                 const double rD = 1.0 / a.diag[gi];
                 const double extra = (1 - a.omega) * xi + a.omega * rD * accI;
                 a.y[gi] = extra - a.omega * rD * acc;
+            } else if (OP == OP_PROLOGUE) {
+                a.y[gi] = acc;
+                if (a.y2) a.y2[gi] = a.b[gi] - acc;
+                if (a.y3) a.y3[gi] = accI;
             } else if (a.flags & 4) __builtin_nontemporal_store(acc, a.y + go);
             else a.y[go] = acc;
             if (OP == OP_AMUL) { dot = fma(acc, xi, dot); if (a.dotPartial2) dot2 = fma(a.b[gi], xi, dot2); }
@@ -470,7 +483,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, const int p, double
 // the symmetric Jacobi sweep 75, and a CU holds three workgroups instead of four).
 // (the opt-in compact asymmetric form would spill two registers under that budget and is left alone)
 template <int OP, bool ASYM, bool TRANS, int BS, bool C16>
-__global__ __launch_bounds__(BS, (BS >= 512 && !(C16 && ASYM)) ? 8 : 1) void tile_kernel(const TileArgs a)
+__global__ __launch_bounds__(BS, (BS >= 512 && !(C16 && ASYM) && OP != OP_PROLOGUE) ? 8 : 1) void tile_kernel(const TileArgs a)   // (the prologue runs once per solve and carries two accumulators: no register cap)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (a.done && *a.done) return;
@@ -574,12 +587,14 @@ struct MultiVec {
     double* dotPartial[NRHS];
     const double* b[NRHS];
     double* y2[2 * NRHS];
+    double* sumA[NRHS];            // OP_PROLOGUE: lduMatrix::sumA with component c's diagonal (or nullptr) -- the sumA pass's additions in its order
 };
 
 template <int OP, int NRHS, bool SRD, int BS>
 __global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const MultiVec<NRHS> V)
 {
-    static_assert(OP == OP_AMUL || OP == OP_AINV || OP == OP_SUMA, "multi-vector form: Amul/Tmul pairs, AINV / AINV^T pairs, sumA per diagonal");
+    static_assert(OP == OP_AMUL || OP == OP_AINV || OP == OP_SUMA || OP == OP_PROLOGUE, "multi-vector form: Amul/Tmul pairs (OP_PROLOGUE: + sumA per diagonal in the same pass), AINV / AINV^T pairs, sumA per diagonal");
+    constexpr bool MUL = (OP == OP_AMUL || OP == OP_PROLOGUE);
     constexpr int NV = (OP == OP_SUMA) ? NRHS : 2 * NRHS;
     constexpr int NRD = SRD ? 1 : NRHS;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -710,14 +725,15 @@ __global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const 
         const int i = s * 64 + lane;
         const bool live = i < nc;
         const int gi = c0 + (live ? i : 0);
-        double xi[NV], acc[NV];
+        double xi[NV], acc[NV], accS[OP == OP_PROLOGUE ? NRHS : 1];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             xi[v] = (OP != OP_SUMA && live && act[v % NRHS]) ? xs[v * xlen + i] : 0.0;
             const double dgv = (OP == OP_AINV) ? 0.0 : (s == wave ? dg0[v % NRHS] : V.diag[v % NRHS][gi]);
-            if (OP == OP_AMUL) acc[v] = dgv * xi[v];
+            if (MUL) acc[v] = dgv * xi[v];
             else if (OP == OP_SUMA) acc[v] = dgv;
             else acc[v] = 0.0;
+            if (OP == OP_PROLOGUE && v < NRHS) accS[v] = dgv;
         }
         auto accumulate = [&](uint32_t en) {
             const int o = en & 0xFFFFu, sl = (en >> 16) & 0x7FFFu;
@@ -738,6 +754,10 @@ __global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const 
             } else {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) acc[v] = fma(v < NRHS ? cPlain : cTrans, xs[v * xlen + o], acc[v]);
+                if (OP == OP_PROLOGUE) {
+#pragma unroll
+                    for (int c = 0; c < NRHS; ++c) accS[c] += cPlain;
+                }
             }
         };
 #pragma unroll
@@ -752,7 +772,8 @@ __global__ __launch_bounds__(BS) void tile_kernel_multi(const TileArgs a, const 
                 if (!act[v % NRHS]) continue;
                 const double out = (OP == OP_AINV) ? rDs[(SRD ? 0 : (v % NRHS)) * xlen + i] * (xi[v] - acc[v]) : acc[v];
                 if (V.y[v]) V.y[v][gi] = out;
-                if (OP == OP_AMUL && V.y2[v]) V.y2[v][gi] = V.b[v % NRHS][gi] - out;
+                if (MUL && V.y2[v]) V.y2[v][gi] = V.b[v % NRHS][gi] - out;
+                if (OP == OP_PROLOGUE && v < NRHS && V.sumA[v]) V.sumA[v][gi] = accS[v];
                 if (OP != OP_SUMA && v < NRHS) dot[v] = fma(out, xi[(NRHS + v) % NV], dot[v]);
             }
         }
@@ -1039,6 +1060,58 @@ __global__ __launch_bounds__(RB) void k_normfactor_dev(const double* __restrict_
         [&](int64_t i) { const double t0 = avg * sumA[i]; acc0 += fabs(Apsi[i] - t0) + fabs(src[i] - t0); });
     const double t = block_sum<RB>(acc0 + acc1, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// normFactor partials AND the partials of gSumMag(source - Apsi) in one pass over Apsi / source / sumA: the residual is formed again
+// from its two operands (the rounding of k_sub / of the prologue tile pass), each sum keeps the per-thread order of its own kernel
+// (k_normfactor_dev, k_reduce<RED_MAG>): same partials bit for bit, one vector pass instead of two.  gAverage(psi) from the RG partials
+// of its sum (SCALAR = false: every block re-reduces them in sum_partials' order, no finalize launch) or from the all-reduced scalar.
+template <bool SCALAR>
+__global__ __launch_bounds__(RB, 8) void k_normfactor_mag(const double* __restrict__ Apsi, const double* __restrict__ src, const double* __restrict__ sumA,
+                                                       const double* __restrict__ sumPsi, double nGlobal, int64_t n,
+                                                       double* __restrict__ partialNF, double* __restrict__ partialMag)
+{
+    __shared__ double red[RB / 64];
+    const double avg = (SCALAR ? sumPsi[0] : sum_partials(sumPsi, red)) / nGlobal;
+    double acc0 = 0, acc1 = 0, m0 = 0, m1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 A = ld2(Apsi, i), b = ld2(src, i), s = ld2(sumA, i);
+          const double t0 = avg * s.x, t1 = avg * s.y;
+          acc0 += fabs(A.x - t0) + fabs(b.x - t0); acc1 += fabs(A.y - t1) + fabs(b.y - t1);
+          m0 += fabs(b.x - A.x); m1 += fabs(b.y - A.y); },
+        [&](int64_t i) { const double t0 = avg * sumA[i]; acc0 += fabs(Apsi[i] - t0) + fabs(src[i] - t0); m0 += fabs(src[i] - Apsi[i]); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    const double u = block_sum<RB>(m0 + m1, red);
+    if (threadIdx.x == 0) { partialNF[blockIdx.x] = t; partialMag[blockIdx.x] = u; }
+}
+// the multi-vector solver's prologue: the same for up to three components in one launch (blockIdx.y = component), and the sums of
+// their psi likewise
+struct NormMag3 { const double *Apsi[3], *src[3], *sumA[3], *sumPsi[3]; double *partialNF[3], *partialMag[3]; };
+template <bool SCALAR>
+__global__ __launch_bounds__(RB, 8) void k_normfactor_mag3(const NormMag3 A3, double nGlobal, int64_t n)
+{
+    __shared__ double red[RB / 64];
+    const int k = blockIdx.y;
+    const double* __restrict__ Apsi = A3.Apsi[k]; const double* __restrict__ src = A3.src[k]; const double* __restrict__ sumA = A3.sumA[k];
+    const double avg = (SCALAR ? A3.sumPsi[k][0] : sum_partials(A3.sumPsi[k], red)) / nGlobal;
+    double acc0 = 0, acc1 = 0, m0 = 0, m1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 A = ld2(Apsi, i), b = ld2(src, i), s = ld2(sumA, i);
+          const double t0 = avg * s.x, t1 = avg * s.y;
+          acc0 += fabs(A.x - t0) + fabs(b.x - t0); acc1 += fabs(A.y - t1) + fabs(b.y - t1);
+          m0 += fabs(b.x - A.x); m1 += fabs(b.y - A.y); },
+        [&](int64_t i) { const double t0 = avg * sumA[i]; acc0 += fabs(Apsi[i] - t0) + fabs(src[i] - t0); m0 += fabs(src[i] - Apsi[i]); });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    const double u = block_sum<RB>(m0 + m1, red);
+    if (threadIdx.x == 0) { A3.partialNF[k][blockIdx.x] = t; A3.partialMag[k][blockIdx.x] = u; }
+}
+struct Sum3 { const double* a[3]; double* partial[3]; };
+__global__ __launch_bounds__(RB) void k_sum3(const Sum3 S, int64_t n)
+{
+    __shared__ double red[RB / 64];
+    const double* __restrict__ a = S.a[blockIdx.y];
+    double acc0 = 0, acc1 = 0;
+    chunk_loop(n, [&](int64_t i) { const double2 x = ld2(a, i); acc0 += x.x; acc1 += x.y; }, [&](int64_t i) { acc0 += a[i]; });
+    const double t = block_sum<RB>(acc0 + acc1, red);
+    if (threadIdx.x == 0) S.partial[blockIdx.y][blockIdx.x] = t;
 }
 
 // ---------------------------------------------------------------------------
@@ -1450,11 +1523,10 @@ __global__ __launch_bounds__(RB) void k_pcg_final(PcgState* __restrict__ st, int
 }
 
 // start of a solve: normFactor, initial residual, first convergence test   [PCG.C:105-121]
-template <bool DIST = false>
-__global__ __launch_bounds__(RB) void k_solve_init(PcgState* __restrict__ st, const double* __restrict__ partialNF,
-                                                   const double* __restrict__ partialR, double* __restrict__ hist, int histLen)
+template <bool DIST>
+__device__ __forceinline__ void solve_init_body(PcgState* __restrict__ st, const double* __restrict__ partialNF,
+                                                const double* __restrict__ partialR, double* __restrict__ hist, int histLen, double* red)
 {
-    __shared__ double red[RB / 64];
     const double nf = (DIST ? partialNF[0] : sum_partials(partialNF, red)) + SP_SMALL;
     const double sr = DIST ? partialR[0] : sum_partials(partialR, red);
     if (threadIdx.x != 0) return;
@@ -1467,6 +1539,22 @@ __global__ __launch_bounds__(RB) void k_solve_init(PcgState* __restrict__ st, co
     const bool conv = sp_converged(st, res);
     st->converged = conv;
     st->done = (st->minIter > 0 || !conv) ? 0 : 1;
+}
+template <bool DIST = false>
+__global__ __launch_bounds__(RB) void k_solve_init(PcgState* __restrict__ st, const double* __restrict__ partialNF,
+                                                   const double* __restrict__ partialR, double* __restrict__ hist, int histLen)
+{
+    __shared__ double red[RB / 64];
+    solve_init_body<DIST>(st, partialNF, partialR, hist, histLen, red);
+}
+// up to three components' solves in one launch (block k: component k)
+struct Init3 { PcgState* st[3]; const double *partialNF[3], *partialR[3]; double* hist[3]; };
+template <bool DIST = false>
+__global__ __launch_bounds__(RB) void k_solve_init3(const Init3 I, int histLen)
+{
+    __shared__ double red[RB / 64];
+    const int k = blockIdx.x;
+    solve_init_body<DIST>(I.st[k], I.partialNF[k], I.partialR[k], I.hist[k], histLen, red);
 }
 
 } // namespace mi
