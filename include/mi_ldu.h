@@ -798,6 +798,11 @@ int mi_smooth_solve(mi_matrix_t m, double *psi_dev, const double *source_dev,
 int mi_bench_amul(mi_matrix_t m, int32_t reps, float *ms_out);
 /* diagnostic: resident Amul workgroups per CU as the HIP runtime computes it, LDS bytes per workgroup, block size */
 int mi_debug_occupancy(mi_matrix_t m, int32_t *blocks_per_cu, int32_t *lds_bytes_out, int32_t *block_size);
+/* diagnostic / test hook: the dense inversions behind GAMG's direct coarsest-level solve (GAMGSolverSolve.C:551-573: the reference
+ * LU-solves the coarsest matrix on the host every cycle; the engine inverts it once per set of coefficients) on a row-major n x n
+ * matrix in device memory.  which = 0 host Gauss-Jordan with partial pivoting, 1 / 2 the register-resident kernels (n <= 192; same
+ * bits as 0), 3 the global-memory kernel.  *singular_out = 1: zero pivot column met.                                              */
+int mi_debug_dense_invert(mi_ctx_t ctx, const double *a_dev, int32_t n, double *inv_dev, int32_t which, int32_t *singular_out);
 int mi_bench_pcg_iters(mi_matrix_t m, const double *source_dev, int32_t iters, int precond,
                        float *ms_out, float *amul_ms_out);
 

@@ -59,7 +59,7 @@ SYMBOLS = [
     "mi_residual_engine", "mi_jacobi_smooth_engine",
     "mi_pcg_solve", "mi_pcg_begin", "mi_pcg_iterate", "mi_pcg_end",
     "mi_pbicg_solve", "mi_pbicgstab_solve", "mi_smooth_solve",
-    "mi_bench_amul", "mi_bench_pcg_iters", "mi_debug_occupancy",
+    "mi_bench_amul", "mi_bench_pcg_iters", "mi_debug_occupancy", "mi_debug_dense_invert",
     "mi_layout_build_host", "mi_layout_array", "mi_layout_free", "mi_layout_build_host_given", "mi_layout_inherit_tiles",
     "mi_dpcg_set_buffers", "mi_dpcg_phase", "mi_dpcg_status", "mi_event_record", "mi_event_elapsed_ms",
     "mi_gamg_create", "mi_gamg_update", "mi_gamg_level_matrix", "mi_gamg_scale", "mi_gamg_solve_coarsest", "mi_gamg_destroy", "mi_gamg_n_levels", "mi_gamg_forward_out", "mi_gamg_level_sizes",
@@ -225,6 +225,12 @@ class Context:
     def set_option(self, name: str, value: int):
         """mi_ctx_set_option: "pcg_persist", "pcg_fuse_rp", "win_direct", "gamg_graph_attached" 0 / 1"""
         _chk(lib().mi_ctx_set_option(self.h, name.encode(), C.c_int32(int(value))))
+
+    def dense_invert(self, a_dev, inv_dev, n: int, which: int) -> bool:
+        """diagnostic: invert the row-major n x n matrix a_dev into inv_dev with path `which` (mi_debug_dense_invert); False: singular"""
+        sing = C.c_int32()
+        _chk(lib().mi_debug_dense_invert(self.h, _ptr(a_dev), C.c_int32(n), _ptr(inv_dev), C.c_int32(which), C.byref(sing)))
+        return sing.value == 0
 
     def stat(self, which: int) -> int:
         """mi_ctx_stat: 0 = launches of the persistent PCG kernel on plain matrices, 1 = on communicator-attached ones,

@@ -802,3 +802,46 @@ def test_level_matrices_straight_into_the_tile_slots(pkg, orc, monkeypatch):
     for name in ("sym", "asym", "cyclic"):
         for k in range(3):
             assert np.array_equal(out["1", name][k], out["0", name][k]), (name, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_rebound_coefficients_step_after_step_with_both_inversion_kernels(pkg, orc, symmetric, monkeypatch):
+    """Round 6: a sequence of 'time steps' -- new coefficients, solve: the graph-replayed agglomeration, the coarsest inversion on the
+    side stream beside the (one-pass) prologue -- incl. a solve that converges in its prologue and is followed at once by a re-bind.
+    k_dense_invert_reg2 (default) and k_dense_invert_reg (MI_GAMG_INVERT_V2=0) perform the same operations: SAME BITS step for step."""
+    import torch
+    eng, syn = pkg.engine, pkg.synthetic
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    case = syn.box_case(40, 32, 24, symmetric=symmetric)
+    n = case.n_cells
+    w = orc.box_face_weights(case)
+    out = {}
+    for mode, env in (("v2", {}), ("v1", {"MI_GAMG_INVERT_V2": "0"}), ("host", {"MI_GAMG_DEVICE_INVERT": "0"})):
+        for k in ("MI_GAMG_DEVICE_INVERT", "MI_GAMG_INVERT_V2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = eng.Context(0, torch.cuda.current_stream().cuda_stream)
+        addr = eng.Addressing(ctx, n, case.lower_addr, case.upper_addr)
+        mat = eng.Matrix(addr)
+        G = eng.Gamg(addr, w, 60)
+        res = []
+        psi = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        for step in range(5):
+            f = 1.0 + 0.07 * step
+            mat.set_coeffs(dev(case.diag * f - 0.01 * step), dev(case.upper * (2.0 - f)), None if symmetric else dev(case.lower * f))
+            perf = G.solve(mat, psi, dev(case.source), tolerance=1e-9, maxIter=40)
+            res.append((perf["history"], perf["nIterations"], psi.cpu().numpy().copy()))
+            if step == 2:   # converged already: the prologue ends the solve; then straight into the next re-bind
+                p2 = G.solve(mat, psi, dev(case.source), tolerance=1e-3, maxIter=40)
+                assert p2["nIterations"] == 0
+                mat.set_coeffs(dev(case.diag * 3.0), dev(case.upper * 0.5), None if symmetric else dev(case.lower * 0.5))
+                p3 = G.solve(mat, psi, dev(case.source), tolerance=1e-3, maxIter=40)
+                res.append((p3["history"], p3["nIterations"], psi.cpu().numpy().copy()))
+        out[mode] = res
+        del G, mat, addr, ctx
+    for mode in ("v1", "host"):
+        for (ha, na, xa), (hb, nb, xb) in zip(out["v2"], out[mode]):
+            assert na == nb and np.array_equal(ha, hb) and np.array_equal(xa, xb), mode
+    assert out["v2"][0][1] > 2
