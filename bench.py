@@ -294,6 +294,7 @@ def main():
     host_loop = "single-GPU device-resident pipeline (mi_pcg_iterate)"
     allreduce_kind = "none (one rank)"
     path_taken, fallback_reason = "single-gpu five-launch pipeline", None
+    fused_rp = False
     weak = None
     supplements = {}
     if single:
@@ -316,7 +317,8 @@ def main():
             rep_s.append(time.perf_counter() - t0); rep_amul_ms.append(a_ms)
         perf = mat.pcg_end(None, history_len=W + R * K + 2)
         assert perf["nIterations"] == W + R * K, perf          # every timed step really iterated (no device-side early exit)
-        if ctx.stat(4) > 0:                                      # (csrc/pcg_fused.inc ran: three launches per iteration instead of five)
+        fused_rp = ctx.stat(4) > 0
+        if fused_rp:                                             # (csrc/pcg_fused.inc ran: three launches per iteration instead of five)
             host_loop += ": Amul, fold, then ONE launch for residual update + test + next direction (z = rD o rA stays on the chip)"
         assert np.all(np.isfinite(perf["history"])) and perf["history"][-1] < perf["history"][0]
         n_amul_cells, n_amul_faces = N, F
@@ -412,7 +414,7 @@ def main():
         allreduce_kind = (getattr(solver, "allreduce", "torch.distributed") + peer_note) if world > 1 else "none (one rank)"
         # the same, machine-readable (VERDICT r04 "next" 9): which inner loop the timed region ran and, if it is not the first choice, why
         if world == 1:
-            path_taken = "single-gpu five-launch pipeline"
+            path_taken = "single-gpu pipeline, fused residual / direction update (csrc/pcg_fused.inc)" if fused_rp else "single-gpu five-launch pipeline"
         elif solver.driver == "native" and getattr(solver.comms[0], "peer_mode", False):
             path_taken = "peer windows, persistent kernel" if in_kernel else "peer windows, five launches"
         elif solver.driver == "native":
