@@ -1,9 +1,12 @@
 // polyMesh.C -- see polyMesh.H
 #include "polyMesh.H"
 
+#include <cerrno>
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
+#include <sys/stat.h>
 
 namespace Foam
 {
@@ -318,5 +321,102 @@ scalarField readVolScalarInternalField(const std::string& file, label nCells)
     scalarField v = readList<scalar>(is, [](IFstream& s) { return s.readScalar(); });
     if ((label)v.size() != nCells) FatalErrorIn("readVolScalarInternalField", "field size does not match the mesh in " + file);
     return v;
+}
+
+vectorField readVolVectorInternalField(const std::string& file, label nCells)
+{
+    IFstream is(file);
+    is.header();
+    for (;;) {
+        if (is.eof()) FatalErrorIn("readVolVectorInternalField", "no internalField in " + file);
+        const std::string k = is.token();
+        if (k == "internalField") break;
+        if (k == "{") { int depth = 1; while (depth) { const std::string t = is.token(); if (t == "{") ++depth; else if (t == "}") --depth; } continue; }
+        if (k == "dimensions") { while (is.token() != ";") {} continue; }
+    }
+    const std::string kind = is.token();
+    if (kind == "uniform") return vectorField((std::size_t)nCells, readVec(is));
+    if (kind != "nonuniform") FatalErrorIn("readVolVectorInternalField", "internalField must be uniform or nonuniform in " + file);
+    const std::string cls = is.token();
+    if (cls != "List<vector>") FatalErrorIn("readVolVectorInternalField", "expected List<vector> but found " + cls + " in " + file);
+    vectorField v = readList<vector>(is, readVec);
+    if ((label)v.size() != nCells) FatalErrorIn("readVolVectorInternalField", "field size does not match the mesh in " + file);
+    return v;
+}
+
+namespace
+{
+// one value of a list: a scalar, or a vector as "(x y z)"
+void putValue(std::ostream& os, const scalar* v, int nCmpt)
+{
+    if (nCmpt == 1) { os << v[0]; return; }
+    os << '(';
+    for (int d = 0; d < nCmpt; ++d) { if (d) os << ' '; os << v[d]; }
+    os << ')';
+}
+// Field<Type>::writeEntry (Field.C:652-684) over UList's operator<< (UListIO.C:63-135); n values of nCmpt components each
+void writeFieldEntry(std::ostream& os, const std::string& indent, const char* keyword, const scalar* v, std::size_t n, int nCmpt, bool binary)
+{
+    std::string kw = keyword;
+    os << indent << kw << std::string(kw.size() < 15 ? 16 - kw.size() : 1, ' ');   // Ostream::writeKeyword: entryIndentation_ = 16
+    bool uniform = n > 0;
+    for (std::size_t i = 1; uniform && i < n; ++i)
+        for (int d = 0; d < nCmpt; ++d) if (v[i * nCmpt + d] != v[d]) { uniform = false; break; }
+    if (uniform) { os << "uniform "; putValue(os, v, nCmpt); os << ";\n"; return; }
+    os << "nonuniform " << (n ? (nCmpt == 1 ? "List<scalar> " : "List<vector> ") : "");
+    if (binary) {
+        os << '\n' << n << '\n';
+        if (n) { os << '('; os.write(reinterpret_cast<const char*>(v), (std::streamsize)(sizeof(scalar) * n * (std::size_t)nCmpt)); os << ')'; }
+    } else if (n <= 1 || n < 11) {
+        os << n << '(';
+        for (std::size_t i = 0; i < n; ++i) { if (i) os << ' '; putValue(os, v + i * nCmpt, nCmpt); }
+        os << ')';
+    } else {
+        os << '\n' << n << "\n(";
+        for (std::size_t i = 0; i < n; ++i) { os << '\n'; putValue(os, v + i * nCmpt, nCmpt); }
+        os << "\n)\n";
+    }
+    os << ";\n";
+}
+void writeVolField(const std::string& caseDir, const std::string& timeName, const word& object, const char* cls, const std::string& dimensions,
+                   const scalar* internal, std::size_t nCells, int nCmpt, const std::vector<patchFieldOut>& boundaryField, bool binary, int precision)
+{
+    const std::string dir = caseDir + "/" + timeName;
+    if (::mkdir(dir.c_str(), 0777) != 0 && errno != EEXIST) FatalErrorIn("writeVolField", "cannot create directory " + dir);
+    const std::string file = dir + "/" + object;
+    std::ofstream os(file, std::ios::binary);
+    if (!os) FatalErrorIn("writeVolField", "cannot open " + file + " for writing");
+    os << std::setprecision(precision);
+    os << "FoamFile\n{\n    version     2.0;\n    format      " << (binary ? "binary" : "ascii") << ";\n    class       " << cls << ";\n";
+    if (binary) os << "    arch        \"LSB;label=" << 8 * sizeof(label) << ";scalar=" << 8 * sizeof(scalar) << "\";\n";
+    os << "    location    \"" << timeName << "\";\n    object      " << object << ";\n}\n"
+       << "// * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * //\n\n";
+    os << "dimensions      " << dimensions << ";\n\n";
+    writeFieldEntry(os, "", "internalField", internal, nCells, nCmpt, binary);
+    os << "\nboundaryField\n{\n";
+    for (const patchFieldOut& P : boundaryField) {
+        os << "    " << P.patchName << "\n    {\n        type            " << P.type << ";\n";
+        if (P.hasValue) {
+            if (P.value.size() % (std::size_t)nCmpt) FatalErrorIn("writeVolField", "patch " + P.patchName + ": value size is not a multiple of the components");
+            writeFieldEntry(os, "        ", "value", P.value.data(), P.value.size() / (std::size_t)nCmpt, nCmpt, binary);
+        }
+        os << "    }\n";
+    }
+    os << "}\n\n\n// ************************************************************************* //\n";
+    if (!os) FatalErrorIn("writeVolField", "write to " + file + " failed");
+}
+} // namespace
+
+void writeVolScalarField(const std::string& caseDir, const std::string& timeName, const word& object, const std::string& dimensions,
+                         const scalarField& internalField, const std::vector<patchFieldOut>& boundaryField, bool binary, int precision)
+{
+    writeVolField(caseDir, timeName, object, "volScalarField", dimensions, internalField.data(), internalField.size(), 1, boundaryField, binary, precision);
+}
+void writeVolVectorField(const std::string& caseDir, const std::string& timeName, const word& object, const std::string& dimensions,
+                         const vectorField& internalField, const std::vector<patchFieldOut>& boundaryField, bool binary, int precision)
+{
+    static_assert(sizeof(vector) == 3 * sizeof(scalar), "vectorField is a packed array of 3 scalars");
+    writeVolField(caseDir, timeName, object, "volVectorField", dimensions, internalField.empty() ? nullptr : internalField[0].data(), internalField.size(), 3,
+                  boundaryField, binary, precision);
 }
 } // namespace Foam

@@ -4,7 +4,10 @@
 // caller of the hot path; this application shows the path fed from OpenFOAM's own on-disk format instead of the synthetic
 // box (tests/test_polymesh.py writes the case, recomputes geometry and coefficients with numpy and checks every line).
 //
-// usage: polyMeshFoam <caseDir> [-nonOrthCorrectors N]      (source term: <caseDir>/0/S, volScalarField)
+// usage: polyMeshFoam <caseDir> [-nonOrthCorrectors N] [-write <timeName> [-writeFormat ascii|binary] [-writePrecision N]]
+//        (source term: <caseDir>/0/S, volScalarField; -write: the GAMG solution goes back into the case as <caseDir>/<timeName>/p)
+//        polyMeshFoam <caseDir> -roundTrip <object> <timeName> <ascii|binary> <precision>
+//        (host only: <caseDir>/0/<object> is read, written as <caseDir>/<timeName>/<object>, read again and compared)
 // -nonOrthCorrectors N: afterwards, laplacianFoam's non-orthogonal corrector loop (laplacianFoam.C:60-70) with the `corrected`
 // snGrad scheme: N times { assemble fvm::laplacian incl. the explicit correction from the current p; solve with PCG + DIC }.
 #include "polyMesh.H"
@@ -22,6 +25,34 @@ int main(int argc, char** argv)
         polyMesh mesh(caseDir);
         const label n = mesh.nCells, nI = mesh.nInternalFaces();
         Info << std::setprecision(17);
+        for (int k = 2; k + 4 < argc; ++k) if (std::string(argv[k]) == "-roundTrip") {   // field I/O only: no device, no engine context
+            const std::string obj = argv[k + 1], time = argv[k + 2];
+            const bool bin = std::string(argv[k + 3]) == "binary";
+            const int prec = std::atoi(argv[k + 4]);
+            const scalarField in = readVolScalarInternalField(caseDir + "/0/" + obj, n);
+            std::vector<patchFieldOut> bf;
+            for (label p = 0; p < (label)mesh.boundary.size(); ++p) {
+                patchFieldOut e; e.patchName = mesh.boundary[p].name;
+                if (mesh.boundary[p].type == "patch") { e.type = "fixedValue"; e.hasValue = true; e.value = scalarField((std::size_t)mesh.boundary[p].nFaces, 0.25 * (p + 1)); }
+                else if (mesh.boundary[p].type == "processor") { e.type = "processor"; e.hasValue = true; e.value.resize((std::size_t)mesh.boundary[p].nFaces); for (std::size_t i = 0; i < e.value.size(); ++i) e.value[i] = in[(std::size_t)mesh.patchFaceCells(p)[i]]; }
+                else e.type = "zeroGradient";
+                bf.push_back(e);
+            }
+            writeVolScalarField(caseDir, time, obj, "[0 0 -1 0 0 0 0]", in, bf, bin, prec);
+            const scalarField back = readVolScalarInternalField(caseDir + "/" + time + "/" + obj, n);
+            scalar d = 0;
+            for (label c = 0; c < n; ++c) d = std::max(d, std::fabs(back[c] - in[c]));
+            vectorField U((std::size_t)n);                                              // ... and a vector field: the cell centres
+            for (label c = 0; c < n; ++c) U[c] = mesh.C[c];
+            std::vector<patchFieldOut> bfU;
+            for (const polyPatch& P : mesh.boundary) { patchFieldOut e; e.patchName = P.name; e.type = "zeroGradient"; bfU.push_back(e); }
+            writeVolVectorField(caseDir, time, "C", "[0 1 0 0 0 0 0]", U, bfU, bin, prec);
+            const vectorField Ub = readVolVectorInternalField(caseDir + "/" + time + "/C", n);
+            scalar dU = 0;
+            for (label c = 0; c < n; ++c) for (int q = 0; q < 3; ++q) dU = std::max(dU, std::fabs(Ub[c][q] - U[c][q]));
+            Info << "roundTrip " << obj << " nCells " << n << " maxAbsDiff " << d << " vector maxAbsDiff " << dU << std::endl << "End" << std::endl;
+            return 0;
+        }
         Info << "Create mesh: nPoints " << mesh.points.size() << " nCells " << n << " nFaces " << mesh.nFaces() << " nInternalFaces " << nI << std::endl;
         scalar sumV = 0, sumMagSf = 0, sumW = 0, sumD = 0;
         for (scalar v : mesh.V) sumV += v;
@@ -59,6 +90,24 @@ int main(int argc, char** argv)
             scalar s = 0, m = 0;
             for (scalar v : h) { s += v; m = std::max(m, std::fabs(v)); }
             Info << "p sum max: " << s << " " << m << std::endl;
+            // -write <timeName>: the solution as a volScalarField of the case (fixedValue 0 on `patch`, zeroGradient on `wall`)
+            std::string timeName, fmt = "ascii"; int prec = 6;
+            for (int k = 2; k + 1 < argc; ++k) {
+                if (std::string(argv[k]) == "-write") timeName = argv[k + 1];
+                if (std::string(argv[k]) == "-writeFormat") fmt = argv[k + 1];
+                if (std::string(argv[k]) == "-writePrecision") prec = std::atoi(argv[k + 1]);
+            }
+            if (!timeName.empty()) {
+                std::vector<patchFieldOut> bf;
+                for (const polyPatch& P : mesh.boundary) {
+                    patchFieldOut e; e.patchName = P.name;
+                    if (P.type == "patch") { e.type = "fixedValue"; e.hasValue = true; e.value = scalarField((std::size_t)P.nFaces, 0.0); }
+                    else e.type = "zeroGradient";
+                    bf.push_back(e);
+                }
+                writeVolScalarField(caseDir, timeName, "p", "[0 2 -2 0 0 0 0]", h, bf, fmt == "binary", prec);
+                Info << "wrote " << caseDir << "/" << timeName << "/p (" << fmt << ")" << std::endl;
+            }
         }
         label nCorr = 0;
         for (int k = 2; k + 1 < argc; ++k) if (std::string(argv[k]) == "-nonOrthCorrectors") nCorr = (label)std::atoi(argv[k + 1]);

@@ -170,7 +170,8 @@ def test_polyMeshFoam_reads_a_case_and_matches_the_oracle(pkg, orc, tmp_path, bi
     S = np.sin(4 * G["C"][:, 0]) * np.cos(3 * G["C"][:, 1]) + G["C"][:, 2]
     case_dir = str(tmp_path / "case")
     write_case(case_dir, pts, faces, owner, neighbour, patches, S, binary)
-    out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir, "-nonOrthCorrectors", "3"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir, "-nonOrthCorrectors", "3", "-write", "1", "-writeFormat", "binary" if binary else "ascii",
+                          "-writePrecision", "12"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     assert f"nCells {n} nFaces {len(faces)} nInternalFaces {len(neighbour)}" in out.stdout
     m = GEOM.search(out.stdout)
@@ -227,6 +228,158 @@ def test_polyMeshFoam_reads_a_case_and_matches_the_oracle(pkg, orc, tmp_path, bi
     mm = re.search(r"p sum max: (\S+) (\S+)", out.stdout)
     assert abs(float(mm.group(1)) - x2.sum()) < 1e-6 * np.abs(x2).sum() and abs(float(mm.group(2)) - np.abs(x2).max()) < 1e-6 * np.abs(x2).max()
     assert out.stdout.strip().endswith("End")
+    # the solution went back into the case as <case>/1/p: a volScalarField file as GeometricField writes it
+    fld = read_vol_field(os.path.join(case_dir, "1", "p"))
+    assert fld["header"]["class"] == "volScalarField" and fld["header"]["object"] == "p" and fld["header"]["location"] == "1"
+    assert fld["header"]["format"] == ("binary" if binary else "ascii") and fld["dimensions"] == "[0 2 -2 0 0 0 0]"
+    assert fld["internalField"].shape == (n,) and np.max(np.abs(fld["internalField"] - x2)) < 1e-7 * np.abs(x2).max()
+    assert [b[0] for b in fld["boundaryField"]] == [pt[0] for pt in patches]
+    for (name, entries), (_, ptype, cnt, _) in zip(fld["boundaryField"], patches):
+        assert entries["type"] == ("fixedValue" if ptype == "patch" else "zeroGradient")
+        assert ("value" in entries) == (ptype == "patch") and (ptype != "patch" or entries["value"] == ("uniform", 0.0))
+
+
+def read_vol_field(path):
+    """a volScalarField / volVectorField file, parsed independently of the C++ reader: FoamFile header entries, dimensions, internalField
+    (uniform -> ("uniform", v); nonuniform -> numpy array; ascii or binary lists), boundaryField as [(patch, {key: value})]"""
+    raw = open(path, "rb").read()
+    pos = [0]
+
+    def skip():
+        while True:
+            while pos[0] < len(raw) and raw[pos[0]:pos[0] + 1].isspace():
+                pos[0] += 1
+            if raw[pos[0]:pos[0] + 2] == b"//":
+                pos[0] = raw.index(b"\n", pos[0])
+                continue
+            if raw[pos[0]:pos[0] + 2] == b"/*":
+                pos[0] = raw.index(b"*/", pos[0]) + 2
+                continue
+            return
+
+    def tok():
+        skip()
+        c = raw[pos[0]:pos[0] + 1]
+        if c in b"(){};" and c:
+            pos[0] += 1
+            return c.decode()
+        if c == b'"':
+            e = raw.index(b'"', pos[0] + 1)
+            t = raw[pos[0] + 1:e].decode(); pos[0] = e + 1
+            return t
+        b0 = pos[0]
+        while pos[0] < len(raw) and not raw[pos[0]:pos[0] + 1].isspace() and raw[pos[0]:pos[0] + 1] not in b"(){};":
+            pos[0] += 1
+        return raw[b0:pos[0]].decode()
+
+    assert tok() == "FoamFile" and tok() == "{"
+    header = {}
+    while True:
+        k = tok()
+        if k == "}":
+            break
+        header[k] = tok()
+        assert tok() == ";"
+    binary = header["format"] == "binary"
+    ncmpt = 3 if header["class"] == "volVectorField" else 1
+
+    def value():
+        if ncmpt == 1:
+            return float(tok())
+        assert tok() == "("
+        v = [float(tok()) for _ in range(3)]
+        assert tok() == ")"
+        return v
+
+    def field_entry():
+        kind = tok()
+        if kind == "uniform":
+            v = value(); assert tok() == ";"
+            return ("uniform", v)
+        assert kind == "nonuniform"
+        t = tok()
+        if t.startswith("List<"):
+            assert t == ("List<vector>" if ncmpt == 3 else "List<scalar>")
+            t = tok()
+        cnt = int(t)
+        if binary and cnt:
+            skip(); assert raw[pos[0]:pos[0] + 1] == b"("
+            a = np.frombuffer(raw, dtype=np.float64, count=cnt * ncmpt, offset=pos[0] + 1).copy(); pos[0] += 1 + 8 * cnt * ncmpt
+            assert tok() == ")"
+        else:
+            assert tok() == "("
+            a = np.array([value() for _ in range(cnt)], dtype=np.float64)
+            assert tok() == ")"
+        assert tok() == ";"
+        return a.reshape(cnt, 3) if ncmpt == 3 else a.reshape(cnt)
+
+    assert tok() == "dimensions"
+    dims = []
+    while True:
+        t = tok()
+        if t == ";":
+            break
+        dims.append(t)
+    assert tok() == "internalField"
+    internal = field_entry()
+    assert tok() == "boundaryField" and tok() == "{"
+    bf = []
+    while True:
+        name = tok()
+        if name == "}":
+            break
+        assert tok() == "{"
+        entries = {}
+        while True:
+            k = tok()
+            if k == "}":
+                break
+            if k == "value":
+                entries[k] = field_entry()
+            else:
+                entries[k] = tok(); assert tok() == ";"
+        bf.append((name, entries))
+    return dict(header=header, dimensions=" ".join(dims), internalField=internal, boundaryField=bf, raw=raw)
+
+
+@pytest.mark.parametrize("fmt, precision", [("ascii", 17), ("binary", 6), ("ascii", 6)])
+def test_field_output_round_trip(pkg, tmp_path, fmt, precision):
+    """field I/O without a device (polyMeshFoam -roundTrip): <case>/0/S is read, written as <case>/5/S by writeVolScalarField, read again;
+    plus the cell centres as a volVectorField.  Binary and 17-digit ascii are exact, 6 digits (IOstream::defaultPrecision) to 6 digits;
+    the files are what GeometricField writes -- header, dimensions, internalField via Field::writeEntry, one boundaryField block per patch,
+    lists of 11 entries and more one value per line (UListIO.C:110-125), uniform patch values as `uniform v` (Field.C:672-675)."""
+    dims = (5, 4, 3)
+    pts, faces, owner, neighbour, patches = make_box_mesh(dims)
+    n = int(owner.max()) + 1
+    G = geometry(pts, faces, owner, neighbour)
+    S = np.sin(4 * G["C"][:, 0]) * np.cos(3 * G["C"][:, 1]) + G["C"][:, 2] * 1e3
+    case_dir = str(tmp_path / "case")
+    write_case(case_dir, pts, faces, owner, neighbour, patches, S, False)
+    out = subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir, "-roundTrip", "S", "5", fmt, str(precision)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"roundTrip S nCells (\d+) maxAbsDiff (\S+) vector maxAbsDiff (\S+)", out.stdout)
+    assert m and int(m.group(1)) == n
+    exact = fmt == "binary" or precision >= 17
+    tol = 0.0 if exact else 5e-6 * np.abs(S).max()
+    assert float(m.group(2)) <= tol and float(m.group(3)) <= (0.0 if exact else 5e-6 * np.abs(G["C"]).max())
+    f = read_vol_field(os.path.join(case_dir, "5", "S"))
+    assert f["header"] == {**f["header"], "version": "2.0", "format": fmt, "class": "volScalarField", "location": "5", "object": "S"}
+    assert ("arch" in f["header"]) == (fmt == "binary")
+    assert f["dimensions"] == "[0 0 -1 0 0 0 0]"
+    assert (np.array_equal(f["internalField"], S) if exact else np.max(np.abs(f["internalField"] - S)) <= tol)
+    for (name, entries), (pname, ptype, cnt, start) in zip(f["boundaryField"], patches):
+        assert name == pname
+        if ptype == "patch":
+            assert entries["type"] == "fixedValue" and entries["value"][0] == "uniform" and entries["value"][1] > 0
+        else:
+            assert entries == {"type": "zeroGradient"}
+    if fmt == "ascii":   # one value per line from 11 entries on, as UList's operator<< writes them
+        body = f["raw"].decode()
+        assert f"internalField   nonuniform List<scalar> \n{n}\n(\n" in body and "\n)\n;\n" in body
+    c = read_vol_field(os.path.join(case_dir, "5", "C"))
+    assert c["header"]["class"] == "volVectorField" and c["internalField"].shape == (n, 3)
+    assert (np.array_equal(c["internalField"], G["C"]) if exact else np.max(np.abs(c["internalField"] - G["C"])) <= 5e-6 * np.abs(G["C"]).max()) or \
+        np.max(np.abs(c["internalField"] - G["C"])) < 1e-12      # (the C++ geometry and numpy's agree to rounding, not to the bit)
 
 
 def test_reader_rejects_broken_meshes(pkg, tmp_path):
