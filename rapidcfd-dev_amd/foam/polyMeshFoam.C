@@ -6,13 +6,19 @@
 //
 // usage: polyMeshFoam <caseDir> [-nonOrthCorrectors N] [-write <timeName> [-writeFormat ascii|binary] [-writePrecision N]]
 //        (source term: <caseDir>/0/S, volScalarField; -write: the GAMG solution goes back into the case as <caseDir>/<timeName>/p)
+//        With a <caseDir>/system/fvSolution the pressure solves take their controls from it, as fvMatrix::solve() does:
+//        solvers.p for the first solve, solvers.pFinal (if present, else solvers.p) for the second -- without one: PCG + DIC, then GAMG.
+//        polyMeshFoam <caseDir> -solverDict <fieldName>      (host only: the controls lduMatrix::solver::New would be handed, and the
+//                                                             relaxation factors of that name, read from <caseDir>/system/fvSolution)
 //        polyMeshFoam <caseDir> -roundTrip <object> <timeName> <ascii|binary> <precision>
 //        (host only: <caseDir>/0/<object> is read, written as <caseDir>/<timeName>/<object>, read again and compared)
 // -nonOrthCorrectors N: afterwards, laplacianFoam's non-orthogonal corrector loop (laplacianFoam.C:60-70) with the `corrected`
 // snGrad scheme: N times { assemble fvm::laplacian incl. the explicit correction from the current p; solve with PCG + DIC }.
 #include "polyMesh.H"
+#include "solution.H"
 
 #include <cmath>
+#include <fstream>
 #include <iomanip>
 
 using namespace Foam;
@@ -25,6 +31,23 @@ int main(int argc, char** argv)
         polyMesh mesh(caseDir);
         const label n = mesh.nCells, nI = mesh.nInternalFaces();
         Info << std::setprecision(17);
+        for (int k = 2; k + 1 < argc; ++k) if (std::string(argv[k]) == "-solverDict") {   // dictionary I/O only: no device
+            const solution sol(caseDir);
+            const word field = argv[k + 1];
+            const dictionary d = sol.solverDict(field);
+            Info << "solvers." << field << std::endl;
+            for (const auto& kv : d.entries()) Info << "    " << kv.first << " = " << kv.second << std::endl;
+            Info << "relaxField " << sol.relaxField(field) << " relaxEquation " << sol.relaxEquation(field) << std::endl;
+            if (sol.relaxField(field)) Info << "fieldRelaxationFactor " << sol.fieldRelaxationFactor(field) << std::endl;
+            if (sol.relaxEquation(field)) Info << "equationRelaxationFactor " << sol.equationRelaxationFactor(field) << std::endl;
+            for (const char* alg : {"PISO", "SIMPLE", "PIMPLE"}) if (sol.solutionDict().found(alg)) {
+                Info << alg << std::endl;
+                const dictionary ad = sol.dict(alg);
+                for (const auto& kv : ad.entries()) Info << "    " << kv.first << " = " << kv.second << std::endl;
+            }
+            Info << "End" << std::endl;
+            return 0;
+        }
         for (int k = 2; k + 4 < argc; ++k) if (std::string(argv[k]) == "-roundTrip") {   // field I/O only: no device, no engine context
             const std::string obj = argv[k + 1], time = argv[k + 2];
             const bool bin = std::string(argv[k + 3]) == "binary";
@@ -78,14 +101,26 @@ int main(int argc, char** argv)
         pEqn.source() = S;
         const scalarField w = mesh.faceAreaPairWeights();
         setFaceAreaPairWeights(&w);
+        // the solver controls: solvers.p / solvers.pFinal of <caseDir>/system/fvSolution when the case has one (fvMatrixSolve.C:56-101)
+        dictionary first{{"solver", "PCG"}, {"preconditioner", "DIC"}, {"tolerance", "1e-09"}, {"relTol", "0"}};
+        dictionary second{{"solver", "GAMG"}, {"smoother", "GaussSeidel"}, {"agglomerator", "faceAreaPair"}, {"nCellsInCoarsestLevel", "10"},
+                          {"mergeLevels", "1"}, {"tolerance", "1e-09"}, {"relTol", "0"}, {"cacheAgglomeration", "true"}};
         {
-            scalargpuField psi(n);
-            pEqn.solve(psi, dictionary{{"solver", "PCG"}, {"preconditioner", "DIC"}, {"tolerance", "1e-09"}, {"relTol", "0"}});
+            std::ifstream probe(caseDir + "/system/fvSolution");
+            if (probe) {
+                const solution sol(caseDir);
+                first = sol.solverDict("p");
+                second = sol.solutionDict().subDict("solvers").found("pFinal") ? sol.solverDict("pFinal") : first;
+                Info << "solver controls from " << caseDir << "/system/fvSolution" << std::endl;
+            }
         }
         {
             scalargpuField psi(n);
-            pEqn.solve(psi, dictionary{{"solver", "GAMG"}, {"smoother", "GaussSeidel"}, {"agglomerator", "faceAreaPair"}, {"nCellsInCoarsestLevel", "10"},
-                                       {"mergeLevels", "1"}, {"tolerance", "1e-09"}, {"relTol", "0"}, {"cacheAgglomeration", "true"}});
+            pEqn.solve(psi, first);
+        }
+        {
+            scalargpuField psi(n);
+            pEqn.solve(psi, second);
             std::vector<scalar> h = psi.asHost();
             scalar s = 0, m = 0;
             for (scalar v : h) { s += v; m = std::max(m, std::fabs(v)); }

@@ -1,0 +1,211 @@
+"""<case>/system/fvSolution -> the controls lduMatrix::solver::New is handed (rapidcfd-dev_amd/foam/solution.{H,C}).
+
+fvMatrix::solve() passes solvers.<fieldName> of the mesh's `solution` (fvMatrixSolve.C:56-101 -> solution.C:365-374) and relax() the
+equation's relaxation factor (solution.C:268-349).  The reader is host code (no device): `polyMeshFoam <case> -solverDict <field>` prints
+what the look-ups return.  Checked here on a file written the way the tutorials write theirs: comments, nested dictionaries, quoted keys as
+regular expressions with the LAST matching pattern winning, exact keys before patterns, `$p;` to inherit a whole dictionary and `$tol` for a
+value, a `preconditioner { ... }` given as a dictionary, both forms of `relaxationFactors`; and the errors of the reference for what is
+missing.  The gpu test runs polyMeshFoam with its solvers chosen by the file."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_polymesh import PKG, make_box_mesh, geometry, write_case, LINE
+
+FVSOLUTION = r'''/*--------------------------------*- C++ -*----------------------------------*\
+| =========                 |                                                 |
+\*---------------------------------------------------------------------------*/
+FoamFile
+{
+    version     2.0;
+    format      ascii;
+    class       dictionary;
+    location    "system";
+    object      fvSolution;
+}
+// * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * //
+
+tol     1e-07;   // a top-level variable
+
+solvers
+{
+    p
+    {
+        solver          GAMG;
+        tolerance       $tol;
+        relTol          0.05;
+        smoother        GaussSeidel;
+        cacheAgglomeration true;
+        nCellsInCoarsestLevel 10;
+        agglomerator    faceAreaPair;
+        mergeLevels     1;
+    }
+
+    pFinal
+    {
+        $p;
+        relTol          0;      /* overrides the inherited one */
+    }
+
+    "(U|k|epsilon)"
+    {
+        solver          PBiCG;
+        preconditioner  DILU;
+        tolerance       1e-05;
+        relTol          0.1;
+    }
+
+    "(U|k|epsilon)Final"
+    {
+        $U;
+        relTol          0;
+    }
+
+    "k.*"          // a later pattern: tried before the earlier ones
+    {
+        solver          smoothSolver;
+        smoother        GaussSeidel;
+        nSweeps         2;
+        tolerance       1e-08;
+    }
+
+    T
+    {
+        solver          PCG;
+        preconditioner
+        {
+            preconditioner  DIC;
+            someOption      3;
+        }
+        tolerance       1e-06;
+        relTol          0;
+    }
+}
+
+PISO
+{
+    nCorrectors     2;
+    nNonOrthogonalCorrectors 0;
+    pRefCell        0;
+    pRefValue       0;
+}
+
+relaxationFactors
+{
+    fields
+    {
+        p               0.3;
+    }
+    equations
+    {
+        U               0.7;
+        "(k|epsilon).*" 0.5;
+        default         0.9;
+    }
+}
+
+// ************************************************************************* //
+'''
+
+
+def run(case_dir, *args):
+    return subprocess.run([os.path.join(PKG, "polyMeshFoam"), case_dir, *args], capture_output=True, text=True, timeout=300)
+
+
+def parse(out):
+    blocks, cur = {}, None
+    scal = {}
+    for line in out.splitlines():
+        if line.startswith("    ") and cur is not None:
+            k, v = line.strip().split(" = ", 1)
+            blocks[cur][k] = v
+        elif re.match(r"^(relaxField|fieldRelaxationFactor|equationRelaxationFactor)\b", line):
+            t = line.split()
+            scal.update({t[i]: float(t[i + 1]) for i in range(0, len(t), 2)})
+            cur = None
+        else:
+            cur = line.strip()
+            blocks[cur] = {}
+    return blocks, scal
+
+
+@pytest.fixture()
+def case(pkg, tmp_path):
+    dims = (6, 5, 4)
+    pts, faces, owner, neighbour, patches = make_box_mesh(dims)
+    G = geometry(pts, faces, owner, neighbour)
+    S = np.sin(4 * G["C"][:, 0]) * np.cos(3 * G["C"][:, 1]) + G["C"][:, 2]
+    case_dir = str(tmp_path / "case")
+    write_case(case_dir, pts, faces, owner, neighbour, patches, S, False)
+    os.makedirs(os.path.join(case_dir, "system"), exist_ok=True)
+    open(os.path.join(case_dir, "system", "fvSolution"), "w").write(FVSOLUTION)
+    return case_dir
+
+
+def test_solver_dictionaries_and_relaxation_factors(case):
+    def sd(field):
+        out = run(case, "-solverDict", field)
+        assert out.returncode == 0, out.stderr
+        b, s = parse(out.stdout)
+        return b["solvers." + field], s, b
+
+    d, s, b = sd("p")
+    assert d == {"solver": "GAMG", "tolerance": "1e-07", "relTol": "0.05", "smoother": "GaussSeidel", "cacheAgglomeration": "true",
+                 "nCellsInCoarsestLevel": "10", "agglomerator": "faceAreaPair", "mergeLevels": "1"}          # $tol substituted
+    assert s["relaxField"] == 1 and s["fieldRelaxationFactor"] == 0.3 and s["relaxEquation"] == 1 and s["equationRelaxationFactor"] == 0.9   # equations: the default
+    assert b["PISO"] == {"nCorrectors": "2", "nNonOrthogonalCorrectors": "0", "pRefCell": "0", "pRefValue": "0"}
+    d, s, _ = sd("pFinal")
+    assert d["solver"] == "GAMG" and d["relTol"] == "0" and d["tolerance"] == "1e-07" and d["smoother"] == "GaussSeidel"   # `$p;` + the override
+    assert s["relaxField"] == 0                                                       # no field factor for pFinal, no field default
+    d, s, _ = sd("U")
+    assert d == {"solver": "PBiCG", "preconditioner": "DILU", "tolerance": "1e-05", "relTol": "0.1"} and s["equationRelaxationFactor"] == 0.7
+    d, s, _ = sd("UFinal")
+    assert d["solver"] == "PBiCG" and d["relTol"] == "0"                              # `$U;` resolved through the pattern "(U|k|epsilon)"
+    d, s, _ = sd("epsilon")
+    assert d["solver"] == "PBiCG" and s["equationRelaxationFactor"] == 0.5            # the pattern "(k|epsilon).*"
+    d, s, _ = sd("k")
+    assert d["solver"] == "smoothSolver" and d["nSweeps"] == "2"                      # "k.*" was added after "(U|k|epsilon)": it is tried first
+    d, s, _ = sd("kFinal")
+    assert d["solver"] == "smoothSolver"                                              # ... also before "(U|k|epsilon)Final"
+    d, s, _ = sd("T")
+    assert d["preconditioner"] == "DIC" and d["preconditioner.someOption"] == "3" and d["solver"] == "PCG"   # preconditioner given as a dictionary
+    out = run(case, "-solverDict", "nuTilda")
+    assert out.returncode != 0 and "keyword nuTilda is undefined in dictionary" in out.stderr
+
+
+def test_old_style_relaxation_factors_and_broken_files(case):
+    path = os.path.join(case, "system", "fvSolution")
+    text = FVSOLUTION[:FVSOLUTION.index("relaxationFactors")] + "relaxationFactors\n{\n    p 0.3;\n    rho 0.05;\n    U 0.7;\n}\n"
+    open(path, "w").write(text)
+    out = run(case, "-solverDict", "p"); _, s = parse(out.stdout)
+    assert s["fieldRelaxationFactor"] == 0.3 and s["equationRelaxationFactor"] == 0.3     # solution.C:77-101: p* and rho* are field factors, everything an equation factor
+    out = run(case, "-solverDict", "U"); _, s = parse(out.stdout)
+    assert s["relaxField"] == 0 and s["equationRelaxationFactor"] == 0.7
+    out = run(case, "-solverDict", "T"); _, s = parse(out.stdout)
+    assert s["relaxField"] == 0 and s["relaxEquation"] == 0
+    for bad, msg in (("solvers { p { solver GAMG; }", "missing '}'"), ("solvers { p { solver GAMG } }", "not terminated by ';'"),
+                     ("#include \"other\"\nsolvers { p { solver PCG; } }", "not supported"), ("solvers { pFinal { $p; } }", "no dictionary of that name")):
+        open(path, "w").write(bad)
+        out = run(case, "-solverDict", "p")
+        assert out.returncode != 0 and msg in out.stderr, (bad, out.stderr)
+
+
+@pytest.mark.gpu
+def test_polyMeshFoam_takes_its_solvers_from_fvSolution(case):
+    out = run(case)
+    assert out.returncode == 0, out.stderr
+    assert "solver controls from" in out.stdout
+    got = [(m.group(1), float(m.group(3)), float(m.group(4)), int(m.group(5))) for m in map(LINE.match, out.stdout.splitlines()) if m]
+    assert [g[0] for g in got] == ["GAMG", "GAMG"]                                   # solvers.p, then solvers.pFinal
+    assert got[0][2] <= 0.05 * got[0][1] * (1 + 1e-12) and got[0][3] < got[1][3]      # relTol 0.05 stops the first early; pFinal (relTol 0) runs to 1e-7
+    assert got[1][2] < 1e-7
+    # and with other controls in the file
+    path = os.path.join(case, "system", "fvSolution")
+    open(path, "w").write("solvers\n{\n    \"p.*\"\n    {\n        solver PCG;\n        preconditioner DIC;\n        tolerance 1e-10;\n        relTol 0;\n        maxIter 7;\n    }\n}\n")
+    out = run(case)
+    got = [(m.group(1), int(m.group(5))) for m in map(LINE.match, out.stdout.splitlines()) if m]
+    # DIC resolves to AINV in this reference; maxIter from the file -- and PCG.C:204's `nIterations++ < maxIter_` runs one iteration more
+    assert got == [("AINVPCG", 8), ("AINVPCG", 8)]
