@@ -10,6 +10,7 @@
 //        solvers.p for the first solve, solvers.pFinal (if present, else solvers.p) for the second -- without one: PCG + DIC, then GAMG.
 //        polyMeshFoam <caseDir> -solverDict <fieldName>      (host only: the controls lduMatrix::solver::New would be handed, and the
 //                                                             relaxation factors of that name, read from <caseDir>/system/fvSolution)
+//        polyMeshFoam <caseDir> -scheme <ddt|div|grad|laplacian|interpolation|snGrad|d2dt2> <name>   (host only: <caseDir>/system/fvSchemes)
 //        polyMeshFoam <caseDir> -roundTrip <object> <timeName> <ascii|binary> <precision>
 //        (host only: <caseDir>/0/<object> is read, written as <caseDir>/<timeName>/<object>, read again and compared)
 // -nonOrthCorrectors N: afterwards, laplacianFoam's non-orthogonal corrector loop (laplacianFoam.C:60-70) with the `corrected`
@@ -46,6 +47,19 @@ int main(int argc, char** argv)
                 for (const auto& kv : ad.entries()) Info << "    " << kv.first << " = " << kv.second << std::endl;
             }
             Info << "End" << std::endl;
+            return 0;
+        }
+        for (int k = 2; k + 2 < argc; ++k) if (std::string(argv[k]) == "-scheme") {      // <kind> <name>: what mesh.<kind>Scheme(name) returns
+            const fvSchemes sch(caseDir);
+            const word kind = argv[k + 1], name = argv[k + 2];
+            wordList t;
+            if (kind == "ddt") t = sch.ddtScheme(name); else if (kind == "div") t = sch.divScheme(name); else if (kind == "grad") t = sch.gradScheme(name);
+            else if (kind == "laplacian") t = sch.laplacianScheme(name); else if (kind == "interpolation") t = sch.interpolationScheme(name);
+            else if (kind == "snGrad") t = sch.snGradScheme(name); else if (kind == "d2dt2") t = sch.d2dt2Scheme(name);
+            else FatalErrorIn("polyMeshFoam -scheme", "unknown kind " + kind);
+            Info << kind << "Scheme(" << name << ") =";
+            for (const word& w : t) Info << " " << w;
+            Info << std::endl << "steady " << sch.steady() << " fluxRequired " << sch.fluxRequired(name) << std::endl << "End" << std::endl;
             return 0;
         }
         for (int k = 2; k + 4 < argc; ++k) if (std::string(argv[k]) == "-roundTrip") {   // field I/O only: no device, no engine context

@@ -210,4 +210,60 @@ scalar solution::equationRelaxationFactor(const word& name) const
     if (eqnRelaxDefault_ > 1e-15) return eqnRelaxDefault_;
     FatalErrorIn("Foam::solution::eqnRelaxationFactor(const word&)", "Cannot find equation relaxation factor for '" + name + "' or a suitable default value.");
 }
+
+// ---- fvSchemes ---------------------------------------------------------------------------------------------------------------
+namespace
+{
+wordList splitTokens(const word& v)
+{
+    wordList t; std::size_t b = 0;
+    while (b < v.size()) {
+        while (b < v.size() && v[b] == ' ') ++b;
+        std::size_t e = b;
+        while (e < v.size() && v[e] != ' ') ++e;
+        if (e > b) t.push_back(v.substr(b, e - b));
+        b = e;
+    }
+    return t;
+}
+}
+fvSchemes::fvSchemes(const std::string& caseDir, const std::string& dictName) : dict_(readDictionaryFile(caseDir + "/system/" + dictName)) { read(); }
+fvSchemes::fvSchemes(const std::string& text, const std::string& nameForErrors, int) : dict_(parseDictionary(text, nameForErrors)) { read(); }
+void fvSchemes::readKind(kind& k, const char* name, bool setNoneWhenAbsent)
+{
+    k.d = std::make_shared<dictTree>();
+    if (sch_->found(name)) *k.d = sch_->subDict(name);
+    else if (setNoneWhenAbsent) { dictTree::entry e; e.key = "default"; e.value = "none"; k.d->entries.push_back(e); }   // (ddtSchemes / d2dt2Schemes: fvSchemes.C:100-103,132-135)
+    k.d->parent = nullptr;
+    k.def.clear();
+    if (k.d->found("default")) { const word v = k.d->lookup("default"); if (splitTokens(v).empty() || splitTokens(v)[0] != "none") k.def = v; }
+}
+void fvSchemes::read()
+{
+    sch_ = dict_->found("select") ? &dict_->subDict(dict_->lookup("select")) : dict_.get();   // fvSchemes.C:411-421
+    readKind(ddt_, "ddtSchemes", true);
+    if (!sch_->found("ddtSchemes") && sch_->found("timeScheme")) {   // backward compatibility, fvSchemes.C:64-99
+        word n = sch_->lookup("timeScheme");
+        if (n == "EulerImplicit") n = "Euler"; else if (n == "BackwardDifferencing") n = "backward"; else if (n == "SteadyState") n = "steadyState";
+        else FatalErrorIn("fvSchemes::read()", "\n    Only EulerImplicit, BackwardDifferencing and SteadyState\n    are supported by the old timeScheme specification.\n    Please use ddtSchemes instead.");
+        ddt_.d->entries.clear(); dictTree::entry e; e.key = "default"; e.value = n; ddt_.d->entries.push_back(e); ddt_.def = n;
+    }
+    steady_ = ddt_.def == "steadyState";
+    readKind(d2dt2_, "d2dt2Schemes", true);
+    readKind(interpolation_, "interpolationSchemes", false);
+    readKind(div_, "divSchemes", false);
+    readKind(grad_, "gradSchemes", false);
+    readKind(snGrad_, "snGradSchemes", false);
+    readKind(laplacian_, "laplacianSchemes", false);
+    fluxRequired_ = std::make_shared<dictTree>();
+    if (sch_->found("fluxRequired")) {
+        *fluxRequired_ = sch_->subDict("fluxRequired"); fluxRequired_->parent = nullptr;
+        if (fluxRequired_->found("default")) { const word v = fluxRequired_->lookup("default"); defaultFluxRequired_ = v != "none" && (v == "yes" || v == "true" || v == "on"); }
+    }
+}
+wordList fvSchemes::lookupIn(const kind& k, const word& name)
+{
+    if (k.d->found(name) || k.def.empty()) return splitTokens(k.d->lookup(name));   // (lookup: the reference's "keyword ... is undefined in dictionary")
+    return splitTokens(k.def);
+}
 } // namespace Foam

@@ -209,3 +209,50 @@ def test_polyMeshFoam_takes_its_solvers_from_fvSolution(case):
     got = [(m.group(1), int(m.group(5))) for m in map(LINE.match, out.stdout.splitlines()) if m]
     # DIC resolves to AINV in this reference; maxIter from the file -- and PCG.C:204's `nIterations++ < maxIter_` runs one iteration more
     assert got == [("AINVPCG", 8), ("AINVPCG", 8)]
+
+
+FVSCHEMES = r'''FoamFile { version 2.0; format ascii; class dictionary; location "system"; object fvSchemes; }
+
+ddtSchemes          { default Euler; }
+gradSchemes         { default Gauss linear; grad(p) Gauss linear; }
+divSchemes
+{
+    default         none;
+    div(phi,U)      Gauss limitedLinear 1;
+    div(phi,k)      Gauss upwind;
+    "div\(phi,(epsilon|omega)\)" Gauss upwind;
+    div((nuEff*dev(T(grad(U))))) Gauss linear;
+}
+laplacianSchemes    { default Gauss linear corrected; }
+interpolationSchemes { default linear; }
+snGradSchemes       { default corrected; }
+fluxRequired        { default no; p; }
+'''
+
+
+def test_discretisation_schemes_from_fvSchemes(case):
+    """mesh.divScheme("div(phi,U)") and friends (fvSchemes.C:424-576): the named entry, else the kind's default unless that is `none`;
+    keys with nested parentheses, a regular-expression key, ddtSchemes' implied `default none`, fluxRequired"""
+    path = os.path.join(case, "system", "fvSchemes")
+    open(path, "w").write(FVSCHEMES)
+
+    def sc(kind, name):
+        out = run(case, "-scheme", kind, name)
+        return out, (re.search(r"Scheme\(.*\) =(.*)", out.stdout).group(1).split() if out.returncode == 0 else None)
+
+    assert sc("div", "div(phi,U)")[1] == ["Gauss", "limitedLinear", "1"]
+    assert sc("div", "div(phi,k)")[1] == ["Gauss", "upwind"]
+    assert sc("div", "div(phi,omega)")[1] == ["Gauss", "upwind"]                      # through the pattern key
+    assert sc("div", "div((nuEff*dev(T(grad(U)))))")[1] == ["Gauss", "linear"]
+    out, t = sc("div", "div(phi,T)")                                                  # default none: the reference's error
+    assert out.returncode != 0 and "keyword div(phi,T) is undefined in dictionary" in out.stderr
+    assert sc("laplacian", "laplacian(nu,U)")[1] == ["Gauss", "linear", "corrected"]  # the kind's default
+    assert sc("grad", "grad(U)")[1] == ["Gauss", "linear"] and sc("snGrad", "snGrad(p)")[1] == ["corrected"]
+    out, t = sc("ddt", "ddt(U)")
+    assert t == ["Euler"] and "steady 0" in out.stdout
+    assert "fluxRequired 1" in sc("interpolation", "p")[0].stdout and "fluxRequired 0" in sc("interpolation", "U")[0].stdout
+    open(path, "w").write(FVSCHEMES.replace("ddtSchemes          { default Euler; }", "ddtSchemes { default steadyState; }"))
+    assert "steady 1" in sc("ddt", "ddt(U)")[0].stdout
+    open(path, "w").write(FVSCHEMES.replace("ddtSchemes          { default Euler; }", ""))     # no ddtSchemes: `default none` is implied, a look-up fails
+    out, t = sc("ddt", "ddt(U)")
+    assert out.returncode != 0 and "keyword ddt(U) is undefined in dictionary" in out.stderr
