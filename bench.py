@@ -320,6 +320,7 @@ def main():
         fused_rp = ctx.stat(4) > 0
         if fused_rp:                                             # (csrc/pcg_fused.inc ran: three launches per iteration instead of five)
             host_loop += ": Amul, fold, then ONE launch for residual update + test + next direction (z = rD o rA stays on the chip)"
+            path_taken = "single-gpu pipeline, fused residual / direction update (csrc/pcg_fused.inc)"
         assert np.all(np.isfinite(perf["history"])) and perf["history"][-1] < perf["history"][0]
         n_amul_cells, n_amul_faces = N, F
         # Amul alone, out of the solver loop: rotating vectors (4 input/output pairs = 645 MB > the 256 MiB Infinity Cache),
