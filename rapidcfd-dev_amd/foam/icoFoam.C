@@ -1,0 +1,237 @@
+// icoFoam.C -- BASELINE config 1's application on the engine: transient incompressible laminar flow, PISO, written against the mirror
+// the way applications/solvers/incompressible/icoFoam/icoFoam.C is written against OpenFOAM -- statement for statement:
+//
+//     fvVectorMatrix UEqn(fvm::ddt(U) + fvm::div(phi, U) - fvm::laplacian(nu, U));
+//     solve(UEqn == -fvc::grad(p));
+//     PISO: rAU = 1/UEqn.A(); HbyA = rAU*UEqn.H(); phiHbyA = (interpolate(HbyA) & Sf) + interpolate(rAU)*ddtCorr(U, phi);
+//           pEqn(fvm::laplacian(rAU, p) == fvc::div(phiHbyA)); setReference; solve; phi = phiHbyA - pEqn.flux();
+//           continuity errors; U = HbyA - rAU*fvc::grad(p)
+//
+// on a real case directory: constant/polyMesh, constant/transportProperties (nu), system/controlDict (deltaT, endTime, writeFormat,
+// writePrecision), system/fvSchemes (div(phi,U): Gauss linear | Gauss upwind), system/fvSolution (solvers U, p [pFinal]; PISO: nCorrectors,
+// pRefCell, pRefValue), 0/U (fixedValue / noSlip patches), 0/p (zeroGradient patches: a closed domain, hence the reference level).
+// The momentum matrix is held per component (three scalar matrices with the same coefficients: for fixedValue patches
+// fvMatrix<vector>::A() / H() reduce to the scalar forms, fvMatrix.C:1384-1506); every field operation is a call of the path.
+// At the end U and p go back into the case as <case>/<endTime>/{U,p}.   usage: icoFoam <caseDir> [-nSteps N]
+// tests/test_icofoam.py runs the same steps on the oracle and compares every solver line, the continuity errors and the written fields.
+#include "polyMesh.H"
+#include "solution.H"
+
+#include <cmath>
+#include <iomanip>
+#include <memory>
+
+using namespace Foam;
+
+namespace
+{
+scalar lastNumber(const word& v) { const std::size_t at = v.find_last_of(' '); return std::strtod(v.c_str() + (at == std::string::npos ? 0 : at + 1), nullptr); }
+scalargpuField product(const scalargpuField& x, const scalargpuField& y)
+{
+    scalargpuField out(x.size());            // zero-initialised
+    fieldSubMul(out, x, y);                  // -(x*y), the product rounded once
+    fieldAxpby(out, -1.0, out, 0.0, out);    // sign flip: exact
+    return out;
+}
+}
+
+int main(int argc, char** argv)
+{
+    try {
+        if (argc < 2) { std::cerr << "usage: icoFoam <caseDir> [-nSteps N]" << std::endl; return 2; }
+        const std::string caseDir = argv[1];
+        Info << std::setprecision(12);
+        polyMesh mesh(caseDir);
+        const label n = mesh.nCells, nI = mesh.nInternalFaces(), nP = (label)mesh.boundary.size();
+        const std::shared_ptr<dictTree> transport = readDictionaryFile(caseDir + "/constant/transportProperties");
+        const std::shared_ptr<dictTree> control = readDictionaryFile(caseDir + "/system/controlDict");
+        const scalar nu = lastNumber(transport->lookup("nu"));                       // "nu [0 2 -1 0 0 0 0] 0.01" or "0.01"
+        const scalar deltaT = lastNumber(control->lookup("deltaT")), endTime = lastNumber(control->lookup("endTime"));
+        label nSteps = (label)std::llround(endTime / deltaT);
+        for (int k = 2; k + 1 < argc; ++k) if (std::string(argv[k]) == "-nSteps") nSteps = (label)std::atoi(argv[k + 1]);
+        const bool writeBinary = control->found("writeFormat") && control->lookup("writeFormat") == "binary";
+        const int writePrecision = control->found("writePrecision") ? (int)lastNumber(control->lookup("writePrecision")) : 6;
+        const solution fvSolution(caseDir);
+        const fvSchemes schemes(caseDir);
+        const dictionary piso = fvSolution.dict("PISO");
+        const label nCorr = piso.lookupOrDefault<label>("nCorrectors", 1), nNonOrthCorr = piso.lookupOrDefault<label>("nNonOrthogonalCorrectors", 0);
+        const label pRefCell = piso.lookupOrDefault<label>("pRefCell", 0); const scalar pRefValue = piso.lookupOrDefault<scalar>("pRefValue", 0.0);
+        if (schemes.ddtScheme("ddt(U)") != wordList{"Euler"}) FatalErrorIn("icoFoam", "ddtSchemes: only Euler");
+        const wordList divU = schemes.divScheme("div(phi,U)");
+        if (divU.size() < 2 || divU[0] != "Gauss" || (divU[1] != "linear" && divU[1] != "upwind")) FatalErrorIn("icoFoam", "div(phi,U): Gauss linear | Gauss upwind");
+        const bool upwind = divU[1] == "upwind";
+        Info << "Create mesh: nCells " << n << " nInternalFaces " << nI << " patches " << nP << "; nu " << nu << " deltaT " << deltaT << " steps " << nSteps
+             << " nCorrectors " << nCorr << " div(phi,U) " << divU[1] << std::endl;
+
+        // ---- mesh-side device fields
+        labelList lower(mesh.owner.begin(), mesh.owner.begin() + nI);
+        std::vector<labelList> patchCells;
+        for (label p = 0; p < nP; ++p) patchCells.push_back(mesh.patchFaceCells(p));
+        lduAddressing addr(n, lower, mesh.neighbour);
+        auto comp = [&](const vectorField& v, std::size_t b, std::size_t e) {
+            vectorgpuField out((label)(e - b));
+            for (direction d = 0; d < 3; ++d) { scalarField h(e - b); for (std::size_t i = b; i < e; ++i) h[i - b] = v[i][d]; out.component(d) = h; }
+            return out;
+        };
+        const vectorgpuField SfI = comp(mesh.Sf, 0, (std::size_t)nI);
+        const scalargpuField V(mesh.V), weights(mesh.weights), deltaCoeffs(mesh.nonOrthDeltaCoeffs);
+        scalarField nuMagSfH((std::size_t)nI); for (label f = 0; f < nI; ++f) nuMagSfH[f] = nu * mesh.magSf[f];
+        const scalargpuField nuMagSf(nuMagSfH), magSfI(scalarField(mesh.magSf.begin(), mesh.magSf.begin() + nI));
+        scalarField onesH((std::size_t)n, 1.0); const scalargpuField ones(onesH);
+        std::vector<std::unique_ptr<fvPatchCells>> patch;
+        std::vector<vectorgpuField> patchSf;
+        for (label p = 0; p < nP; ++p) {
+            patch.emplace_back(new fvPatchCells(n, patchCells[p]));
+            patchSf.push_back(comp(mesh.Sf, (std::size_t)mesh.boundary[p].startFace, (std::size_t)(mesh.boundary[p].startFace + mesh.boundary[p].nFaces)));
+        }
+        const scalarField faceAreaPair = mesh.faceAreaPairWeights();
+        setFaceAreaPairWeights(&faceAreaPair);
+
+        // ---- fields: U (fixedValue | noSlip on every patch), p (zeroGradient on every patch), phi = interpolate(U) & Sf
+        vectorField U0 = readVolVectorInternalField(caseDir + "/0/U", n);
+        const std::vector<patchFieldIn> Ub = readVolFieldBoundary(caseDir + "/0/U", 3), pb = readVolFieldBoundary(caseDir + "/0/p", 1);
+        if ((label)Ub.size() != nP || (label)pb.size() != nP) FatalErrorIn("icoFoam", "0/U and 0/p need one boundaryField entry per patch");
+        std::vector<vectorField> UbVal((std::size_t)nP);            // boundary values of U per patch face
+        for (label p = 0; p < nP; ++p) {
+            const label np = mesh.boundary[p].nFaces;
+            if (Ub[p].patchName != mesh.boundary[p].name || pb[p].patchName != mesh.boundary[p].name) FatalErrorIn("icoFoam", "boundaryField entries must follow the mesh's patch order");
+            if (pb[p].type != "zeroGradient") FatalErrorIn("icoFoam", "p: zeroGradient patches only (patch " + pb[p].patchName + " is " + pb[p].type + ")");
+            UbVal[p].assign((std::size_t)np, vector{0, 0, 0});
+            if (Ub[p].type == "fixedValue") {
+                if (!Ub[p].hasValue) FatalErrorIn("icoFoam", "U: fixedValue patch " + Ub[p].patchName + " without a value");
+                for (label i = 0; i < np; ++i) for (int d = 0; d < 3; ++d) UbVal[p][i][d] = Ub[p].uniform ? Ub[p].value[d] : Ub[p].value[3 * i + d];
+            } else if (Ub[p].type != "noSlip") FatalErrorIn("icoFoam", "U: fixedValue | noSlip patches only (patch " + Ub[p].patchName + " is " + Ub[p].type + ")");
+        }
+        vectorgpuField U(n), gradP(n), HbyA(n);
+        for (direction d = 0; d < 3; ++d) { scalarField h((std::size_t)n); for (label c = 0; c < n; ++c) h[c] = U0[c][d]; U.component(d) = h; }
+        scalargpuField p(readVolScalarInternalField(caseDir + "/0/p", n));
+        scalargpuField phi(nI), phiHbyA(nI), ddtCorrF(nI), rAUf(nI), gammaMagSf(nI), divPhi(n), pflux(nI);
+        fvc::fluxDiv(phi, nullptr, addr, weights, SfI, U);                                // createPhi.H: linearInterpolate(U) & mesh.Sf()
+        // per patch: the boundary flux (U_b & Sf_b), the diffusive coefficient nu |Sf| deltaCoeffs, U_b per component (device)
+        std::vector<scalargpuField> phiB, diffB; std::vector<vectorgpuField> UbDev;
+        for (label p = 0; p < nP; ++p) {
+            const label np = mesh.boundary[p].nFaces, f0 = mesh.boundary[p].startFace;
+            scalarField ph((std::size_t)np), df((std::size_t)np);
+            for (label i = 0; i < np; ++i) {
+                ph[i] = UbVal[p][i][0] * mesh.Sf[f0 + i][0] + UbVal[p][i][1] * mesh.Sf[f0 + i][1] + UbVal[p][i][2] * mesh.Sf[f0 + i][2];
+                df[i] = nu * mesh.patchMagSf[p][i] * mesh.patchDeltaCoeffs[p][i];
+            }
+            phiB.emplace_back(ph); diffB.emplace_back(df);
+            UbDev.push_back(comp(UbVal[p], 0, (std::size_t)np));
+        }
+        // fvc::grad(p), Gauss linear: internal faces, then p_b Sf_b of every patch (zeroGradient: p_b = patchInternalField), / V
+        auto gradOfP = [&]() {
+            scalargpuField pf(nI);
+            fvc::interpolate(pf, addr, weights, p);
+            miCheck(mi_gauss_grad(addr.handle(), SfI.component(0).data(), SfI.component(1).data(), SfI.component(2).data(), pf.data(), nullptr,
+                                  gradP.component(0).data(), gradP.component(1).data(), gradP.component(2).data()), "gaussGrad::gradf");
+            for (label q = 0; q < nP; ++q) {
+                scalargpuField pif(patch[q]->size());
+                patch[q]->patchInternalField(p, pif);
+                for (direction d = 0; d < 3; ++d) patch[q]->addProduct(patchSf[q].component(d), pif, gradP.component(d));
+            }
+            for (direction d = 0; d < 3; ++d) fieldDivide(gradP.component(d), gradP.component(d), V);
+        };
+        const dictionary UControls = fvSolution.solverDict("U"), pControls = fvSolution.solverDict("p");
+        const dictionary pFinalControls = fvSolution.solutionDict().subDict("solvers").found("pFinal") ? fvSolution.solverDict("pFinal") : pControls;
+        const scalar rDeltaT = 1.0 / deltaT;
+        scalar cumulativeContErr = 0, totalV = 0;
+        for (scalar v : mesh.V) totalV += v;
+        const std::vector<bool> notCoupled((std::size_t)nP, false);
+
+        Info << std::endl << "Starting time loop" << std::endl << std::endl;
+        for (label step = 1; step <= nSteps; ++step) {
+            Info << "Time = " << step * deltaT << std::endl << std::endl;
+            const vectorgpuField Uold(U); const scalargpuField phiOld(phi);
+            scalargpuField upw(nI);
+            if (upwind) upwindWeights(upw, phi);
+            const scalargpuField& convWeights = upwind ? upw : weights;
+            // UEqn = fvm::ddt(U) + fvm::div(phi, U) - fvm::laplacian(nu, U), one matrix per component (same coefficients)
+            std::vector<std::unique_ptr<fvScalarMatrix>> UEqn;
+            const char* cname[3] = {"Ux", "Uy", "Uz"};
+            gradOfP();
+            for (direction d = 0; d < 3; ++d) {
+                UEqn.emplace_back(new fvScalarMatrix(cname[d], addr, patchCells, notCoupled));
+                fvScalarMatrix& M = *UEqn[d];
+                fvm::assemble(M, rDeltaT, 1.0, V, Uold.component(d), &phi, &convWeights, &deltaCoeffs, &nuMagSf);
+                for (label q = 0; q < nP; ++q) {
+                    // fixedValue patch: convection valueInternalCoeffs 0 / valueBoundaryCoeffs U_b (gaussConvectionScheme.C:96-110: boundaryCoeffs = -phi_b U_b);
+                    // diffusion, with the sign of `- fvm::laplacian`: internalCoeffs = nu |Sf| deltaCoeffs, boundaryCoeffs = nu |Sf| deltaCoeffs U_b
+                    M.internalCoeffs()[q] = diffB[q];
+                    scalargpuField bc = product(diffB[q], UbDev[q].component(d));
+                    fieldSubMul(bc, phiB[q], UbDev[q].component(d));
+                    M.boundaryCoeffs()[q] = bc;
+                }
+            }
+            // solve(UEqn == -fvc::grad(p)): the temporary's source is source - V*grad(p)   (fvMatrix.C: operator==, operator-(fvMatrix, field))
+            for (direction d = 0; d < 3; ++d) {
+                fvScalarMatrix& M = *UEqn[d];
+                const scalargpuField keep(M.source());
+                fieldSubMul(M.source(), V, gradP.component(d));
+                M.solve(U.component(d), UControls);
+                M.source() = keep;
+            }
+            // --- PISO loop
+            for (label corr = 0; corr < nCorr; ++corr) {
+                scalargpuField A(n), rAU(n);
+                UEqn[0]->A(A, V);
+                fieldDivide(rAU, ones, A);                                           // volScalarField rAU(1.0/UEqn.A());
+                for (direction d = 0; d < 3; ++d) {                                  // HbyA = rAU*UEqn.H();
+                    scalargpuField H(n);
+                    UEqn[d]->H(H, U.component(d), V);
+                    HbyA.component(d) = product(rAU, H);
+                }
+                fvc::interpolate(rAUf, addr, weights, rAU);
+                fvc::ddtCorr(ddtCorrF, addr, rDeltaT, weights, SfI, Uold, phiOld);
+                // phiHbyA = (fvc::interpolate(HbyA) & mesh.Sf()) + fvc::interpolate(rAU)*fvc::ddtCorr(U, phi), and sum over the cell's faces = V*fvc::div(phiHbyA)
+                fvc::fluxDiv(phiHbyA, &divPhi, addr, weights, SfI, HbyA, &rAUf, &ddtCorrF, nullptr);
+                for (label q = 0; q < nP; ++q) patch[q]->add(phiB[q], divPhi);      // boundary faces: HbyA_b = U_b
+                // adjustPhi(phiHbyA, U, p): no inflow / outflow on fixedValue walls whose flux is zero -- nothing to adjust in a closed domain
+                for (label nonOrth = 0; nonOrth <= nNonOrthCorr; ++nonOrth) {
+                    fvScalarMatrix pEqn("p", addr, patchCells, notCoupled);
+                    gammaMagSf = product(rAUf, magSfI);
+                    fvm::laplacian(pEqn, deltaCoeffs, gammaMagSf);                   // fvm::laplacian(rAU, p) == fvc::div(phiHbyA)
+                    pEqn.source() = divPhi;
+                    pEqn.setReference(pRefCell, pRefValue);
+                    pEqn.solve(p, (corr == nCorr - 1 && nonOrth == nNonOrthCorr) ? pFinalControls : pControls);
+                    if (nonOrth == nNonOrthCorr) {                                   // phi = phiHbyA - pEqn.flux();
+                        FieldFieldScalar bflux;
+                        pEqn.flux(pflux, bflux, p);
+                        fieldAxpby(phi, 1.0, phiHbyA, -1.0, pflux);
+                    }
+                }
+                {   // continuityErrs.H
+                    scalargpuField contErr(n);
+                    fvc::surfaceIntegrate(contErr, addr, phi, nullptr);
+                    for (label q = 0; q < nP; ++q) patch[q]->add(phiB[q], contErr);
+                    const scalarField ce = contErr.asHost();                         // = V * fvc::div(phi)
+                    scalar sumLocal = 0, global = 0;
+                    for (label c = 0; c < n; ++c) { sumLocal += std::fabs(ce[c]); global += ce[c]; }
+                    sumLocal *= deltaT / totalV; global *= deltaT / totalV; cumulativeContErr += global;
+                    Info << "time step continuity errors : sum local = " << sumLocal << ", global = " << global << ", cumulative = " << cumulativeContErr << std::endl;
+                }
+                gradOfP();
+                for (direction d = 0; d < 3; ++d) { U.component(d) = HbyA.component(d); fieldSubMul(U.component(d), rAU, gradP.component(d)); }   // U = HbyA - rAU*fvc::grad(p)
+            }
+            Info << std::endl;
+        }
+        // runTime.write(): U and p of the last time
+        std::ostringstream tn; tn << std::setprecision(10) << nSteps * deltaT;
+        {
+            vectorField Uh((std::size_t)n);
+            for (direction d = 0; d < 3; ++d) { const scalarField h = U.component(d).asHost(); for (label c = 0; c < n; ++c) Uh[c][d] = h[c]; }
+            std::vector<patchFieldOut> bu, bp;
+            for (label q = 0; q < nP; ++q) {
+                patchFieldOut e; e.patchName = mesh.boundary[q].name; e.type = Ub[q].type; e.hasValue = Ub[q].type == "fixedValue";
+                if (e.hasValue) for (const vector& v : UbVal[q]) e.value.insert(e.value.end(), v.begin(), v.end());
+                bu.push_back(e);
+                patchFieldOut z; z.patchName = mesh.boundary[q].name; z.type = "zeroGradient"; bp.push_back(z);
+            }
+            writeVolVectorField(caseDir, tn.str(), "U", "[0 1 -1 0 0 0 0]", Uh, bu, writeBinary, writePrecision);
+            writeVolScalarField(caseDir, tn.str(), "p", "[0 2 -2 0 0 0 0]", p.asHost(), bp, writeBinary, writePrecision);
+            Info << "wrote " << caseDir << "/" << tn.str() << "/{U,p}" << std::endl;
+        }
+        Info << "End" << std::endl;
+        return 0;
+    } catch (const Foam::error& e) { std::cerr << e.what() << std::endl; return 1; }
+}

@@ -727,6 +727,53 @@ void fvc::interpolate(scalargpuField& sf, const lduAddressing& a, const scalargp
 {
     miCheck(mi_face_interpolate(a.handle(), weights.data(), vf.data(), sf.data()), "fvc::interpolate");
 }
+void fvc::surfaceIntegrate(scalargpuField& ivf, const lduAddressing& a, const scalargpuField& ssf, const scalargpuField* V)
+{
+    miCheck(mi_surface_integrate(a.handle(), ssf.data(), V ? V->data() : nullptr, ivf.data()), "fvc::surfaceIntegrate");
+}
+void fvc::fluxDiv(scalargpuField& phi, scalargpuField* divOut, const lduAddressing& a, const scalargpuField& weights, const vectorgpuField& Sf,
+                  const vectorgpuField& Vf, const scalargpuField* addA, const scalargpuField* addB, const scalargpuField* V)
+{
+    scalargpuField scratch(divOut ? 0 : a.size());
+    miCheck(mi_flux_div(a.handle(), weights.data(), Sf.component(0).data(), Sf.component(1).data(), Sf.component(2).data(),
+                        Vf.component(0).data(), Vf.component(1).data(), Vf.component(2).data(), nullptr, addA ? addA->data() : nullptr,
+                        addB ? addB->data() : nullptr, phi.data(), V ? V->data() : nullptr, divOut ? divOut->data() : scratch.data()), "fvc::flux + fvc::div");
+}
+void fvc::ddtCorr(scalargpuField& out, const lduAddressing& a, scalar rDeltaT, const scalargpuField& weights, const vectorgpuField& Sf,
+                  const vectorgpuField& Uold, const scalargpuField& phiOld)
+{
+    miCheck(mi_ddt_phi_corr(a.handle(), rDeltaT, weights.data(), Sf.component(0).data(), Sf.component(1).data(), Sf.component(2).data(),
+                            Uold.component(0).data(), Uold.component(1).data(), Uold.component(2).data(), nullptr, phiOld.data(), out.data()), "fvc::ddtCorr");
+}
+void fieldAxpby(scalargpuField& out, scalar a, const scalargpuField& x, scalar b, const scalargpuField& y)
+{
+    miCheck(mi_vec_axpby(miEngine::New().ctx, out.size(), a, x.data(), b, y.data(), out.data()), "gpuField: a x + b y");
+}
+void fieldDivide(scalargpuField& out, const scalargpuField& x, const scalargpuField& y)
+{
+    miCheck(mi_vec_div(miEngine::New().ctx, out.size(), x.data(), y.data(), out.data()), "gpuField: x / y");
+}
+void fieldSubMul(scalargpuField& inout, const scalargpuField& x, const scalargpuField& y)
+{
+    miCheck(mi_vec_submul(miEngine::New().ctx, inout.size(), x.data(), y.data(), inout.data()), "gpuField: -= x*y");
+}
+fvPatchCells::fvPatchCells(label nCells, const labelList& faceCells) : h_(nullptr), n_((label)faceCells.size())
+{
+    miCheck(mi_patch_create(miEngine::New().ctx, nCells, n_, faceCells.data(), &h_), "fvPatch::faceCells");
+}
+fvPatchCells::~fvPatchCells() { if (h_) mi_patch_destroy(h_); }
+void fvPatchCells::add(const scalargpuField& pf, scalargpuField& intf, bool subtract) const
+{
+    if (n_) miCheck(mi_patch_add(h_, pf.data(), intf.data(), subtract ? 1 : 0), "fvPatch: cells += patch field");
+}
+void fvPatchCells::addProduct(const scalargpuField& pf, const scalargpuField& q, scalargpuField& intf, bool subtract) const
+{
+    if (n_) miCheck(mi_patch_add_product(h_, pf.data(), q.data(), intf.data(), subtract ? 1 : 0), "fvPatch: cells += patch field * patch field");
+}
+void fvPatchCells::patchInternalField(const scalargpuField& psi, scalargpuField& out) const
+{
+    if (n_) miCheck(mi_patch_internal_field(h_, psi.data(), out.data()), "fvPatchField::patchInternalField");
+}
 void upwindWeights(scalargpuField& w, const scalargpuField& faceFlux)
 {
     miCheck(mi_upwind_weights(miEngine::New().ctx, faceFlux.size(), faceFlux.data(), w.data()), "upwind::weights");

@@ -344,6 +344,63 @@ vectorField readVolVectorInternalField(const std::string& file, label nCells)
     return v;
 }
 
+std::vector<patchFieldIn> readVolFieldBoundary(const std::string& file, int nCmpt)
+{
+    IFstream is(file);
+    is.header();
+    for (;;) {
+        if (is.eof()) FatalErrorIn("readVolFieldBoundary", "no boundaryField in " + file);
+        const std::string k = is.token();
+        if (k == "boundaryField") break;
+        if (k == "dimensions") { while (is.token() != ";") {} continue; }
+        if (k == "internalField") {   // skipped: uniform v; | nonuniform List<T> N(...);
+            const std::string kind = is.token();
+            if (kind == "uniform") { while (is.token() != ";") {} continue; }
+            const std::string cls = is.token();
+            if (cls == "List<scalar>") (void)readList<scalar>(is, [](IFstream& s) { return s.readScalar(); });
+            else if (cls == "List<vector>") (void)readList<vector>(is, readVec);
+            else FatalErrorIn("readVolFieldBoundary", "internalField of class " + cls + " in " + file);
+            is.expect(";");
+        }
+    }
+    is.expect("{");
+    std::vector<patchFieldIn> out;
+    for (;;) {
+        const std::string name = is.token();
+        if (name == "}") break;
+        patchFieldIn P; P.patchName = name;
+        is.expect("{");
+        for (;;) {
+            const std::string k = is.token();
+            if (k == "}") break;
+            if (k == "type") { P.type = is.token(); is.expect(";"); continue; }
+            if (k == "value") {
+                P.hasValue = true;
+                const std::string kind = is.token();
+                if (kind == "uniform") {
+                    P.uniform = true;
+                    if (nCmpt == 1) P.value.push_back(is.readScalar());
+                    else { const vector v = readVec(is); P.value.assign(v.begin(), v.end()); }
+                } else if (kind == "nonuniform") {
+                    std::string cls = is.token();
+                    if (cls == "0") { is.expect("("); is.expect(")"); }          // an empty patch: "nonuniform 0()"
+                    else if (nCmpt == 1) { if (cls != "List<scalar>") FatalErrorIn("readVolFieldBoundary", "patch " + name + ": expected List<scalar> in " + file); P.value = readList<scalar>(is, [](IFstream& s) { return s.readScalar(); }); }
+                    else {
+                        if (cls != "List<vector>") FatalErrorIn("readVolFieldBoundary", "patch " + name + ": expected List<vector> in " + file);
+                        const vectorField v = readList<vector>(is, readVec);
+                        for (const vector& q : v) P.value.insert(P.value.end(), q.begin(), q.end());
+                    }
+                } else FatalErrorIn("readVolFieldBoundary", "patch " + name + ": value must be uniform or nonuniform in " + file);
+                is.expect(";");
+                continue;
+            }
+            while (is.token() != ";") {}      // any other entry of the patch field (inGroups, gradient, ...): skipped
+        }
+        out.push_back(P);
+    }
+    return out;
+}
+
 namespace
 {
 // one value of a list: a scalar, or a vector as "(x y z)"
