@@ -148,9 +148,10 @@ def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t,
 CONT = re.compile(r"time step continuity errors : sum local = (\S+), global = (\S+), cumulative = (\S+)")
 
 
-@pytest.mark.parametrize("div_scheme, write_format", [("linear", "binary"), ("upwind", "ascii")])
-def test_icoFoam_cavity_matches_the_oracle_statement_for_statement(pkg, orc, tmp_path, div_scheme, write_format):
-    dims, nu, delta_t, n_steps = (10, 8, 6), 0.01, 0.005, 3
+@pytest.mark.parametrize("dims, n_steps, div_scheme, write_format", [((10, 8, 6), 3, "linear", "binary"), ((10, 8, 6), 3, "upwind", "ascii"),
+                                                                     ((32, 32, 32), 2, "linear", "binary")])   # the last: BASELINE config 1's size
+def test_icoFoam_cavity_matches_the_oracle_statement_for_statement(pkg, orc, tmp_path, dims, n_steps, div_scheme, write_format):
+    nu, delta_t = 0.01, 0.005
     case_dir = str(tmp_path / "cavity")
     pts, faces, owner, neighbour, patches = write_cavity(case_dir, dims, nu, delta_t, n_steps, div_scheme, write_format)
     out = subprocess.run([os.path.join(PKG, "icoFoam"), case_dir], capture_output=True, text=True, timeout=600)
