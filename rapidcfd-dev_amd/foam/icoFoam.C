@@ -8,7 +8,7 @@
 //           continuity errors; U = HbyA - rAU*fvc::grad(p)
 //
 // on a real case directory: constant/polyMesh, constant/transportProperties (nu), system/controlDict (deltaT, endTime, writeFormat,
-// writePrecision), system/fvSchemes (div(phi,U): Gauss linear | Gauss upwind), system/fvSolution (solvers U, p [pFinal]; PISO: nCorrectors,
+// writePrecision), system/fvSchemes (div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k), system/fvSolution (solvers U, p [pFinal]; PISO: nCorrectors,
 // pRefCell, pRefValue), 0/U (fixedValue / noSlip patches), 0/p (zeroGradient patches: a closed domain, hence the reference level).
 // The momentum matrix is held per component (three scalar matrices with the same coefficients: for fixedValue patches
 // fvMatrix<vector>::A() / H() reduce to the scalar forms, fvMatrix.C:1384-1506); every field operation is a call of the path.
@@ -58,8 +58,10 @@ int main(int argc, char** argv)
         const label pRefCell = piso.lookupOrDefault<label>("pRefCell", 0); const scalar pRefValue = piso.lookupOrDefault<scalar>("pRefValue", 0.0);
         if (schemes.ddtScheme("ddt(U)") != wordList{"Euler"}) FatalErrorIn("icoFoam", "ddtSchemes: only Euler");
         const wordList divU = schemes.divScheme("div(phi,U)");
-        if (divU.size() < 2 || divU[0] != "Gauss" || (divU[1] != "linear" && divU[1] != "upwind")) FatalErrorIn("icoFoam", "div(phi,U): Gauss linear | Gauss upwind");
-        const bool upwind = divU[1] == "upwind";
+        if (divU.size() < 2 || divU[0] != "Gauss" || (divU[1] != "linear" && divU[1] != "upwind" && !(divU[1] == "limitedLinear" && divU.size() == 3)))
+            FatalErrorIn("icoFoam", "div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k");
+        const bool upwind = divU[1] == "upwind", limited = divU[1] == "limitedLinear";
+        const scalar limiterK = limited ? std::strtod(divU[2].c_str(), nullptr) : 0.0;
         Info << "Create mesh: nCells " << n << " nInternalFaces " << nI << " patches " << nP << "; nu " << nu << " deltaT " << deltaT << " steps " << nSteps
              << " nCorrectors " << nCorr << " div(phi,U) " << divU[1] << std::endl;
 
@@ -119,6 +121,13 @@ int main(int argc, char** argv)
             phiB.emplace_back(ph); diffB.emplace_back(df);
             UbDev.push_back(comp(UbVal[p], 0, (std::size_t)np));
         }
+        const vectorgpuField Cc = comp(mesh.C, 0, (std::size_t)n);
+        std::vector<scalargpuField> magSqrUb;                          // magSqr of the boundary values (the limiter's gradient takes them on the patch faces)
+        for (label q = 0; q < nP; ++q) {
+            scalarField h(UbVal[q].size());
+            for (std::size_t i = 0; i < h.size(); ++i) h[i] = (UbVal[q][i][0] * UbVal[q][i][0] + UbVal[q][i][1] * UbVal[q][i][1]) + UbVal[q][i][2] * UbVal[q][i][2];
+            magSqrUb.emplace_back(h);
+        }
         // fvc::grad(p), Gauss linear: internal faces, then p_b Sf_b of every patch (zeroGradient: p_b = patchInternalField), / V
         auto gradOfP = [&]() {
             scalargpuField pf(nI);
@@ -145,7 +154,23 @@ int main(int argc, char** argv)
             const vectorgpuField Uold(U); const scalargpuField phiOld(phi);
             scalargpuField upw(nI);
             if (upwind) upwindWeights(upw, phi);
-            const scalargpuField& convWeights = upwind ? upw : weights;
+            if (limited) {
+                // limitedLinear on a vector field: LimitedScheme<vector, limitedLinearLimiter<NVDTVD>, limitFuncs::magSqr> (limitedLinear.C) -- ONE limiter for
+                // the three components, formed from magSqr(U) and its Gauss gradient (LimitedScheme.C:39-110, NVDTVD.H); magSqr = (Ux Ux + Uy Uy) + Uz Uz,
+                // every product and sum rounded on its own here
+                scalargpuField m2 = product(U.component(0), U.component(0));
+                fieldAxpby(m2, 1.0, m2, 1.0, product(U.component(1), U.component(1)));
+                fieldAxpby(m2, 1.0, m2, 1.0, product(U.component(2), U.component(2)));
+                scalargpuField m2f(nI);
+                fvc::interpolate(m2f, addr, weights, m2);
+                vectorgpuField g(n);
+                miCheck(mi_gauss_grad(addr.handle(), SfI.component(0).data(), SfI.component(1).data(), SfI.component(2).data(), m2f.data(), nullptr,
+                                      g.component(0).data(), g.component(1).data(), g.component(2).data()), "gaussGrad::gradf");
+                for (label q = 0; q < nP; ++q) for (direction d = 0; d < 3; ++d) patch[q]->addProduct(patchSf[q].component(d), magSqrUb[q], g.component(d));
+                for (direction d = 0; d < 3; ++d) fieldDivide(g.component(d), g.component(d), V);
+                limitedLinearWeights(upw, addr, limiterK, weights, phi, m2, g, Cc);
+            }
+            const scalargpuField& convWeights = (upwind || limited) ? upw : weights;
             // UEqn = fvm::ddt(U) + fvm::div(phi, U) - fvm::laplacian(nu, U), one matrix per component (same coefficients)
             std::vector<std::unique_ptr<fvScalarMatrix>> UEqn;
             const char* cname[3] = {"Ux", "Uy", "Uz"};

@@ -60,7 +60,7 @@ PISO { nCorrectors 2; nNonOrthogonalCorrectors 0; pRefCell 0; pRefValue 0; }
     return pts, faces, owner, neighbour, patches
 
 
-def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, upwind):
+def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, scheme):
     """icoFoam.C on the oracle; returns the solver lines [(name, field, initial, final, iterations)], the continuity errors and U, p"""
     syn = pkg.synthetic
     G = geometry(pts, faces, owner, neighbour)
@@ -89,9 +89,21 @@ def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t,
                 g[k] = orc.patch_add_product(q["fc"], q["sf"][k], p[q["fc"]], g[k], 0)
         return [x / V for x in g]
 
+    centres = [np.ascontiguousarray(G["C"][:, k]) for k in range(3)]
     for step in range(n_steps):
         Uold, phiOld = [u.copy() for u in U], phi.copy()
-        w = orc.upwind_weights(phi) if upwind else lam
+        if scheme == "upwind":
+            w = orc.upwind_weights(phi)
+        elif scheme.startswith("limitedLinear"):     # one limiter for the three components, from magSqr(U) and its Gauss gradient
+            m2 = (U[0] * U[0] + U[1] * U[1]) + U[2] * U[2]
+            g = orc.gauss_grad(n, lo, up, Sf, orc.face_interpolate(lo, up, lam, m2), None)
+            for q in P:
+                mb = (q["ub"][:, 0] * q["ub"][:, 0] + q["ub"][:, 1] * q["ub"][:, 1]) + q["ub"][:, 2] * q["ub"][:, 2]
+                for k in range(3):
+                    g[k] = orc.patch_add_product(q["fc"], q["sf"][k], mb, g[k], 0)
+            w, _ = orc.limited_linear_weights(lo, up, float(scheme.split()[1]), lam, phi, m2, [x / V for x in g], centres)
+        else:
+            w = lam
         lB, uB, dB = orc.fvm_div(n, lo, up, w, phi)
         uL, dL = orc.fvm_laplacian(n, lo, up, delta, nu * magSf)
         lower, upper = lB - uL, uB - uL
@@ -148,7 +160,7 @@ def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t,
 CONT = re.compile(r"time step continuity errors : sum local = (\S+), global = (\S+), cumulative = (\S+)")
 
 
-@pytest.mark.parametrize("dims, n_steps, div_scheme, write_format", [((10, 8, 6), 3, "linear", "binary"), ((10, 8, 6), 3, "upwind", "ascii"),
+@pytest.mark.parametrize("dims, n_steps, div_scheme, write_format", [((10, 8, 6), 3, "linear", "binary"), ((10, 8, 6), 3, "upwind", "ascii"), ((12, 10, 8), 4, "limitedLinear 1", "binary"),
                                                                      ((32, 32, 32), 2, "linear", "binary")])   # the last: BASELINE config 1's size
 def test_icoFoam_cavity_matches_the_oracle_statement_for_statement(pkg, orc, tmp_path, dims, n_steps, div_scheme, write_format):
     nu, delta_t = 0.01, 0.005
@@ -158,7 +170,7 @@ def test_icoFoam_cavity_matches_the_oracle_statement_for_statement(pkg, orc, tmp
     assert out.returncode == 0, out.stderr + out.stdout[-2000:]
     got = [(m.group(1), m.group(2), float(m.group(3)), float(m.group(4)), int(m.group(5))) for m in map(LINE.match, out.stdout.splitlines()) if m]
     cont = [tuple(map(float, m.groups())) for m in map(CONT.match, out.stdout.splitlines()) if m]
-    ref_lines, ref_cont, refU, refp = oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, div_scheme == "upwind")
+    ref_lines, ref_cont, refU, refp = oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, div_scheme)
     assert len(got) == len(ref_lines) == n_steps * 5 and len(cont) == len(ref_cont) == n_steps * 2
     for g, r in zip(got, ref_lines):
         assert g[0] == r[0] and g[1] == r[1], (g, r)
@@ -175,5 +187,8 @@ def test_icoFoam_cavity_matches_the_oracle_statement_for_statement(pkg, orc, tmp
     assert fU["internalField"].shape == Uref.shape and np.max(np.abs(fU["internalField"] - Uref)) <= tolU * np.max(np.abs(Uref))
     assert np.max(np.abs(fp["internalField"] - refp)) <= tolU * np.max(np.abs(refp))
     assert np.max(np.abs(Uref)) > 1e-3                                                # the lid really drives a flow
+    if div_scheme.startswith("limitedLinear"):                                         # ... and the limiter really limits: not the linear scheme's result
+        _, _, Ulin, _ = oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, "linear")
+        assert np.max(np.abs(np.stack(Ulin, axis=1) - Uref)) > 1e-7 * np.max(np.abs(Uref))
     bf = dict(fU["boundaryField"])
     assert bf["inlet"]["type"] == "fixedValue" and bf["inlet"]["value"] == ("uniform", [0.0, 1.0, 0.0]) and bf["walls"] == {"type": "noSlip"}
