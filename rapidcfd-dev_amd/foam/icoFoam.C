@@ -8,7 +8,7 @@
 //           continuity errors; U = HbyA - rAU*fvc::grad(p)
 //
 // on a real case directory: constant/polyMesh, constant/transportProperties (nu), system/controlDict (deltaT, endTime, writeFormat,
-// writePrecision), system/fvSchemes (div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k), system/fvSolution (solvers U, p [pFinal]; PISO: nCorrectors,
+// writePrecision), system/fvSchemes (div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k; laplacian: Gauss linear orthogonal), system/fvSolution (solvers U, p [pFinal]; PISO: nCorrectors,
 // pRefCell, pRefValue), 0/U (fixedValue / noSlip patches), 0/p (zeroGradient patches: a closed domain, hence the reference level).
 // The momentum matrix is held per component (three scalar matrices with the same coefficients: for fixedValue patches
 // fvMatrix<vector>::A() / H() reduce to the scalar forms, fvMatrix.C:1384-1506); every field operation is a call of the path.
@@ -60,6 +60,11 @@ int main(int argc, char** argv)
         const wordList divU = schemes.divScheme("div(phi,U)");
         if (divU.size() < 2 || divU[0] != "Gauss" || (divU[1] != "linear" && divU[1] != "upwind" && !(divU[1] == "limitedLinear" && divU.size() == 3)))
             FatalErrorIn("icoFoam", "div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k");
+        for (const char* term : {"laplacian(nu,U)", "laplacian((1|A(U)),p)"}) {   // this application assembles the uncorrected Laplacian: say so instead of ignoring a `corrected`
+            const wordList l = schemes.laplacianScheme(term);
+            if (l.size() != 3 || l[0] != "Gauss" || l[1] != "linear" || (l[2] != "orthogonal" && l[2] != "uncorrected"))
+                FatalErrorIn("icoFoam", std::string("laplacianSchemes ") + term + ": Gauss linear orthogonal | Gauss linear uncorrected only (polyMeshFoam -nonOrthCorrectors shows the corrected form)");
+        }
         const bool upwind = divU[1] == "upwind", limited = divU[1] == "limitedLinear";
         const scalar limiterK = limited ? std::strtod(divU[2].c_str(), nullptr) : 0.0;
         Info << "Create mesh: nCells " << n << " nInternalFaces " << nI << " patches " << nP << "; nu " << nu << " deltaT " << deltaT << " steps " << nSteps

@@ -157,6 +157,26 @@ def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t,
     return lines, cont, U, p
 
 
+def test_icoFoam_refuses_what_it_does_not_assemble(pkg, tmp_path):
+    """a `corrected` Laplacian, another ddt scheme, a p patch that is not zeroGradient: an error that says so, not a silently different equation"""
+    case_dir = str(tmp_path / "cavity")
+    write_cavity(case_dir, (4, 3, 2), 0.01, 0.005, 1, "linear", "ascii")
+    sch = os.path.join(case_dir, "system", "fvSchemes")
+    good = open(sch).read()
+    for bad, msg in ((good.replace("Gauss linear orthogonal", "Gauss linear corrected"), "Gauss linear orthogonal | Gauss linear uncorrected only"),
+                     (good.replace("default Euler", "default backward"), "only Euler"), (good.replace("Gauss linear;  ", "Gauss QUICK;"), None)):
+        open(sch, "w").write(bad)
+        out = subprocess.run([os.path.join(PKG, "icoFoam"), case_dir], capture_output=True, text=True, timeout=120)
+        if msg:
+            assert out.returncode != 0 and msg in out.stderr, out.stderr
+    open(sch, "w").write(good)
+    pf = os.path.join(case_dir, "0", "p")
+    text = open(pf).read()
+    open(pf, "w").write(text.replace("type            zeroGradient;", "type            fixedValue; value uniform 0;", 1))
+    out = subprocess.run([os.path.join(PKG, "icoFoam"), case_dir], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "zeroGradient patches only" in out.stderr
+
+
 CONT = re.compile(r"time step continuity errors : sum local = (\S+), global = (\S+), cumulative = (\S+)")
 
 
