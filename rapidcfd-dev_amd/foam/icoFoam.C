@@ -8,7 +8,8 @@
 //           continuity errors; U = HbyA - rAU*fvc::grad(p)
 //
 // on a real case directory: constant/polyMesh, constant/transportProperties (nu), system/controlDict (deltaT, endTime, writeFormat,
-// writePrecision), system/fvSchemes (div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k; laplacian: Gauss linear orthogonal), system/fvSolution (solvers U, p [pFinal]; PISO: nCorrectors,
+// writePrecision), system/fvSchemes (div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k; laplacian: Gauss linear corrected |
+// uncorrected -- the corrected form with its explicit non-orthogonal flux in UEqn's and pEqn's sources and in pEqn.flux()), system/fvSolution (solvers U, p [pFinal]; PISO: nCorrectors,
 // pRefCell, pRefValue), 0/U (fixedValue / noSlip patches), 0/p (zeroGradient patches: a closed domain, hence the reference level).
 // The momentum matrix is held per component (three scalar matrices with the same coefficients: for fixedValue patches
 // fvMatrix<vector>::A() / H() reduce to the scalar forms, fvMatrix.C:1384-1506); every field operation is a call of the path.
@@ -60,10 +61,12 @@ int main(int argc, char** argv)
         const wordList divU = schemes.divScheme("div(phi,U)");
         if (divU.size() < 2 || divU[0] != "Gauss" || (divU[1] != "linear" && divU[1] != "upwind" && !(divU[1] == "limitedLinear" && divU.size() == 3)))
             FatalErrorIn("icoFoam", "div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k");
-        for (const char* term : {"laplacian(nu,U)", "laplacian((1|A(U)),p)"}) {   // this application assembles the uncorrected Laplacian: say so instead of ignoring a `corrected`
+        bool corrected = false;
+        for (const char* term : {"laplacian(nu,U)", "laplacian((1|A(U)),p)"}) {
             const wordList l = schemes.laplacianScheme(term);
-            if (l.size() != 3 || l[0] != "Gauss" || l[1] != "linear" || (l[2] != "orthogonal" && l[2] != "uncorrected"))
-                FatalErrorIn("icoFoam", std::string("laplacianSchemes ") + term + ": Gauss linear orthogonal | Gauss linear uncorrected only (polyMeshFoam -nonOrthCorrectors shows the corrected form)");
+            if (l.size() != 3 || l[0] != "Gauss" || l[1] != "linear" || (l[2] != "orthogonal" && l[2] != "uncorrected" && l[2] != "corrected"))
+                FatalErrorIn("icoFoam", std::string("laplacianSchemes ") + term + ": Gauss linear corrected | uncorrected | orthogonal");
+            corrected = corrected || l[2] == "corrected";
         }
         const bool upwind = divU[1] == "upwind", limited = divU[1] == "limitedLinear";
         const scalar limiterK = limited ? std::strtod(divU[2].c_str(), nullptr) : 0.0;
@@ -133,18 +136,31 @@ int main(int argc, char** argv)
             for (std::size_t i = 0; i < h.size(); ++i) h[i] = (UbVal[q][i][0] * UbVal[q][i][0] + UbVal[q][i][1] * UbVal[q][i][1]) + UbVal[q][i][2] * UbVal[q][i][2];
             magSqrUb.emplace_back(h);
         }
-        // fvc::grad(p), Gauss linear: internal faces, then p_b Sf_b of every patch (zeroGradient: p_b = patchInternalField), / V
-        auto gradOfP = [&]() {
-            scalargpuField pf(nI);
-            fvc::interpolate(pf, addr, weights, p);
-            miCheck(mi_gauss_grad(addr.handle(), SfI.component(0).data(), SfI.component(1).data(), SfI.component(2).data(), pf.data(), nullptr,
-                                  gradP.component(0).data(), gradP.component(1).data(), gradP.component(2).data()), "gaussGrad::gradf");
+        // fvc::grad(vf), Gauss linear: internal faces, then vf_b Sf_b of every patch (patchValue q given: fixedValue; nullptr: zeroGradient = patchInternalField), / V
+        auto gaussGrad = [&](vectorgpuField& g, const scalargpuField& vf, const std::vector<const scalargpuField*>& patchValue) {
+            scalargpuField ff(nI);
+            fvc::interpolate(ff, addr, weights, vf);
+            miCheck(mi_gauss_grad(addr.handle(), SfI.component(0).data(), SfI.component(1).data(), SfI.component(2).data(), ff.data(), nullptr,
+                                  g.component(0).data(), g.component(1).data(), g.component(2).data()), "gaussGrad::gradf");
             for (label q = 0; q < nP; ++q) {
                 scalargpuField pif(patch[q]->size());
-                patch[q]->patchInternalField(p, pif);
-                for (direction d = 0; d < 3; ++d) patch[q]->addProduct(patchSf[q].component(d), pif, gradP.component(d));
+                const scalargpuField* pv = patchValue[(std::size_t)q];
+                if (!pv) { patch[q]->patchInternalField(vf, pif); pv = &pif; }
+                for (direction d = 0; d < 3; ++d) patch[q]->addProduct(patchSf[q].component(d), *pv, g.component(d));
             }
-            for (direction d = 0; d < 3; ++d) fieldDivide(gradP.component(d), gradP.component(d), V);
+            for (direction d = 0; d < 3; ++d) fieldDivide(g.component(d), g.component(d), V);
+        };
+        const std::vector<const scalargpuField*> zeroGradientPatches((std::size_t)nP, nullptr);
+        auto gradOfP = [&]() { gaussGrad(gradP, p, zeroGradientPatches); };
+        const vectorgpuField corrVecs = comp(mesh.nonOrthCorrectionVectors, 0, (std::size_t)nI);
+        scalargpuField negNuMagSf(nI); fieldAxpby(negNuMagSf, -1.0, nuMagSf, 0.0, nuMagSf);
+        // source -= V * fvc::div(gammaMagSf * correction(vf)): the explicit part of a `corrected` fvm::laplacian(gamma, vf) (gaussLaplacianSchemes.C:64-90);
+        // returns the correction flux (pEqn keeps it: fvMatrix::flux() adds faceFluxCorrectionPtr, fvMatrix.C:1655-1658)
+        auto correctLaplacian = [&](fvScalarMatrix& M, const vectorgpuField& gradVf, const scalargpuField& gMagSf, scalargpuField& corrFlux) {
+            fvc::snGradCorrectionFlux(corrFlux, addr, corrVecs, weights, gradVf, gMagSf);
+            scalargpuField d(n);
+            fvc::surfaceIntegrate(d, addr, corrFlux, &V);
+            fieldSubMul(M.source(), V, d);
         };
         const dictionary UControls = fvSolution.solverDict("U"), pControls = fvSolution.solverDict("p");
         const dictionary pFinalControls = fvSolution.solutionDict().subDict("solvers").found("pFinal") ? fvSolution.solverDict("pFinal") : pControls;
@@ -192,6 +208,13 @@ int main(int argc, char** argv)
                     fieldSubMul(bc, phiB[q], UbDev[q].component(d));
                     M.boundaryCoeffs()[q] = bc;
                 }
+                if (corrected) {   // - fvm::laplacian(nu, U), corrected: its explicit part enters with the opposite sign -- gamma = -nu
+                    std::vector<const scalargpuField*> fixedValues;
+                    for (label q = 0; q < nP; ++q) fixedValues.push_back(&UbDev[q].component(d));
+                    vectorgpuField gU(n); scalargpuField cf(nI);
+                    gaussGrad(gU, Uold.component(d), fixedValues);
+                    correctLaplacian(M, gU, negNuMagSf, cf);
+                }
             }
             // solve(UEqn == -fvc::grad(p)): the temporary's source is source - V*grad(p)   (fvMatrix.C: operator==, operator-(fvMatrix, field))
             for (direction d = 0; d < 3; ++d) {
@@ -222,11 +245,14 @@ int main(int argc, char** argv)
                     gammaMagSf = product(rAUf, magSfI);
                     fvm::laplacian(pEqn, deltaCoeffs, gammaMagSf);                   // fvm::laplacian(rAU, p) == fvc::div(phiHbyA)
                     pEqn.source() = divPhi;
+                    scalargpuField pCorrFlux(nI);
+                    if (corrected) { gradOfP(); correctLaplacian(pEqn, gradP, gammaMagSf, pCorrFlux); }
                     pEqn.setReference(pRefCell, pRefValue);
                     pEqn.solve(p, (corr == nCorr - 1 && nonOrth == nNonOrthCorr) ? pFinalControls : pControls);
                     if (nonOrth == nNonOrthCorr) {                                   // phi = phiHbyA - pEqn.flux();
                         FieldFieldScalar bflux;
                         pEqn.flux(pflux, bflux, p);
+                        if (corrected) fieldAxpby(pflux, 1.0, pflux, 1.0, pCorrFlux);   // + faceFluxCorrection (formed from p before this solve)
                         fieldAxpby(phi, 1.0, phiHbyA, -1.0, pflux);
                     }
                 }

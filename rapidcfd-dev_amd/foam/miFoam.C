@@ -739,6 +739,13 @@ void fvc::fluxDiv(scalargpuField& phi, scalargpuField* divOut, const lduAddressi
                         Vf.component(0).data(), Vf.component(1).data(), Vf.component(2).data(), nullptr, addA ? addA->data() : nullptr,
                         addB ? addB->data() : nullptr, phi.data(), V ? V->data() : nullptr, divOut ? divOut->data() : scratch.data()), "fvc::flux + fvc::div");
 }
+void fvc::snGradCorrectionFlux(scalargpuField& flux, const lduAddressing& a, const vectorgpuField& corrVecs, const scalargpuField& weights,
+                               const vectorgpuField& gradVf, const scalargpuField& gammaMagSf)
+{
+    miCheck(mi_sngrad_correction_flux(a.handle(), corrVecs.component(0).data(), corrVecs.component(1).data(), corrVecs.component(2).data(), weights.data(),
+                                      gradVf.component(0).data(), gradVf.component(1).data(), gradVf.component(2).data(), gammaMagSf.data(), flux.data()),
+            "correctedSnGrad::correction");
+}
 void fvc::ddtCorr(scalargpuField& out, const lduAddressing& a, scalar rDeltaT, const scalargpuField& weights, const vectorgpuField& Sf,
                   const vectorgpuField& Uold, const scalargpuField& phiOld)
 {

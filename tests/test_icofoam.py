@@ -18,8 +18,8 @@ from test_polymesh import PKG, HEADER, make_box_mesh, geometry, write_case, LINE
 pytestmark = pytest.mark.gpu
 
 
-def write_cavity(case_dir, dims, nu, delta_t, n_steps, div_scheme, write_format="binary"):
-    pts, faces, owner, neighbour, patches = make_box_mesh(dims, seed=None)
+def write_cavity(case_dir, dims, nu, delta_t, n_steps, div_scheme, write_format="binary", corrected=False):
+    pts, faces, owner, neighbour, patches = make_box_mesh(dims, seed=5 if corrected else None)   # corrected: a distorted, non-orthogonal box
     n = int(owner.max()) + 1
     write_case(case_dir, pts, faces, owner, neighbour, patches, np.zeros(n), False)
     hd = lambda cls, loc, obj: HEADER.format(fmt="ascii", cls=cls, note="", obj=obj).replace('location    "constant/polyMesh"', f'location    "{loc}"')
@@ -39,9 +39,9 @@ writePrecision  12;
     open(os.path.join(case_dir, "system", "fvSchemes"), "w").write(hd("dictionary", "system", "fvSchemes") + f"""ddtSchemes {{ default Euler; }}
 gradSchemes {{ default Gauss linear; }}
 divSchemes {{ default none; div(phi,U) Gauss {div_scheme}; }}
-laplacianSchemes {{ default Gauss linear orthogonal; }}
+laplacianSchemes {{ default Gauss linear {'corrected' if corrected else 'orthogonal'}; }}
 interpolationSchemes {{ default linear; }}
-snGradSchemes {{ default orthogonal; }}
+snGradSchemes {{ default {'corrected' if corrected else 'orthogonal'}; }}
 """)
     open(os.path.join(case_dir, "system", "fvSolution"), "w").write(hd("dictionary", "system", "fvSolution") + """solvers
 {
@@ -49,8 +49,8 @@ snGradSchemes {{ default orthogonal; }}
     pFinal  { $p; relTol 0; }
     "U.*"   { solver PBiCG; preconditioner DILU; tolerance 1e-09; relTol 0; }
 }
-PISO { nCorrectors 2; nNonOrthogonalCorrectors 0; pRefCell 0; pRefValue 0; }
-""")
+PISO { nCorrectors 2; nNonOrthogonalCorrectors NONORTH; pRefCell 0; pRefValue 0; }
+""".replace("NONORTH", "1" if corrected else "0"))
     bU = "".join(f"    {name}\n    {{\n        type            {'fixedValue' if name != 'walls' else 'noSlip'};\n"
                  + ("        value           uniform (0 1 0);\n" if name == "inlet" else "        value           uniform (0 0 0);\n" if name == "outlet" else "") + "    }\n"
                  for name, _, _, _ in patches)
@@ -60,7 +60,7 @@ PISO { nCorrectors 2; nNonOrthogonalCorrectors 0; pRefCell 0; pRefValue 0; }
     return pts, faces, owner, neighbour, patches
 
 
-def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, scheme):
+def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, scheme, corrected=False):
     """icoFoam.C on the oracle; returns the solver lines [(name, field, initial, final, iterations)], the continuity errors and U, p"""
     syn = pkg.synthetic
     G = geometry(pts, faces, owner, neighbour)
@@ -90,6 +90,16 @@ def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t,
         return [x / V for x in g]
 
     centres = [np.ascontiguousarray(G["C"][:, k]) for k in range(3)]
+    nhat = G["Sf"][:nI] / magSf[:, None]
+    cv = nhat - (G["C"][up] - G["C"][lo]) * delta[:, None]                            # nonOrthCorrectionVectors (surfaceInterpolation.C:498-580)
+    cv = [np.ascontiguousarray(cv[:, k]) for k in range(3)]
+
+    def full_grad(vf, patch_values):
+        g = orc.gauss_grad(n, lo, up, Sf, orc.face_interpolate(lo, up, lam, vf), None)
+        for q, pv in zip(P, patch_values):
+            for k in range(3):
+                g[k] = orc.patch_add_product(q["fc"], q["sf"][k], vf[q["fc"]] if pv is None else pv, g[k], 0)
+        return [x / V for x in g]
     for step in range(n_steps):
         Uold, phiOld = [u.copy() for u in U], phi.copy()
         if scheme == "upwind":
@@ -114,6 +124,10 @@ def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t,
             diag, source = (dD + dB) - dL, sD
             ic = [q["diff"] for q in P]
             bc = [q["diff"] * q["ub"][:, k] - q["phi"] * q["ub"][:, k] for q in P]
+            if corrected:   # - fvm::laplacian(nu, U) corrected: source += V*div(nu |Sf| correction(U_k))
+                gU = full_grad(Uold[k], [q["ub"][:, k].copy() for q in P])
+                cf = orc.sngrad_correction_flux(lo, up, cv, lam, gU, -(nu * magSf))
+                source = orc.submul(V, orc.surface_integrate(n, lo, up, cf, V), source)
             mats.append(dict(diag=diag, source=source, ic=ic, bc=bc))
         for k in range(3):
             M = mats[k]
@@ -139,13 +153,18 @@ def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t,
             phiHbyA, div = orc.flux_div(n, lo, up, lam, Sf, HbyA, None, rAUf, ddtc, None, True)
             for q in P:
                 div = orc.patch_add(q["fc"], q["phi"], div, 0)
-            upP, dP = orc.fvm_laplacian(n, lo, up, delta, rAUf * magSf)
-            sP = div.copy()
-            sP[0] += dP[0] * 0.0; dP = dP.copy(); dP[0] += dP[0]                        # setReference(0, 0): source += diag*value; diag += diag
-            final = corr == 1
-            p, perf = orc.System([syn.LduCase(n, lo, up, dP, upP, None, sP)]).pcg(p, sP, "AINV", tolerance=1e-8, relTol=0.0 if final else 0.05)
-            lines.append(("AINVPCG", "p", perf["initialResidual"], perf["finalResidual"], perf["nIterations"]))
-            phi = phiHbyA - orc.System([syn.LduCase(n, lo, up, dP, upP, None, sP)]).faceH(p)
+            for non_orth in range(2 if corrected else 1):
+                upP, dP = orc.fvm_laplacian(n, lo, up, delta, rAUf * magSf)
+                sP = div.copy()
+                if corrected:
+                    cfp = orc.sngrad_correction_flux(lo, up, cv, lam, grad_p(), rAUf * magSf)
+                    sP = orc.submul(V, orc.surface_integrate(n, lo, up, cfp, V), sP)
+                sP[0] += dP[0] * 0.0; dP = dP.copy(); dP[0] += dP[0]                    # setReference(0, 0): source += diag*value; diag += diag
+                final = corr == 1 and non_orth == (1 if corrected else 0)
+                p, perf = orc.System([syn.LduCase(n, lo, up, dP, upP, None, sP)]).pcg(p, sP, "AINV", tolerance=1e-8, relTol=0.0 if final else 0.05)
+                lines.append(("AINVPCG", "p", perf["initialResidual"], perf["finalResidual"], perf["nIterations"]))
+            flux = orc.System([syn.LduCase(n, lo, up, dP, upP, None, sP)]).faceH(p)
+            phi = phiHbyA - ((flux + cfp) if corrected else flux)
             ce = orc.surface_integrate(n, lo, up, phi, None)
             for q in P:
                 ce = orc.patch_add(q["fc"], q["phi"], ce, 0)
@@ -163,7 +182,7 @@ def test_icoFoam_refuses_what_it_does_not_assemble(pkg, tmp_path):
     write_cavity(case_dir, (4, 3, 2), 0.01, 0.005, 1, "linear", "ascii")
     sch = os.path.join(case_dir, "system", "fvSchemes")
     good = open(sch).read()
-    for bad, msg in ((good.replace("Gauss linear orthogonal", "Gauss linear corrected"), "Gauss linear orthogonal | Gauss linear uncorrected only"),
+    for bad, msg in ((good.replace("Gauss linear orthogonal", "Gauss linear limited 0.5"), "Gauss linear corrected | uncorrected | orthogonal"),
                      (good.replace("default Euler", "default backward"), "only Euler"), (good.replace("Gauss linear;  ", "Gauss QUICK;"), None)):
         open(sch, "w").write(bad)
         out = subprocess.run([os.path.join(PKG, "icoFoam"), case_dir], capture_output=True, text=True, timeout=120)
@@ -180,18 +199,20 @@ def test_icoFoam_refuses_what_it_does_not_assemble(pkg, tmp_path):
 CONT = re.compile(r"time step continuity errors : sum local = (\S+), global = (\S+), cumulative = (\S+)")
 
 
-@pytest.mark.parametrize("dims, n_steps, div_scheme, write_format", [((10, 8, 6), 3, "linear", "binary"), ((10, 8, 6), 3, "upwind", "ascii"), ((12, 10, 8), 4, "limitedLinear 1", "binary"),
-                                                                     ((32, 32, 32), 2, "linear", "binary")])   # the last: BASELINE config 1's size
-def test_icoFoam_cavity_matches_the_oracle_statement_for_statement(pkg, orc, tmp_path, dims, n_steps, div_scheme, write_format):
+@pytest.mark.parametrize("dims, n_steps, div_scheme, write_format, corrected", [((10, 8, 6), 3, "linear", "binary", False), ((10, 8, 6), 3, "upwind", "ascii", False),
+                                                                                ((12, 10, 8), 4, "limitedLinear 1", "binary", False),
+                                                                                ((12, 9, 7), 3, "linear", "binary", True),            # a distorted box, `corrected` Laplacians, one non-orthogonal corrector
+                                                                                ((32, 32, 32), 2, "linear", "binary", False)])        # BASELINE config 1's size
+def test_icoFoam_cavity_matches_the_oracle_statement_for_statement(pkg, orc, tmp_path, dims, n_steps, div_scheme, write_format, corrected):
     nu, delta_t = 0.01, 0.005
     case_dir = str(tmp_path / "cavity")
-    pts, faces, owner, neighbour, patches = write_cavity(case_dir, dims, nu, delta_t, n_steps, div_scheme, write_format)
+    pts, faces, owner, neighbour, patches = write_cavity(case_dir, dims, nu, delta_t, n_steps, div_scheme, write_format, corrected)
     out = subprocess.run([os.path.join(PKG, "icoFoam"), case_dir], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr + out.stdout[-2000:]
     got = [(m.group(1), m.group(2), float(m.group(3)), float(m.group(4)), int(m.group(5))) for m in map(LINE.match, out.stdout.splitlines()) if m]
     cont = [tuple(map(float, m.groups())) for m in map(CONT.match, out.stdout.splitlines()) if m]
-    ref_lines, ref_cont, refU, refp = oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, div_scheme)
-    assert len(got) == len(ref_lines) == n_steps * 5 and len(cont) == len(ref_cont) == n_steps * 2
+    ref_lines, ref_cont, refU, refp = oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, div_scheme, corrected)
+    assert len(got) == len(ref_lines) == n_steps * (7 if corrected else 5) and len(cont) == len(ref_cont) == n_steps * 2
     for g, r in zip(got, ref_lines):
         assert g[0] == r[0] and g[1] == r[1], (g, r)
         assert g[4] == r[4], (g, r)                                                   # the same iteration counts
@@ -207,6 +228,9 @@ def test_icoFoam_cavity_matches_the_oracle_statement_for_statement(pkg, orc, tmp
     assert fU["internalField"].shape == Uref.shape and np.max(np.abs(fU["internalField"] - Uref)) <= tolU * np.max(np.abs(Uref))
     assert np.max(np.abs(fp["internalField"] - refp)) <= tolU * np.max(np.abs(refp))
     assert np.max(np.abs(Uref)) > 1e-3                                                # the lid really drives a flow
+    if corrected:                                                                      # ... the non-orthogonal correction really corrects
+        _, _, Uun, _ = oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, div_scheme, False)
+        assert np.max(np.abs(np.stack(Uun, axis=1) - Uref)) > 1e-6 * np.max(np.abs(Uref))
     if div_scheme.startswith("limitedLinear"):                                         # ... and the limiter really limits: not the linear scheme's result
         _, _, Ulin, _ = oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t, n_steps, "linear")
         assert np.max(np.abs(np.stack(Ulin, axis=1) - Uref)) > 1e-7 * np.max(np.abs(Uref))
