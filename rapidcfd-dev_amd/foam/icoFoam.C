@@ -11,8 +11,9 @@
 // writePrecision), system/fvSchemes (div(phi,U): Gauss linear | Gauss upwind | Gauss limitedLinear k; laplacian: Gauss linear corrected |
 // uncorrected -- the corrected form with its explicit non-orthogonal flux in UEqn's and pEqn's sources and in pEqn.flux()), system/fvSolution (solvers U, p [pFinal]; PISO: nCorrectors,
 // pRefCell, pRefValue), 0/U (fixedValue / noSlip patches), 0/p (zeroGradient patches: a closed domain, hence the reference level).
-// The momentum matrix is held per component (three scalar matrices with the same coefficients: for fixedValue patches
-// fvMatrix<vector>::A() / H() reduce to the scalar forms, fvMatrix.C:1384-1506); every field operation is a call of the path.
+// UEqn is the mirror's fvVectorMatrix: one set of coefficients and three sources out of ONE assembly pass (mi_fvm_assemble), the three
+// components solved as one batched PBiCG (fvMatrix<vector>::solveSegregated on the engine), A() and H() as fvMatrix.C:1374-1506; every
+// field operation is a call of the path.
 // At the end U and p go back into the case as <case>/<endTime>/{U,p}.   usage: icoFoam <caseDir> [-nSteps N]
 // tests/test_icofoam.py runs the same steps on the oracle and compares every solver line, the continuity errors and the written fields.
 #include "polyMesh.H"
@@ -192,47 +193,45 @@ int main(int argc, char** argv)
                 limitedLinearWeights(upw, addr, limiterK, weights, phi, m2, g, Cc);
             }
             const scalargpuField& convWeights = (upwind || limited) ? upw : weights;
-            // UEqn = fvm::ddt(U) + fvm::div(phi, U) - fvm::laplacian(nu, U), one matrix per component (same coefficients)
-            std::vector<std::unique_ptr<fvScalarMatrix>> UEqn;
-            const char* cname[3] = {"Ux", "Uy", "Uz"};
+            // fvVectorMatrix UEqn(fvm::ddt(U) + fvm::div(phi, U) - fvm::laplacian(nu, U)): the coefficients once, the three sources out of the same pass
+            fvVectorMatrix UEqn("U", addr, patchCells, notCoupled);
             gradOfP();
-            for (direction d = 0; d < 3; ++d) {
-                UEqn.emplace_back(new fvScalarMatrix(cname[d], addr, patchCells, notCoupled));
-                fvScalarMatrix& M = *UEqn[d];
-                fvm::assemble(M, rDeltaT, 1.0, V, Uold.component(d), &phi, &convWeights, &deltaCoeffs, &nuMagSf);
-                for (label q = 0; q < nP; ++q) {
+            fvm::assemble(UEqn, rDeltaT, 1.0, V, Uold, &phi, &convWeights, &deltaCoeffs, &nuMagSf);
+            for (label q = 0; q < nP; ++q)
+                for (direction d = 0; d < 3; ++d) {
                     // fixedValue patch: convection valueInternalCoeffs 0 / valueBoundaryCoeffs U_b (gaussConvectionScheme.C:96-110: boundaryCoeffs = -phi_b U_b);
                     // diffusion, with the sign of `- fvm::laplacian`: internalCoeffs = nu |Sf| deltaCoeffs, boundaryCoeffs = nu |Sf| deltaCoeffs U_b
-                    M.internalCoeffs()[q] = diffB[q];
+                    UEqn.internalCoeffs()[q].component(d) = diffB[q];
                     scalargpuField bc = product(diffB[q], UbDev[q].component(d));
                     fieldSubMul(bc, phiB[q], UbDev[q].component(d));
-                    M.boundaryCoeffs()[q] = bc;
+                    UEqn.boundaryCoeffs()[q].component(d) = bc;
                 }
-                if (corrected) {   // - fvm::laplacian(nu, U), corrected: its explicit part enters with the opposite sign -- gamma = -nu
+            if (corrected)   // - fvm::laplacian(nu, U), corrected: its explicit part enters with the opposite sign -- gamma = -nu
+                for (direction d = 0; d < 3; ++d) {
                     std::vector<const scalargpuField*> fixedValues;
                     for (label q = 0; q < nP; ++q) fixedValues.push_back(&UbDev[q].component(d));
-                    vectorgpuField gU(n); scalargpuField cf(nI);
+                    vectorgpuField gU(n); scalargpuField cf(nI), dv(n);
                     gaussGrad(gU, Uold.component(d), fixedValues);
-                    correctLaplacian(M, gU, negNuMagSf, cf);
+                    fvc::snGradCorrectionFlux(cf, addr, corrVecs, weights, gU, negNuMagSf);
+                    fvc::surfaceIntegrate(dv, addr, cf, &V);
+                    fieldSubMul(UEqn.source().component(d), V, dv);
                 }
-            }
-            // solve(UEqn == -fvc::grad(p)): the temporary's source is source - V*grad(p)   (fvMatrix.C: operator==, operator-(fvMatrix, field))
-            for (direction d = 0; d < 3; ++d) {
-                fvScalarMatrix& M = *UEqn[d];
-                const scalargpuField keep(M.source());
-                fieldSubMul(M.source(), V, gradP.component(d));
-                M.solve(U.component(d), UControls);
-                M.source() = keep;
+            {   // solve(UEqn == -fvc::grad(p)): the temporary's source is source - V*grad(p)   (fvMatrix.C: operator==, operator-(fvMatrix, field));
+                // fvMatrix<vector>::solveSegregated -- the three components as ONE batched PBiCG on the engine (mi_pbicg_solve_multi)
+                const vectorgpuField keep(UEqn.source());
+                for (direction d = 0; d < 3; ++d) fieldSubMul(UEqn.source().component(d), V, gradP.component(d));
+                UEqn.solve(U, UControls);
+                for (direction d = 0; d < 3; ++d) UEqn.source().component(d) = keep.component(d);
             }
             // --- PISO loop
             for (label corr = 0; corr < nCorr; ++corr) {
                 scalargpuField A(n), rAU(n);
-                UEqn[0]->A(A, V);
+                UEqn.A(A, V);
                 fieldDivide(rAU, ones, A);                                           // volScalarField rAU(1.0/UEqn.A());
-                for (direction d = 0; d < 3; ++d) {                                  // HbyA = rAU*UEqn.H();
-                    scalargpuField H(n);
-                    UEqn[d]->H(H, U.component(d), V);
-                    HbyA.component(d) = product(rAU, H);
+                {                                                                    // HbyA = rAU*UEqn.H();
+                    vectorgpuField H(n);
+                    UEqn.H(H, U, V);
+                    for (direction d = 0; d < 3; ++d) HbyA.component(d) = product(rAU, H.component(d));
                 }
                 fvc::interpolate(rAUf, addr, weights, rAU);
                 fvc::ddtCorr(ddtCorrF, addr, rDeltaT, weights, SfI, Uold, phiOld);

@@ -606,6 +606,44 @@ solverPerformance fvVectorMatrix::solve(vectorgpuField& psi, const dictionary& s
     return solverPerfVec;
 }
 
+void fvVectorMatrix::A(scalargpuField& Aphi, const scalargpuField& V) const
+{
+    mi_ctx_t ctx = miEngine::New().ctx;
+    Aphi = diag();
+    for (std::size_t p = 0; p < patchFaceCells_.size(); ++p) {
+        const label np = (label)patchFaceCells_[p].size();
+        if (np == 0) continue;
+        scalargpuField av(np), three(std::vector<scalar>((std::size_t)np, 3.0));       // cmptAv(v) = (v.x() + v.y() + v.z())/3
+        miCheck(mi_vec_axpby(ctx, np, 1.0, internalCoeffs_[p].component(0).data(), 1.0, internalCoeffs_[p].component(1).data(), av.data()), "cmptAv");
+        miCheck(mi_vec_axpby(ctx, np, 1.0, av.data(), 1.0, internalCoeffs_[p].component(2).data(), av.data()), "cmptAv");
+        miCheck(mi_vec_div(ctx, np, av.data(), three.data(), av.data()), "cmptAv");
+        miCheck(mi_patch_add(patchOf(patches_, p, lduAddr().size(), patchFaceCells_[p]), av.data(), Aphi.data(), 0), "fvMatrix::addCmptAvBoundaryDiag");
+    }
+    miCheck(mi_vec_div(ctx, Aphi.size(), Aphi.data(), V.data(), Aphi.data()), "fvMatrix::A");
+}
+void fvVectorMatrix::H(vectorgpuField& Hphi, const vectorgpuField& psi, const scalargpuField& V) const
+{
+    static const FieldFieldScalar none; static const lduInterfaceFieldPtrsList noIfs;
+    mi_ctx_t ctx = miEngine::New().ctx;
+    for (direction d = 0; d < 3; ++d) {
+        miCheck(mi_H(handle(none, none, noIfs), psi.component(d).data(), Hphi.component(d).data()), "lduMatrix::H");
+        miCheck(mi_vec_axpby(ctx, Hphi.size(), 1.0, Hphi.component(d).data(), 1.0, source_.component(d).data(), Hphi.component(d).data()), "fvMatrix::H");
+    }
+    addBoundarySource(Hphi);
+    for (direction d = 0; d < 3; ++d) miCheck(mi_vec_div(ctx, Hphi.size(), Hphi.component(d).data(), V.data(), Hphi.component(d).data()), "fvMatrix::H");
+}
+void fvm::assemble(fvVectorMatrix& M, scalar rDeltaT, scalar rho, const scalargpuField& V, const vectorgpuField& psiOld, const scalargpuField* faceFlux,
+                   const scalargpuField* weights, const scalargpuField* deltaCoeffs, const scalargpuField* gammaMagSf)
+{
+    mi_fvm_terms t{};
+    t.ddt = 1; t.r_delta_t = rDeltaT; t.rho_value = rho; t.vol_dev = V.data();
+    t.div_flux_dev = faceFlux ? faceFlux->data() : nullptr; t.div_weights_dev = weights ? weights->data() : nullptr;
+    t.lap_delta_coeffs_dev = deltaCoeffs ? deltaCoeffs->data() : nullptr; t.lap_gamma_magsf_dev = gammaMagSf ? gammaMagSf->data() : nullptr;
+    const double* po[3] = {psiOld.component(0).data(), psiOld.component(1).data(), psiOld.component(2).data()};
+    t.n_rhs = 3; t.psi_old_dev = po;
+    double* so[3] = {M.source().component(0).data(), M.source().component(1).data(), M.source().component(2).data()};
+    miCheck(mi_fvm_assemble(M.lduAddr().handle(), &t, faceFlux ? M.lower().data() : nullptr, M.upper().data(), M.diag().data(), so, nullptr), "fvm::assemble");
+}
 void fvm::laplacian(fvScalarMatrix& M, const scalargpuField& deltaCoeffs, const scalargpuField& gammaMagSf)
 {
     miCheck(mi_fvm_laplacian(M.lduAddr().handle(), deltaCoeffs.data(), gammaMagSf.data(), M.upper().data(), M.diag().data()), "fvm::laplacian");

@@ -138,8 +138,8 @@ def oracle_icofoam(pkg, orc, pts, faces, owner, neighbour, patches, nu, delta_t,
             lines.append(("AINVPBiCG", "Ux Uy Uz".split()[k], perf["initialResidual"], perf["finalResidual"], perf["nIterations"]))
         for corr in range(2):
             A = mats[0]["diag"].copy()
-            for q, ic in zip(P, mats[0]["ic"]):
-                A = orc.patch_add(q["fc"], ic, A, 0)
+            for q in P:                                                               # D() = diag + cmptAv(internalCoeffs): (x + y + z)/3 as floating point does it
+                A = orc.patch_add(q["fc"], ((q["diff"] + q["diff"]) + q["diff"]) / 3.0, A, 0)
             rAU = 1.0 / (A / V)
             HbyA = []
             for k in range(3):
